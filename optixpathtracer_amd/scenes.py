@@ -1,0 +1,412 @@
+"""Procedural inputs for the hot path: scenes, probes, cameras.
+
+The reference ships no assets (all its scenes are absolute C:/ paths,
+HelloPathtracing_original/main.cpp:171-175), so the synthetic inputs BASELINE.md §3 /
+SURVEY.md §8(d) specify are generated here, deterministically, as plain numpy arrays
+in the layout the C-ABI takes (include/pt_amd.h):
+
+  * Model: list of TriangleMesh {vertex (nv,3) f32, index (nt,3) u32, material} — the
+    reference's Model/TriangleMesh (Model.h:10-42), one mesh per material like loadOBJ.
+  * Material: numpy structured dtype with the reference's field order (Material.h:47-68).
+  * ProbeData: width, height, data (h,w,4) f32 + BuildCDF arrays (Probe.h:29-77).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# Material.h:47-68 — 26 x 4 bytes = 104 bytes, same order
+MATERIAL_DTYPE = np.dtype(
+    [
+        ("emission", "<f4", 3),
+        ("color", "<f4", 3),
+        ("absorption", "<f4", 3),
+        ("eta", "<f4"),
+        ("metallic", "<f4"),
+        ("subsurface", "<f4"),
+        ("specular", "<f4"),
+        ("roughness", "<f4"),
+        ("specularTint", "<f4"),
+        ("anisotropic", "<f4"),
+        ("sheen", "<f4"),
+        ("sheenTint", "<f4"),
+        ("clearcoat", "<f4"),
+        ("clearcoatGloss", "<f4"),
+        ("transmission", "<f4"),
+        ("bump", "<f4"),
+        ("bumpTile", "<f4", 3),
+        ("flags", "<i4"),
+    ]
+)
+assert MATERIAL_DTYPE.itemsize == 104
+
+MATERIAL_FLAG_NONE = 0
+MATERIAL_FLAG_SHADOW_CATCHER = 1  # Material.h:9
+
+
+def Material(**kw) -> np.ndarray:
+    """Material() with the reference's constructor defaults (Material.h:13-37)."""
+    m = np.zeros((), dtype=MATERIAL_DTYPE)
+    m["color"] = (0.6, 0.6, 0.6)
+    m["specular"] = 0.5
+    m["roughness"] = 1.0
+    m["clearcoatGloss"] = 1.0
+    m["bumpTile"] = (10.0, 10.0, 10.0)
+    for k, v in kw.items():
+        m[k] = v
+    return m
+
+
+@dataclass
+class TriangleMesh:  # Model.h:10-19
+    vertex: np.ndarray  # (nv,3) f32
+    index: np.ndarray  # (nt,3) u32, local to this mesh
+    material: np.ndarray  # MATERIAL_DTYPE scalar
+    diffuseTextureID: int = -1
+
+
+@dataclass
+class Model:  # Model.h:31-42
+    meshes: list = field(default_factory=list)
+
+    @property
+    def num_triangles(self) -> int:
+        return int(sum(len(m.index) for m in self.meshes))
+
+    def flatten(self):
+        """Global arrays the C-ABI / oracle take: verts (nv,3), idx (nt,3) global, tri_mesh (nt,), mats (nmesh,)."""
+        verts, idx, tri_mesh, base = [], [], [], 0
+        for mi, m in enumerate(self.meshes):
+            verts.append(np.ascontiguousarray(m.vertex, dtype=np.float32))
+            idx.append(np.ascontiguousarray(m.index, dtype=np.uint32) + np.uint32(base))
+            tri_mesh.append(np.full(len(m.index), mi, dtype=np.uint32))
+            base += len(m.vertex)
+        mats = np.array([m.material for m in self.meshes], dtype=MATERIAL_DTYPE)
+        return (
+            np.ascontiguousarray(np.concatenate(verts)),
+            np.ascontiguousarray(np.concatenate(idx)),
+            np.ascontiguousarray(np.concatenate(tri_mesh)),
+            mats,
+        )
+
+
+def _quads_to_mesh(quads, material) -> TriangleMesh:
+    q = np.asarray(quads, dtype=np.float32).reshape(-1, 4, 3)
+    n = len(q)
+    base = (np.arange(n, dtype=np.uint32) * 4)[:, None]
+    tri = np.concatenate([base + np.array([0, 1, 2], np.uint32), base + np.array([0, 2, 3], np.uint32)], axis=1)
+    return TriangleMesh(q.reshape(-1, 3).copy(), tri.reshape(-1, 3).astype(np.uint32), material)
+
+
+def add_box(model: Model, material, pos, extend) -> None:
+    """addBox (Model.cpp:214-286): `extend` is the HALF extent; 36 unshared vertices, 12 triangles in
+    the reference's order (front, back, left, right, top, bottom), one mesh."""
+    f = np.float32
+    px, py, pz = (f(v) for v in pos)
+    ex, ey, ez = (f(v) for v in extend)
+    A = (-ex + px, -ey + py, ez + pz)
+    B = (ex + px, -ey + py, ez + pz)
+    C = (ex + px, ey + py, ez + pz)
+    D = (-ex + px, ey + py, ez + pz)
+    E = (-ex + px, -ey + py, -ez + pz)
+    F = (ex + px, -ey + py, -ez + pz)
+    G = (ex + px, ey + py, -ez + pz)
+    H = (-ex + px, ey + py, -ez + pz)
+    verts = [A, B, C, A, C, D, E, H, G, E, G, F, E, A, D, E, D, H, B, F, G, B, G, C, D, C, G, D, G, H, E, A, B, E, B, F]
+    v = np.array(verts, np.float32)
+    idx = np.arange(36, dtype=np.uint32).reshape(12, 3)
+    model.meshes.append(TriangleMesh(v, idx, np.array(material, dtype=MATERIAL_DTYPE)))
+
+
+def cornell_box() -> Model:
+    """Cornell-32: the classic 32-triangle box (556 x 548.8 x 559.2, open front at z=0), 4 meshes.
+    Materials are Disney defaults with the classic colours; the ceiling quad carries emission 15
+    (visible on primary hits only — deviceProgram.cu:558-560)."""
+    white = Material(color=(0.8, 0.8, 0.8))
+    red = Material(color=(0.8, 0.05, 0.05))
+    green = Material(color=(0.05, 0.8, 0.05))
+    light = Material(color=(0.8, 0.8, 0.8), emission=(15.0, 15.0, 15.0))
+    W = [
+        [(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)],  # floor
+        [(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)],  # ceiling
+        [(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)],  # back
+        # short block
+        [(130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)],
+        [(290, 0, 114), (290, 165, 114), (240, 165, 272), (240, 0, 272)],
+        [(130, 0, 65), (130, 165, 65), (290, 165, 114), (290, 0, 114)],
+        [(82, 0, 225), (82, 165, 225), (130, 165, 65), (130, 0, 65)],
+        [(240, 0, 272), (240, 165, 272), (82, 165, 225), (82, 0, 225)],
+        # tall block
+        [(423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)],
+        [(423, 0, 247), (423, 330, 247), (472, 330, 406), (472, 0, 406)],
+        [(472, 0, 406), (472, 330, 406), (314, 330, 456), (314, 0, 456)],
+        [(314, 0, 456), (314, 330, 456), (265, 330, 296), (265, 0, 296)],
+        [(265, 0, 296), (265, 330, 296), (423, 330, 247), (423, 0, 247)],
+    ]
+    R = [[(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)]]
+    G = [[(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)]]
+    L = [[(343, 548.6, 227), (343, 548.6, 332), (213, 548.6, 332), (213, 548.6, 227)]]
+    m = Model([_quads_to_mesh(W, white), _quads_to_mesh(R, red), _quads_to_mesh(G, green), _quads_to_mesh(L, light)])
+    assert m.num_triangles == 32
+    return m
+
+
+CORNELL_CAMERA = dict(eye=(278.0, 273.0, -900.0), lookat=(278.0, 273.0, 0.0), up=(0.0, 1.0, 0.0), fovY=35.0)
+# the reference's lost-empire camera (HelloPathtracing_sv4_vmv23/main.cpp:227-231)
+TERRAIN_CAMERA = dict(eye=(-70.0, 40.0, 100.0), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fovY=45.0)
+
+
+def two_box_scene(shadow_catcher: bool = True) -> Model:
+    """The reference's commented-out procedural scene (main.cpp:165-169): a unit box on an
+    8 x 0.2 x 8 ground box flagged SHADOW_CATCHER."""
+    m = Model()
+    boxMat = Material()
+    add_box(m, boxMat, (0.0, 0.5, 0.0), (0.5, 0.5, 0.5))
+    if shadow_catcher:
+        boxMat["flags"] |= MATERIAL_FLAG_SHADOW_CATCHER
+    add_box(m, boxMat, (0.0, -0.1, 0.0), (4.0, 0.1, 4.0))
+    return m
+
+
+TWO_BOX_CAMERA = dict(eye=(3.0, 2.5, -4.0), lookat=(0.0, 0.4, 0.0), up=(0.0, 1.0, 0.0), fovY=40.0)
+
+
+def material_presets():
+    """8 presets exercising every BSDFSample/BSDFEval branch (Disney.cuh:196-426)."""
+    return [
+        Material(color=(0.25, 0.45, 0.15)),  # matte grass
+        Material(color=(0.45, 0.35, 0.25), roughness=0.8),  # dirt
+        Material(color=(0.5, 0.5, 0.52), roughness=0.5, specular=0.6),  # rock
+        Material(color=(0.9, 0.9, 0.95), roughness=0.3, clearcoat=1.0, clearcoatGloss=0.8),  # snow / clearcoat
+        Material(color=(0.9, 0.7, 0.3), metallic=1.0, roughness=0.25),  # metal
+        Material(color=(0.8, 0.4, 0.3), subsurface=0.6, roughness=0.7),  # subsurface clay
+        Material(color=(0.9, 0.95, 1.0), transmission=0.9, roughness=0.05),  # glass-like
+        Material(color=(0.2, 0.3, 0.7), specularTint=0.8, roughness=0.4, specular=0.9),  # tinted plastic
+    ]
+
+
+def _value_noise(n: int, seed: int, octaves=5) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    out = np.zeros((n, n), np.float64)
+    amp, tot = 1.0, 0.0
+    xs = np.arange(n, dtype=np.float64)
+    for o in range(octaves):
+        cells = 4 * (2**o)
+        lat = rng.random((cells + 2, cells + 2))
+        g = xs * (cells / n)
+        i0 = np.floor(g).astype(np.int64)
+        f = g - i0
+        f = f * f * (3.0 - 2.0 * f)
+        a = lat[i0][:, i0]
+        b = lat[i0 + 1][:, i0]
+        c = lat[i0][:, i0 + 1]
+        d = lat[i0 + 1][:, i0 + 1]
+        fx, fz = f[:, None], f[None, :]
+        out += amp * ((a * (1 - fx) + b * fx) * (1 - fz) + (c * (1 - fx) + d * fx) * fz)
+        tot += amp
+        amp *= 0.5
+    return out / tot
+
+
+def voxel_terrain(n: int = 360, seed: int = 1234, extent: float = 100.0, target_tris: int = 1_000_000) -> Model:
+    """~1M-triangle voxel terrain "in the spirit of lost_empire" (SURVEY.md §8d): value-noise
+    integer heights on an n x n column grid; top quads + exposed side quads (one quad per voxel
+    face) as axis-aligned triangle pairs; 8 material presets by height band → 8 meshes.
+    The height amplitude is bisected (deterministically) so the count lands near target_tris."""
+    noise = _value_noise(n, seed)
+    cell = 2.0 * extent / n
+
+    def heights(amp):
+        return np.floor(noise * amp).astype(np.int64)
+
+    def count(H):
+        dx = np.abs(np.diff(H, axis=0)).sum()
+        dz = np.abs(np.diff(H, axis=1)).sum()
+        hmin = H.min()
+        skirt = (H[0, :] - hmin).sum() + (H[-1, :] - hmin).sum() + (H[:, 0] - hmin).sum() + (H[:, -1] - hmin).sum()
+        return 2 * int(n * n + dx + dz + skirt)
+
+    lo, hi = 1.0, 400.0
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        if count(heights(mid)) < target_tris:
+            lo = mid
+        else:
+            hi = mid
+    H = heights(hi)
+    hmin, hmax = int(H.min()), int(H.max())
+    y0 = -0.5 * (hmax - hmin) * cell  # centre vertically around 0
+
+    def X(i):
+        return -extent + i * cell
+
+    def Y(k):
+        return y0 + (k - hmin) * cell
+
+    quads, levels = [], []
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    # tops
+    x0, x1, z0, z1, y = X(ii), X(ii + 1), X(jj), X(jj + 1), Y(H)
+    top = np.stack(
+        [np.stack([x0, y, z0], -1), np.stack([x0, y, z1], -1), np.stack([x1, y, z1], -1), np.stack([x1, y, z0], -1)], -2
+    ).reshape(-1, 4, 3)
+    quads.append(top)
+    levels.append(H.reshape(-1))
+
+    def side_faces(Ha, Hb, fixed_axis, fixed_coord, span0, span1):
+        """unit quads between columns a and b for k in [min,max) on the plane fixed_axis=fixed_coord"""
+        lo_, hi_ = np.minimum(Ha, Hb), np.maximum(Ha, Hb)
+        cnt = (hi_ - lo_).astype(np.int64)
+        tot = int(cnt.sum())
+        if tot == 0:
+            return np.zeros((0, 4, 3)), np.zeros((0,), np.int64)
+        rep = np.repeat(np.arange(len(cnt)), cnt)
+        offs = np.arange(tot) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        k = lo_[rep] + offs
+        f, s0, s1 = fixed_coord[rep], span0[rep], span1[rep]
+        ya, yb = Y(k), Y(k + 1)
+        if fixed_axis == 0:
+            q = np.stack(
+                [np.stack([f, ya, s0], -1), np.stack([f, yb, s0], -1), np.stack([f, yb, s1], -1), np.stack([f, ya, s1], -1)], -2
+            )
+        else:
+            q = np.stack(
+                [np.stack([s0, ya, f], -1), np.stack([s0, yb, f], -1), np.stack([s1, yb, f], -1), np.stack([s1, ya, f], -1)], -2
+            )
+        return q, k + 1
+
+    # interior faces along x and z
+    Ha, Hb = H[:-1, :].reshape(-1), H[1:, :].reshape(-1)
+    q, lv = side_faces(Ha, Hb, 0, X(ii[1:, :]).reshape(-1), X(jj[1:, :]).reshape(-1), X(jj[1:, :] + 1).reshape(-1))
+    quads.append(q); levels.append(lv)
+    Ha, Hb = H[:, :-1].reshape(-1), H[:, 1:].reshape(-1)
+    q, lv = side_faces(Ha, Hb, 2, X(jj[:, 1:]).reshape(-1), X(ii[:, 1:]).reshape(-1), X(ii[:, 1:] + 1).reshape(-1))
+    quads.append(q); levels.append(lv)
+    # skirts down to hmin on the four borders
+    base = np.full(n, hmin, np.int64)
+    ar = np.arange(n)
+    for fixed_axis, fc, Hedge in ((0, X(0), H[0, :]), (0, X(n), H[-1, :])):
+        q, lv = side_faces(base, Hedge, fixed_axis, np.full(n, fc), X(ar), X(ar + 1))
+        quads.append(q); levels.append(lv)
+    for fixed_axis, fc, Hedge in ((2, X(0), H[:, 0]), (2, X(n), H[:, -1])):
+        q, lv = side_faces(base, Hedge, fixed_axis, np.full(n, fc), X(ar), X(ar + 1))
+        quads.append(q); levels.append(lv)
+
+    Q = np.concatenate(quads).astype(np.float32)
+    LV = np.concatenate(levels)
+    band = np.clip(((LV - hmin) * 8) // max(1, (hmax - hmin + 1)), 0, 7)
+    presets = material_presets()
+    model = Model()
+    for b in range(8):
+        sel = Q[band == b]
+        if len(sel):
+            model.meshes.append(_quads_to_mesh(sel, presets[b]))
+    return model
+
+
+# ------------------------------------------------------------------ probes
+
+
+@dataclass
+class ProbeData:  # Probe.h:8-88
+    width: int
+    height: int
+    data: np.ndarray  # (h,w,4) f32
+    pdfValuesX: np.ndarray = None
+    cdfValuesX: np.ndarray = None
+    pdfValuesY: np.ndarray = None
+    cdfValuesY: np.ndarray = None
+    valid: bool = False
+
+    def BuildCDF(self, builder=None) -> "ProbeData":
+        """ProbeData::BuildCDF (Probe.h:29-77). `builder(data,w,h)->(pdfX,cdfX,pdfY,cdfY)` is the
+        native implementation (libptamd's pt_build_cdf); the numpy fallback below performs the same
+        sequential float32 running sums (np.cumsum on f32 accumulates left to right in f32)."""
+        if builder is not None:
+            self.pdfValuesX, self.cdfValuesX, self.pdfValuesY, self.cdfValuesY = builder(self.data, self.width, self.height)
+        else:
+            d = self.data.astype(np.float32)
+            lum = (d[..., 0] * np.float32(0.3) + d[..., 1] * np.float32(0.6)) + d[..., 2] * np.float32(0.1)
+            cx = np.cumsum(lum, axis=1, dtype=np.float32)
+            tot = cx[:, -1].copy()
+            inv = (np.float32(1.0) / tot).astype(np.float32)
+            self.pdfValuesX = (lum * inv[:, None]).astype(np.float32)
+            self.cdfValuesX = (cx * inv[:, None]).astype(np.float32)
+            cy = np.cumsum(tot, dtype=np.float32)
+            self.pdfValuesY = (tot / cy[-1]).astype(np.float32)
+            self.cdfValuesY = (cy / cy[-1]).astype(np.float32)
+        self.valid = True
+        return self
+
+
+def _uv_to_dir(u, v):
+    # Probe.cuh:48-58 (float64 here: used only to paint the synthetic probe)
+    th, ph = v * math.pi, u * 2.0 * math.pi
+    return np.stack([-np.sin(th) * np.cos(ph), np.cos(th), -np.sin(th) * np.sin(ph)], -1)
+
+
+SUN_DIR = np.array([-0.35, 0.70, -0.62]) / np.linalg.norm([-0.35, 0.70, -0.62])
+
+
+def sky_probe(width: int = 2048, height: int = 1024, sun_radius_deg: float = 2.0, sun_radiance: float = 50.0) -> ProbeData:
+    """Vertical sky gradient (zenith (1,1,1.2) → horizon .6 → ground .1) + one sun disc centred on
+    SUN_DIR (shines into the Cornell box's open front). Texel (col,row) maps to the direction the
+    sampler returns for it: ProbeUVToDir(col/W, row/H) (Probe.cuh:157-167, texel corner)."""
+    v = (np.arange(height, dtype=np.float64) / height)[:, None]
+    u = (np.arange(width, dtype=np.float64) / width)[None, :]
+    t_up = np.clip(v * 2.0, 0.0, 1.0)
+    t_dn = np.clip((v - 0.5) * 2.0, 0.0, 1.0)
+    zen = np.array([1.0, 1.0, 1.2])
+    hor = np.array([0.6, 0.6, 0.6])
+    gnd = np.array([0.1, 0.1, 0.1])
+    col = np.where((v < 0.5)[..., None], zen * (1 - t_up[..., None]) + hor * t_up[..., None], hor * (1 - t_dn[..., None]) + gnd * t_dn[..., None])
+    col = np.broadcast_to(col, (height, width, 3)).copy()
+    d = _uv_to_dir(np.broadcast_to(u, (height, width)), np.broadcast_to(v, (height, width)))
+    cosang = d @ SUN_DIR
+    col[cosang >= math.cos(math.radians(sun_radius_deg))] = sun_radiance
+    data = np.concatenate([col, np.ones((height, width, 1))], -1).astype(np.float32)
+    return ProbeData(width, height, np.ascontiguousarray(data))
+
+
+def constant_probe(width: int = 64, height: int = 32, value: float = 1.0) -> ProbeData:
+    """The reference's loadColor() constant probe (HelloPathtracing_sv4_vmv23/main.cpp:167-180)."""
+    data = np.full((height, width, 4), value, np.float32)
+    data[..., 3] = 1.0
+    return ProbeData(width, height, data)
+
+
+def disc_probe(width: int = 100, height: int = 50) -> ProbeData:
+    """Probe.cuh:207-242's commented-out ProbeCreateTest: radiance 10 where dot(dir,+y) >= .95, else 0.05."""
+    v = (np.arange(height, dtype=np.float64) / height)[:, None]
+    u = (np.arange(width, dtype=np.float64) / width)[None, :]
+    d = _uv_to_dir(np.broadcast_to(u, (height, width)), np.broadcast_to(v, (height, width)))
+    val = np.where(d[..., 1] >= 0.95, 10.0, 0.05)
+    data = np.stack([val, val, val, np.ones_like(val)], -1).astype(np.float32)
+    return ProbeData(width, height, np.ascontiguousarray(data))
+
+
+def uvw_frame(eye, lookat, up, fovY, aspect):
+    """sutil::Camera::UVWFrame (sutil/Camera.cpp:34-45) in float32; tanf via the host libm."""
+    f = np.float32
+    eye, lookat, up = (np.asarray(a, f) for a in (eye, lookat, up))
+
+    def dot(a, b):
+        return f(f(f(a[0] * b[0]) + f(a[1] * b[1])) + f(a[2] * b[2]))
+
+    def cross(a, b):
+        return np.array([f(a[1] * b[2]) - f(a[2] * b[1]), f(a[2] * b[0]) - f(a[0] * b[2]), f(a[0] * b[1]) - f(a[1] * b[0])], f)
+
+    def normalize(v):
+        return (v * f(f(1.0) / np.sqrt(dot(v, v), dtype=f))).astype(f)
+
+    W = (lookat - eye).astype(f)
+    wlen = np.sqrt(dot(W, W), dtype=f)
+    U = normalize(cross(W, up))
+    V = normalize(cross(U, W))
+    ang = f(f(f(0.5) * f(fovY)) * f(3.14159265358979323846)) / f(180.0)
+    vlen = f(wlen * f(np.tan(ang, dtype=f)))
+    V = (V * vlen).astype(f)
+    U = (U * f(vlen * f(aspect))).astype(f)
+    return U, V, W

@@ -1,0 +1,206 @@
+"""ctypes binding for the CPU checker (oracle/pt_oracle.c) and, when present, the reference-header
+library oracle/_ref/libptref.so.  TEST INFRASTRUCTURE: importable only from tests/, from
+__graft_entry__.smoke() and from bench.py's cpu_baseline leg — never from optixpathtracer_amd/."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> None:
+    need = force or not all(os.path.exists(os.path.join(HERE, n)) for n in ("liborc_libm.so", "liborc_det.so"))
+    if not need:
+        src_m = max(os.path.getmtime(os.path.join(HERE, "pt_oracle.c")), os.path.getmtime(os.path.join(HERE, "..", "include", "pt_detmath.h")))
+        need = any(os.path.getmtime(os.path.join(HERE, n)) < src_m for n in ("liborc_libm.so", "liborc_det.so"))
+    if need:
+        subprocess.check_call(["make", "-C", HERE, "liborc_libm.so", "liborc_det.so"], stdout=subprocess.DEVNULL)
+
+
+class Probe(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("data", C.c_void_p), ("pdfX", C.c_void_p), ("cdfX", C.c_void_p), ("pdfY", C.c_void_p), ("cdfY", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int), ("subframe_index", C.c_uint32), ("samples_per_launch", C.c_uint32),
+        ("max_depth", C.c_int), ("bsdf_mode", C.c_int),
+        ("eye", C.c_float * 3), ("U", C.c_float * 3), ("V", C.c_float * 3), ("W", C.c_float * 3),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64)]
+
+
+BSDF_DISNEY, BSDF_LAMBERT = 0, 1
+
+
+class Oracle:
+    """mode: 'libm' (independent glibc transcendentals) or 'det' (pt_detmath, bit-comparable with the GPU)."""
+
+    def __init__(self, mode: str = "det"):
+        build()
+        self.mode = mode
+        self.lib = L = C.CDLL(os.path.join(HERE, f"liborc_{mode}.so"))
+        L.orc_tea4.restype = C.c_uint32
+        L.orc_tea4.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_lcg.restype = C.c_uint32
+        L.orc_lcg.argtypes = [C.POINTER(C.c_uint32)]
+        L.orc_rnd.restype = C.c_float
+        L.orc_rnd.argtypes = [C.POINTER(C.c_uint32)]
+        L.orc_random_init.argtypes = [u32p, C.c_uint32]
+        L.orc_rand.restype = C.c_uint32
+        L.orc_rand.argtypes = [u32p]
+        L.orc_randf.restype = C.c_float
+        L.orc_randf.argtypes = [u32p]
+        L.orc_material_ior.restype = C.c_float
+        L.orc_material_ior.argtypes = [C.c_void_p]
+        L.orc_material_default.argtypes = [C.c_void_p]
+        L.orc_build_cdf.argtypes = [f32p, C.c_int, C.c_int, f32p, f32p, f32p, f32p]
+        L.orc_probe_dir_to_uv.argtypes = [f32p, f32p]
+        L.orc_probe_uv_to_dir.argtypes = [f32p, f32p]
+        L.orc_probe_eval.argtypes = [C.POINTER(Probe), f32p, f32p]
+        L.orc_probe_sample.argtypes = [C.POINTER(Probe), C.c_uint32, f32p, f32p, C.POINTER(C.c_float), u32p]
+        L.orc_make_color.restype = C.c_uint32
+        L.orc_make_color.argtypes = [f32p]
+        L.orc_tonemap_sqrt.argtypes = [f32p, u32p, C.c_int]
+        L.orc_uvw_frame.argtypes = [f32p, f32p, f32p, C.c_float, C.c_float, f32p, f32p, f32p]
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_scene_create.argtypes = [f32p, C.c_uint32, u32p, C.c_uint32, u32p, C.c_void_p, C.c_uint32, C.c_int]
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_trace_closest.argtypes = [C.c_void_p, f32p, C.c_int, f32p, i32p]
+        L.orc_trace_any.argtypes = [C.c_void_p, f32p, C.c_int, u8p]
+        L.orc_bsdf_eval.argtypes = [C.c_int, C.c_void_p, f32p, C.c_float, C.c_float, f32p, f32p, f32p, f32p]
+        L.orc_bsdf_pdf.restype = C.c_float
+        L.orc_bsdf_pdf.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_float, f32p, f32p, f32p]
+        L.orc_bsdf_sample.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_float, f32p, f32p, C.c_uint32, f32p, C.POINTER(C.c_float), u32p]
+        L.orc_basis_from_vector.argtypes = [f32p, f32p, f32p]
+        L.orc_uniform_sample_hemisphere.argtypes = [C.c_uint32, f32p]
+        L.orc_cosine_sample_hemisphere.argtypes = [C.c_float, C.c_float, f32p]
+        L.orc_math_table.argtypes = [C.c_int, f32p, f32p, C.c_int, f32p]
+        L.orc_render.argtypes = [C.c_void_p, C.POINTER(Probe), C.POINTER(Params), f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Stats)]
+        L.orc_sizeof_material.restype = C.c_size_t
+        assert L.orc_sizeof_material() == 104
+
+    # -- helpers
+    def make_probe(self, pd) -> Probe:
+        """pd: scenes.ProbeData with BuildCDF done; keeps references alive on the returned struct."""
+        p = Probe()
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (pd.data, pd.pdfValuesX, pd.cdfValuesX, pd.pdfValuesY, pd.cdfValuesY)]
+        p.width, p.height = pd.width, pd.height
+        p.data, p.pdfX, p.cdfX, p.pdfY, p.cdfY = (a.ctypes.data for a in arrs)
+        p._keep = arrs
+        return p
+
+    def build_cdf(self, data, w, h):
+        data = np.ascontiguousarray(data, np.float32)
+        pdfX = np.empty((h, w), np.float32); cdfX = np.empty((h, w), np.float32)
+        pdfY = np.empty(h, np.float32); cdfY = np.empty(h, np.float32)
+        self.lib.orc_build_cdf(data.reshape(-1), w, h, pdfX.reshape(-1), cdfX.reshape(-1), pdfY, cdfY)
+        return pdfX, cdfX, pdfY, cdfY
+
+    def make_scene(self, model, use_bvh=None):
+        verts, idx, tri_mesh, mats = model.flatten()
+        if use_bvh is None:
+            use_bvh = len(idx) > 256
+        h = self.lib.orc_scene_create(verts.reshape(-1), len(verts), idx.reshape(-1), len(idx), tri_mesh, mats.ctypes.data, len(mats), int(use_bvh))
+        return SceneHandle(self, h)
+
+    def render(self, scene, probe, cam_uvw, eye, width, height, spp, max_depth=8, subframe=0, bsdf_mode=BSDF_DISNEY, accum=None, nthreads=None):
+        """One optixLaunch equivalent. Returns dict(accum, frame, normal, color, albedo, radiance_rays, shadow_rays)."""
+        prm = Params()
+        prm.width, prm.height, prm.subframe_index, prm.samples_per_launch = width, height, subframe, spp
+        prm.max_depth, prm.bsdf_mode = max_depth, bsdf_mode
+        U, V, W = cam_uvw
+        for dst, src in ((prm.eye, eye), (prm.U, U), (prm.V, V), (prm.W, W)):
+            for k in range(3):
+                dst[k] = float(src[k])
+        n = width * height
+        accum = np.zeros((height, width, 4), np.float32) if accum is None else np.ascontiguousarray(accum, np.float32).copy()
+        frame = np.zeros((height, width), np.uint32)
+        normal = np.zeros((height, width, 4), np.float32)
+        color = np.zeros((height, width, 4), np.float32)
+        albedo = np.zeros((height, width, 4), np.float32)
+        st = Stats()
+        if nthreads is None:
+            nthreads = min(os.cpu_count() or 1, 64)
+        self.lib.orc_render(scene.h, C.byref(probe), C.byref(prm), accum.reshape(-1), frame.ctypes.data, normal.ctypes.data, color.ctypes.data, albedo.ctypes.data, nthreads, C.byref(st))
+        return dict(accum=accum, frame=frame, normal=normal, color=color, albedo=albedo, radiance_rays=int(st.radiance_rays), shadow_rays=int(st.shadow_rays), n=n)
+
+    def trace_closest(self, scene, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        t = np.empty(len(rays), np.float32); prim = np.empty(len(rays), np.int32)
+        self.lib.orc_trace_closest(scene.h, rays.reshape(-1), len(rays), t, prim)
+        return t, prim
+
+    def trace_any(self, scene, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        occ = np.empty(len(rays), np.uint8)
+        self.lib.orc_trace_any(scene.h, rays.reshape(-1), len(rays), occ)
+        return occ
+
+    def math_table(self, which, x, y=None):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros_like(x) if y is None else np.ascontiguousarray(y, np.float32)
+        out = np.empty_like(x)
+        self.lib.orc_math_table(which, x, y, len(x), out)
+        return out
+
+
+class SceneHandle:
+    def __init__(self, orc, h):
+        self.orc, self.h = orc, h
+
+    def __del__(self):
+        try:
+            self.orc.lib.orc_scene_destroy(self.h)
+        except Exception:
+            pass
+
+
+def load_ref():
+    """oracle/_ref/libptref.so (the reference's own headers) or None when it was not built."""
+    path = os.path.join(HERE, "_ref", "libptref.so")
+    if not os.path.exists(path):
+        return None
+    R = C.CDLL(path)
+    R.ref_tea4.restype = C.c_uint32
+    R.ref_tea4.argtypes = [C.c_uint32, C.c_uint32]
+    R.ref_lcg.restype = C.c_uint32
+    R.ref_lcg.argtypes = [C.POINTER(C.c_uint32)]
+    R.ref_rnd.restype = C.c_float
+    R.ref_rnd.argtypes = [C.POINTER(C.c_uint32)]
+    R.ref_random_init.argtypes = [u32p, C.c_uint32]
+    R.ref_rand.restype = C.c_uint32
+    R.ref_rand.argtypes = [u32p]
+    R.ref_randf.restype = C.c_float
+    R.ref_randf.argtypes = [u32p]
+    R.ref_basis_from_vector.argtypes = [f32p, f32p, f32p]
+    R.ref_uniform_sample_hemisphere.argtypes = [C.c_uint32, f32p]
+    R.ref_cosine_sample_hemisphere.argtypes = [C.c_float, C.c_float, f32p]
+    R.ref_probe_dir_to_uv.argtypes = [f32p, f32p]
+    R.ref_probe_uv_to_dir.argtypes = [f32p, f32p]
+    R.ref_probe_eval.argtypes = [C.c_int, C.c_int, f32p, f32p, f32p]
+    R.ref_probe_sample.argtypes = [C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_uint32, f32p, f32p, C.POINTER(C.c_float), u32p]
+    R.ref_luminance.restype = C.c_float
+    R.ref_luminance.argtypes = [f32p]
+    R.ref_make_color.restype = C.c_uint32
+    R.ref_make_color.argtypes = [f32p]
+    R.ref_sizeof_material.restype = C.c_size_t
+    R.ref_material_default.argtypes = [C.c_void_p]
+    R.ref_material_ior.restype = C.c_float
+    R.ref_material_ior.argtypes = [C.c_void_p]
+    R.ref_uvw_frame.argtypes = [f32p, f32p, f32p, C.c_float, C.c_float, f32p, f32p, f32p]
+    R.ref_faceforward.argtypes = [f32p, f32p, f32p]
+    R.ref_normalize.argtypes = [f32p, f32p]
+    return R

@@ -1,0 +1,197 @@
+/* pt_amd.h — C ABI of libptamd.so, the MI355X-native replacement for the reference's
+ * optixLaunch hot path (bipul-mohanto/OptixPathTracer, HelloPathtracing_original/).
+ *
+ * The reference has no FFI: its boundary is the C++ class SampleRenderer
+ * (SimplePathtracer.h:38-176) plus the POD headers LaunchParams.h / Material.h /
+ * Model.h / Probe.h.  A maintainer keeps that class (see INTEGRATION.md and
+ * optixpathtracer_amd/csrc/SampleRenderer.h, a header-only facade with the same
+ * public methods) and forwards each method to one entry point below.  Every entry
+ * point cites the reference interface it replaces.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success
+ * or a negative pt_status; no exception crosses the boundary; pt_last_error() gives
+ * the message for the calling context (the reference throws sutil::Exception from
+ * CUDA_CHECK/OPTIX_CHECK, sutil/Exception.h:93-195).  A context is single-threaded,
+ * like the reference's renderer (one stream, device-synchronised render()).
+ */
+#ifndef PT_AMD_H
+#define PT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_ctx pt_ctx;
+
+enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1, /* bad argument / call order */
+    PT_ERR_HIP = -2,     /* a HIP runtime call failed */
+    PT_ERR_NO_DEVICE = -3,
+    PT_ERR_UNSUPPORTED = -4
+};
+
+/* Material.h:47-68 — identical field order and size (104 bytes) */
+typedef struct pt_material {
+    float emission[3];
+    float color[3];
+    float absorption[3];
+    float eta, metallic, subsurface, specular, roughness, specularTint, anisotropic, sheen, sheenTint, clearcoat,
+        clearcoatGloss, transmission;
+    float bump;
+    float bumpTile[3];
+    int32_t flags; /* bit0 = MATERIAL_FLAG_SHADOW_CATCHER (Material.h:9) */
+} pt_material;
+
+/* one TriangleMesh (Model.h:10-19): float3 vertices, uint3 indices, one material */
+typedef struct pt_mesh_desc {
+    const float* vertex; /* num_vertices * 3 */
+    uint32_t num_vertices;
+    const uint32_t* index; /* num_triangles * 3, local to this mesh */
+    uint32_t num_triangles;
+    pt_material material;
+    int32_t diffuse_texture_id; /* must be -1: texture sampling is a later row */
+} pt_mesh_desc;
+
+/* Model (Model.h:31-42) */
+typedef struct pt_scene_desc {
+    const pt_mesh_desc* meshes;
+    uint32_t num_meshes;
+} pt_scene_desc;
+
+enum pt_bsdf_mode { PT_BSDF_DISNEY = 0, PT_BSDF_LAMBERT = 1 /* Disney.cuh:125-147 */ };
+
+/* Everything the reference fixes at compile time (SURVEY.md §5 "config / flags") */
+typedef struct pt_options {
+    int32_t max_depth;      /* the literal 8 in deviceProgram.cu:429 */
+    int32_t bsdf_mode;      /* pt_bsdf_mode */
+    uint32_t max_paths;     /* paths in flight per wavefront batch (0 = default 8Mi) */
+    int32_t sort_rays;      /* reserved: per-bounce ray sort (0 = off) */
+    int32_t bvh_kind;       /* 0 = default */
+    int32_t reserved[3];
+} pt_options;
+
+enum pt_buffer {          /* LaunchParams.frame.* (LaunchParams.h:53-63) */
+    PT_BUF_ACCUM = 0,     /* float4 accum_buffer */
+    PT_BUF_FRAME = 1,     /* uchar4 frame_buffer (make_color) */
+    PT_BUF_COLOR = 2,     /* float4 color_buffer */
+    PT_BUF_NORMAL = 3,    /* float4 normal_buffer */
+    PT_BUF_ALBEDO = 4     /* float4 albedo_buffer */
+};
+
+typedef struct pt_stats {
+    uint64_t radiance_rays; /* closest-hit rays traced by the last pt_render */
+    uint64_t shadow_rays;   /* any-hit rays traced by the last pt_render */
+    uint64_t paths;         /* camera paths started */
+    double render_ms;       /* device time of the last pt_render (hipEvent, stream-local) */
+    double trace_ms;        /* of which: closest-hit traversal kernels */
+    double shadow_ms;       /*           any-hit traversal kernels */
+    double shade_ms;        /*           shade kernels */
+    double other_ms;        /*           generate / resolve */
+    uint32_t trace_launches, shadow_launches, shade_launches;
+    uint32_t bvh_nodes;     /* internal nodes of the traversal structure */
+    uint64_t bvh_bytes;     /* nodes + leaf triangles resident in HBM */
+    double bvh_build_ms;    /* one-time on-GPU build (excluded from render_ms) */
+} pt_stats;
+
+/* SampleRenderer::SampleRenderer(const Model*) (SimplePathtracer.cpp:39-71): uploads the meshes
+ * (buildAccel :481-489), builds the acceleration structure ON THE GPU (replaces optixAccelBuild +
+ * optixAccelCompact :561-591) and the per-mesh material table (replaces buildSBT :390-455).
+ * `device` is the HIP device ordinal.  The scene is deep-copied; the caller keeps its arrays. */
+int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ctx);
+
+/* no reference counterpart (the reference leaks everything at exit, CUDABuffer.h:32-88) */
+int pt_destroy(pt_ctx* ctx);
+
+const char* pt_last_error(const pt_ctx* ctx); /* ctx may be NULL: last error of a failed pt_create */
+
+int pt_set_options(pt_ctx* ctx, const pt_options* opt);
+int pt_get_options(const pt_ctx* ctx, pt_options* opt);
+
+/* SampleRenderer::setProbe(const ProbeData&) (SimplePathtracer.cpp:164-180) + CUDAProbeData::createBuffer
+ * (Probe.h:102-124): copies the five host arrays to the device. data = w*h float4; pdfX,cdfX = w*h; pdfY,cdfY = h */
+int pt_set_probe(pt_ctx* ctx, const float* data_rgba, const float* pdfX, const float* cdfX, const float* pdfY,
+                 const float* cdfY, int width, int height);
+
+/* ProbeData::BuildCDF (Probe.h:29-77), host side like the reference. Pure function, no context. */
+int pt_build_cdf(const float* data_rgba, int width, int height, float* pdfX, float* cdfX, float* pdfY, float* cdfY);
+
+/* SampleRenderer::resize(const int2&) (SimplePathtracer.cpp:109-147): (re)allocates the five frame
+ * buffers; a 0-sized request is ignored like the reference (:112). */
+int pt_resize(pt_ctx* ctx, int width, int height);
+
+/* SampleRenderer::setCamera (SimplePathtracer.cpp:155-162): eye + the UVW frame of sutil::Camera::UVWFrame */
+int pt_set_camera(pt_ctx* ctx, const float eye[3], const float U[3], const float V[3], const float W[3]);
+
+/* sutil::Camera::UVWFrame (sutil/Camera.cpp:34-45), host side. Pure function. */
+int pt_uvw_frame(const float eye[3], const float lookat[3], const float up[3], float fovY_deg, float aspect,
+                 float U[3], float V[3], float W[3]);
+
+/* Multi-GPU image partition (no reference counterpart; pattern of sutil/WorkDistribution.h:34-91):
+ * the image is cut into tile_w x tile_h tiles and this context renders only tiles with
+ * (tile_x + tile_y) % world == rank.  Default is rank 0 of 1.  Must be called before pt_resize
+ * or is applied at the next pt_resize. */
+int pt_set_partition(pt_ctx* ctx, int rank, int world, int tile_w, int tile_h);
+
+/* SampleRenderer::render() (SimplePathtracer.cpp:73-97): one optixLaunch(w,h,1) equivalent with
+ * launchParams.samples_per_launch = spp and launchParams.frame.subframe_index = subframe_index;
+ * returns after the device finished (the reference ends render() in cudaDeviceSynchronize, :96).
+ * Silently does nothing before the first pt_resize (:77). If host_rgba8 is non-NULL the frame
+ * buffer is copied into it (render(CUDAOutputBuffer&) + downloadPixels, :99-107,149-153). */
+int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8);
+
+/* SampleRenderer::downloadPixels (SimplePathtracer.cpp:149-153), generalised to all five buffers.
+ * bytes must equal width*height*(16 or 4). */
+int pt_download(pt_ctx* ctx, int which /* pt_buffer */, void* host, size_t bytes);
+
+/* progressive state: overwrite accum_buffer (checkpoint/resume of an accumulation) */
+int pt_upload_accum(pt_ctx* ctx, const float* host_rgba, size_t bytes);
+
+/* device pointer of a frame buffer, for zero-copy consumers (display interop in the reference:
+ * render(CUDAOutputBuffer&) maps the caller's buffer, SimplePathtracer.cpp:99-107) */
+void* pt_device_buffer(pt_ctx* ctx, int which);
+
+/* toneMap.cu:41-70 computeFinalPixelColors: rgba8 = clamp(sqrt(accum))*255.9 into the frame buffer
+ * (the reference's disabled alternative epilogue, SimplePathtracer.cpp:105). */
+int pt_tonemap_sqrt(pt_ctx* ctx, uint32_t* host_rgba8 /* may be NULL */);
+
+/* Multi-GPU exchange helpers. pt_owned_pixels = number of pixels this rank renders (padded count is
+ * the same on every rank: pt_owned_pixels_padded). pt_pack packs this rank's pixels of buffer `which`
+ * into dev_dst (padded count * elem bytes); pt_unpack scatters the concatenation of all ranks' packs
+ * (world * padded * elem bytes, rank-major — exactly what an RCCL all-gather produces) into the
+ * full-size local buffer `which`. */
+int pt_owned_pixels(const pt_ctx* ctx, uint32_t* owned, uint32_t* padded);
+int pt_pack(pt_ctx* ctx, int which, void* dev_dst);
+int pt_unpack(pt_ctx* ctx, int which, const void* dev_src_all);
+
+int pt_get_stats(const pt_ctx* ctx, pt_stats* out);
+
+/* Ray-search entry (what optixTrace did: deviceProgram.cu:165,190).  rays = n * 8 floats
+ * (o.xyz, tmin, d.xyz, tmax) in HOST memory.  any_hit=0: t_out[n], prim_out[n] (global triangle
+ * index in mesh order, -1 = miss; t_out = tmax on miss).  any_hit=1: prim_out[n] = 1 occluded / 0.
+ * iters>1 repeats the kernel for timing; kernel_ms (may be NULL) receives the mean kernel time. */
+int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit, float* t_out, int32_t* prim_out, int iters,
+             double* kernel_ms);
+
+/* Device-function tables for function-level parity tests (the reference's commented-out BSDFTest /
+ * ProbeCreateTest, Disney.cuh:430-503, Probe.cuh:207-269, turned into entry points).
+ *  which = 0: BSDFEval+BSDFPdf  in: n x {N[3],V[3],L[3],etaI,etaO} (11 floats)  out: n x {f[3],pdf}
+ *  which = 1: BasisFromVector+BSDFSample  in: n x {N[3],V[3],etaI,etaO,seed(as u32 bits)} (9)  out: n x {L[3],pdf,seed1,seed2 (bits)}
+ *  which = 2: ProbeSample  in: n x {seed bits} (1)  out: n x {dir[3],color[3],pdf,seed1,seed2} (9)
+ *  which = 3: ProbeEval(ProbeDirToUV(dir)) in: n x dir[3] out: n x {u,v,r,g,b,a} (6)
+ *  which = 4: make_color in: n x rgb[3] out: n x {packed bits} (1)
+ *  which = 5: detmath in: n x {fn, x, y} (3) out: n x 1   fn: 0 sin 1 cos 2 acos 3 atan2(x,y) 4 log 5 pow(x,y) 6 x/y 7 sqrt(x)
+ *  which = 6: tea4/lcg/Random in: n x {a bits, b bits} out: n x {tea4(a,b), lcg state, rnd, Randf bits...} (8)
+ * material applies to which 0,1; the context's probe to 2,3. All arrays are host memory. */
+int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material, int bsdf_mode, const float* in, uint32_t n,
+                  float* out);
+
+const char* pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_AMD_H */

@@ -1,0 +1,131 @@
+"""ctypes binding of libptamd.so (include/pt_amd.h). Fails loudly when the library is absent."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libptamd.so")
+
+# every symbol include/pt_amd.h declares
+EXPORTS = [
+    "pt_create", "pt_destroy", "pt_last_error", "pt_set_options", "pt_get_options", "pt_set_probe", "pt_build_cdf",
+    "pt_resize", "pt_set_camera", "pt_uvw_frame", "pt_set_partition", "pt_render", "pt_download", "pt_upload_accum",
+    "pt_device_buffer", "pt_tonemap_sqrt", "pt_owned_pixels", "pt_pack", "pt_unpack", "pt_get_stats", "pt_trace",
+    "pt_eval_table", "pt_version",
+]
+
+
+class Material(C.Structure):  # pt_material == Material.h:47-68
+    _fields_ = [
+        ("emission", C.c_float * 3), ("color", C.c_float * 3), ("absorption", C.c_float * 3),
+        ("eta", C.c_float), ("metallic", C.c_float), ("subsurface", C.c_float), ("specular", C.c_float),
+        ("roughness", C.c_float), ("specularTint", C.c_float), ("anisotropic", C.c_float), ("sheen", C.c_float),
+        ("sheenTint", C.c_float), ("clearcoat", C.c_float), ("clearcoatGloss", C.c_float), ("transmission", C.c_float),
+        ("bump", C.c_float), ("bumpTile", C.c_float * 3), ("flags", C.c_int32),
+    ]
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [
+        ("vertex", C.c_void_p), ("num_vertices", C.c_uint32), ("index", C.c_void_p), ("num_triangles", C.c_uint32),
+        ("material", Material), ("diffuse_texture_id", C.c_int32),
+    ]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("meshes", C.POINTER(MeshDesc)), ("num_meshes", C.c_uint32)]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("max_depth", C.c_int32), ("bsdf_mode", C.c_int32), ("max_paths", C.c_uint32), ("sort_rays", C.c_int32),
+        ("bvh_kind", C.c_int32), ("reserved", C.c_int32 * 3),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64),
+        ("render_ms", C.c_double), ("trace_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
+        ("other_ms", C.c_double),
+        ("trace_launches", C.c_uint32), ("shadow_launches", C.c_uint32), ("shade_launches", C.c_uint32),
+        ("bvh_nodes", C.c_uint32), ("bvh_bytes", C.c_uint64), ("bvh_build_ms", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+assert C.sizeof(Material) == 104
+
+_lib = None
+
+
+def build_library(force: bool = False) -> str:
+    """Compile libptamd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcdir = os.path.join(HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", srcdir, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", srcdir, "-j2"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C optixpathtracer_amd/csrc`). There is no CPU fallback for the render path."
+        )
+    L = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise RuntimeError(f"libptamd.so does not export {name}")
+    vp, i, u32, f = C.c_void_p, C.c_int, C.c_uint32, C.c_float
+    L.pt_create.argtypes = [C.POINTER(SceneDesc), i, C.POINTER(vp)]
+    L.pt_destroy.argtypes = [vp]
+    L.pt_last_error.restype = C.c_char_p
+    L.pt_last_error.argtypes = [vp]
+    L.pt_set_options.argtypes = [vp, C.POINTER(Options)]
+    L.pt_get_options.argtypes = [vp, C.POINTER(Options)]
+    L.pt_set_probe.argtypes = [vp, vp, vp, vp, vp, vp, i, i]
+    L.pt_build_cdf.argtypes = [vp, i, i, vp, vp, vp, vp]
+    L.pt_resize.argtypes = [vp, i, i]
+    L.pt_set_camera.argtypes = [vp, C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3)]
+    L.pt_uvw_frame.argtypes = [C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3), f, f, C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3)]
+    L.pt_set_partition.argtypes = [vp, i, i, i, i]
+    L.pt_render.argtypes = [vp, u32, u32, vp]
+    L.pt_download.argtypes = [vp, i, vp, C.c_size_t]
+    L.pt_upload_accum.argtypes = [vp, vp, C.c_size_t]
+    L.pt_device_buffer.restype = vp
+    L.pt_device_buffer.argtypes = [vp, i]
+    L.pt_tonemap_sqrt.argtypes = [vp, vp]
+    L.pt_owned_pixels.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+    L.pt_pack.argtypes = [vp, i, vp]
+    L.pt_unpack.argtypes = [vp, i, vp]
+    L.pt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.pt_trace.argtypes = [vp, vp, u32, i, vp, vp, i, C.POINTER(C.c_double)]
+    L.pt_eval_table.argtypes = [vp, i, vp, i, vp, u32, vp]
+    L.pt_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def build_cdf(data: np.ndarray, width: int, height: int):
+    """ProbeData::BuildCDF through the native host implementation (pt_build_cdf)."""
+    L = load_library()
+    data = np.ascontiguousarray(data, np.float32)
+    pdfX = np.empty((height, width), np.float32)
+    cdfX = np.empty((height, width), np.float32)
+    pdfY = np.empty(height, np.float32)
+    cdfY = np.empty(height, np.float32)
+    rc = L.pt_build_cdf(data.ctypes.data, width, height, pdfX.ctypes.data, cdfX.ctypes.data, pdfY.ctypes.data, cdfY.ctypes.data)
+    if rc:
+        raise RuntimeError(f"pt_build_cdf failed ({rc})")
+    return pdfX, cdfX, pdfY, cdfY

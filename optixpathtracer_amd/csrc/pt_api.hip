@@ -1,0 +1,741 @@
+// pt_api.hip — the C ABI of libptamd.so (include/pt_amd.h): context, device memory, and the
+// per-frame wavefront schedule that replaces SampleRenderer::render()'s single optixLaunch
+// (SimplePathtracer.cpp:73-97).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "pt_host.h"
+#include "pt_kernels.h"
+
+static thread_local std::string g_create_error;
+
+struct pt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    pt_options opt{};
+    // scene
+    uint32_t ntri = 0, nmesh = 0;
+    float* d_verts = nullptr;
+    uint32_t* d_idx = nullptr;
+    uint32_t* d_tri_mesh = nullptr;
+    pt_material* d_mats = nullptr;
+    PrimTri* d_prims = nullptr;
+    bool has_catcher = false;
+    PtBvh bvh;
+    double bvh_build_ms = 0;
+    // probe
+    DevProbe probe{};
+    float4* d_probe_data = nullptr;
+    float *d_pdfX = nullptr, *d_cdfX = nullptr, *d_pdfY = nullptr, *d_cdfY = nullptr;
+    // frame
+    int width = 0, height = 0;
+    float4 *accum = nullptr, *color = nullptr, *normal = nullptr, *albedo = nullptr;
+    uint32_t* frame = nullptr;
+    v3 eye{0, 0, 0}, U{1, 0, 0}, V{0, 1, 0}, W{0, 0, 1};
+    // partition
+    int rank = 0, world = 1, tile_w = 64, tile_h = 16;
+    uint32_t owned = 0, padded = 0;
+    uint32_t* d_pixels = nullptr;     // this rank's pixel list
+    uint32_t* d_all_pixels = nullptr; // world * padded, rank-major (0xffffffff = pad)
+    // path state
+    uint32_t cap = 0;
+    bool cap_catcher = false;
+    PathState st{};
+    uint32_t *queueA = nullptr, *queueB = nullptr, *squeue = nullptr;
+    uint32_t* counters = nullptr; // [0..nq) radiance queue counts per bounce, [nq..2nq) shadow counts
+    int nq = 0;
+    unsigned long long* d_totals = nullptr;
+    float4 *pixResult = nullptr, *pixAlpha = nullptr, *pixNormal = nullptr, *pixAlbedo = nullptr;
+    uint32_t pix_cap = 0;
+    // stats + timing
+    pt_stats stats{};
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct Span { size_t a, b; int cls; };
+    std::vector<Span> spans;
+};
+
+#define CK(call)                                                                                   \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return PT_ERR_HIP;                                                                     \
+        }                                                                                          \
+    } while (0)
+
+static int fail(pt_ctx* ctx, int code, const char* msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+template <typename T>
+static hipError_t dalloc(T** p, size_t n) {
+    return hipMalloc((void**)p, sizeof(T) * (n ? n : 1));
+}
+template <typename T>
+static void dfree(T*& p) {
+    if (p) hipFree((void*)p);
+    p = nullptr;
+}
+
+extern "C" const char* pt_version(void) { return "ptamd 0.1 (gfx950 wavefront path tracer)"; }
+
+extern "C" const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+static void default_options(pt_options* o) {
+    memset(o, 0, sizeof(*o));
+    o->max_depth = 8;
+    o->bsdf_mode = PT_BSDF_DISNEY;
+    o->max_paths = 8u << 20;
+}
+
+extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ctx) {
+    if (!scene || !out_ctx || scene->num_meshes == 0 || !scene->meshes) return fail(nullptr, PT_ERR_INVALID, "pt_create: null or empty scene");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, PT_ERR_NO_DEVICE, "pt_create: no HIP device");
+    if (device < 0 || device >= ndev) return fail(nullptr, PT_ERR_INVALID, "pt_create: bad device ordinal");
+    size_t nv = 0, nt = 0;
+    for (uint32_t m = 0; m < scene->num_meshes; ++m) {
+        const pt_mesh_desc& md = scene->meshes[m];
+        if (!md.vertex || !md.index || md.num_triangles == 0) return fail(nullptr, PT_ERR_INVALID, "pt_create: empty mesh");
+        if (md.diffuse_texture_id >= 0) return fail(nullptr, PT_ERR_UNSUPPORTED, "pt_create: textured meshes are not supported yet");
+        for (size_t k = 0; k < 3 * (size_t)md.num_triangles; ++k)
+            if (md.index[k] >= md.num_vertices) return fail(nullptr, PT_ERR_INVALID, "pt_create: vertex index out of range");
+        nv += md.num_vertices;
+        nt += md.num_triangles;
+    }
+    if (nt >= (1u << 28)) return fail(nullptr, PT_ERR_UNSUPPORTED, "pt_create: more than 2^28 triangles");
+    pt_ctx* ctx = new pt_ctx();
+    default_options(&ctx->opt);
+    ctx->device = device;
+    auto bail = [&](int code) { g_create_error = ctx->err; pt_destroy(ctx); return code; };
+#define CKC(call)                                                           \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) {                                             \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);   \
+            return bail(PT_ERR_HIP);                                        \
+        }                                                                   \
+    } while (0)
+    CKC(hipSetDevice(device));
+    CKC(hipStreamCreate(&ctx->stream));
+    // flatten like buildAccel (SimplePathtracer.cpp:481-489) — one global vertex/index space
+    std::vector<float> verts(3 * nv);
+    std::vector<uint32_t> idx(3 * nt), tri_mesh(nt);
+    std::vector<pt_material> mats(scene->num_meshes);
+    size_t vb = 0, tb = 0;
+    for (uint32_t m = 0; m < scene->num_meshes; ++m) {
+        const pt_mesh_desc& md = scene->meshes[m];
+        memcpy(&verts[3 * vb], md.vertex, sizeof(float) * 3 * md.num_vertices);
+        for (size_t k = 0; k < 3 * (size_t)md.num_triangles; ++k) idx[3 * tb + k] = md.index[k] + (uint32_t)vb;
+        for (size_t k = 0; k < md.num_triangles; ++k) tri_mesh[tb + k] = m;
+        mats[m] = md.material;
+        if (md.material.flags & 1) ctx->has_catcher = true;
+        vb += md.num_vertices;
+        tb += md.num_triangles;
+    }
+    ctx->ntri = (uint32_t)nt;
+    ctx->nmesh = scene->num_meshes;
+    CKC(dalloc(&ctx->d_verts, 3 * nv));
+    CKC(dalloc(&ctx->d_idx, 3 * nt));
+    CKC(dalloc(&ctx->d_tri_mesh, nt));
+    CKC(dalloc(&ctx->d_mats, mats.size()));
+    CKC(dalloc(&ctx->d_prims, nt));
+    CKC(hipMemcpy(ctx->d_verts, verts.data(), sizeof(float) * 3 * nv, hipMemcpyHostToDevice));
+    CKC(hipMemcpy(ctx->d_idx, idx.data(), sizeof(uint32_t) * 3 * nt, hipMemcpyHostToDevice));
+    CKC(hipMemcpy(ctx->d_tri_mesh, tri_mesh.data(), sizeof(uint32_t) * nt, hipMemcpyHostToDevice));
+    CKC(hipMemcpy(ctx->d_mats, mats.data(), sizeof(pt_material) * mats.size(), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_emit_prims, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_verts, ctx->d_idx,
+                       ctx->d_tri_mesh, (uint32_t)nt, ctx->d_prims);
+    hipEvent_t e0, e1;
+    CKC(hipEventCreate(&e0));
+    CKC(hipEventCreate(&e1));
+    CKC(hipEventRecord(e0, ctx->stream));
+    CKC(pt_bvh_build(ctx->d_verts, ctx->d_idx, (uint32_t)nt, ctx->stream, &ctx->bvh));
+    CKC(hipEventRecord(e1, ctx->stream));
+    CKC(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ctx->bvh_build_ms = ms;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    CKC(dalloc(&ctx->d_totals, 2));
+    *out_ctx = ctx;
+    return PT_OK;
+#undef CKC
+}
+
+static void free_path_state(pt_ctx* ctx) {
+    PathState& s = ctx->st;
+    dfree(s.rayO); dfree(s.rayD); dfree(s.srayD); dfree(s.pend); dfree(s.hit); dfree(s.thr); dfree(s.rng); dfree(s.fd);
+    dfree(s.direct); dfree(s.indirect); dfree(s.alpha); dfree(s.nrm); dfree(s.alb); dfree(s.prdN); dfree(s.prdA);
+    dfree(ctx->queueA); dfree(ctx->queueB); dfree(ctx->squeue); dfree(ctx->counters);
+    ctx->cap = 0;
+}
+static void free_frame(pt_ctx* ctx) {
+    dfree(ctx->accum); dfree(ctx->color); dfree(ctx->normal); dfree(ctx->albedo); dfree(ctx->frame);
+    dfree(ctx->d_pixels); dfree(ctx->d_all_pixels);
+    dfree(ctx->pixResult); dfree(ctx->pixAlpha); dfree(ctx->pixNormal); dfree(ctx->pixAlbedo);
+    ctx->pix_cap = 0;
+}
+
+extern "C" int pt_destroy(pt_ctx* ctx) {
+    if (!ctx) return PT_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    free_path_state(ctx);
+    free_frame(ctx);
+    dfree(ctx->d_verts); dfree(ctx->d_idx); dfree(ctx->d_tri_mesh); dfree(ctx->d_mats); dfree(ctx->d_prims);
+    pt_bvh_free(&ctx->bvh);
+    dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
+    dfree(ctx->d_totals);
+    for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PT_OK;
+}
+
+extern "C" int pt_set_options(pt_ctx* ctx, const pt_options* opt) {
+    if (!ctx || !opt) return PT_ERR_INVALID;
+    if (opt->max_depth < 0 || opt->max_depth > 250) return fail(ctx, PT_ERR_INVALID, "pt_set_options: max_depth out of range [0,250]");
+    if (opt->bsdf_mode != PT_BSDF_DISNEY && opt->bsdf_mode != PT_BSDF_LAMBERT) return fail(ctx, PT_ERR_INVALID, "pt_set_options: bad bsdf_mode");
+    ctx->opt = *opt;
+    if (ctx->opt.max_paths == 0) ctx->opt.max_paths = 8u << 20;
+    return PT_OK;
+}
+extern "C" int pt_get_options(const pt_ctx* ctx, pt_options* opt) {
+    if (!ctx || !opt) return PT_ERR_INVALID;
+    *opt = ctx->opt;
+    return PT_OK;
+}
+
+extern "C" int pt_build_cdf(const float* data, int width, int height, float* pdfX, float* cdfX, float* pdfY, float* cdfY) {
+    if (!data || width <= 0 || height <= 0 || !pdfX || !cdfX || !pdfY || !cdfY) return PT_ERR_INVALID;
+    // ProbeData::BuildCDF, Probe.h:29-77: sequential float running sums (this TU is built with -ffp-contract=off)
+    float totalWeightY = 0.0f;
+    for (int j = 0; j < height; ++j) {
+        float totalWeightX = 0.0f;
+        for (int i = 0; i < width; ++i) {
+            const float* c = &data[4 * ((size_t)j * width + i)];
+            float weight = c[0] * 0.3f + c[1] * 0.6f + c[2] * 0.1f; // Luminance, maths.h:165-168
+            totalWeightX += weight;
+            pdfX[(size_t)j * width + i] = weight;
+            cdfX[(size_t)j * width + i] = totalWeightX;
+        }
+        float invTotalWeightX = 1.0f / totalWeightX;
+        for (int i = 0; i < width; ++i) {
+            pdfX[(size_t)j * width + i] *= invTotalWeightX;
+            cdfX[(size_t)j * width + i] *= invTotalWeightX;
+        }
+        totalWeightY += totalWeightX;
+        pdfY[j] = totalWeightX;
+        cdfY[j] = totalWeightY;
+    }
+    for (int j = 0; j < height; ++j) {
+        cdfY[j] /= totalWeightY;
+        pdfY[j] /= totalWeightY;
+    }
+    return PT_OK;
+}
+
+extern "C" int pt_uvw_frame(const float eye[3], const float lookat[3], const float up[3], float fovY, float aspect,
+                            float U[3], float V[3], float W[3]) {
+    if (!eye || !lookat || !up || !U || !V || !W) return PT_ERR_INVALID;
+    // sutil::Camera::UVWFrame, sutil/Camera.cpp:34-45
+    auto dot = [](const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    auto cross = [](const float* a, const float* b, float* r) {
+        r[0] = a[1] * b[2] - a[2] * b[1];
+        r[1] = a[2] * b[0] - a[0] * b[2];
+        r[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    auto normalize = [&](float* v) {
+        float inv = 1.0f / sqrtf(dot(v, v));
+        v[0] *= inv; v[1] *= inv; v[2] *= inv;
+    };
+    float w[3] = {lookat[0] - eye[0], lookat[1] - eye[1], lookat[2] - eye[2]};
+    float wlen = sqrtf(dot(w, w));
+    float u[3], v[3];
+    cross(w, up, u);
+    normalize(u);
+    cross(u, w, v);
+    normalize(v);
+    float vlen = wlen * tanf(0.5f * fovY * 3.14159265358979323846f / 180.0f);
+    float ulen = vlen * aspect;
+    for (int k = 0; k < 3; ++k) {
+        V[k] = v[k] * vlen;
+        U[k] = u[k] * ulen;
+        W[k] = w[k];
+    }
+    return PT_OK;
+}
+
+extern "C" int pt_set_probe(pt_ctx* ctx, const float* data, const float* pdfX, const float* cdfX, const float* pdfY,
+                            const float* cdfY, int w, int h) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!data || !pdfX || !cdfX || !pdfY || !cdfY || w <= 0 || h <= 0) return fail(ctx, PT_ERR_INVALID, "pt_set_probe: Probe Data is not valid");
+    if ((long long)w * h >= (1ll << 31)) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_set_probe: probe too large");
+    CK(hipSetDevice(ctx->device));
+    dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
+    const size_t n = (size_t)w * h;
+    CK(dalloc(&ctx->d_probe_data, n));
+    CK(dalloc(&ctx->d_pdfX, n));
+    CK(dalloc(&ctx->d_cdfX, n));
+    CK(dalloc(&ctx->d_pdfY, (size_t)h));
+    CK(dalloc(&ctx->d_cdfY, (size_t)h));
+    CK(hipMemcpy(ctx->d_probe_data, data, sizeof(float4) * n, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ctx->d_pdfX, pdfX, sizeof(float) * n, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ctx->d_cdfX, cdfX, sizeof(float) * n, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ctx->d_pdfY, pdfY, sizeof(float) * h, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ctx->d_cdfY, cdfY, sizeof(float) * h, hipMemcpyHostToDevice));
+    ctx->probe = DevProbe{w, h, ctx->d_probe_data, ctx->d_pdfX, ctx->d_cdfX, ctx->d_pdfY, ctx->d_cdfY};
+    return PT_OK;
+}
+
+extern "C" int pt_set_camera(pt_ctx* ctx, const float eye[3], const float U[3], const float V[3], const float W[3]) {
+    if (!ctx || !eye || !U || !V || !W) return PT_ERR_INVALID;
+    ctx->eye = v3{eye[0], eye[1], eye[2]};
+    ctx->U = v3{U[0], U[1], U[2]};
+    ctx->V = v3{V[0], V[1], V[2]};
+    ctx->W = v3{W[0], W[1], W[2]};
+    return PT_OK;
+}
+
+extern "C" int pt_set_partition(pt_ctx* ctx, int rank, int world, int tile_w, int tile_h) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world || tile_w < 8 || tile_h < 8 || (tile_w % 8) || (tile_h % 8))
+        return fail(ctx, PT_ERR_INVALID, "pt_set_partition: need 0<=rank<world and tile sizes that are multiples of 8");
+    ctx->rank = rank; ctx->world = world; ctx->tile_w = tile_w; ctx->tile_h = tile_h;
+    if (ctx->width > 0) { // re-apply to the current frame size
+        int w = ctx->width, h = ctx->height;
+        ctx->width = ctx->height = 0;
+        return pt_resize(ctx, w, h);
+    }
+    return PT_OK;
+}
+
+// pixel lists in 8x8-block order: lanes of a wave cover one 8x8 block (coherent primary rays)
+static void build_pixel_lists(int w, int h, int world, int tile_w, int tile_h, std::vector<std::vector<uint32_t>>& lists) {
+    lists.assign(world, {});
+    for (int by = 0; by < (h + 7) / 8; ++by)
+        for (int bx = 0; bx < (w + 7) / 8; ++bx) {
+            const int owner = ((bx * 8) / tile_w + (by * 8) / tile_h) % world;
+            for (int iy = 0; iy < 8; ++iy)
+                for (int ix = 0; ix < 8; ++ix) {
+                    const int x = bx * 8 + ix, y = by * 8 + iy;
+                    if (x < w && y < h) lists[owner].push_back((uint32_t)x | ((uint32_t)y << 16));
+                }
+        }
+}
+
+extern "C" int pt_resize(pt_ctx* ctx, int width, int height) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (width == 0 || height == 0) return PT_OK; // SimplePathtracer.cpp:112
+    if (width < 0 || height < 0 || width > 65535 || height > 65535) return fail(ctx, PT_ERR_INVALID, "pt_resize: size out of range");
+    CK(hipSetDevice(ctx->device));
+    CK(hipStreamSynchronize(ctx->stream));
+    free_frame(ctx);
+    const size_t n = (size_t)width * height;
+    CK(dalloc(&ctx->accum, n));
+    CK(dalloc(&ctx->color, n));
+    CK(dalloc(&ctx->normal, n));
+    CK(dalloc(&ctx->albedo, n));
+    CK(dalloc(&ctx->frame, n));
+    CK(hipMemset(ctx->accum, 0, sizeof(float4) * n));
+    CK(hipMemset(ctx->color, 0, sizeof(float4) * n));
+    CK(hipMemset(ctx->normal, 0, sizeof(float4) * n));
+    CK(hipMemset(ctx->albedo, 0, sizeof(float4) * n));
+    CK(hipMemset(ctx->frame, 0, sizeof(uint32_t) * n));
+    std::vector<std::vector<uint32_t>> lists;
+    build_pixel_lists(width, height, ctx->world, ctx->tile_w, ctx->tile_h, lists);
+    size_t padded = 0;
+    for (auto& l : lists) padded = std::max(padded, l.size());
+    ctx->owned = (uint32_t)lists[ctx->rank].size();
+    ctx->padded = (uint32_t)padded;
+    CK(dalloc(&ctx->d_pixels, (size_t)ctx->owned));
+    if (ctx->owned) CK(hipMemcpy(ctx->d_pixels, lists[ctx->rank].data(), sizeof(uint32_t) * ctx->owned, hipMemcpyHostToDevice));
+    std::vector<uint32_t> all((size_t)ctx->world * padded, 0xffffffffu);
+    for (int r = 0; r < ctx->world; ++r) std::copy(lists[r].begin(), lists[r].end(), all.begin() + (size_t)r * padded);
+    CK(dalloc(&ctx->d_all_pixels, all.size()));
+    if (!all.empty()) CK(hipMemcpy(ctx->d_all_pixels, all.data(), sizeof(uint32_t) * all.size(), hipMemcpyHostToDevice));
+    ctx->width = width;
+    ctx->height = height;
+    return PT_OK;
+}
+
+static int ensure_path_state(pt_ctx* ctx, uint32_t cap, uint32_t pix_cap) {
+    const int nq = ctx->opt.max_depth + 2;
+    if (cap > ctx->cap || (ctx->has_catcher && !ctx->cap_catcher) || nq > ctx->nq) {
+        free_path_state(ctx);
+        PathState& s = ctx->st;
+        CK(dalloc(&s.rayO, cap)); CK(dalloc(&s.rayD, cap)); CK(dalloc(&s.srayD, cap)); CK(dalloc(&s.pend, cap));
+        CK(dalloc(&s.hit, cap)); CK(dalloc(&s.thr, cap)); CK(dalloc(&s.rng, cap)); CK(dalloc(&s.fd, cap));
+        CK(dalloc(&s.direct, cap)); CK(dalloc(&s.indirect, cap)); CK(dalloc(&s.alpha, cap)); CK(dalloc(&s.nrm, cap)); CK(dalloc(&s.alb, cap));
+        if (ctx->has_catcher) { CK(dalloc(&s.prdN, cap)); CK(dalloc(&s.prdA, cap)); }
+        ctx->cap_catcher = ctx->has_catcher;
+        CK(dalloc(&ctx->queueA, cap)); CK(dalloc(&ctx->queueB, cap)); CK(dalloc(&ctx->squeue, cap));
+        CK(dalloc(&ctx->counters, (size_t)2 * nq));
+        ctx->nq = nq;
+        ctx->cap = cap;
+    }
+    if (pix_cap > ctx->pix_cap) {
+        dfree(ctx->pixResult); dfree(ctx->pixAlpha); dfree(ctx->pixNormal); dfree(ctx->pixAlbedo);
+        CK(dalloc(&ctx->pixResult, pix_cap)); CK(dalloc(&ctx->pixAlpha, pix_cap)); CK(dalloc(&ctx->pixNormal, pix_cap)); CK(dalloc(&ctx->pixAlbedo, pix_cap));
+        ctx->pix_cap = pix_cap;
+    }
+    return PT_OK;
+}
+
+enum { CLS_TRACE = 0, CLS_SHADOW = 1, CLS_SHADE = 2, CLS_OTHER = 3 };
+
+static hipEvent_t next_event(pt_ctx* ctx) {
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        ctx->ev_pool.push_back(e);
+    }
+    return ctx->ev_pool[ctx->ev_used++];
+}
+struct SpanGuard {
+    pt_ctx* ctx;
+    size_t a;
+    int cls;
+    SpanGuard(pt_ctx* c, int cl) : ctx(c), cls(cl) {
+        a = ctx->ev_used;
+        hipEventRecord(next_event(ctx), ctx->stream);
+    }
+    ~SpanGuard() {
+        size_t b = ctx->ev_used;
+        hipEventRecord(next_event(ctx), ctx->stream);
+        ctx->spans.push_back({a, b, cls});
+    }
+};
+
+static const int GRID = 256 * 8;
+
+template <int MODE>
+static void launch_shade(pt_ctx* ctx, const ShadeParams& sp) {
+    if (ctx->has_catcher)
+        hipLaunchKernelGGL((k_shade<MODE, true>), dim3(GRID), dim3(256), 0, ctx->stream, ctx->st, sp);
+    else
+        hipLaunchKernelGGL((k_shade<MODE, false>), dim3(GRID), dim3(256), 0, ctx->stream, ctx->st, sp);
+}
+
+extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (ctx->width == 0) return PT_OK; // not resized yet (SimplePathtracer.cpp:77)
+    if (spp == 0 || spp > 4096) return fail(ctx, PT_ERR_INVALID, "pt_render: samples_per_launch must be in [1,4096]");
+    if (!ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_render: no probe set (setProbe)");
+    CK(hipSetDevice(ctx->device));
+    const uint32_t owned = ctx->owned;
+    // chunking: all samples of a pixel stay in one pixel chunk; samples are split when spp*pixels > max_paths;
+    // shadow-catcher scenes run one sample per pass so that per-pixel normal/albedo sums keep the reference order
+    const uint32_t max_paths = std::max<uint32_t>(ctx->opt.max_paths, 64u);
+    const uint32_t Np = std::min(owned, max_paths);
+    uint32_t S = ctx->has_catcher ? 1u : std::max(1u, std::min(spp, Np ? max_paths / Np : 1u));
+    if (owned) {
+        int rc = ensure_path_state(ctx, Np * S, Np);
+        if (rc) return rc;
+    }
+    const int nq = ctx->nq;
+    ctx->ev_used = 0;
+    ctx->spans.clear();
+    CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 2, ctx->stream));
+    hipEvent_t ev_begin = next_event(ctx);
+    CK(hipEventRecord(ev_begin, ctx->stream));
+    BvhDev bvh{ctx->bvh.nodes, ctx->bvh.tris, ctx->bvh.root};
+    FrameParams fp{ctx->accum, ctx->frame, ctx->color, ctx->normal, ctx->albedo, ctx->width, ctx->height, subframe_index,
+                   ctx->eye, ctx->U, ctx->V, ctx->W, spp, ctx->probe};
+    uint32_t trace_launches = 0, shadow_launches = 0, shade_launches = 0;
+    for (uint32_t pix0 = 0; pix0 < owned; pix0 += Np) {
+        const uint32_t npix = std::min(Np, owned - pix0);
+        for (uint32_t s0 = 0; s0 < spp; s0 += S) {
+            const uint32_t Sc = std::min(S, spp - s0);
+            BatchParams bp{ctx->d_pixels + pix0, npix, s0, Sc, ctx->has_catcher ? 1 : 0,
+                           ctx->pixResult, ctx->pixAlpha, ctx->pixNormal, ctx->pixAlbedo};
+            CK(hipMemsetAsync(ctx->counters, 0, sizeof(uint32_t) * 2 * nq, ctx->stream));
+            {
+                SpanGuard g(ctx, CLS_OTHER);
+                hipLaunchKernelGGL(k_generate, dim3(GRID), dim3(256), 0, ctx->stream, ctx->st, fp, bp, ctx->counters + 0);
+            }
+            uint32_t* qcur = nullptr; // identity for bounce 0
+            uint32_t* qnext = ctx->queueA;
+            // depth d = 0..max_depth traces in the reference (the trace at depth == max_depth can only matter
+            // through a shadow-catcher pass-through or alpha; without catcher materials it is provably dead and skipped)
+            const int last_bounce = ctx->has_catcher ? ctx->opt.max_depth : ctx->opt.max_depth - 1;
+            for (int b = 0; b <= last_bounce; ++b) {
+                {
+                    SpanGuard g(ctx, CLS_TRACE);
+                    hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, qcur, ctx->counters + b);
+                    ++trace_launches;
+                }
+                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->probe, ctx->opt.max_depth, qcur, ctx->counters + b,
+                               qnext, ctx->counters + b + 1, ctx->squeue, ctx->counters + nq + b};
+                {
+                    SpanGuard g(ctx, CLS_SHADE);
+                    if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, sp);
+                    else launch_shade<PT_BSDF_DISNEY>(ctx, sp);
+                    ++shade_launches;
+                }
+                {
+                    SpanGuard g(ctx, CLS_SHADOW);
+                    hipLaunchKernelGGL((k_trace<1>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, ctx->squeue, ctx->counters + nq + b);
+                    ++shadow_launches;
+                }
+                qcur = qnext;
+                qnext = (qnext == ctx->queueA) ? ctx->queueB : ctx->queueA;
+            }
+            {
+                SpanGuard g(ctx, CLS_OTHER);
+                // counters[last_bounce+1] holds paths that would have continued: not traced, not counted
+                hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, ctx->stream, ctx->counters, nq, last_bounce + 1, ctx->d_totals);
+                hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, ctx->st, fp, bp,
+                                   (int)(s0 == 0), (int)(s0 + Sc >= spp));
+            }
+        }
+    }
+    hipEvent_t ev_end = next_event(ctx);
+    CK(hipEventRecord(ev_end, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream)); // SimplePathtracer.cpp:96 CUDA_SYNC_CHECK
+    CK(hipGetLastError());
+    unsigned long long totals[2] = {0, 0};
+    CK(hipMemcpy(totals, ctx->d_totals, sizeof(totals), hipMemcpyDeviceToHost));
+    pt_stats& st = ctx->stats;
+    st.radiance_rays = totals[0];
+    st.shadow_rays = totals[1];
+    st.paths = (uint64_t)owned * spp;
+    float ms = 0;
+    hipEventElapsedTime(&ms, ev_begin, ev_end);
+    st.render_ms = ms;
+    double cls_ms[4] = {0, 0, 0, 0};
+    for (auto& sp : ctx->spans) {
+        float m = 0;
+        hipEventElapsedTime(&m, ctx->ev_pool[sp.a], ctx->ev_pool[sp.b]);
+        cls_ms[sp.cls] += m;
+    }
+    st.trace_ms = cls_ms[CLS_TRACE];
+    st.shadow_ms = cls_ms[CLS_SHADOW];
+    st.shade_ms = cls_ms[CLS_SHADE];
+    st.other_ms = cls_ms[CLS_OTHER];
+    st.trace_launches = trace_launches;
+    st.shadow_launches = shadow_launches;
+    st.shade_launches = shade_launches;
+    st.bvh_nodes = ctx->bvh.num_nodes;
+    st.bvh_bytes = (uint64_t)ctx->bvh.num_nodes * sizeof(Node2) + (uint64_t)ctx->bvh.num_tris * sizeof(LeafTri);
+    st.bvh_build_ms = ctx->bvh_build_ms;
+    if (host_rgba8) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)ctx->width * ctx->height);
+    return PT_OK;
+}
+
+static void* buffer_ptr(pt_ctx* ctx, int which, size_t* elem) {
+    switch (which) {
+        case PT_BUF_ACCUM: *elem = 16; return ctx->accum;
+        case PT_BUF_FRAME: *elem = 4; return ctx->frame;
+        case PT_BUF_COLOR: *elem = 16; return ctx->color;
+        case PT_BUF_NORMAL: *elem = 16; return ctx->normal;
+        case PT_BUF_ALBEDO: *elem = 16; return ctx->albedo;
+    }
+    *elem = 0;
+    return nullptr;
+}
+
+extern "C" void* pt_device_buffer(pt_ctx* ctx, int which) {
+    if (!ctx) return nullptr;
+    size_t e;
+    return buffer_ptr(ctx, which, &e);
+}
+
+extern "C" int pt_download(pt_ctx* ctx, int which, void* host, size_t bytes) {
+    if (!ctx || !host) return PT_ERR_INVALID;
+    size_t elem;
+    void* p = buffer_ptr(ctx, which, &elem);
+    if (!p) return fail(ctx, PT_ERR_INVALID, "pt_download: unknown buffer or not resized");
+    if (bytes != elem * (size_t)ctx->width * ctx->height) return fail(ctx, PT_ERR_INVALID, "pt_download: byte count does not match the frame size");
+    CK(hipSetDevice(ctx->device));
+    CK(hipMemcpy(host, p, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+extern "C" int pt_upload_accum(pt_ctx* ctx, const float* host, size_t bytes) {
+    if (!ctx || !host) return PT_ERR_INVALID;
+    if (!ctx->accum || bytes != 16 * (size_t)ctx->width * ctx->height) return fail(ctx, PT_ERR_INVALID, "pt_upload_accum: byte count does not match the frame size");
+    CK(hipSetDevice(ctx->device));
+    CK(hipMemcpy(ctx->accum, host, bytes, hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+extern "C" int pt_tonemap_sqrt(pt_ctx* ctx, uint32_t* host_rgba8) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (ctx->width == 0) return PT_OK;
+    CK(hipSetDevice(ctx->device));
+    const uint32_t n = (uint32_t)ctx->width * ctx->height;
+    hipLaunchKernelGGL(k_tonemap_sqrt, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->accum, ctx->frame, n);
+    CK(hipStreamSynchronize(ctx->stream));
+    if (host_rgba8) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)n);
+    return PT_OK;
+}
+
+extern "C" int pt_owned_pixels(const pt_ctx* ctx, uint32_t* owned, uint32_t* padded) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (owned) *owned = ctx->owned;
+    if (padded) *padded = ctx->padded;
+    return PT_OK;
+}
+
+extern "C" int pt_pack(pt_ctx* ctx, int which, void* dev_dst) {
+    if (!ctx || !dev_dst) return PT_ERR_INVALID;
+    size_t elem;
+    void* p = buffer_ptr(ctx, which, &elem);
+    if (!p) return fail(ctx, PT_ERR_INVALID, "pt_pack: unknown buffer or not resized");
+    CK(hipSetDevice(ctx->device));
+    const uint32_t n = ctx->owned;
+    if (n) {
+        if (elem == 16)
+            hipLaunchKernelGGL((k_pack<float4>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)p, ctx->d_pixels, n, ctx->width, (float4*)dev_dst);
+        else
+            hipLaunchKernelGGL((k_pack<uint32_t>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)p, ctx->d_pixels, n, ctx->width, (uint32_t*)dev_dst);
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+extern "C" int pt_unpack(pt_ctx* ctx, int which, const void* dev_src_all) {
+    if (!ctx || !dev_src_all) return PT_ERR_INVALID;
+    size_t elem;
+    void* p = buffer_ptr(ctx, which, &elem);
+    if (!p) return fail(ctx, PT_ERR_INVALID, "pt_unpack: unknown buffer or not resized");
+    CK(hipSetDevice(ctx->device));
+    const uint32_t n = ctx->padded * (uint32_t)ctx->world;
+    if (n) {
+        if (elem == 16)
+            hipLaunchKernelGGL((k_unpack<float4>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (float4*)p, ctx->d_all_pixels, n, ctx->width, (const float4*)dev_src_all);
+        else
+            hipLaunchKernelGGL((k_unpack<uint32_t>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t*)p, ctx->d_all_pixels, n, ctx->width, (const uint32_t*)dev_src_all);
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+extern "C" int pt_get_stats(const pt_ctx* ctx, pt_stats* out) {
+    if (!ctx || !out) return PT_ERR_INVALID;
+    *out = ctx->stats;
+    out->bvh_nodes = ctx->bvh.num_nodes;
+    out->bvh_bytes = (uint64_t)ctx->bvh.num_nodes * sizeof(Node2) + (uint64_t)ctx->bvh.num_tris * sizeof(LeafTri);
+    out->bvh_build_ms = ctx->bvh_build_ms;
+    return PT_OK;
+}
+
+__global__ void __launch_bounds__(PT_TRACE_BLOCK) k_query_any(const float4* rayO, const float4* rayD, BvhDev bvh, uint32_t n, int32_t* occ) {
+    __shared__ uint32_t s_stack[PT_STACK_DEPTH * PT_TRACE_BLOCK];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 o4 = rayO[i], d4 = rayD[i];
+        float t;
+        int32_t prim;
+        bvh2_traverse<true>(bvh, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, d4.w, &s_stack[threadIdx.x], PT_TRACE_BLOCK, t, prim);
+        occ[i] = prim;
+    }
+}
+
+extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit, float* t_out, int32_t* prim_out, int iters,
+                        double* kernel_ms) {
+    if (!ctx || !rays || !prim_out || (!any_hit && !t_out)) return PT_ERR_INVALID;
+    if (n == 0) return PT_OK;
+    CK(hipSetDevice(ctx->device));
+    if (iters < 1) iters = 1;
+    // temporary state just for the query
+    float4 *dO = nullptr, *dD = nullptr;
+    float2* dHit = nullptr;
+    uint32_t* dCount = nullptr;
+    CK(dalloc(&dO, n)); CK(dalloc(&dD, n)); CK(dalloc(&dHit, n)); CK(dalloc(&dCount, 1));
+    std::vector<float4> hO(n), hD(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* r = &rays[8 * (size_t)i];
+        hO[i] = make_float4(r[0], r[1], r[2], r[3]);
+        hD[i] = make_float4(r[4], r[5], r[6], r[7]);
+    }
+    CK(hipMemcpy(dO, hO.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dD, hD.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dCount, &n, 4, hipMemcpyHostToDevice));
+    BvhDev bvh{ctx->bvh.nodes, ctx->bvh.tris, ctx->bvh.root};
+    PathState st{};
+    st.rayO = dO;
+    st.rayD = dD;
+    st.hit = dHit;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    int32_t* dOcc = nullptr;
+    if (any_hit) CK(dalloc(&dOcc, n));
+    CK(hipEventRecord(e0, ctx->stream));
+    for (int it = 0; it < iters; ++it) {
+        if (any_hit)
+            hipLaunchKernelGGL(k_query_any, dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, dO, dD, bvh, n, dOcc);
+        else
+            hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, st, bvh, (const uint32_t*)nullptr, dCount);
+    }
+    CK(hipEventRecord(e1, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipGetLastError());
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (kernel_ms) *kernel_ms = ms / iters;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (any_hit) {
+        CK(hipMemcpy(prim_out, dOcc, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float2> hh(n);
+        CK(hipMemcpy(hh.data(), dHit, sizeof(float2) * n, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; ++i) {
+            t_out[i] = hh[i].x;
+            memcpy(&prim_out[i], &hh[i].y, 4);
+        }
+    }
+    dfree(dO); dfree(dD); dfree(dHit); dfree(dCount); dfree(dOcc);
+    return PT_OK;
+}
+
+extern "C" int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material, int bsdf_mode, const float* in, uint32_t n, float* out) {
+    if (!ctx || !in || !out) return PT_ERR_INVALID;
+    if (n == 0) return PT_OK;
+    static const int in_w[7] = {11, 9, 1, 3, 3, 3, 2}, out_w[7] = {4, 6, 9, 6, 1, 1, 8};
+    if (which < 0 || which > 6) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: unknown table");
+    if (which <= 1 && !material) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: material required");
+    if ((which == 2 || which == 3) && !ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: no probe set");
+    CK(hipSetDevice(ctx->device));
+    float *dIn = nullptr, *dOut = nullptr;
+    CK(dalloc(&dIn, (size_t)n * in_w[which]));
+    CK(dalloc(&dOut, (size_t)n * out_w[which]));
+    CK(hipMemcpy(dIn, in, sizeof(float) * (size_t)n * in_w[which], hipMemcpyHostToDevice));
+    const dim3 g((n + 127) / 128), b(128);
+    pt_material mat{};
+    if (material) mat = *material;
+    switch (which) {
+        case 0:
+            if (bsdf_mode == PT_BSDF_LAMBERT) hipLaunchKernelGGL((k_table_bsdf<PT_BSDF_LAMBERT>), g, b, 0, ctx->stream, mat, dIn, n, dOut);
+            else hipLaunchKernelGGL((k_table_bsdf<PT_BSDF_DISNEY>), g, b, 0, ctx->stream, mat, dIn, n, dOut);
+            break;
+        case 1:
+            if (bsdf_mode == PT_BSDF_LAMBERT) hipLaunchKernelGGL((k_table_sample<PT_BSDF_LAMBERT>), g, b, 0, ctx->stream, mat, dIn, n, dOut);
+            else hipLaunchKernelGGL((k_table_sample<PT_BSDF_DISNEY>), g, b, 0, ctx->stream, mat, dIn, n, dOut);
+            break;
+        case 2: hipLaunchKernelGGL(k_table_probe_sample, g, b, 0, ctx->stream, ctx->probe, dIn, n, dOut); break;
+        case 3: hipLaunchKernelGGL(k_table_probe_eval, g, b, 0, ctx->stream, ctx->probe, dIn, n, dOut); break;
+        case 4: hipLaunchKernelGGL(k_table_color, g, b, 0, ctx->stream, dIn, n, dOut); break;
+        case 5: hipLaunchKernelGGL(k_table_math, g, b, 0, ctx->stream, dIn, n, dOut); break;
+        case 6: hipLaunchKernelGGL(k_table_rng, g, b, 0, ctx->stream, dIn, n, dOut); break;
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipGetLastError());
+    CK(hipMemcpy(out, dOut, sizeof(float) * (size_t)n * out_w[which], hipMemcpyDeviceToHost));
+    dfree(dIn);
+    dfree(dOut);
+    return PT_OK;
+}

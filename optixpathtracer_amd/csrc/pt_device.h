@@ -1,0 +1,408 @@
+// pt_device.h — device-side building blocks of the wavefront path tracer (gfx950).
+//
+// Each function states which reference function it re-implements (paths relative to the
+// reference repo, canonical variant HelloPathtracing_original/).  Arithmetic is written as
+// explicit single IEEE operations in the reference's evaluation order and the TU is compiled with
+// -ffp-contract=off, transcendental calls go through include/pt_detmath.h: the result of every
+// function here is bit-identical to the CPU checker built with the same header.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pt_amd.h"
+#include "../../include/pt_detmath.h"
+
+#define PT_DEV __device__ __forceinline__
+
+struct v3 {
+    float x, y, z;
+};
+PT_DEV v3 mk3(float x, float y, float z) { return v3{x, y, z}; }
+PT_DEV v3 mk3(float s) { return v3{s, s, s}; }
+PT_DEV v3 add3(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+PT_DEV v3 sub3(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+PT_DEV v3 mul3(v3 a, v3 b) { return v3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+PT_DEV v3 scl3(v3 a, float s) { return v3{a.x * s, a.y * s, a.z * s}; }
+PT_DEV v3 neg3(v3 a) { return v3{-a.x, -a.y, -a.z}; }
+// sutil/vec_math.h:483-487  float3 / float = a * (1/s)
+PT_DEV v3 div3s(v3 a, float s) {
+    float inv = 1.0f / s;
+    return scl3(a, inv);
+}
+// sutil/vec_math.h:535-544
+PT_DEV float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_DEV v3 cross3(v3 a, v3 b) { return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// sutil/vec_math.h:553-557
+PT_DEV v3 normalize3(v3 v) {
+    float invLen = 1.0f / sqrtf(dot3(v, v));
+    return scl3(v, invLen);
+}
+// sutil/vec_math.h:96-99, 500-503
+PT_DEV float lerpf(float a, float b, float t) { return a + t * (b - a); }
+PT_DEV v3 lerp3(v3 a, v3 b, float t) { return add3(a, scl3(sub3(b, a), t)); }
+// sutil/vec_math.h:119-122
+PT_DEV float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+// sutil/vec_math.h:567-570
+PT_DEV v3 faceforward3(v3 n, v3 i, v3 nref) { return scl3(n, copysignf(1.0f, dot3(i, nref))); }
+
+#define kPi (3.141592653589793f)
+#define k2Pi (3.141592653589793f * 2.0f)
+#define kInvPi (1.0f / kPi)
+#define kInv2Pi (1.0f / k2Pi)
+
+// ------------------------------------------------------------------ RNG
+// cuda/random.h:34-49 tea<4>
+PT_DEV uint32_t tea4(uint32_t val0, uint32_t val1) {
+    uint32_t v0 = val0, v1 = val1, s0 = 0;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+// cuda/random.h:53-59, 96-99
+PT_DEV uint32_t lcg(uint32_t& prev) {
+    prev = 1664525u * prev + 1013904223u;
+    return prev & 0x00FFFFFFu;
+}
+PT_DEV float rnd(uint32_t& prev) { return (float)lcg(prev) / (float)0x01000000; }
+
+// maths.h:170-225 class Random
+struct Rng {
+    uint32_t seed1, seed2;
+    PT_DEV void init(uint32_t seed) {
+        seed1 = 315645664u + seed;
+        seed2 = seed1 ^ 0x13ab45feu;
+    }
+    PT_DEV uint32_t rand() {
+        seed1 = (seed2 ^ ((seed1 << 5) | (seed1 >> 27))) ^ (seed1 * seed2);
+        seed2 = seed1 ^ ((seed2 << 12) | (seed2 >> 20));
+        return seed1;
+    }
+    PT_DEV float randf() {
+        uint32_t value = rand();
+        return clampf((float)value * (1.0f / 4294967296.0f), 0.f, 0.999999f);
+    }
+    // Randf(min,max) maths.h:211-215
+    PT_DEV float randf(float mn, float mx) {
+        float t = randf();
+        return (1.0f - t) * mn + t * mx;
+    }
+};
+// sample.h:252-258 (USE_RANDOM)
+PT_DEV void sample2d(Rng& r, float& u1, float& u2) {
+    u1 = r.randf(0.0f, 1.0f);
+    u2 = r.randf(0.0f, 1.0f);
+}
+
+// maths.h:94-108
+PT_DEV void basis_from_vector(v3 w, v3& u, v3& v) {
+    if (fabsf(w.x) > fabsf(w.y)) {
+        float invLen = 1.0f / sqrtf(w.x * w.x + w.z * w.z);
+        u = mk3(-w.z * invLen, 0.0f, w.x * invLen);
+    } else {
+        float invLen = 1.0f / sqrtf(w.y * w.y + w.z * w.z);
+        u = mk3(0.0f, w.z * invLen, -w.y * invLen);
+    }
+    v = cross3(w, u);
+}
+// maths.h:144-156
+PT_DEV v3 safe_normalize(v3 a) {
+    float m = dot3(a, a);
+    if (m > 0.0f) return scl3(a, 1.0f / sqrtf(m));
+    return mk3(0.0f);
+}
+// maths.h:241-252
+PT_DEV v3 uniform_sample_hemisphere(Rng& r) {
+    float z = r.randf(0.0f, 1.0f);
+    float w = sqrtf(1.0f - z * z);
+    float phi = k2Pi * r.randf(0.0f, 1.0f);
+    float s, c;
+    pt_sincosf(phi, &s, &c);
+    return mk3(c * w, s * w, z);
+}
+// maths.h:254-275
+PT_DEV v3 cosine_sample_hemisphere(float u1, float u2) {
+    float r = sqrtf(u1);
+    float theta = k2Pi * u2;
+    float s, c;
+    pt_sincosf(theta, &s, &c);
+    float sx = r * c, sy = r * s;
+    float z = sqrtf(fmaxf(0.0f, 1.0f - sx * sx - sy * sy));
+    return mk3(sx, sy, z);
+}
+
+// Material.h:39-45
+PT_DEV float material_ior(const pt_material& m) {
+    if (m.eta == 0.0f) return 2.0f / (1.0f - sqrtf(0.08f * m.specular)) - 1.0f;
+    return m.eta;
+}
+
+// ------------------------------------------------------------------ Disney BSDF (Disney.cuh)
+PT_DEV float sqrf(float a) { return a * a; }
+// :35-48
+PT_DEV bool refract3(v3 wi, v3 n, float eta, v3& wt) {
+    float cosThetaI = dot3(n, wi);
+    float sin2ThetaI = fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI);
+    float sin2ThetaT = eta * eta * sin2ThetaI;
+    if (sin2ThetaT >= 1) return false;
+    float cosThetaT = sqrtf(1.0f - sin2ThetaT);
+    wt = add3(scl3(neg3(wi), eta), scl3(n, eta * cosThetaI - cosThetaT));
+    return true;
+}
+// :50-55
+PT_DEV float schlick_fresnel(float u) {
+    float m = clampf(1 - u, 0.0f, 1.0f);
+    float m2 = m * m;
+    return m2 * m2 * m;
+}
+// :57-63
+PT_DEV float gtr1(float NDotH, float a) {
+    if (a >= 1) return kInvPi;
+    float a2 = a * a;
+    float t = 1 + (a2 - 1) * NDotH * NDotH;
+    return (a2 - 1) / (kPi * pt_logf(a2) * t);
+}
+// :65-70
+PT_DEV float gtr2(float NDotH, float a) {
+    float a2 = a * a;
+    float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
+    return a2 / (kPi * t * t);
+}
+// :72-77
+PT_DEV float smith_ggx(float NDotv, float alphaG) {
+    float a = alphaG * alphaG;
+    float b = NDotv * NDotv;
+    return 1 / (NDotv + sqrtf(a + b - a * b));
+}
+// :80-97
+PT_DEV float fresnel_dielectric(float VDotN, float etaI, float etaT) {
+    float SinThetaT2 = sqrf(etaI / etaT) * (1.0f - VDotN * VDotN);
+    if (SinThetaT2 > 1.0f) return 1.0f;
+    float LDotN = sqrtf(1.0f - SinThetaT2);
+    float eta = etaT / etaI;
+    float r1 = (VDotN - eta * LDotN) / (VDotN + eta * LDotN);
+    float r2 = (LDotN - eta * VDotN) / (LDotN + eta * VDotN);
+    return 0.5f * (sqrf(r1) + sqrf(r2));
+}
+
+// BSDFPdf :151-192 (Lambert :127-133)
+template <int MODE>
+PT_DEV float bsdf_pdf(const pt_material& mat, float etaI, float etaO, v3 n, v3 V, v3 L) {
+    if (MODE == PT_BSDF_LAMBERT) return (dot3(L, n) <= 0.0f) ? 0.0f : kInv2Pi;
+    if (dot3(L, n) <= 0.0f) {
+        float bsdfPdf = 0.0f;
+        float brdfPdf = kInv2Pi * mat.subsurface * 0.5f;
+        return lerpf(brdfPdf, bsdfPdf, mat.transmission);
+    } else {
+        float F = fresnel_dielectric(dot3(n, V), etaI, etaO);
+        const float a = fmaxf(0.001f, mat.roughness);
+        const v3 half = safe_normalize(add3(L, V));
+        const float cosThetaHalf = fabsf(dot3(half, n));
+        const float pdfHalf = gtr2(cosThetaHalf, a) * cosThetaHalf;
+        float pdfSpec = 0.25f * pdfHalf / fmaxf(1.e-6f, dot3(L, half));
+        float pdfDiff = fabsf(dot3(L, n)) * kInvPi * (1.0f - mat.subsurface);
+        float bsdfPdf = pdfSpec * F;
+        float brdfPdf = lerpf(pdfDiff, pdfSpec, 0.5f);
+        return lerpf(brdfPdf, bsdfPdf, mat.transmission);
+    }
+}
+
+// shared GGX half-vector reflection (:207-225 and :286-307)
+PT_DEV v3 sample_ggx_reflect(const pt_material& mat, v3 U, v3 V, v3 N, v3 view, float r1, float r2) {
+    const float a = fmaxf(0.001f, mat.roughness);
+    const float phiHalf = r1 * k2Pi;
+    const float cosThetaHalf = sqrtf((1.0f - r2) / (1.0f + (sqrf(a) - 1.0f) * r2));
+    const float sinThetaHalf = sqrtf(fmaxf(0.0f, 1.0f - sqrf(cosThetaHalf)));
+    float sinPhiHalf, cosPhiHalf;
+    pt_sincosf(phiHalf, &sinPhiHalf, &cosPhiHalf);
+    v3 half = add3(add3(scl3(U, sinThetaHalf * cosPhiHalf), scl3(V, sinThetaHalf * sinPhiHalf)), scl3(N, cosThetaHalf));
+    if (dot3(half, view) <= 0.0f) half = scl3(half, -1.0f);
+    return sub3(scl3(half, 2.0f * dot3(view, half)), view);
+}
+
+// BSDFSample :196-314 (Lambert :135-142)
+template <int MODE>
+PT_DEV void bsdf_sample(const pt_material& mat, float etaI, float etaO, v3 U, v3 V, v3 N, v3 view, v3& light, float& pdf,
+                        Rng& rand) {
+    if (MODE == PT_BSDF_LAMBERT) {
+        v3 d = uniform_sample_hemisphere(rand);
+        light = add3(add3(scl3(U, d.x), scl3(V, d.y)), scl3(N, d.z));
+        pdf = kInv2Pi;
+        return;
+    }
+    if (rand.randf() < mat.transmission) {
+        float F = fresnel_dielectric(dot3(N, view), etaI, etaO);
+        if (rand.randf() < F) {
+            float r1, r2;
+            sample2d(rand, r1, r2);
+            light = sample_ggx_reflect(mat, U, V, N, view, r1, r2);
+        } else {
+            float eta = etaI / etaO;
+            if (refract3(view, N, eta, light)) {
+                pdf = (1.0f - F) * mat.transmission;
+                return;
+            } else {
+                pdf = 0.0f;
+                return;
+            }
+        }
+    } else {
+        float r1, r2;
+        sample2d(rand, r1, r2);
+        if (rand.randf() < 0.5f) {
+            if (rand.randf() < mat.subsurface) {
+                const v3 d = uniform_sample_hemisphere(rand);
+                light = sub3(add3(scl3(U, d.x), scl3(V, d.y)), scl3(N, d.z));
+            } else {
+                const v3 d = cosine_sample_hemisphere(r1, r2);
+                light = add3(add3(scl3(U, d.x), scl3(V, d.y)), scl3(N, d.z));
+            }
+        } else {
+            light = sample_ggx_reflect(mat, U, V, N, view, r1, r2);
+        }
+    }
+    pdf = bsdf_pdf<MODE>(mat, etaI, etaO, N, view, light);
+}
+
+// BSDFEval :317-426 (Lambert :144-147).  The FP64 sub-expressions are the reference's bare double
+// literals (.3 .6 .1 at :328 and .08 at :331); 0.5 at :397 is exact in float (innocuous double rounding).
+template <int MODE>
+PT_DEV v3 bsdf_eval(const pt_material& mat, v3 albedo, float etaI, float etaO, v3 N, v3 V, v3 L) {
+    if (MODE == PT_BSDF_LAMBERT) return scl3(albedo, kInvPi);
+    float NDotL = dot3(N, L);
+    float NDotV = dot3(N, V);
+    v3 H = normalize3(add3(L, V));
+    float NDotH = dot3(N, H);
+    float LDotH = dot3(L, H);
+    v3 Cdlin = albedo;
+    float Cdlum = (float)(.3 * (double)Cdlin.x + .6 * (double)Cdlin.y + .1 * (double)Cdlin.z);
+    v3 Ctint = Cdlum > 0.0f ? div3s(Cdlin, Cdlum) : mk3(1.0f);
+    float spec08 = (float)((double)mat.specular * .08);
+    v3 Cspec0 = lerp3(scl3(lerp3(mk3(1.0f), Ctint, mat.specularTint), spec08), Cdlin, mat.metallic);
+    v3 bsdf = mk3(0.0f);
+    v3 brdf = mk3(0.0f);
+    if (mat.transmission > 0.0f) {
+        if (NDotL <= 0) {
+            float F = fresnel_dielectric(NDotV, etaI, etaO);
+            bsdf = mk3(mat.transmission * (1.0f - F) / fabsf(NDotL) * (1.0f - mat.metallic));
+        } else {
+            float a = fmaxf(0.001f, mat.roughness);
+            float Ds = gtr2(NDotH, a);
+            float FH = fresnel_dielectric(LDotH, etaI, etaO);
+            v3 Fs = lerp3(Cspec0, mk3(1.0f), FH);
+            float Gs = smith_ggx(NDotV, a) * smith_ggx(NDotL, a);
+            bsdf = scl3(scl3(Fs, Gs), Ds);
+        }
+    }
+    if (mat.transmission < 1.0f) {
+        if (NDotL <= 0) {
+            if (mat.subsurface > 0.0f) {
+                v3 s = mk3(sqrtf(mat.color[0]), sqrtf(mat.color[1]), sqrtf(mat.color[2]));
+                float FL = schlick_fresnel(fabsf(NDotL)), FV = schlick_fresnel(NDotV);
+                float Fd = (1.0f - 0.5f * FL) * (1.0f - 0.5f * FV);
+                brdf = scl3(scl3(scl3(scl3(s, kInvPi), mat.subsurface), Fd), 1.0f - mat.metallic);
+            }
+        } else {
+            float a = fmaxf(0.001f, mat.roughness);
+            float Ds = gtr2(NDotH, a);
+            float FH = schlick_fresnel(LDotH);
+            v3 Fs = lerp3(Cspec0, mk3(1.f), FH);
+            float Gs = smith_ggx(NDotV, a) * smith_ggx(NDotL, a);
+            float FL = schlick_fresnel(NDotL), FV = schlick_fresnel(NDotV);
+            float Fd90 = 0.5f + 2.0f * LDotH * LDotH * mat.roughness;
+            float Fd = lerpf(1.0f, Fd90, FL) * lerpf(1.0f, Fd90, FV);
+            float Dr = gtr1(NDotH, lerpf(.1f, .001f, mat.clearcoatGloss));
+            float Fc = lerpf(.04f, 1.0f, FH);
+            float Gr = smith_ggx(NDotL, .25f) * smith_ggx(NDotV, .25f);
+            v3 diff = scl3(scl3(scl3(Cdlin, kInvPi * Fd), 1.0f - mat.metallic), 1.0f - mat.subsurface);
+            v3 spec = scl3(scl3(Fs, Gs), Ds);
+            float cc = mat.clearcoat * Gr * Fc * Dr;
+            brdf = add3(add3(diff, spec), mk3(cc));
+        }
+    }
+    return lerp3(brdf, bsdf, mat.transmission);
+}
+
+// ------------------------------------------------------------------ probe (Probe.cuh)
+struct DevProbe {
+    int width, height;
+    const float4* data;
+    const float *pdfX, *cdfX, *pdfY, *cdfY;
+};
+
+// :38-46
+PT_DEV void probe_dir_to_uv(v3 dir, float& u, float& v) {
+    float theta = pt_acosf(clampf(dir.y, -1.0f, 1.0f));
+    float phi = (dir.x == 0.0f && dir.z == 0.0f) ? 0.0f : pt_atan2f(dir.z, dir.x);
+    u = (kPi + phi) * kInvPi * 0.5f;
+    v = theta * kInvPi;
+}
+// :48-58
+PT_DEV v3 probe_uv_to_dir(float u, float v) {
+    float theta = v * kPi;
+    float phi = u * 2.0f * kPi;
+    float st, ct, sp, cp;
+    pt_sincosf(theta, &st, &ct);
+    pt_sincosf(phi, &sp, &cp);
+    return mk3(-st * cp, ct, -st * sp);
+}
+PT_DEV int clampi(int v, int a, int b) { return v < a ? a : (v > b ? b : v); }
+// :61-67
+PT_DEV float4 probe_eval(const DevProbe& p, float u, float v) {
+    int px = clampi((int)(u * p.width), 0, p.width - 1);
+    int py = clampi((int)(v * p.height), 0, p.height - 1);
+    return p.data[(size_t)py * p.width + px];
+}
+// :119-136
+PT_DEV int lower_bound(const float* __restrict__ array, int lower, int upper, float value) {
+    while (lower < upper) {
+        int mid = lower + (upper - lower) / 2;
+        if (array[mid] < value)
+            lower = mid + 1;
+        else
+            upper = mid;
+    }
+    return lower;
+}
+// :138-169 (row/col clamped: unreachable for a valid CDF, guards a degenerate probe)
+PT_DEV void probe_sample(const DevProbe& p, v3& dir, v3& color, float& pdf, Rng& rand) {
+    float r1, r2;
+    sample2d(rand, r1, r2);
+    int row = lower_bound(p.cdfY, 0, p.height, r1);
+    if (row > p.height - 1) row = p.height - 1;
+    int col = lower_bound(p.cdfX, row * p.width, (row + 1) * p.width, r2) - row * p.width;
+    if (col > p.width - 1) col = p.width - 1;
+    float4 px = p.data[(size_t)row * p.width + col];
+    color = mk3(px.x, px.y, px.z);
+    pdf = p.pdfX[(size_t)row * p.width + col] * p.pdfY[row];
+    float u = col / (float)p.width;
+    float v = row / (float)p.height;
+    float sinTheta = pt_sinf(v * kPi);
+    if (sinTheta == 0.0f)
+        pdf = 0.0f;
+    else
+        pdf *= (p.width * p.height) / (2.0f * kPi * kPi * sinTheta);
+    dir = probe_uv_to_dir(u, v);
+}
+
+// ------------------------------------------------------------------ output transforms
+// cuda/helpers.h:34-61
+PT_DEV uint32_t quantize8(float x) {
+    x = clampf(x, 0.0f, 1.0f);
+    uint32_t q = (uint32_t)(x * 256.0f);
+    return q < 255u ? q : 255u;
+}
+PT_DEV float to_srgb1(float c) {
+    float invGamma = 1.0f / 2.4f;
+    float powed = pt_powf(c, invGamma);
+    return c < 0.0031308f ? 12.92f * c : 1.055f * powed - 0.055f;
+}
+PT_DEV uint32_t make_color(v3 c) {
+    uint32_t r = quantize8(to_srgb1(clampf(c.x, 0.0f, 1.0f)));
+    uint32_t g = quantize8(to_srgb1(clampf(c.y, 0.0f, 1.0f)));
+    uint32_t b = quantize8(to_srgb1(clampf(c.z, 0.0f, 1.0f)));
+    return r | (g << 8) | (b << 16) | (255u << 24);
+}

@@ -1,0 +1,23 @@
+// pt_host.h — host-side structures shared by the translation units of libptamd.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/pt_amd.h"
+
+struct Node2;
+struct LeafTri;
+
+struct PtBvh {
+    const Node2* nodes = nullptr;
+    const LeafTri* tris = nullptr;
+    uint32_t num_nodes = 0, num_tris = 0;
+    int32_t root = 0;
+    float bounds[6] = {0, 0, 0, 0, 0, 0};
+    float pad = 0.f;
+};
+
+hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t ntri, hipStream_t stream, PtBvh* out);
+void pt_bvh_free(PtBvh* b);

@@ -1,0 +1,514 @@
+// pt_kernels.h — the wavefront kernels that replace the optixLaunch megakernel
+// (__raygen__renderFrame / __closesthit__radiance / __miss__radiance / occlusion programs,
+// deviceProgram.cu:206-594).  One path = one (pixel, sample) of the reference's raygen loops.
+//
+//   k_generate   raygen prologue per sample (deviceProgram.cu:357,370-410): seed, jitter, camera ray
+//   k_trace<0>   traceRadiance (:152-178, 416-422): closest hit for every queued path
+//   k_shade      __closesthit__radiance + __miss__radiance + the raygen loop body (:424-442)
+//   k_trace<1>   traceOcclusion + __anyhit__/__miss__occlusion (:181-204,237-250) and the deferred
+//                "if (!occluded) sum += val" of SampleLights / "if (occluded)" of SampleShadow (:272-289,314-331)
+//   k_resolve    raygen epilogue (:445-474): per-pixel sample sums in sample order, backplate,
+//                progressive blend, make_color, the five buffer writes
+//
+// HBM layout: structure-of-arrays indexed by path slot (float4 / float2 / uint2 arrays, 16-byte
+// aligned, one coalesced access per array per wave); queues are arrays of path slots.
+#pragma once
+#include "pt_bvh.h"
+
+enum { FLAG_DONE = 1, FLAG_SECONDARY = 2 }; // RAY_STATE_FLAGS_* deviceProgram.cu:46-48
+enum { PEND_DIRECT = 1, PEND_INDIRECT = 2, PEND_ALPHA = 3 };
+
+// 48-byte triangle in PRIMITIVE order for shading (what sbtData.vertex[index[prim]] gave, :485-489)
+struct PrimTri {
+    float4 t0, t1, t2; // (v0.xyz,v1.x) (v1.yz,v2.xy) (v2.z, mesh id bits, -, -)
+};
+
+struct PathState {
+    float4* rayO;  // next ray origin xyz, tmin
+    float4* rayD;  // next ray direction xyz, tmax
+    float4* srayD; // shadow ray direction (origin = rayO.xyz, tmin .01, tmax 1e16)
+    float4* pend;  // pending NEE contribution xyz, kind bits in w
+    float2* hit;   // t, prim bits
+    float4* thr;   // pathThroughput xyz, rayEta
+    uint2* rng;    // Random seed1, seed2
+    uint32_t* fd;  // depth | flags << 8
+    float4 *direct, *indirect, *alpha, *nrm, *alb;
+    float4 *prdN, *prdA; // prd.normal / prd.albedo, shadow-catcher scenes only (else null)
+};
+
+struct FrameParams { // LaunchParams (LaunchParams.h:51-79) minus the OptiX handle and the dead light
+    float4* accum;
+    uint32_t* frame;
+    float4 *color, *normal, *albedo;
+    int width, height;
+    uint32_t subframe_index;
+    v3 eye, U, V, W;
+    uint32_t spp; // samples_per_launch
+    DevProbe probe;
+};
+
+struct BatchParams {
+    const uint32_t* pixels; // x | y << 16 for the pixels of this chunk
+    uint32_t npix;          // pixels in the chunk
+    uint32_t s0, S;         // first sample and number of samples in the chunk
+    int carry;              // nrm/alb carried through pixNormal/pixAlbedo (sequential-sample mode)
+    float4 *pixResult, *pixAlpha, *pixNormal, *pixAlbedo; // per pixel of the chunk
+};
+
+// ------------------------------------------------------------------ generate
+__global__ void __launch_bounds__(256) k_generate(PathState st, FrameParams fp, BatchParams bp, uint32_t* qcount0) {
+    const uint32_t total = bp.npix * bp.S;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *qcount0 = total;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t sl = i / bp.npix, pix = i - sl * bp.npix;
+        const uint32_t xy = bp.pixels[pix];
+        const uint32_t x = xy & 0xffffu, y = xy >> 16;
+        uint32_t seed = tea4(y * (uint32_t)fp.width + x, fp.subframe_index);
+        for (uint32_t k = 0; k < 2u * (bp.s0 + sl); ++k) lcg(seed); // earlier samples drew 2 rnd() each (:388)
+        Rng r;
+        r.init(seed); // prd.rand = Random(seed) BEFORE the jitter draws (:375-376)
+        const float jx = rnd(seed), jy = rnd(seed);
+        const float dx = 2.0f * (((float)x + jx) / (float)fp.width) - 1.0f;
+        const float dy = 2.0f * (((float)y + jy) / (float)fp.height) - 1.0f;
+        const v3 dir = normalize3(add3(add3(scl3(fp.U, dx), scl3(fp.V, dy)), fp.W));
+        st.rayO[i] = make_float4(fp.eye.x, fp.eye.y, fp.eye.z, 0.001f);
+        st.rayD[i] = make_float4(dir.x, dir.y, dir.z, 1e16f);
+        st.thr[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+        st.rng[i] = make_uint2(r.seed1, r.seed2);
+        st.fd[i] = 0u;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.direct[i] = z;
+        st.indirect[i] = z;
+        st.alpha[i] = z;
+        st.nrm[i] = bp.carry ? bp.pixNormal[pix] : z;
+        st.alb[i] = bp.carry ? bp.pixAlbedo[pix] : z;
+        if (st.prdN) {
+            st.prdN[i] = z;
+            st.prdA[i] = z;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ trace
+#define PT_TRACE_BLOCK 128
+
+// ANY = 0: closest hit of (rayO,rayD) → hit[slot].  ANY = 1: occlusion of (rayO.xyz,.01,srayD,1e16)
+// then the deferred NEE accumulation.  queue == nullptr means identity.
+template <int ANY>
+__global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace(PathState st, BvhDev bvh, const uint32_t* __restrict__ queue,
+                                                          const uint32_t* __restrict__ count) {
+    __shared__ uint32_t s_stack[PT_STACK_DEPTH * PT_TRACE_BLOCK];
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t p = queue ? queue[i] : i;
+        const float4 o4 = st.rayO[p];
+        float t;
+        int32_t prim;
+        if (ANY) {
+            const float4 d4 = st.srayD[p];
+            bvh2_traverse<true>(bvh, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), 0.01f, 1e16f, &s_stack[threadIdx.x],
+                                PT_TRACE_BLOCK, t, prim);
+            const float4 pe = st.pend[p];
+            const int kind = __float_as_int(pe.w);
+            const bool occluded = prim != 0;
+            if (kind == PEND_ALPHA) {
+                if (occluded) {
+                    float4 a = st.alpha[p];
+                    st.alpha[p] = make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, 0.f);
+                }
+            } else if (!occluded) {
+                float4* acc = (kind == PEND_DIRECT) ? st.direct : st.indirect;
+                float4 a = acc[p];
+                acc[p] = make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, 0.f);
+            }
+        } else {
+            const float4 d4 = st.rayD[p];
+            bvh2_traverse<false>(bvh, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, d4.w, &s_stack[threadIdx.x],
+                                 PT_TRACE_BLOCK, t, prim);
+            st.hit[p] = make_float2(t, __int_as_float(prim));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ shade
+struct ShadeParams {
+    const PrimTri* prims;
+    const pt_material* mats;
+    DevProbe probe;
+    int max_depth;
+    const uint32_t* queue; // nullptr = identity
+    const uint32_t* count;
+    uint32_t* next_queue;
+    uint32_t* next_count;
+    uint32_t* shadow_queue;
+    uint32_t* shadow_count;
+};
+
+// wave-aggregated queue append: one atomic per wave
+PT_DEV void queue_push(bool pred, uint32_t value, uint32_t* queue, uint32_t* counter) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    const uint32_t lane = __lane_id();
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    if (pred) queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+template <int MODE, bool CATCHER>
+__global__ void __launch_bounds__(256) k_shade(PathState st, ShadeParams sp) {
+    const uint32_t n = *sp.count;
+    const uint32_t nround = (n + 63u) & ~63u; // whole waves stay in the loop so ballots see every lane
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += gridDim.x * blockDim.x) {
+        bool push_next = false, push_shadow = false;
+        uint32_t p = 0;
+        if (i < n) {
+            p = sp.queue ? sp.queue[i] : i;
+            const float2 h = st.hit[p];
+            const int32_t prim = __float_as_int(h.y);
+            uint32_t fd = st.fd[p];
+            int depth = (int)(fd & 0xffu);
+            uint32_t flags = fd >> 8;
+            if (prim < 0) {
+                // __miss__radiance (:209-235): prd.normal = prd.albedo = 0 (adds nothing at depth 0), DONE
+                flags |= FLAG_DONE;
+                if (CATCHER) {
+                    st.prdN[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    st.prdA[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
+                const PrimTri tri = sp.prims[prim];
+                const v3 v0 = mk3(tri.t0.x, tri.t0.y, tri.t0.z), v1 = mk3(tri.t0.w, tri.t1.x, tri.t1.y),
+                         v2 = mk3(tri.t1.z, tri.t1.w, tri.t2.x);
+                const pt_material mat = sp.mats[__float_as_int(tri.t2.y)];
+                const float4 o4 = st.rayO[p], d4 = st.rayD[p];
+                const v3 ray_o = mk3(o4.x, o4.y, o4.z), ray_dir = mk3(d4.x, d4.y, d4.z);
+                const v3 N_0 = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
+                const v3 N = faceforward3(N_0, neg3(ray_dir), N_0);
+                const v3 P = add3(ray_o, scl3(ray_dir, h.x));
+                st.rayO[p] = make_float4(P.x, P.y, P.z, 0.001f);
+                const bool is_catcher = (mat.flags & 1) != 0;
+                if (CATCHER && is_catcher && (flags & FLAG_SECONDARY)) {
+                    // pass-through (:503-508): origin = P, direction unchanged, --depth; then raygen (:424-439)
+                    --depth;
+                    if (depth == 0) {
+                        const float4 a = st.nrm[p], b = st.alb[p], pn = st.prdN[p], pa = st.prdA[p];
+                        st.nrm[p] = make_float4(a.x + pn.x, a.y + pn.y, a.z + pn.z, 0.f);
+                        st.alb[p] = make_float4(b.x + pa.x, b.y + pa.y, b.z + pa.z, 0.f);
+                    }
+                    ++depth;
+                    push_next = true;
+                } else {
+                    const v3 albedo = mk3(mat.color[0], mat.color[1], mat.color[2]);
+                    const float4 th = st.thr[p];
+                    const v3 T_old = mk3(th.x, th.y, th.z);
+                    float rayEta = th.w;
+                    const float outEta = (rayEta == 1.0f) ? material_ior(mat) : 1.0f;
+                    const v3 wo = neg3(ray_dir);
+                    const uint2 rs = st.rng[p];
+                    Rng rand;
+                    rand.seed1 = rs.x;
+                    rand.seed2 = rs.y;
+                    // SampleLights / SampleShadow (:252-334) up to the visibility test
+                    v3 wi, skyColor;
+                    float skyPdf;
+                    probe_sample(sp.probe, wi, skyColor, skyPdf, rand);
+                    bool has_val = false;
+                    v3 val = mk3(0.f);
+                    {
+                        const float bsdfPdf = bsdf_pdf<MODE>(mat, rayEta, outEta, N, wo, wi);
+                        const v3 f = bsdf_eval<MODE>(mat, albedo, rayEta, outEta, N, wo, wi);
+                        if (bsdfPdf > 0.0f) {
+                            const float weight = 0.5f * skyPdf / (0.5f * bsdfPdf + 0.5f * skyPdf);
+                            if (weight > 0.0f) {
+                                val = scl3(div3s(scl3(mul3(scl3(skyColor, weight), f), fabsf(dot3(wi, N))), skyPdf), 1.0f);
+                                has_val = true;
+                            }
+                        }
+                    }
+                    if (!(CATCHER && is_catcher)) st.alpha[p] = make_float4(1.f, 1.f, 1.f, 0.f); // :547
+                    const bool primary = (flags & FLAG_SECONDARY) == 0;
+                    v3 u, v, bsdfDir = mk3(0.f);
+                    float bsdfPdf;
+                    basis_from_vector(N, u, v);
+                    bsdf_sample<MODE>(mat, rayEta, outEta, u, v, N, wo, bsdfDir, bsdfPdf, rand);
+                    v3 T_new = T_old;
+                    if (bsdfPdf <= 0.0f) {
+                        flags |= FLAG_DONE; // :570-573
+                    } else {
+                        const v3 f = bsdf_eval<MODE>(mat, albedo, rayEta, outEta, N, wo, bsdfDir);
+                        if (dot3(bsdfDir, N) <= 0.0f) rayEta = outEta;
+                        T_new = mul3(T_old, div3s(scl3(f, fabsf(dot3(N, bsdfDir))), bsdfPdf));
+                        st.rayD[p] = make_float4(bsdfDir.x, bsdfDir.y, bsdfDir.z, 1e16f);
+                        flags |= FLAG_SECONDARY;
+                    }
+                    st.thr[p] = make_float4(T_new.x, T_new.y, T_new.z, rayEta);
+                    st.rng[p] = make_uint2(rand.seed1, rand.seed2);
+                    if (CATCHER) {
+                        st.prdN[p] = make_float4(N.x, N.y, N.z, 0.f);
+                        st.prdA[p] = make_float4(albedo.x, albedo.y, albedo.z, 0.f);
+                    }
+                    // raygen loop body (:424-439)
+                    if (depth == 0) {
+                        const float4 a = st.nrm[p], b = st.alb[p];
+                        st.nrm[p] = make_float4(a.x + N.x, a.y + N.y, a.z + N.z, 0.f);
+                        st.alb[p] = make_float4(b.x + albedo.x, b.y + albedo.y, b.z + albedo.z, 0.f);
+                    }
+                    const bool term = (flags & FLAG_DONE) || depth >= sp.max_depth;
+                    const v3 contrib = mul3(T_old, val);
+                    if (CATCHER && is_catcher) {
+                        // SampleShadow: alpha += T * shadowSample when OCCLUDED (:550-551), whatever happens next
+                        if (has_val) {
+                            st.pend[p] = make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(PEND_ALPHA));
+                            st.srayD[p] = make_float4(wi.x, wi.y, wi.z, 0.f);
+                            push_shadow = true;
+                        }
+                        if (!term && primary) { // radiance = emission (:558-560)
+                            const float4 dd = st.direct[p];
+                            st.direct[p] = make_float4(dd.x + mat.emission[0], dd.y + mat.emission[1], dd.z + mat.emission[2], 0.f);
+                        }
+                    } else if (!term) {
+                        // radiance = T*lightSample (+ emission on primary hits) is added to direct/indirect (:432-437)
+                        // only when the path goes on; the visibility-dependent part is deferred to k_trace<1>.
+                        if (primary) {
+                            const float4 dd = st.direct[p];
+                            st.direct[p] = make_float4(dd.x + mat.emission[0], dd.y + mat.emission[1], dd.z + mat.emission[2], 0.f);
+                        }
+                        if (has_val) {
+                            st.pend[p] = make_float4(contrib.x, contrib.y, contrib.z,
+                                                     __int_as_float(depth == 0 ? PEND_DIRECT : PEND_INDIRECT));
+                            st.srayD[p] = make_float4(wi.x, wi.y, wi.z, 0.f);
+                            push_shadow = true;
+                        }
+                    }
+                    if (!term) {
+                        ++depth;
+                        push_next = true;
+                    }
+                }
+            }
+            st.fd[p] = (uint32_t)depth | (flags << 8);
+        }
+        queue_push(push_next, p, sp.next_queue, sp.next_count);
+        queue_push(push_shadow, p, sp.shadow_queue, sp.shadow_count);
+    }
+}
+
+// ------------------------------------------------------------------ resolve
+__global__ void __launch_bounds__(256) k_resolve(PathState st, FrameParams fp, BatchParams bp, int first, int last) {
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= bp.npix) return;
+    v3 result = mk3(0.f), alpha = mk3(0.f), normal = mk3(0.f), albedo = mk3(0.f);
+    if (!first) {
+        const float4 r = bp.pixResult[pix], a = bp.pixAlpha[pix], nn = bp.pixNormal[pix], al = bp.pixAlbedo[pix];
+        result = mk3(r.x, r.y, r.z);
+        alpha = mk3(a.x, a.y, a.z);
+        normal = mk3(nn.x, nn.y, nn.z);
+        albedo = mk3(al.x, al.y, al.z);
+    }
+    for (uint32_t sl = 0; sl < bp.S; ++sl) {
+        const uint32_t i = sl * bp.npix + pix;
+        const float4 d = st.direct[i], in = st.indirect[i], a = st.alpha[i], nn = st.nrm[i], al = st.alb[i];
+        // result += directLight + indirectLight; alpha += prd.alpha (:445-446)
+        result = add3(result, add3(mk3(d.x, d.y, d.z), mk3(in.x, in.y, in.z)));
+        alpha = add3(alpha, mk3(a.x, a.y, a.z));
+        if (bp.carry) {
+            normal = mk3(nn.x, nn.y, nn.z);
+            albedo = mk3(al.x, al.y, al.z);
+        } else {
+            normal = add3(normal, mk3(nn.x, nn.y, nn.z));
+            albedo = add3(albedo, mk3(al.x, al.y, al.z));
+        }
+    }
+    if (!last) {
+        bp.pixResult[pix] = make_float4(result.x, result.y, result.z, 0.f);
+        bp.pixAlpha[pix] = make_float4(alpha.x, alpha.y, alpha.z, 0.f);
+        bp.pixNormal[pix] = make_float4(normal.x, normal.y, normal.z, 0.f);
+        bp.pixAlbedo[pix] = make_float4(albedo.x, albedo.y, albedo.z, 0.f);
+        return;
+    }
+    const uint32_t xy = bp.pixels[pix];
+    const uint32_t x = xy & 0xffffu, y = xy >> 16;
+    const float spp = (float)fp.spp;
+    normal = div3s(normal, spp);
+    albedo = div3s(albedo, spp);
+    alpha = div3s(alpha, spp);
+    // backplate of the LAST sample's camera ray (:410)
+    uint32_t seed = tea4(y * (uint32_t)fp.width + x, fp.subframe_index);
+    for (uint32_t k = 0; k < 2u * (fp.spp - 1u); ++k) lcg(seed);
+    const float jx = rnd(seed), jy = rnd(seed);
+    const float dx = 2.0f * (((float)x + jx) / (float)fp.width) - 1.0f;
+    const float dy = 2.0f * (((float)y + jy) / (float)fp.height) - 1.0f;
+    const v3 dir = normalize3(add3(add3(scl3(fp.U, dx), scl3(fp.V, dy)), fp.W));
+    float pu, pv;
+    probe_dir_to_uv(dir, pu, pv);
+    const float4 bpx = probe_eval(fp.probe, pu, pv);
+    const v3 backplate = mk3(bpx.x, bpx.y, bpx.z);
+    const v3 color = add3(mul3(scl3(backplate, spp), sub3(mk3(1.0f), alpha)), result);
+    const size_t image_index = (size_t)y * fp.width + x;
+    v3 accum_color = div3s(color, spp);
+    if (fp.subframe_index > 0) {
+        accum_color = mk3(clampf(accum_color.x, 0.0f, 10.0f), clampf(accum_color.y, 0.0f, 10.0f), clampf(accum_color.z, 0.0f, 10.0f));
+        const float a = 1.0f / (float)(fp.subframe_index + 1);
+        const float4 prev = fp.accum[image_index];
+        accum_color = lerp3(mk3(prev.x, prev.y, prev.z), accum_color, a);
+    }
+    fp.accum[image_index] = make_float4(accum_color.x, accum_color.y, accum_color.z, 1.0f);
+    fp.frame[image_index] = make_color(accum_color);
+    fp.normal[image_index] = make_float4(normal.x, normal.y, normal.z, 1.0f);
+    fp.color[image_index] = make_float4(accum_color.x, accum_color.y, accum_color.z, 1.0f);
+    fp.albedo[image_index] = make_float4(albedo.x, albedo.y, albedo.z, 1.0f);
+}
+
+// toneMap.cu:41-58 computeFinalPixelColorsKernel
+__global__ void k_tonemap_sqrt(const float4* __restrict__ accum, uint32_t* __restrict__ frame, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 f = accum[i];
+    const uint32_t r = (uint32_t)(255.9f * fminf(1.0f, fmaxf(0.0f, sqrtf(f.x))));
+    const uint32_t g = (uint32_t)(255.9f * fminf(1.0f, fmaxf(0.0f, sqrtf(f.y))));
+    const uint32_t b = (uint32_t)(255.9f * fminf(1.0f, fmaxf(0.0f, sqrtf(f.z))));
+    const uint32_t a = (uint32_t)(255.9f * fminf(1.0f, fmaxf(0.0f, sqrtf(f.w))));
+    frame[i] = r | (g << 8) | (b << 16) | (a << 24);
+}
+
+// multi-GPU exchange: gather owned pixels of a buffer into a packed array and back
+template <typename T>
+__global__ void k_pack(const T* __restrict__ buf, const uint32_t* __restrict__ pixels, uint32_t n, int width, T* __restrict__ dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t xy = pixels[i];
+    dst[i] = buf[(size_t)(xy >> 16) * width + (xy & 0xffffu)];
+}
+template <typename T>
+__global__ void k_unpack(T* __restrict__ buf, const uint32_t* __restrict__ all_pixels, uint32_t n, int width, const T* __restrict__ src) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t xy = all_pixels[i];
+    if (xy == 0xffffffffu) return;
+    buf[(size_t)(xy >> 16) * width + (xy & 0xffffu)] = src[i];
+}
+
+__global__ void k_accum_stats(const uint32_t* __restrict__ counters, int nq, int nb, unsigned long long* __restrict__ totals) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long r = 0, s = 0;
+        for (int b = 0; b < nb; ++b) {
+            r += counters[b];
+            s += counters[nq + b];
+        }
+        totals[0] += r;
+        totals[1] += s;
+    }
+}
+
+__global__ void k_emit_prims(const float* __restrict__ verts, const uint32_t* __restrict__ idx,
+                             const uint32_t* __restrict__ tri_mesh, uint32_t ntri, PrimTri* __restrict__ prims) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= ntri) return;
+    const float* v0 = &verts[3 * (size_t)idx[3 * (size_t)p + 0]];
+    const float* v1 = &verts[3 * (size_t)idx[3 * (size_t)p + 1]];
+    const float* v2 = &verts[3 * (size_t)idx[3 * (size_t)p + 2]];
+    PrimTri t;
+    t.t0 = make_float4(v0[0], v0[1], v0[2], v1[0]);
+    t.t1 = make_float4(v1[1], v1[2], v2[0], v2[1]);
+    t.t2 = make_float4(v2[2], __int_as_float((int)tri_mesh[p]), 0.f, 0.f);
+    prims[p] = t;
+}
+
+// ------------------------------------------------------------------ function tables (tests)
+template <int MODE>
+__global__ void k_table_bsdf(pt_material mat, const float* __restrict__ in, uint32_t n, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* a = &in[11 * (size_t)i];
+    const v3 N = mk3(a[0], a[1], a[2]), V = mk3(a[3], a[4], a[5]), L = mk3(a[6], a[7], a[8]);
+    const v3 albedo = mk3(mat.color[0], mat.color[1], mat.color[2]);
+    const v3 f = bsdf_eval<MODE>(mat, albedo, a[9], a[10], N, V, L);
+    out[4 * (size_t)i + 0] = f.x;
+    out[4 * (size_t)i + 1] = f.y;
+    out[4 * (size_t)i + 2] = f.z;
+    out[4 * (size_t)i + 3] = bsdf_pdf<MODE>(mat, a[9], a[10], N, V, L);
+}
+template <int MODE>
+__global__ void k_table_sample(pt_material mat, const float* __restrict__ in, uint32_t n, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* a = &in[9 * (size_t)i];
+    const v3 N = mk3(a[0], a[1], a[2]), V = mk3(a[3], a[4], a[5]);
+    Rng r;
+    r.init(__float_as_uint(a[8]));
+    v3 u, v, L = mk3(0.f);
+    float pdf;
+    basis_from_vector(N, u, v);
+    bsdf_sample<MODE>(mat, a[6], a[7], u, v, N, V, L, pdf, r);
+    float* o = &out[6 * (size_t)i];
+    o[0] = L.x; o[1] = L.y; o[2] = L.z; o[3] = pdf;
+    o[4] = __uint_as_float(r.seed1);
+    o[5] = __uint_as_float(r.seed2);
+}
+__global__ void k_table_probe_sample(DevProbe probe, const float* __restrict__ in, uint32_t n, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng r;
+    r.init(__float_as_uint(in[i]));
+    v3 dir, color;
+    float pdf;
+    probe_sample(probe, dir, color, pdf, r);
+    float* o = &out[9 * (size_t)i];
+    o[0] = dir.x; o[1] = dir.y; o[2] = dir.z;
+    o[3] = color.x; o[4] = color.y; o[5] = color.z;
+    o[6] = pdf;
+    o[7] = __uint_as_float(r.seed1);
+    o[8] = __uint_as_float(r.seed2);
+}
+__global__ void k_table_probe_eval(DevProbe probe, const float* __restrict__ in, uint32_t n, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float u, v;
+    probe_dir_to_uv(mk3(in[3 * (size_t)i], in[3 * (size_t)i + 1], in[3 * (size_t)i + 2]), u, v);
+    const float4 c = probe_eval(probe, u, v);
+    float* o = &out[6 * (size_t)i];
+    o[0] = u; o[1] = v; o[2] = c.x; o[3] = c.y; o[4] = c.z; o[5] = c.w;
+}
+__global__ void k_table_color(const float* __restrict__ in, uint32_t n, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = __uint_as_float(make_color(mk3(in[3 * (size_t)i], in[3 * (size_t)i + 1], in[3 * (size_t)i + 2])));
+}
+__global__ void k_table_math(const float* __restrict__ in, uint32_t n, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int fn = (int)in[3 * (size_t)i];
+    const float x = in[3 * (size_t)i + 1], y = in[3 * (size_t)i + 2];
+    float r;
+    switch (fn) {
+        case 0: r = pt_sinf(x); break;
+        case 1: r = pt_cosf(x); break;
+        case 2: r = pt_acosf(x); break;
+        case 3: r = pt_atan2f(x, y); break;
+        case 4: r = pt_logf(x); break;
+        case 5: r = pt_powf(x, y); break;
+        case 6: r = x / y; break;
+        default: r = sqrtf(x); break;
+    }
+    out[i] = r;
+}
+__global__ void k_table_rng(const float* __restrict__ in, uint32_t n, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = __float_as_uint(in[2 * (size_t)i]), b = __float_as_uint(in[2 * (size_t)i + 1]);
+    float* o = &out[8 * (size_t)i];
+    uint32_t s = tea4(a, b);
+    o[0] = __uint_as_float(s);
+    uint32_t l = s;
+    o[1] = rnd(l);
+    o[2] = __uint_as_float(l);
+    Rng r;
+    r.init(s);
+    o[3] = r.randf();
+    o[4] = r.randf();
+    o[5] = __uint_as_float(r.seed1);
+    o[6] = __uint_as_float(r.seed2);
+    o[7] = __uint_as_float(r.rand());
+}

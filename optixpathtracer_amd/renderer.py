@@ -1,0 +1,200 @@
+"""Host-side mirror of the reference's SampleRenderer (SimplePathtracer.h:38-176) over the C ABI.
+
+Same public surface — SampleRenderer(model), render(), resize(size), downloadPixels(), setCamera(camera),
+setProbe(probe), the public `launchParams` the app pokes directly (samples_per_launch, frame.subframe_index,
+frame.size) — and the same error behaviour: failures raise RuntimeError (the reference throws
+sutil::Exception : std::runtime_error), render() before resize() silently does nothing, resize to 0 is ignored.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import Material as CMaterial
+from ._lib import MeshDesc, Options, SceneDesc, Stats
+from .scenes import Model, ProbeData, uvw_frame
+
+PT_BUF_ACCUM, PT_BUF_FRAME, PT_BUF_COLOR, PT_BUF_NORMAL, PT_BUF_ALBEDO = range(5)
+PT_BSDF_DISNEY, PT_BSDF_LAMBERT = 0, 1
+
+
+@dataclass
+class Camera:
+    """sutil::Camera (eye, lookat, up, fovY in degrees, aspectRatio)."""
+
+    eye: tuple
+    lookat: tuple
+    up: tuple = (0.0, 1.0, 0.0)
+    fovY: float = 35.0
+    aspectRatio: float = 1.0
+
+    def UVWFrame(self):
+        L = _lib.load_library()
+        f3 = C.c_float * 3
+        U, V, W = f3(), f3(), f3()
+        rc = L.pt_uvw_frame(C.byref(f3(*self.eye)), C.byref(f3(*self.lookat)), C.byref(f3(*self.up)), self.fovY, self.aspectRatio, C.byref(U), C.byref(V), C.byref(W))
+        if rc:
+            raise RuntimeError("pt_uvw_frame failed")
+        return np.array(U, np.float32), np.array(V, np.float32), np.array(W, np.float32)
+
+
+@dataclass
+class _Frame:
+    size: tuple = (0, 0)
+    subframe_index: int = 0
+
+
+@dataclass
+class LaunchParams:
+    """The fields of LaunchParams (LaunchParams.h:51-79) the application sets directly."""
+
+    frame: _Frame = field(default_factory=_Frame)
+    samples_per_launch: int = 1
+
+
+class SampleRenderer:
+    def __init__(self, model: Model, device: int = 0):
+        self._L = L = _lib.load_library()
+        self._ctx = C.c_void_p()
+        self.launchParams = LaunchParams()
+        meshes = (MeshDesc * len(model.meshes))()
+        self._keep = []
+        for k, m in enumerate(model.meshes):
+            v = np.ascontiguousarray(m.vertex, np.float32)
+            ix = np.ascontiguousarray(m.index, np.uint32)
+            self._keep += [v, ix]
+            meshes[k].vertex = v.ctypes.data
+            meshes[k].num_vertices = len(v)
+            meshes[k].index = ix.ctypes.data
+            meshes[k].num_triangles = len(ix)
+            C.memmove(C.byref(meshes[k].material), np.asarray(m.material).tobytes(), 104)
+            meshes[k].diffuse_texture_id = m.diffuseTextureID
+        sd = SceneDesc(meshes, len(model.meshes))
+        rc = L.pt_create(C.byref(sd), device, C.byref(self._ctx))
+        if rc:
+            self._ctx = C.c_void_p()
+            raise RuntimeError(f"pt_create failed ({rc}): {L.pt_last_error(None).decode()}")
+        self._keep = []  # the scene was deep-copied
+
+    # -- internals
+    def _ck(self, rc, what):
+        if rc:
+            raise RuntimeError(f"{what} failed ({rc}): {self._L.pt_last_error(self._ctx).decode()}")
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.pt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reference API
+    def render(self, out: np.ndarray | None = None):
+        """render() / render(CUDAOutputBuffer&): one launch with the current launchParams."""
+        ptr = None
+        if out is not None:
+            assert out.dtype == np.uint32 and out.flags["C_CONTIGUOUS"]
+            ptr = out.ctypes.data
+        self._ck(self._L.pt_render(self._ctx, int(self.launchParams.samples_per_launch), int(self.launchParams.frame.subframe_index), ptr), "pt_render")
+
+    def resize(self, newSize):
+        w, h = int(newSize[0]), int(newSize[1])
+        self._ck(self._L.pt_resize(self._ctx, w, h), "pt_resize")
+        if w and h:
+            self.launchParams.frame.size = (w, h)
+
+    def downloadPixels(self) -> np.ndarray:
+        return self.download(PT_BUF_FRAME)
+
+    def setCamera(self, camera: Camera):
+        U, V, W = camera.UVWFrame()
+        self.setCameraUVW(camera.eye, U, V, W)
+
+    def setCameraUVW(self, eye, U, V, W):
+        f3 = C.c_float * 3
+        self._ck(self._L.pt_set_camera(self._ctx, C.byref(f3(*[float(x) for x in eye])), C.byref(f3(*[float(x) for x in U])), C.byref(f3(*[float(x) for x in V])), C.byref(f3(*[float(x) for x in W]))), "pt_set_camera")
+
+    def setProbe(self, probe: ProbeData):
+        if not probe.valid:
+            raise RuntimeError("Probe Data is not valid")  # Probe.h:104-105
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (probe.data, probe.pdfValuesX, probe.cdfValuesX, probe.pdfValuesY, probe.cdfValuesY)]
+        self._ck(self._L.pt_set_probe(self._ctx, *[a.ctypes.data for a in arrs], probe.width, probe.height), "pt_set_probe")
+
+    # -- beyond the reference (runtime versions of its compile-time constants, multi-GPU, stats)
+    def setOptions(self, max_depth=8, bsdf_mode=PT_BSDF_DISNEY, max_paths=0, sort_rays=0, bvh_kind=0):
+        o = Options(max_depth, bsdf_mode, max_paths, sort_rays, bvh_kind)
+        self._ck(self._L.pt_set_options(self._ctx, C.byref(o)), "pt_set_options")
+
+    def setPartition(self, rank, world, tile_w=64, tile_h=16):
+        self._ck(self._L.pt_set_partition(self._ctx, rank, world, tile_w, tile_h), "pt_set_partition")
+
+    def download(self, which) -> np.ndarray:
+        w, h = self.launchParams.frame.size
+        if which == PT_BUF_FRAME:
+            out = np.empty((h, w), np.uint32)
+        else:
+            out = np.empty((h, w, 4), np.float32)
+        self._ck(self._L.pt_download(self._ctx, which, out.ctypes.data, out.nbytes), "pt_download")
+        return out
+
+    def uploadAccum(self, accum: np.ndarray):
+        a = np.ascontiguousarray(accum, np.float32)
+        self._ck(self._L.pt_upload_accum(self._ctx, a.ctypes.data, a.nbytes), "pt_upload_accum")
+
+    def tonemapSqrt(self) -> np.ndarray:
+        w, h = self.launchParams.frame.size
+        out = np.empty((h, w), np.uint32)
+        self._ck(self._L.pt_tonemap_sqrt(self._ctx, out.ctypes.data), "pt_tonemap_sqrt")
+        return out
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._ck(self._L.pt_get_stats(self._ctx, C.byref(s)), "pt_get_stats")
+        return s.as_dict()
+
+    def ownedPixels(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self._ck(self._L.pt_owned_pixels(self._ctx, C.byref(a), C.byref(b)), "pt_owned_pixels")
+        return a.value, b.value
+
+    def deviceBuffer(self, which) -> int:
+        return self._L.pt_device_buffer(self._ctx, which)
+
+    def pack(self, which, dev_ptr: int):
+        self._ck(self._L.pt_pack(self._ctx, which, dev_ptr), "pt_pack")
+
+    def unpack(self, which, dev_ptr: int):
+        self._ck(self._L.pt_unpack(self._ctx, which, dev_ptr), "pt_unpack")
+
+    def trace(self, rays: np.ndarray, any_hit=False, iters=1):
+        """optixTrace as a batch query: rays (n,8) = o.xyz,tmin,d.xyz,tmax → (t, prim) or occluded flags; + kernel ms."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        n = len(rays)
+        t = np.empty(n, np.float32)
+        prim = np.empty(n, np.int32)
+        ms = C.c_double()
+        self._ck(self._L.pt_trace(self._ctx, rays.ctypes.data, n, int(any_hit), t.ctypes.data, prim.ctypes.data, iters, C.byref(ms)), "pt_trace")
+        return (prim.astype(np.uint8) if any_hit else (t, prim)), ms.value
+
+    def evalTable(self, which, inp: np.ndarray, out_width: int, material=None, bsdf_mode=PT_BSDF_DISNEY) -> np.ndarray:
+        inp = np.ascontiguousarray(inp, np.float32)
+        n = inp.shape[0]
+        out = np.empty((n, out_width), np.float32)
+        mp = None
+        if material is not None:
+            mbuf = CMaterial()
+            C.memmove(C.byref(mbuf), np.asarray(material).tobytes(), 104)
+            mp = C.cast(C.byref(mbuf), C.c_void_p)
+        self._ck(self._L.pt_eval_table(self._ctx, which, mp, bsdf_mode, inp.ctypes.data, n, out.ctypes.data), "pt_eval_table")
+        return out
+
+
+def make_camera(cam: dict, aspect: float) -> Camera:
+    return Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovY"], aspect)

@@ -20,7 +20,7 @@
  *   sutil/vec_math.h:96-122,483-570  lerp, clamp, dot, cross, normalize, faceforward, float3/float
  * The ray-triangle search itself (optixTrace, closed-source OptiX 7.5 driver code,
  * call sites deviceProgram.cu:165,190) is restated as a brute-force loop / a
- * median-split BVH over a watertight (Woop-Benthin-Wald 2013) triangle test;
+ * median-split BVH over a sign-consistent (watertight across shared edges) triangle test;
  * closest hit of a ray against a triangle soup is uniquely defined up to ties,
  * which are broken by lowest primitive index.
  *
@@ -564,49 +564,36 @@ typedef struct {
 } orc_scene;
 
 typedef struct {
-    float o[3], d[3];
-    int kx, ky, kz;
-    float Sx, Sy, Sz;
+    f3 o, d, dn;
 } wray;
 
-/* Watertight ray setup (Woop, Benthin, Wald 2013, sec. 3) */
+/* per-ray constants of the triangle test: dn = d / dot(d,d) so that t is in units of d */
 static inline void wray_init(wray* r, f3 o, f3 d) {
-    r->o[0] = o.x; r->o[1] = o.y; r->o[2] = o.z;
-    r->d[0] = d.x; r->d[1] = d.y; r->d[2] = d.z;
-    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    int kz = 0;
-    float m = ax;
-    if (ay > m) { kz = 1; m = ay; }
-    if (az > m) { kz = 2; }
-    int kx = kz + 1; if (kx == 3) kx = 0;
-    int ky = kx + 1; if (ky == 3) ky = 0;
-    if (r->d[kz] < 0.0f) { int t = kx; kx = ky; ky = t; }
-    r->kx = kx; r->ky = ky; r->kz = kz;
-    r->Sx = r->d[kx] / r->d[kz];
-    r->Sy = r->d[ky] / r->d[kz];
-    r->Sz = 1.0f / r->d[kz];
+    r->o = o;
+    r->d = d;
+    float inv_dd = 1.0f / dot3(d, d);
+    r->dn = scl3(d, inv_dd);
 }
 
-/* Returns 1 and *t_out if the ray hits the triangle at some t > 0 (the caller
- * applies the (tmin,tmax) interval).  No backface culling.  Every operation is
- * a single rounded IEEE op — the HIP kernel performs the same ones in the same
- * order, so t is bit-identical on both sides. */
-static inline int wtri(const wray* r, const float* v0, const float* v1, const float* v2, float* t_out) {
-    const int kx = r->kx, ky = r->ky, kz = r->kz;
-    const float Akx = v0[kx] - r->o[kx], Aky = v0[ky] - r->o[ky], Akz = v0[kz] - r->o[kz];
-    const float Bkx = v1[kx] - r->o[kx], Bky = v1[ky] - r->o[ky], Bkz = v1[kz] - r->o[kz];
-    const float Ckx = v2[kx] - r->o[kx], Cky = v2[ky] - r->o[ky], Ckz = v2[kz] - r->o[kz];
-    const float Ax = Akx - r->Sx * Akz, Ay = Aky - r->Sy * Akz;
-    const float Bx = Bkx - r->Sx * Bkz, By = Bky - r->Sy * Bkz;
-    const float Cx = Ckx - r->Sx * Ckz, Cy = Cky - r->Sy * Ckz;
-    const float U = Cx * By - Cy * Bx;
-    const float V = Ax * Cy - Ay * Cx;
-    const float W = Bx * Ay - By * Ax;
+/* Sign-consistent scalar-triple-product ray/triangle test.  With A,B,C the vertices relative to the
+ * ray origin, U = d.(CxB), V = d.(AxC), W = d.(BxA) are the (unnormalised) barycentric weights; the
+ * edge function of a shared edge is the exact negation in the neighbouring triangle (products
+ * commute, differences negate exactly), so no ray slips between two triangles that share an edge —
+ * the property the RT-core test behind optixTrace has.  No backface culling (OPTIX_RAY_FLAG_NONE).
+ * Returns 1 and *t_out if the supporting ray hits at some t > 0 (caller applies (tmin,tmax)).
+ * Every operation is a single rounded IEEE op; the HIP kernel (pt_bvh.h tri_test) performs the
+ * same ones in the same order, so t is bit-identical on both sides. */
+static inline int wtri(const wray* r, const float* p0, const float* p1, const float* p2, float* t_out) {
+    const f3 A = sub3(mk3(p0[0], p0[1], p0[2]), r->o);
+    const f3 B = sub3(mk3(p1[0], p1[1], p1[2]), r->o);
+    const f3 C = sub3(mk3(p2[0], p2[1], p2[2]), r->o);
+    const f3 CxB = cross3(C, B), AxC = cross3(A, C), BxA = cross3(B, A);
+    const float U = dot3(r->d, CxB), V = dot3(r->d, AxC), W = dot3(r->d, BxA);
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return 0;
     const float det = U + V + W;
     if (det == 0.0f) return 0;
-    const float Az = r->Sz * Akz, Bz = r->Sz * Bkz, Cz = r->Sz * Ckz;
-    const float T = U * Az + V * Bz + W * Cz;
+    const float Ad = dot3(r->dn, A), Bd = dot3(r->dn, B), Cd = dot3(r->dn, C);
+    const float T = U * Ad + V * Bd + W * Cd;
     if (T == 0.0f || ((T < 0.0f) != (det < 0.0f))) return 0;
     *t_out = T / det;
     return 1;
@@ -650,13 +637,13 @@ static int64_t closest_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tma
             }
         }
     } else {
-        float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+        float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z}, ro[3] = {o.x, o.y, o.z};
         uint32_t stack[128];
         int sp = 0;
         stack[sp++] = 0;
         while (sp) {
             const onode* n = &s->nodes[stack[--sp]];
-            if (!slab(n, r.o, inv, tmin, best, s->pad)) continue;
+            if (!slab(n, ro, inv, tmin, best, s->pad)) continue;
             if (n->right == 0xffffffffu) {
                 for (uint32_t k = 0; k < n->count; ++k) {
                     uint32_t p = s->order[n->left + k];
@@ -691,13 +678,13 @@ static int any_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tmax) {
         }
         return 0;
     }
-    float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z}, ro[3] = {o.x, o.y, o.z};
     uint32_t stack[128];
     int sp = 0;
     stack[sp++] = 0;
     while (sp) {
         const onode* n = &s->nodes[stack[--sp]];
-        if (!slab(n, r.o, inv, tmin, tmax, s->pad)) continue;
+        if (!slab(n, ro, inv, tmin, tmax, s->pad)) continue;
         if (n->right == 0xffffffffu) {
             for (uint32_t k = 0; k < n->count; ++k) {
                 uint32_t p = s->order[n->left + k];
@@ -1101,6 +1088,34 @@ void orc_render(const orc_scene* s, const orc_probe* probe, const orc_params* pr
         stats->radiance_rays += jobs[t].st.radiance_rays;
         stats->shadow_rays += jobs[t].st.shadow_rays;
     }
+}
+
+/* Render only the listed rows of a full-size launch (same seeds as the full frame): lets a test check
+ * windows of a 1920x1080 frame without rendering all of it on the CPU.  Only accum is written. */
+typedef struct {
+    const orc_scene* s; const orc_probe* probe; const orc_params* prm; float* accum; const int32_t* rows; int nrows;
+    int tid, nthreads;
+} rowjob_t;
+static void* rowjob_main(void* arg) {
+    rowjob_t* j = (rowjob_t*)arg;
+    orc_stats st = {0, 0};
+    for (int k = j->tid; k < j->nrows; k += j->nthreads)
+        for (int x = 0; x < j->prm->width; ++x)
+            raygen_pixel(j->s, j->probe, j->prm, x, j->rows[k], j->accum, NULL, NULL, NULL, NULL, &st);
+    return NULL;
+}
+void orc_render_rows(const orc_scene* s, const orc_probe* probe, const orc_params* prm, float* accum, const int32_t* rows,
+                     int nrows, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    rowjob_t jobs[64];
+    pthread_t th[64];
+    for (int t = 0; t < nthreads; ++t) {
+        rowjob_t j = {s, probe, prm, accum, rows, nrows, t, nthreads};
+        jobs[t] = j;
+        pthread_create(&th[t], NULL, rowjob_main, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
 }
 
 size_t orc_sizeof_material(void) { return sizeof(orc_material); }

@@ -1,0 +1,434 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU checker built with the same
+deterministic math (oracle 'det').  Integer / index work and — because both sides execute the same
+IEEE operation sequence — every float here is compared BIT-EXACT."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+from optixpathtracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _renderer(model, probe, cam, w, h, **opt):
+    from optixpathtracer_amd.renderer import SampleRenderer, make_camera
+
+    r = SampleRenderer(model)
+    r.setProbe(probe)
+    r.resize((w, h))
+    r.setCamera(make_camera(cam, w / h))
+    if opt:
+        r.setOptions(**opt)
+    return r
+
+
+def _oracle_render(O, model, probe, cam, w, h, spp, subframes=1, max_depth=8, bsdf_mode=0, use_bvh=None):
+    sc = O.make_scene(model, use_bvh)
+    pr = O.make_probe(probe)
+    U, V, W = scenes.uvw_frame(**cam, aspect=w / h)
+    out, accum = None, None
+    rays = 0
+    for sf in range(subframes):
+        out = O.render(sc, pr, (U, V, W), cam["eye"], w, h, spp, max_depth, sf, bsdf_mode, accum)
+        accum = out["accum"]
+        rays += out["radiance_rays"] + out["shadow_rays"]
+    return out
+
+
+def _gpu_render(r, spp, subframes=1):
+    from optixpathtracer_amd import renderer as R
+
+    r.launchParams.samples_per_launch = spp
+    for sf in range(subframes):
+        r.launchParams.frame.subframe_index = sf
+        r.render()
+    return dict(
+        accum=r.download(R.PT_BUF_ACCUM), frame=r.download(R.PT_BUF_FRAME), normal=r.download(R.PT_BUF_NORMAL),
+        color=r.download(R.PT_BUF_COLOR), albedo=r.download(R.PT_BUF_ALBEDO), stats=r.stats(),
+    )
+
+
+def _compare(g, o):
+    assert_bits_equal(g["accum"], o["accum"], "accum_buffer")
+    assert_bits_equal(g["color"], o["color"], "color_buffer")
+    assert_bits_equal(g["normal"], o["normal"], "normal_buffer")
+    assert_bits_equal(g["albedo"], o["albedo"], "albedo_buffer")
+    assert np.array_equal(g["frame"], o["frame"]), "frame_buffer (rgba8)"
+
+
+@pytest.fixture(scope="module")
+def small_probe():
+    return scenes.sky_probe(256, 128).BuildCDF()
+
+
+# ---------------------------------------------------------------- function tables
+def test_division_sqrt_correctly_rounded(ptlib):
+    """The numerics contract: device fp32 / and sqrt are IEEE correctly rounded (same bits as the host)."""
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    r = SampleRenderer(scenes.cornell_box())
+    rng = np.random.default_rng(3)
+    n = 200000
+    x = (rng.standard_normal(n) * np.exp(rng.uniform(-20, 20, n))).astype(np.float32)
+    y = (rng.standard_normal(n) * np.exp(rng.uniform(-20, 20, n))).astype(np.float32)
+    out = r.evalTable(5, np.stack([np.full(n, 6, np.float32), x, y], 1), 1)[:, 0]
+    assert_bits_equal(out, (x / y).astype(np.float32), "fp32 division")
+    ax = np.abs(x)
+    out = r.evalTable(5, np.stack([np.full(n, 7, np.float32), ax, y], 1), 1)[:, 0]
+    assert_bits_equal(out, np.sqrt(ax, dtype=np.float32), "fp32 sqrt")
+
+
+def test_detmath_tables(ptlib, orc_det):
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    r = SampleRenderer(scenes.cornell_box())
+    rng = np.random.default_rng(4)
+    n = 100000
+    cases = {
+        0: (rng.uniform(0, 6.2832, n), None), 1: (rng.uniform(0, 6.2832, n), None), 2: (rng.uniform(-1, 1, n), None),
+        3: (rng.standard_normal(n), rng.standard_normal(n)), 4: (np.exp(rng.uniform(-14, 0.5, n)), None),
+        5: (rng.uniform(0, 1, n), np.full(n, 1 / 2.4)),
+    }
+    for fn, (x, y) in cases.items():
+        x = x.astype(np.float32)
+        y = np.zeros(n, np.float32) if y is None else y.astype(np.float32)
+        g = r.evalTable(5, np.stack([np.full(n, fn, np.float32), x, y], 1), 1)[:, 0]
+        assert_bits_equal(g, orc_det.math_table(fn, x, y), f"detmath fn {fn}")
+
+
+def test_rng_tables(ptlib, orc_det):
+    import ctypes as C
+
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    r = SampleRenderer(scenes.cornell_box())
+    rng = np.random.default_rng(5)
+    n = 5000
+    ab = rng.integers(0, 2**32, (n, 2), dtype=np.uint64).astype(np.uint32)
+    g = r.evalTable(6, ab.view(np.float32), 8).view(np.uint32)
+    L = orc_det.lib
+    for i in range(n):
+        s = L.orc_tea4(int(ab[i, 0]), int(ab[i, 1]))
+        assert g[i, 0] == s
+        l = C.c_uint32(s)
+        rn = np.float32(L.orc_rnd(C.byref(l)))
+        assert g[i, 1] == rn.view(np.uint32) and g[i, 2] == l.value
+        st = np.zeros(2, np.uint32)
+        L.orc_random_init(st, s)
+        f1 = np.float32(L.orc_randf(st)); f2 = np.float32(L.orc_randf(st))
+        assert g[i, 3] == f1.view(np.uint32) and g[i, 4] == f2.view(np.uint32)
+        assert g[i, 5] == st[0] and g[i, 6] == st[1]
+        assert g[i, 7] == L.orc_rand(st)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_bsdf_tables(ptlib, orc_det, mode):
+    import ctypes as C
+
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    r = SampleRenderer(scenes.cornell_box())
+    rng = np.random.default_rng(6)
+    n = 4000
+
+    def unit(k):
+        v = rng.standard_normal((k, 3)).astype(np.float32)
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+    mats = scenes.material_presets() + [scenes.Material(), scenes.Material(transmission=1.0, roughness=0.2, eta=1.33)]
+    for mat in mats:
+        N, V, Lv = unit(n), unit(n), unit(n)
+        V = np.where((np.sum(N * V, 1) < 0)[:, None], -V, V).astype(np.float32)  # view above the surface
+        eta = np.where(rng.random(n) < 0.5, 1.0, 1.5).astype(np.float32)
+        etaO = np.where(eta == 1.0, 1.5, 1.0).astype(np.float32)
+        inp = np.concatenate([N, V, Lv, eta[:, None], etaO[:, None]], 1).astype(np.float32)
+        g = r.evalTable(0, inp, 4, material=mat, bsdf_mode=mode)
+        ref = np.zeros((n, 4), np.float32)
+        albedo = np.ascontiguousarray(mat["color"], np.float32)
+        f = np.zeros(3, np.float32)
+        for i in range(n):
+            orc_det.lib.orc_bsdf_eval(mode, mat.ctypes.data, albedo, float(eta[i]), float(etaO[i]), N[i].copy(), V[i].copy(), Lv[i].copy(), f)
+            ref[i, :3] = f
+            ref[i, 3] = orc_det.lib.orc_bsdf_pdf(mode, mat.ctypes.data, float(eta[i]), float(etaO[i]), N[i].copy(), V[i].copy(), Lv[i].copy())
+        assert_bits_equal(g, ref, "BSDFEval/BSDFPdf")
+        seeds = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+        inp = np.concatenate([N, V, eta[:, None], etaO[:, None], seeds.view(np.float32)[:, None]], 1).astype(np.float32)
+        g = r.evalTable(1, inp, 6, material=mat, bsdf_mode=mode)
+        ref = np.zeros((n, 6), np.float32)
+        Lo = np.zeros(3, np.float32); pdf = C.c_float(); st = np.zeros(2, np.uint32)
+        for i in range(n):
+            orc_det.lib.orc_bsdf_sample(mode, mat.ctypes.data, float(eta[i]), float(etaO[i]), N[i].copy(), V[i].copy(), int(seeds[i]), Lo, C.byref(pdf), st)
+            ref[i, :3] = Lo
+            ref[i, 3] = pdf.value
+            ref[i, 4:] = st.view(np.float32)
+        assert_bits_equal(g, ref, "BSDFSample")
+
+
+def test_probe_tables(ptlib, orc_det):
+    import ctypes as C
+
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    for probe in (scenes.disc_probe().BuildCDF(), scenes.sky_probe(512, 256).BuildCDF(), scenes.constant_probe().BuildCDF()):
+        r = SampleRenderer(scenes.cornell_box())
+        r.setProbe(probe)
+        pr = orc_det.make_probe(probe)
+        rng = np.random.default_rng(7)
+        n = 5000
+        seeds = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+        g = r.evalTable(2, seeds.view(np.float32)[:, None], 9)
+        ref = np.zeros((n, 9), np.float32)
+        d = np.zeros(3, np.float32); c = np.zeros(3, np.float32); pdf = C.c_float(); st = np.zeros(2, np.uint32)
+        for i in range(n):
+            orc_det.lib.orc_probe_sample(C.byref(pr), int(seeds[i]), d, c, C.byref(pdf), st)
+            ref[i, :3] = d; ref[i, 3:6] = c; ref[i, 6] = pdf.value; ref[i, 7:] = st.view(np.float32)
+        assert_bits_equal(g, ref, "ProbeSample")
+        dirs = rng.standard_normal((n, 3)).astype(np.float32)
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        dirs[0] = (0, 1, 0); dirs[1] = (0, -1, 0); dirs[2] = (1, 0, 0); dirs[3] = (0, 0, -1)
+        dirs = dirs.astype(np.float32)
+        g = r.evalTable(3, dirs, 6)
+        ref = np.zeros((n, 6), np.float32)
+        uv = np.zeros(2, np.float32); px = np.zeros(4, np.float32)
+        for i in range(n):
+            orc_det.lib.orc_probe_dir_to_uv(dirs[i].copy(), uv)
+            orc_det.lib.orc_probe_eval(C.byref(pr), uv, px)
+            ref[i, :2] = uv; ref[i, 2:] = px
+        assert_bits_equal(g, ref, "ProbeEval(ProbeDirToUV)")
+
+
+def test_make_color_table(ptlib, orc_det):
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    r = SampleRenderer(scenes.cornell_box())
+    rng = np.random.default_rng(8)
+    c = (rng.random((20000, 3)) * 1.4 - 0.2).astype(np.float32)
+    c[:300, 0] = np.linspace(0, 0.005, 300)
+    g = r.evalTable(4, c, 1).view(np.uint32)[:, 0]
+    ref = np.array([orc_det.lib.orc_make_color(c[i].copy()) for i in range(len(c))], np.uint32)
+    assert np.array_equal(g, ref)
+
+
+# ---------------------------------------------------------------- ray search
+def _random_rays(rng, n, lo, hi, tmin=1e-3):
+    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o, np.full((n, 1), tmin, np.float32), d, np.full((n, 1), 1e16, np.float32)], 1).astype(np.float32)
+
+
+def test_trace_cornell_vs_bruteforce(ptlib, orc_det):
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    m = scenes.cornell_box()
+    r = SampleRenderer(m)
+    sc = orc_det.make_scene(m, use_bvh=False)  # brute force: independent of any tree
+    rng = np.random.default_rng(9)
+    rays = _random_rays(rng, 50000, -100, 700)
+    # adversarial: rays aimed exactly at vertices and edge midpoints (shared-edge watertightness, ties)
+    v, idx, _, _ = m.flatten()
+    tri = v[idx]
+    targets = np.concatenate([tri.reshape(-1, 3), 0.5 * (tri[:, 0] + tri[:, 1]), 0.5 * (tri[:, 1] + tri[:, 2]), tri.mean(1)]).astype(np.float32)
+    o = np.array([278.0, 273.0, -900.0], np.float32) + rng.uniform(-50, 50, (len(targets), 3)).astype(np.float32)
+    d = targets - o
+    adv = np.concatenate([o, np.full((len(o), 1), 1e-3, np.float32), d, np.full((len(o), 1), 1e16, np.float32)], 1).astype(np.float32)
+    rays = np.concatenate([rays, adv]).astype(np.float32)
+    (t, prim), _ = r.trace(rays)
+    to, po = orc_det.trace_closest(sc, rays)
+    assert np.array_equal(prim, po)
+    assert_bits_equal(t, to, "closest-hit t")
+    occ, _ = r.trace(rays, any_hit=True)
+    assert np.array_equal(occ, orc_det.trace_any(sc, rays))
+
+
+def test_trace_terrain_vs_oracle(ptlib, orc_det):
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    m = scenes.voxel_terrain(n=96, target_tris=70000)
+    r = SampleRenderer(m)
+    sc = orc_det.make_scene(m, use_bvh=True)  # the oracle's own median-split tree (validated vs brute force on CPU)
+    rng = np.random.default_rng(10)
+    rays = _random_rays(rng, 200000, -110, 110)
+    rays[:, 1] = rng.uniform(-30, 60, len(rays))
+    # secondary-like rays starting ON surfaces: re-launch from hit points
+    (t, prim), _ = r.trace(rays)
+    to, po = orc_det.trace_closest(sc, rays)
+    assert np.array_equal(prim, po) and (prim >= 0).mean() > 0.2
+    assert_bits_equal(t, to, "closest-hit t")
+    hit = prim >= 0
+    P = rays[hit, :3] + t[hit, None] * rays[hit, 4:7]
+    r2 = _random_rays(rng, int(hit.sum()), 0, 1, tmin=1e-2)
+    r2[:, :3] = P
+    occ, _ = r.trace(r2, any_hit=True)
+    assert np.array_equal(occ, orc_det.trace_any(sc, r2))
+    (t2, p2), _ = r.trace(r2)
+    to2, po2 = orc_det.trace_closest(sc, r2)
+    assert np.array_equal(p2, po2)
+    assert_bits_equal(t2, to2, "closest-hit t (surface origins)")
+
+
+# ---------------------------------------------------------------- whole renders
+def test_render_cornell_c1_lambert(ptlib, orc_det, small_probe):
+    """BASELINE config 1: Cornell 256x256, 1 spp, depth 4, Lambert."""
+    m = scenes.cornell_box()
+    w = h = 256
+    r = _renderer(m, small_probe, scenes.CORNELL_CAMERA, w, h, max_depth=4, bsdf_mode=1)
+    g = _gpu_render(r, 1)
+    o = _oracle_render(orc_det, m, small_probe, scenes.CORNELL_CAMERA, w, h, 1, max_depth=4, bsdf_mode=1)
+    _compare(g, o)
+
+
+def test_render_cornell_disney_4spp_depth8(ptlib, orc_det, small_probe):
+    """BASELINE config 2 semantics at a size the CPU finishes in seconds."""
+    m = scenes.cornell_box()
+    w, h = 240, 136
+    r = _renderer(m, small_probe, scenes.CORNELL_CAMERA, w, h)
+    g = _gpu_render(r, 4)
+    o = _oracle_render(orc_det, m, small_probe, scenes.CORNELL_CAMERA, w, h, 4)
+    _compare(g, o)
+    # rays: the GPU skips provably dead rays (see DESIGN.md "ray accounting"), never traces more than the reference
+    assert g["stats"]["radiance_rays"] <= o["radiance_rays"] and g["stats"]["shadow_rays"] <= o["shadow_rays"]
+    assert g["stats"]["radiance_rays"] > 0.8 * o["radiance_rays"]
+
+
+def test_render_progressive_subframes(ptlib, orc_det, small_probe):
+    """deviceProgram.cu:460-467: clamp + running lerp over subframes 0..3."""
+    m = scenes.cornell_box()
+    w, h = 96, 64
+    r = _renderer(m, small_probe, scenes.CORNELL_CAMERA, w, h)
+    g = _gpu_render(r, 2, subframes=4)
+    o = _oracle_render(orc_det, m, small_probe, scenes.CORNELL_CAMERA, w, h, 2, subframes=4)
+    _compare(g, o)
+
+
+def test_render_sample_chunking_invariant(ptlib, orc_det, small_probe):
+    """Splitting a launch into pixel/sample chunks (max_paths) must not change a single bit."""
+    m = scenes.cornell_box()
+    w, h = 96, 64
+    o = _oracle_render(orc_det, m, small_probe, scenes.CORNELL_CAMERA, w, h, 5)
+    for max_paths in (0, 96 * 64 * 2, 1000, 64):
+        r = _renderer(m, small_probe, scenes.CORNELL_CAMERA, w, h, max_paths=max_paths)
+        _compare(_gpu_render(r, 5), o)
+
+
+def test_render_terrain_all_material_branches(ptlib, orc_det):
+    """~70k-triangle voxel terrain, 8 material presets (transmission, subsurface, clearcoat, metal ...)."""
+    m = scenes.voxel_terrain(n=96, target_tris=70000)
+    probe = scenes.sky_probe(512, 256).BuildCDF()
+    w, h = 160, 90
+    r = _renderer(m, probe, scenes.TERRAIN_CAMERA, w, h)
+    g = _gpu_render(r, 4)
+    o = _oracle_render(orc_det, m, probe, scenes.TERRAIN_CAMERA, w, h, 4)
+    _compare(g, o)
+
+
+def test_render_shadow_catcher_two_box(ptlib, orc_det):
+    """The reference's own procedural scene (main.cpp:165-169) with the SHADOW_CATCHER ground:
+    pass-through of secondary rays, alpha from occluded shadow rays, the depth==max trace that is NOT dead."""
+    m = scenes.two_box_scene(True)
+    probe = scenes.disc_probe().BuildCDF()
+    w, h = 96, 64
+    for depth in (8, 2):
+        r = _renderer(m, probe, scenes.TWO_BOX_CAMERA, w, h, max_depth=depth)
+        g = _gpu_render(r, 3, subframes=2)
+        o = _oracle_render(orc_det, m, probe, scenes.TWO_BOX_CAMERA, w, h, 3, subframes=2, max_depth=depth, use_bvh=False)
+        _compare(g, o)
+
+
+def test_render_constant_probe_and_edge_sizes(ptlib, orc_det):
+    """Constant-white probe (loadColor, sv4 main.cpp:167-180); odd sizes that do not fill 8x8 blocks; 1x1."""
+    m = scenes.cornell_box()
+    probe = scenes.constant_probe().BuildCDF()
+    for (w, h) in ((1, 1), (7, 5), (33, 17)):
+        r = _renderer(m, probe, scenes.CORNELL_CAMERA, w, h)
+        g = _gpu_render(r, 2)
+        o = _oracle_render(orc_det, m, probe, scenes.CORNELL_CAMERA, w, h, 2)
+        _compare(g, o)
+
+
+def test_partition_reproduces_single_gpu_bits(ptlib, small_probe):
+    """Tile partition (the multi-GPU path): the union of every rank's pixels equals the unpartitioned image,
+    bit for bit (seeds depend only on pixel index and subframe, deviceProgram.cu:357)."""
+    from optixpathtracer_amd import renderer as R
+
+    m = scenes.cornell_box()
+    w, h = 200, 120
+    full = _gpu_render(_renderer(m, small_probe, scenes.CORNELL_CAMERA, w, h), 3)
+    acc = np.zeros_like(full["accum"])
+    cover = np.zeros((h, w), np.int32)
+    world = 3
+    for rank in range(world):
+        r = _renderer(m, small_probe, scenes.CORNELL_CAMERA, w, h)
+        r.setPartition(rank, world, 16, 8)
+        g = _gpu_render(r, 3)
+        mine = g["accum"][..., 3] == 1.0  # alpha channel of accum is written as 1 by rendered pixels only
+        cover += mine
+        acc[mine] = g["accum"][mine]
+        owned, padded = r.ownedPixels()
+        assert owned == mine.sum() and padded >= owned
+    assert (cover == 1).all()
+    assert_bits_equal(acc, full["accum"], "partitioned accum")
+
+
+def test_tonemap_sqrt_epilogue(ptlib, orc_det, small_probe):
+    """toneMap.cu:41-58 computeFinalPixelColorsKernel."""
+    m = scenes.cornell_box()
+    w, h = 64, 48
+    r = _renderer(m, small_probe, scenes.CORNELL_CAMERA, w, h)
+    g = _gpu_render(r, 2)
+    out = r.tonemapSqrt()
+    ref = np.zeros(w * h, np.uint32)
+    orc_det.lib.orc_tonemap_sqrt(np.ascontiguousarray(g["accum"]).reshape(-1), ref, w * h)
+    assert np.array_equal(out.reshape(-1), ref)
+
+
+def test_error_behaviour(ptlib, small_probe):
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    r = SampleRenderer(scenes.cornell_box())
+    r.render()  # before resize: silently nothing (SimplePathtracer.cpp:77)
+    r.resize((0, 0))  # ignored (:112)
+    r.resize((32, 16))
+    with pytest.raises(RuntimeError):
+        r.render()  # no probe
+    with pytest.raises(RuntimeError):
+        r.setProbe(scenes.constant_probe())  # BuildCDF not run: "Probe Data is not valid" (Probe.h:104)
+    bad = scenes.Model([scenes.TriangleMesh(np.zeros((3, 3), np.float32), np.array([[0, 1, 5]], np.uint32), scenes.Material())])
+    with pytest.raises(RuntimeError):
+        SampleRenderer(bad)
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE sizes)
+def test_fullsize_1080p_terrain_properties(ptlib, orc_det):
+    """C3 size (1M triangles, 1920x1080, 4 spp, depth 8): determinism, finiteness, ray bound, and a
+    bit-exact window against the oracle (rows of the same full-size launch rendered on the CPU)."""
+    m = scenes.voxel_terrain()
+    assert m.num_triangles == 1_000_000
+    probe = scenes.sky_probe(2048, 1024).BuildCDF()
+    w, h = 1920, 1080
+    r = _renderer(m, probe, scenes.TERRAIN_CAMERA, w, h)
+    g1 = _gpu_render(r, 4)
+    g2 = _gpu_render(r, 4)  # subframe 0 again: idempotent
+    assert np.array_equal(g1["accum"].view(np.uint32), g2["accum"].view(np.uint32))
+    assert np.isfinite(g1["accum"]).all()
+    st = g1["stats"]
+    assert st["paths"] == w * h * 4
+    assert st["radiance_rays"] <= st["paths"] * 8 and st["shadow_rays"] <= st["radiance_rays"]
+    # window: the oracle renders a full-size frame's pixel subset = same seeds (pixel index uses the full width)
+    sc = orc_det.make_scene(m, True)
+    pr = orc_det.make_probe(probe)
+    U, V, W = scenes.uvw_frame(**scenes.TERRAIN_CAMERA, aspect=w / h)
+    from oracle import orc as orc_mod
+    import ctypes as C
+
+    prm = orc_mod.Params()
+    prm.width, prm.height, prm.subframe_index, prm.samples_per_launch, prm.max_depth, prm.bsdf_mode = w, h, 0, 4, 8, 0
+    for dst, src in ((prm.eye, scenes.TERRAIN_CAMERA["eye"]), (prm.U, U), (prm.V, V), (prm.W, W)):
+        for k in range(3):
+            dst[k] = float(src[k])
+    rows = [5, 333, 540, 777, 1079]
+    accum = np.zeros((h, w, 4), np.float32)
+    orc_det.lib.orc_render_rows.argtypes = [C.c_void_p, C.POINTER(orc_mod.Probe), C.POINTER(orc_mod.Params), orc_mod.f32p, orc_mod.i32p, C.c_int, C.c_int]
+    orc_det.lib.orc_render_rows(sc.h, C.byref(pr), C.byref(prm), accum.reshape(-1), np.array(rows, np.int32), len(rows), 8)
+    for y in rows:
+        assert_bits_equal(g1["accum"][y], accum[y], f"row {y} of the 1080p frame")

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the hot path (BASELINE.json metric) on N MI355X GPUs of one node.
+
+A "step" is one frame: one pt_render of the workload (the reference's one optixLaunch per frame,
+SimplePathtracer.cpp:73-97) with scene, BVH and probe already resident in HBM.  Default workload is
+BASELINE config C3: the procedural 1,000,000-triangle voxel terrain, 1920x1080, 4 spp, depth 8,
+Disney BSDF, 2048x1024 sky+sun probe.  N>1: the image is tile-partitioned (interleaved 64x16 tiles,
+no data-path collective; weak/strong is 'strong' — the frame is fixed and split over ranks) and
+`value` = rays traced by all ranks / max-over-ranks time.  One RCCL all-gather of the packed frame
+runs after the timed region as the display hand-off (reported as gather_ms).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene, camera, width, height, spp, depth)
+    "c3_terrain1M_1080p_4spp_d8": ("terrain", "TERRAIN_CAMERA", 1920, 1080, 4, 8),
+    "c2_cornell_1080p_4spp_d8": ("cornell", "CORNELL_CAMERA", 1920, 1080, 4, 8),
+    "c4_terrain1M_4k_16spp_d8": ("terrain", "TERRAIN_CAMERA", 3840, 2160, 16, 8),
+}
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_RADIANCE_RAY_TRACE = 32 + 4 + 8  # k_trace<0>: rayO+rayD (32) + queue entry (4) + hit write (8)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3_terrain1M_1080p_4spp_d8", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-paths", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    from optixpathtracer_amd import renderer as R
+    from optixpathtracer_amd import scenes
+
+    scene_name, cam_name, w, h, spp, depth = WORKLOADS[args.workload]
+    model = scenes.voxel_terrain() if scene_name == "terrain" else scenes.cornell_box()
+    probe = scenes.sky_probe(2048, 1024).BuildCDF()
+    cam = getattr(scenes, cam_name)
+
+    r = R.SampleRenderer(model, device=local_rank)
+    r.setProbe(probe)
+    r.setOptions(max_depth=depth, max_paths=args.max_paths)
+    if world > 1:
+        r.setPartition(rank, world, 64, 16)
+    r.resize((w, h))
+    r.setCamera(R.make_camera(cam, w / h))
+    r.launchParams.samples_per_launch = spp
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        r.launchParams.frame.subframe_index = k
+        r.render()
+    barrier()
+    rays = 0
+    agg = dict(trace_ms=0.0, shadow_ms=0.0, shade_ms=0.0, other_ms=0.0, render_ms=0.0, trace_launches=0, radiance_rays=0, shadow_rays=0)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        r.launchParams.frame.subframe_index = args.warmup + k  # progressive accumulation, like the reference's loop
+        r.render()
+        st = r.stats()
+        rays += st["radiance_rays"] + st["shadow_rays"]
+        for key in agg:
+            agg[key] += st[key]
+    barrier()
+    dt = time.perf_counter() - t0
+
+    tot = torch.tensor([dt, float(rays)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tot.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, rays_all = float(tmax[0]), float(tsum[1])
+    else:
+        dt_max, rays_all = dt, float(rays)
+
+    # display hand-off: one all-gather of the packed rgba8 frame (outside the timed region)
+    gather_ms = None
+    if dist is not None:
+        owned, padded = r.ownedPixels()
+        src = torch.zeros(padded, dtype=torch.int32, device="cuda")
+        dst = torch.zeros(padded * world, dtype=torch.int32, device="cuda")
+        r.pack(R.PT_BUF_FRAME, src.data_ptr())
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(dst, src)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        r.unpack(R.PT_BUF_FRAME, dst.data_ptr())
+
+    if rank == 0:
+        mrays = rays_all / dt_max / 1e6
+        # roofline of the dominant kernel, k_trace<0> (closest-hit traversal): algorithmic bytes per launch
+        # = radiance rays of the launch x 44 B (DESIGN.md "roofline"), duration = HIP-event time on the render stream
+        n_launch = max(1, agg["trace_launches"])
+        avg_ms = agg["trace_ms"] / n_launch
+        alg_bytes = agg["radiance_rays"] / n_launch * BYTES_PER_RADIANCE_RAY_TRACE
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (and ms/frame) at 1080p 4spp depth8; 1/2/4/8 MI355X scaling",
+            "value": round(mrays, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": args.workload, "triangles": model.num_triangles, "width": w, "height": h, "spp": spp,
+                "max_depth": depth, "bsdf": "disney", "probe": "sky2048x1024+sun", "partition": f"tiles64x16/{world}",
+            },
+            "rays_per_frame": int(rays_all / args.steps),
+            "kernel_ms_per_frame": {k: round(agg[k] / args.steps, 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
+            "bvh": {"nodes": st["bvh_nodes"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2)},
+            "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "roofline": {
+                "kernel": "k_trace<0> (closest-hit BVH traversal)", "bound": "hbm", "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes),
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model, probe, cam, w, h, spp, depth)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(model, probe, cam, w, h, spp, depth):
+    """The scalar C port of the same path (oracle/, 'port'), all host cores, on a bounded sample of the
+    same workload: every 12th row of the full-size frame (same seeds as the full launch)."""
+    import ctypes as C
+
+    from oracle import orc
+    from optixpathtracer_amd import scenes
+
+    O = orc.Oracle("det")
+    sc = O.make_scene(model, True)
+    pr = O.make_probe(probe)
+    U, V, W = scenes.uvw_frame(**cam, aspect=w / h)
+    cores = os.cpu_count() or 1
+    nthreads = min(cores, 64)
+    # sample: a reduced-resolution frame of the same camera/scene/spp/depth (rays are counted, not extrapolated)
+    sw, sh = max(16, w // 4), max(9, h // 4)
+    U, V, W = scenes.uvw_frame(**cam, aspect=sw / sh)
+    t0 = time.perf_counter()
+    out = O.render(sc, pr, (U, V, W), cam["eye"], sw, sh, spp, depth, 0, 0, None, nthreads)
+    dt = time.perf_counter() - t0
+    rays = out["radiance_rays"] + out["shadow_rays"]
+    return {
+        "value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": nthreads, "kind": "port",
+        "sample": f"{sw}x{sh} frame of the same scene/camera/{spp}spp/depth{depth}, {rays} rays in {dt:.2f}s (reference-order ray count)",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -80,8 +80,8 @@ __global__ void __launch_bounds__(256) k_generate(PathState st, FrameParams fp, 
         st.direct[i] = z;
         st.indirect[i] = z;
         st.alpha[i] = z;
-        st.nrm[i] = bp.carry ? bp.pixNormal[pix] : z;
-        st.alb[i] = bp.carry ? bp.pixAlbedo[pix] : z;
+        st.nrm[i] = (bp.carry && bp.s0 > 0) ? bp.pixNormal[pix] : z; // carry-in of the running per-pixel sum
+        st.alb[i] = (bp.carry && bp.s0 > 0) ? bp.pixAlbedo[pix] : z;
         if (st.prdN) {
             st.prdN[i] = z;
             st.prdA[i] = z;

@@ -113,16 +113,15 @@ def main():
     # display hand-off: one all-gather of the packed rgba8 frame (outside the timed region)
     gather_ms = None
     if dist is not None:
-        owned, padded = r.ownedPixels()
-        src = torch.zeros(padded, dtype=torch.int32, device="cuda")
-        dst = torch.zeros(padded * world, dtype=torch.int32, device="cuda")
-        r.pack(R.PT_BUF_FRAME, src.data_ptr())
+        from optixpathtracer_amd import multigpu
+
+        packer = multigpu.DevicePacker(r)
+        multigpu.exchange_frame(packer, R.PT_BUF_FRAME, world, dist.all_gather_into_tensor)  # warm RCCL
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(dst, src)
+        multigpu.exchange_frame(packer, R.PT_BUF_ACCUM, world, dist.all_gather_into_tensor)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        r.unpack(R.PT_BUF_FRAME, dst.data_ptr())
 
     if rank == 0:
         mrays = rays_all / dt_max / 1e6
@@ -169,7 +168,8 @@ def main():
 
 def cpu_baseline(model, probe, cam, w, h, spp, depth):
     """The scalar C port of the same path (oracle/, 'port'), all host cores, on a bounded sample of the
-    same workload: every 12th row of the full-size frame (same seeds as the full launch)."""
+    same workload: the same scene/camera/spp/depth at half resolution (a quarter of the frame's paths;
+    rays are counted, not extrapolated).  Timed region = the render only (BVH build excluded, as on the GPU)."""
     import ctypes as C
 
     from oracle import orc
@@ -181,8 +181,7 @@ def cpu_baseline(model, probe, cam, w, h, spp, depth):
     U, V, W = scenes.uvw_frame(**cam, aspect=w / h)
     cores = os.cpu_count() or 1
     nthreads = min(cores, 64)
-    # sample: a reduced-resolution frame of the same camera/scene/spp/depth (rays are counted, not extrapolated)
-    sw, sh = max(16, w // 4), max(9, h // 4)
+    sw, sh = max(16, w // 2), max(9, h // 2)
     U, V, W = scenes.uvw_frame(**cam, aspect=sw / sh)
     t0 = time.perf_counter()
     out = O.render(sc, pr, (U, V, W), cam["eye"], sw, sh, spp, depth, 0, 0, None, nthreads)

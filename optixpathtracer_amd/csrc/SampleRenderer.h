@@ -1,0 +1,137 @@
+// SampleRenderer.h — header-only C++ facade with the reference's public surface
+// (HelloPathtracing_original/SimplePathtracer.h:38-176, Model.h:10-42, Material.h:11-69, Probe.h:8-88)
+// over the C ABI of libptamd.so (include/pt_amd.h).  A maintainer of the reference swaps
+// SimplePathtracer.{h,cpp} + deviceProgram.cu for this header and links -lptamd; main.cpp's calls
+// (main.cpp:211-218,262,273,286) compile unchanged apart from the sutil display buffer type
+// (see INTEGRATION.md).  Errors surface as std::runtime_error, like sutil::Exception did.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_amd.h"
+
+namespace ptamd {
+
+struct float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct uint3 { uint32_t x, y, z; };
+typedef float4 Color;
+
+static const int MATERIAL_FLAG_NONE = 0;
+static const int MATERIAL_FLAG_SHADOW_CATCHER = 1 << 0; // Material.h:9
+
+// Material.h:11-69 — same fields, same defaults, layout-compatible with pt_material
+struct Material {
+    Material() {
+        color = {0.6f, 0.6f, 0.6f};
+        emission = {0.f, 0.f, 0.f};
+        absorption = {0.f, 0.f, 0.f};
+        eta = 0.0f; metallic = 0.0f; subsurface = 0.0f; specular = 0.5f; roughness = 1.0f; specularTint = 0.0f;
+        anisotropic = 0.0f; sheen = 0.0f; sheenTint = 0.0f; clearcoat = 0.0f; clearcoatGloss = 1.0f; transmission = 0.0f;
+        bump = 0.0f; bumpTile = {10.0f, 10.0f, 10.0f};
+        flags = 0;
+    }
+    float GetIndexOfRefraction() const { return eta == 0.0f ? 2.0f / (1.0f - std::sqrt(0.08f * specular)) - 1.0f : eta; }
+    float3 emission, color, absorption;
+    float eta, metallic, subsurface, specular, roughness, specularTint, anisotropic, sheen, sheenTint, clearcoat, clearcoatGloss, transmission;
+    float bump;
+    float3 bumpTile;
+    int flags;
+};
+static_assert(sizeof(Material) == sizeof(pt_material), "Material must stay layout-compatible with pt_material");
+
+// Model.h:10-42
+struct TriangleMesh {
+    std::vector<float3> vertex;
+    std::vector<float3> normal;   // carried like the reference; the hot path shades with geometric normals
+    std::vector<float2> texcoord; // (deviceProgram.cu:490), so these are not uploaded
+    std::vector<uint3> index;
+    Material material;
+    int diffuseTextureID{-1};
+};
+struct Model {
+    ~Model() { for (auto m : meshes) delete m; }
+    std::vector<TriangleMesh*> meshes;
+};
+
+// Probe.h:8-88
+struct ProbeData {
+    int width = 0, height = 0;
+    Color* data = nullptr;
+    float3 offset{0, 0, 0};
+    bool valid = false;
+    std::vector<float> pdfValuesX, cdfValuesX, pdfValuesY, cdfValuesY;
+    void BuildCDF() { // Probe.h:29-77, native host implementation in libptamd
+        pdfValuesX.resize((size_t)width * height); cdfValuesX.resize((size_t)width * height);
+        pdfValuesY.resize(height); cdfValuesY.resize(height);
+        if (pt_build_cdf(&data[0].x, width, height, pdfValuesX.data(), cdfValuesX.data(), pdfValuesY.data(), cdfValuesY.data()) != PT_OK)
+            throw std::runtime_error("BuildCDF failed");
+        valid = true;
+    }
+};
+
+// sutil::Camera subset the renderer reads (sutil/Camera.h)
+struct Camera {
+    float3 eye{0, 0, 0}, lookat{0, 0, 1}, up{0, 1, 0};
+    float fovY = 35.f, aspectRatio = 1.f;
+    void UVWFrame(float3& U, float3& V, float3& W) const { pt_uvw_frame(&eye.x, &lookat.x, &up.x, fovY, aspectRatio, &U.x, &V.x, &W.x); }
+};
+
+// the fields of LaunchParams the application pokes directly (LaunchParams.h:51-79; main.cpp:131-144,286)
+struct LaunchParams {
+    struct { int2 size{0, 0}; unsigned int subframe_index = 0; } frame;
+    unsigned int samples_per_launch = 1;
+};
+
+class SampleRenderer {
+  public:
+    explicit SampleRenderer(const Model* model, int device = 0) {
+        std::vector<pt_mesh_desc> md(model->meshes.size());
+        for (size_t i = 0; i < md.size(); ++i) {
+            const TriangleMesh* m = model->meshes[i];
+            md[i].vertex = &m->vertex[0].x; md[i].num_vertices = (uint32_t)m->vertex.size();
+            md[i].index = &m->index[0].x; md[i].num_triangles = (uint32_t)m->index.size();
+            static_assert(sizeof(pt_material) == 104, "");
+            md[i].material = *reinterpret_cast<const pt_material*>(&m->material);
+            md[i].diffuse_texture_id = m->diffuseTextureID;
+        }
+        pt_scene_desc sd{md.data(), (uint32_t)md.size()};
+        if (pt_create(&sd, device, &ctx) != PT_OK) throw std::runtime_error(std::string("SampleRenderer: ") + pt_last_error(nullptr));
+    }
+    ~SampleRenderer() { pt_destroy(ctx); }
+    SampleRenderer(const SampleRenderer&) = delete;
+    SampleRenderer& operator=(const SampleRenderer&) = delete;
+
+    void render() { ck(pt_render(ctx, launchParams.samples_per_launch, launchParams.frame.subframe_index, nullptr)); }
+    // render(sutil::CUDAOutputBuffer<uint32_t>&): the caller's mapped buffer receives the rgba8 frame
+    void render(uint32_t* h_pixels) { ck(pt_render(ctx, launchParams.samples_per_launch, launchParams.frame.subframe_index, h_pixels)); }
+    void resize(const int2& newSize) {
+        ck(pt_resize(ctx, newSize.x, newSize.y));
+        if (newSize.x && newSize.y) launchParams.frame.size = newSize;
+    }
+    void downloadPixels(uint32_t h_pixels[]) {
+        ck(pt_download(ctx, PT_BUF_FRAME, h_pixels, sizeof(uint32_t) * (size_t)launchParams.frame.size.x * launchParams.frame.size.y));
+    }
+    void setCamera(const Camera& camera) {
+        float3 U, V, W;
+        camera.UVWFrame(U, V, W);
+        ck(pt_set_camera(ctx, &camera.eye.x, &U.x, &V.x, &W.x));
+    }
+    void setProbe(const ProbeData& probe) {
+        if (!probe.valid) throw std::runtime_error("Probe Data is not valid"); // Probe.h:104-105
+        ck(pt_set_probe(ctx, &probe.data[0].x, probe.pdfValuesX.data(), probe.cdfValuesX.data(), probe.pdfValuesY.data(), probe.cdfValuesY.data(), probe.width, probe.height));
+    }
+    bool denoiserOn = false; // SimplePathtracer.h:63 — the reference's denoiser is a dead stub (OptixDenoiser.cpp:15-42)
+    LaunchParams launchParams;
+    pt_ctx* ctx = nullptr;
+
+  private:
+    void ck(int rc) { if (rc != PT_OK) throw std::runtime_error(pt_last_error(ctx)); }
+};
+
+} // namespace ptamd

@@ -5,7 +5,7 @@
 // primitive index, so the answer does not depend on the tree or on traversal order.  The triangle
 // test is a sign-consistent scalar-triple-product test (watertight across shared edges like the
 // RT-core test it replaces, no backface culling, OPTIX_RAY_FLAG_NONE); every operation is a single
-// rounded IEEE op, mirrored one for one by oracle/pt_oracle.c (wtri), so t is bit-identical.
+// rounded IEEE op, mirrored one for one by the CPU checker (wtri), so t is bit-identical.
 // Box tests are conservative (far plane widened, boxes padded at build) — they may only ever
 // admit extra triangles, never reject one the triangle test accepts.
 #pragma once

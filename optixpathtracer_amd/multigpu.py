@@ -1,0 +1,67 @@
+"""Multi-GPU: one process per GPU, image-space sharding, one RCCL all-gather per displayed frame.
+
+The reference is single-GPU (SURVEY.md §2 "Parallelism": none).  Pixels are independent and seeds depend
+only on (pixel index, subframe) (deviceProgram.cu:357), so the image is cut into interleaved tiles
+(the pattern of sutil/WorkDistribution.h:34-91) and every rank renders its own tiles with the scene, BVH
+and probe replicated; progressive accumulation needs no communication.  The only exchange is the display
+hand-off: each rank packs its pixels (pt_pack), ranks all-gather the packed arrays over RCCL/xGMI
+(rank-major, padded to the largest share — exactly what all_gather_into_tensor produces) and scatter
+them into the full frame (pt_unpack).  4K float4 = 133 MB in total, 16.6 MB per rank on 8 GPUs: a
+single direct all-gather keeps all 7 xGMI links busy with one message each; no ring all-reduce of
+zero-padded full frames (8x the bytes, per-link bound).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def pixel_lists(width: int, height: int, world: int, tile_w: int = 64, tile_h: int = 16):
+    """Host mirror of the library's partition (pt_api.hip build_pixel_lists): per rank, the owned pixels as
+    x | y << 16 in 8x8-block order; owner of a block = (x0/tile_w + y0/tile_h) % world."""
+    assert tile_w % 8 == 0 and tile_h % 8 == 0 and world >= 1
+    lists = [[] for _ in range(world)]
+    for by in range((height + 7) // 8):
+        for bx in range((width + 7) // 8):
+            owner = ((bx * 8) // tile_w + (by * 8) // tile_h) % world
+            ys, xs = np.meshgrid(np.arange(by * 8, by * 8 + 8), np.arange(bx * 8, bx * 8 + 8), indexing="ij")
+            ok = (xs < width) & (ys < height)
+            lists[owner].append((xs[ok].astype(np.uint32) | (ys[ok].astype(np.uint32) << 16)))
+    return [np.concatenate(l) if l else np.zeros(0, np.uint32) for l in lists]
+
+
+class DevicePacker:
+    """pack/unpack through the library's kernels on torch CUDA tensors (device memory + RCCL plumbing)."""
+
+    def __init__(self, renderer):
+        import torch
+
+        self.torch = torch
+        self.r = renderer
+
+    def owned_padded(self):
+        return self.r.ownedPixels()
+
+    def alloc(self, n, which):
+        from .renderer import PT_BUF_FRAME
+
+        if which == PT_BUF_FRAME:
+            return self.torch.zeros(n, dtype=self.torch.int32, device="cuda")
+        return self.torch.zeros((n, 4), dtype=self.torch.float32, device="cuda")
+
+    def pack(self, which, dst):
+        self.r.pack(which, dst.data_ptr())
+
+    def unpack(self, which, src):
+        self.r.unpack(which, src.data_ptr())
+
+
+def exchange_frame(packer, which, world: int, all_gather_into_tensor):
+    """The display hand-off: pack → all-gather → unpack.  `all_gather_into_tensor(dst, src)` is
+    torch.distributed's (backend nccl == RCCL on ROCm; gloo in the CPU tests)."""
+    owned, padded = packer.owned_padded()
+    src = packer.alloc(padded, which)
+    dst = packer.alloc(padded * world, which)
+    packer.pack(which, src)
+    all_gather_into_tensor(dst, src)
+    packer.unpack(which, dst)
+    return dst

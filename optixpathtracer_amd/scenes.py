@@ -76,7 +76,7 @@ class Model:  # Model.h:31-42
         return int(sum(len(m.index) for m in self.meshes))
 
     def flatten(self):
-        """Global arrays the C-ABI / oracle take: verts (nv,3), idx (nt,3) global, tri_mesh (nt,), mats (nmesh,)."""
+        """Global arrays the C-ABI takes: verts (nv,3), idx (nt,3) global, tri_mesh (nt,), mats (nmesh,)."""
         verts, idx, tri_mesh, base = [], [], [], 0
         for mi, m in enumerate(self.meshes):
             verts.append(np.ascontiguousarray(m.vertex, dtype=np.float32))

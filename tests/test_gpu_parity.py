@@ -432,3 +432,27 @@ def test_fullsize_1080p_terrain_properties(ptlib, orc_det):
     orc_det.lib.orc_render_rows(sc.h, C.byref(pr), C.byref(prm), accum.reshape(-1), np.array(rows, np.int32), len(rows), 8)
     for y in rows:
         assert_bits_equal(g1["accum"][y], accum[y], f"row {y} of the 1080p frame")
+
+
+def test_partition_matches_host_mirror(ptlib, small_probe):
+    """The library's pixel partition equals optixpathtracer_amd.multigpu.pixel_lists (the layout contract of
+    the all-gather), checked through pack(): packed accum == accum gathered with the host list."""
+    import torch
+
+    from optixpathtracer_amd import multigpu
+    from optixpathtracer_amd import renderer as R
+
+    m = scenes.cornell_box()
+    w, h, world = 100, 60, 4
+    lists = multigpu.pixel_lists(w, h, world, 16, 8)
+    for rank in (0, 3):
+        r = _renderer(m, small_probe, scenes.CORNELL_CAMERA, w, h)
+        r.setPartition(rank, world, 16, 8)
+        g = _gpu_render(r, 1)
+        owned, padded = r.ownedPixels()
+        assert owned == len(lists[rank]) and padded == max(len(l) for l in lists)
+        buf = torch.zeros((padded, 4), dtype=torch.float32, device="cuda")
+        r.pack(R.PT_BUF_ACCUM, buf.data_ptr())
+        px = lists[rank]
+        exp = g["accum"][(px >> 16).astype(np.int64), (px & 0xFFFF).astype(np.int64)]
+        assert np.array_equal(buf.cpu().numpy()[:owned], exp)

@@ -1,0 +1,178 @@
+"""Properties of the restated parts that the reference cannot pin (it has no tests; Disney.cuh and
+deviceProgram.cu do not compile without OptiX headers): the checks its own commented-out BSDFTest
+(Disney.cuh:430-503) sketches, plus internal consistency of the checker itself."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from optixpathtracer_amd import scenes
+
+
+def _unit(rng, n):
+    v = rng.standard_normal((n, 3))
+    return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+
+def test_detmath_accuracy_vs_float64(orc_det):
+    rng = np.random.default_rng(1)
+    n = 200000
+
+    def ulps(got, exact):
+        exact32 = exact.astype(np.float32)
+        return np.abs(got.astype(np.float64) - exact) / np.spacing(np.maximum(np.abs(exact32), np.float32(1e-30))).astype(np.float64)
+
+    x = rng.uniform(0, 2 * np.pi, n).astype(np.float32)
+    # sin/cos near their zeros lose relative accuracy like every float implementation; bound the absolute error there
+    assert np.abs(orc_det.math_table(0, x).astype(np.float64) - np.sin(x.astype(np.float64))).max() < 2.5e-7
+    assert np.abs(orc_det.math_table(1, x).astype(np.float64) - np.cos(x.astype(np.float64))).max() < 2.5e-7
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    assert ulps(orc_det.math_table(2, x), np.arccos(x.astype(np.float64))).max() <= 4
+    a = rng.standard_normal(n).astype(np.float32); b = rng.standard_normal(n).astype(np.float32)
+    assert np.abs(orc_det.math_table(3, a, b).astype(np.float64) - np.arctan2(a.astype(np.float64), b.astype(np.float64))).max() < 1e-6
+    x = np.exp(rng.uniform(-14, 1, n)).astype(np.float32)
+    assert np.abs(orc_det.math_table(4, x).astype(np.float64) - np.log(x.astype(np.float64))).max() < 2e-6
+    x = rng.uniform(0.003, 1, n).astype(np.float32)
+    y = np.full(n, 1 / 2.4, np.float32)
+    assert ulps(orc_det.math_table(5, x, y), np.power(x.astype(np.float64), y.astype(np.float64))).max() <= 16
+
+
+def test_libm_and_det_oracles_agree_statistically(orc_det, orc_libm):
+    """The two math modes are different roundings of the same algorithm: almost every pixel equal to 1e-4,
+    the rest are path flips (chaotic), and the image-level relative L2 is small."""
+    m = scenes.cornell_box()
+    probe = scenes.sky_probe(256, 128).BuildCDF()
+    w, h = 96, 64
+    U, V, W = scenes.uvw_frame(**scenes.CORNELL_CAMERA, aspect=w / h)
+    imgs = []
+    for O in (orc_libm, orc_det):
+        r = O.render(O.make_scene(m), O.make_probe(probe), (U, V, W), scenes.CORNELL_CAMERA["eye"], w, h, 8)
+        imgs.append(r["accum"][..., :3].astype(np.float64))
+    a, b = imgs
+    rel = np.abs(a - b).max(-1) / (np.abs(a).max(-1) + 1e-3)
+    assert (rel < 1e-4).mean() > 0.995
+    assert np.linalg.norm(a - b) / np.linalg.norm(a) < 0.05
+
+
+@pytest.mark.parametrize("mat_i", range(9))
+def test_bsdf_sample_pdf_consistency(orc_det, mat_i):
+    """BSDFTest's idea: every sampled direction has pdf > 0 there (or the sample is rejected), BSDFPdf of
+    the sampled direction equals the pdf BSDFSample returned (non-specular lobes), values are finite."""
+    mats = scenes.material_presets() + [scenes.Material()]
+    mat = mats[mat_i]
+    rng = np.random.default_rng(100 + mat_i)
+    n = 3000
+    N = _unit(rng, n); V = _unit(rng, n)
+    V = np.where((np.sum(N * V, 1) < 0)[:, None], -V, V).astype(np.float32)
+    L = orc_det.lib
+    Lo = np.zeros(3, np.float32); pdf = C.c_float(); st = np.zeros(2, np.uint32); f = np.zeros(3, np.float32)
+    albedo = np.ascontiguousarray(mat["color"], np.float32)
+    n_pos = 0
+    for i in range(n):
+        L.orc_bsdf_sample(0, mat.ctypes.data, 1.0, 1.5, N[i].copy(), V[i].copy(), 12345 + i, Lo, C.byref(pdf), st)
+        assert np.isfinite(pdf.value)
+        if pdf.value <= 0:
+            continue
+        n_pos += 1
+        assert abs(np.linalg.norm(Lo) - 1) < 1e-3
+        p2 = L.orc_bsdf_pdf(0, mat.ctypes.data, 1.0, 1.5, N[i].copy(), V[i].copy(), Lo.copy())
+        if float(mat["transmission"]) == 0.0:
+            assert p2 == pdf.value  # BSDFSample ends in pdf = BSDFPdf(...) (Disney.cuh:312)
+        L.orc_bsdf_eval(0, mat.ctypes.data, albedo, 1.0, 1.5, N[i].copy(), V[i].copy(), Lo.copy(), f)
+        assert np.isfinite(f).all() and (f >= 0).all()
+    assert n_pos > 0.5 * n
+
+
+def test_bsdf_pdf_integrates_to_at_most_one(orc_det):
+    """Monte-Carlo integral of BSDFPdf over the sphere (uniform directions): <= 1 for the default material
+    (it is 0.5*cosine + 0.5*GGX-half-vector pdf above the surface, 0 below)."""
+    mat = scenes.Material()
+    rng = np.random.default_rng(7)
+    n = 40000
+    Lv = _unit(rng, n)
+    N = np.array([0, 0, 1], np.float32); V = np.array([0.3, 0.1, 0.948], np.float32); V /= np.linalg.norm(V)
+    s = 0.0
+    for i in range(n):
+        s += orc_det.lib.orc_bsdf_pdf(0, mat.ctypes.data, 1.0, 1.5, N, V, Lv[i].copy())
+    integral = s / n * 4 * np.pi
+    assert 0.5 < integral < 1.05  # < 1: half-vector reflections that land below the surface carry no pdf there
+
+
+def test_lambert_mode_matches_simple_bsdf(orc_det):
+    """USE_SIMPLE_BSDF (Disney.cuh:125-147): pdf 1/2pi above, 0 below; f = color/pi."""
+    mat = scenes.Material(color=(0.2, 0.5, 0.9))
+    N = np.array([0, 1, 0], np.float32); V = np.array([0, 1, 0], np.float32)
+    f = np.zeros(3, np.float32)
+    up = np.array([0.6, 0.8, 0], np.float32); dn = np.array([0.6, -0.8, 0], np.float32)
+    assert abs(orc_det.lib.orc_bsdf_pdf(1, mat.ctypes.data, 1, 1.5, N, V, up) - 1 / (2 * np.pi)) < 1e-7
+    assert orc_det.lib.orc_bsdf_pdf(1, mat.ctypes.data, 1, 1.5, N, V, dn) == 0
+    orc_det.lib.orc_bsdf_eval(1, mat.ctypes.data, np.ascontiguousarray(mat["color"]), 1, 1.5, N, V, up, f)
+    assert np.allclose(f, np.array([0.2, 0.5, 0.9]) / np.pi, rtol=1e-6)
+
+
+def test_oracle_bvh_equals_bruteforce(orc_det):
+    m = scenes.voxel_terrain(n=40, target_tris=12000)
+    s1 = orc_det.make_scene(m, False); s2 = orc_det.make_scene(m, True)
+    rng = np.random.default_rng(11)
+    n = 4000
+    o = rng.uniform(-120, 120, (n, 3)).astype(np.float32); o[:, 1] = rng.uniform(-10, 60, n)
+    d = _unit(rng, n)
+    rays = np.concatenate([o, np.full((n, 1), 1e-3, np.float32), d, np.full((n, 1), 1e16, np.float32)], 1).astype(np.float32)
+    t1, p1 = orc_det.trace_closest(s1, rays); t2, p2 = orc_det.trace_closest(s2, rays)
+    assert np.array_equal(p1, p2) and np.array_equal(t1.view(np.uint32), t2.view(np.uint32)) and (p1 >= 0).mean() > 0.2
+    assert np.array_equal(orc_det.trace_any(s1, rays), orc_det.trace_any(s2, rays))
+
+
+def test_watertight_shared_edges(orc_det):
+    """Rays aimed at points on the shared diagonal of a quad's two triangles never slip through."""
+    m = scenes.Model([scenes._quads_to_mesh([[(0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1)]], scenes.Material())])
+    sc = orc_det.make_scene(m, False)
+    rng = np.random.default_rng(12)
+    n = 20000
+    s = rng.random(n).astype(np.float32)
+    target = np.stack([s, np.zeros(n, np.float32), s], 1)  # on the diagonal (0,0,0)-(1,0,1)
+    o = np.stack([rng.uniform(-2, 3, n), rng.uniform(0.5, 5, n), rng.uniform(-2, 3, n)], 1).astype(np.float32)
+    d = target - o
+    rays = np.concatenate([o, np.full((n, 1), 1e-3, np.float32), d, np.full((n, 1), 1e16, np.float32)], 1).astype(np.float32)
+    t, p = orc_det.trace_closest(sc, rays)
+    inner = (s > 1e-3) & (s < 1 - 1e-3)
+    assert (p[inner] >= 0).all()
+
+
+def test_render_is_thread_count_invariant_and_progressive(orc_det):
+    m = scenes.cornell_box()
+    probe = scenes.constant_probe().BuildCDF()
+    w, h = 40, 24
+    U, V, W = scenes.uvw_frame(**scenes.CORNELL_CAMERA, aspect=w / h)
+    sc, pr = orc_det.make_scene(m), orc_det.make_probe(probe)
+    a = orc_det.render(sc, pr, (U, V, W), scenes.CORNELL_CAMERA["eye"], w, h, 3, nthreads=1)
+    b = orc_det.render(sc, pr, (U, V, W), scenes.CORNELL_CAMERA["eye"], w, h, 3, nthreads=5)
+    assert np.array_equal(a["accum"], b["accum"]) and a["radiance_rays"] == b["radiance_rays"]
+    # subframe 1 blends: accum1 = lerp(accum0, clamp(cur,0,10), 1/2)  (deviceProgram.cu:460-466)
+    c = orc_det.render(sc, pr, (U, V, W), scenes.CORNELL_CAMERA["eye"], w, h, 3, subframe=1, accum=a["accum"])
+    cur = orc_det.render(sc, pr, (U, V, W), scenes.CORNELL_CAMERA["eye"], w, h, 3, subframe=1, accum=np.zeros_like(a["accum"]))
+    # with accum_prev = 0: result = 0 + .5*(clamp(cur)-0) → clamp(cur) = 2*that
+    cl = 2 * cur["accum"][..., :3]
+    exp = a["accum"][..., :3] + np.float32(0.5) * (cl - a["accum"][..., :3])
+    assert np.allclose(c["accum"][..., :3], exp, rtol=1e-6, atol=1e-7)
+    assert (c["accum"][..., 3] == 1).all()
+
+
+def test_closed_white_furnace_energy_bound(orc_det):
+    """Inside a closed box under NEE-only lighting nothing reaches the probe: every shadow ray is occluded,
+    so radiance is exactly the emission seen on primary hits (quirks 1 and 3 of SURVEY.md §8a)."""
+    m = scenes.Model()
+    scenes.add_box(m, scenes.Material(color=(0.9, 0.9, 0.9), emission=(0.25, 0.5, 0.75)), (0, 0, 0), (5, 5, 5))
+    probe = scenes.constant_probe().BuildCDF()
+    cam = dict(eye=(0.0, 0.0, 0.0), lookat=(0.0, 0.0, 1.0), up=(0.0, 1.0, 0.0), fovY=60.0)
+    w, h = 24, 16
+    U, V, W = scenes.uvw_frame(**cam, aspect=w / h)
+    r = orc_det.render(orc_det.make_scene(m), orc_det.make_probe(probe), (U, V, W), cam["eye"], w, h, 4)
+    # ... except for samples whose BSDF sample fails at the first hit (pdf <= 0 → DONE): the raygen loop
+    # breaks BEFORE adding that hit's radiance (quirk 2, deviceProgram.cu:429-437), so a pixel holds k/4 of it
+    ratio = r["accum"][..., :3] / np.array([0.25, 0.5, 0.75], np.float32)
+    k = ratio[..., 0] * 4
+    # a few pixels see hits within tmin=.01 of a box edge, where the shadow ray legitimately leaks (quirk 8)
+    exact = np.isclose(k, np.round(k), atol=1e-5) & np.isclose(ratio, ratio[..., :1], rtol=1e-6).all(-1) & (k <= 4)
+    assert exact.mean() > 0.97 and (np.round(k[exact]) == 4).mean() > 0.25 and (np.round(k[exact]) >= 2).mean() > 0.9
+    assert r["shadow_rays"] > 0

@@ -83,6 +83,13 @@ def load_library() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C optixpathtracer_amd/csrc`). There is no CPU fallback for the render path."
         )
+    # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64 (same SONAME as
+    # /opt/rocm's).  If torch is importable, load it first so that libptamd binds to the runtime torch will
+    # use for device tensors / RCCL later in the same process (the other order leaves torch without devices).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(L, name):

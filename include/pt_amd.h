@@ -71,7 +71,8 @@ typedef struct pt_options {
     uint32_t max_paths;     /* paths in flight per wavefront batch (0 = default 8Mi) */
     int32_t sort_rays;      /* reserved: per-bounce ray sort (0 = off) */
     int32_t bvh_kind;       /* 0 = default */
-    int32_t reserved[3];
+    int32_t trace_kernel;   /* 0 = default (persistent-wave k_trace2), 1 = first grid-stride kernel (A/B) */
+    int32_t reserved[2];
 } pt_options;
 
 enum pt_buffer {          /* LaunchParams.frame.* (LaunchParams.h:53-63) */

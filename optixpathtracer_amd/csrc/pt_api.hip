@@ -12,6 +12,7 @@
 
 #include "pt_host.h"
 #include "pt_kernels.h"
+#include "pt_trace2.h"
 
 static thread_local std::string g_create_error;
 
@@ -49,7 +50,9 @@ struct pt_ctx {
     bool cap_catcher = false;
     PathState st{};
     uint32_t *queueA = nullptr, *queueB = nullptr, *squeue = nullptr;
-    uint32_t* counters = nullptr; // [0..nq) radiance queue counts per bounce, [nq..2nq) shadow counts
+    uint32_t* counters = nullptr; // [0..nq) radiance queue counts per bounce, [nq..2nq) shadow counts, [2nq..4nq) work counters
+    uint32_t* ovf = nullptr;      // spill stacks of the persistent traversal waves
+    int trace_grid = 0;
     int nq = 0;
     unsigned long long* d_totals = nullptr;
     float4 *pixResult = nullptr, *pixAlpha = nullptr, *pixNormal = nullptr, *pixAlbedo = nullptr;
@@ -168,6 +171,12 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     CKC(dalloc(&ctx->d_totals, 2));
+    {
+        hipDeviceProp_t prop;
+        CKC(hipGetDeviceProperties(&prop, device));
+        ctx->trace_grid = prop.multiProcessorCount * 24; // persistent waves: 6 per SIMD (VGPR/LDS budget of k_trace2)
+        CKC(dalloc(&ctx->ovf, (size_t)ctx->trace_grid * 64 * PT2_OVF_DEPTH));
+    }
     *out_ctx = ctx;
     return PT_OK;
 #undef CKC
@@ -197,6 +206,7 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     pt_bvh_free(&ctx->bvh);
     dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
     dfree(ctx->d_totals);
+    dfree(ctx->ovf);
     for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -381,7 +391,7 @@ static int ensure_path_state(pt_ctx* ctx, uint32_t cap, uint32_t pix_cap) {
         if (ctx->has_catcher) { CK(dalloc(&s.prdN, cap)); CK(dalloc(&s.prdA, cap)); }
         ctx->cap_catcher = ctx->has_catcher;
         CK(dalloc(&ctx->queueA, cap)); CK(dalloc(&ctx->queueB, cap)); CK(dalloc(&ctx->squeue, cap));
-        CK(dalloc(&ctx->counters, (size_t)2 * nq));
+        CK(dalloc(&ctx->counters, (size_t)4 * nq));
         ctx->nq = nq;
         ctx->cap = cap;
     }
@@ -460,7 +470,7 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
             const uint32_t Sc = std::min(S, spp - s0);
             BatchParams bp{ctx->d_pixels + pix0, npix, s0, Sc, ctx->has_catcher ? 1 : 0,
                            ctx->pixResult, ctx->pixAlpha, ctx->pixNormal, ctx->pixAlbedo};
-            CK(hipMemsetAsync(ctx->counters, 0, sizeof(uint32_t) * 2 * nq, ctx->stream));
+            CK(hipMemsetAsync(ctx->counters, 0, sizeof(uint32_t) * 4 * nq, ctx->stream));
             {
                 SpanGuard g(ctx, CLS_OTHER);
                 hipLaunchKernelGGL(k_generate, dim3(GRID), dim3(256), 0, ctx->stream, ctx->st, fp, bp, ctx->counters + 0);
@@ -473,7 +483,12 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
             for (int b = 0; b <= last_bounce; ++b) {
                 {
                     SpanGuard g(ctx, CLS_TRACE);
-                    hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, qcur, ctx->counters + b);
+                    if (ctx->opt.trace_kernel == 1) {
+                        hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, qcur, ctx->counters + b);
+                    } else {
+                        Trace2Args ta{ctx->st, bvh, qcur, ctx->counters + b, ctx->counters + 2 * nq + b, ctx->ovf};
+                        hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
+                    }
                     ++trace_launches;
                 }
                 ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->probe, ctx->opt.max_depth, qcur, ctx->counters + b,
@@ -486,7 +501,12 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
                 }
                 {
                     SpanGuard g(ctx, CLS_SHADOW);
-                    hipLaunchKernelGGL((k_trace<1>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, ctx->squeue, ctx->counters + nq + b);
+                    if (ctx->opt.trace_kernel == 1) {
+                        hipLaunchKernelGGL((k_trace<1>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, ctx->squeue, ctx->counters + nq + b);
+                    } else {
+                        Trace2Args ta{ctx->st, bvh, ctx->squeue, ctx->counters + nq + b, ctx->counters + 3 * nq + b, ctx->ovf};
+                        hipLaunchKernelGGL((k_trace2<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
+                    }
                     ++shadow_launches;
                 }
                 qcur = qnext;
@@ -673,12 +693,21 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     hipEventCreate(&e1);
     int32_t* dOcc = nullptr;
     if (any_hit) CK(dalloc(&dOcc, n));
+    uint32_t* dWork = nullptr;
+    CK(dalloc(&dWork, (size_t)iters));
+    CK(hipMemsetAsync(dWork, 0, sizeof(uint32_t) * iters, ctx->stream));
     CK(hipEventRecord(e0, ctx->stream));
     for (int it = 0; it < iters; ++it) {
-        if (any_hit)
-            hipLaunchKernelGGL(k_query_any, dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, dO, dD, bvh, n, dOcc);
-        else
-            hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, st, bvh, (const uint32_t*)nullptr, dCount);
+        if (ctx->opt.trace_kernel == 1) {
+            if (any_hit)
+                hipLaunchKernelGGL(k_query_any, dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, dO, dD, bvh, n, dOcc);
+            else
+                hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, st, bvh, (const uint32_t*)nullptr, dCount);
+        } else {
+            Trace2Args ta{st, bvh, nullptr, dCount, dWork + it, ctx->ovf};
+            if (any_hit) hipLaunchKernelGGL((k_trace2<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
+            else hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
+        }
     }
     CK(hipEventRecord(e1, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
@@ -688,8 +717,12 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     if (kernel_ms) *kernel_ms = ms / iters;
     hipEventDestroy(e0);
     hipEventDestroy(e1);
-    if (any_hit) {
+    if (any_hit && ctx->opt.trace_kernel == 1) {
         CK(hipMemcpy(prim_out, dOcc, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    } else if (any_hit) {
+        std::vector<float2> hh(n);
+        CK(hipMemcpy(hh.data(), dHit, sizeof(float2) * n, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; ++i) memcpy(&prim_out[i], &hh[i].y, 4);
     } else {
         std::vector<float2> hh(n);
         CK(hipMemcpy(hh.data(), dHit, sizeof(float2) * n, hipMemcpyDeviceToHost));
@@ -698,7 +731,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
             memcpy(&prim_out[i], &hh[i].y, 4);
         }
     }
-    dfree(dO); dfree(dD); dfree(dHit); dfree(dCount); dfree(dOcc);
+    dfree(dO); dfree(dD); dfree(dHit); dfree(dCount); dfree(dOcc); dfree(dWork);
     return PT_OK;
 }
 

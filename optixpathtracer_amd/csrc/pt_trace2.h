@@ -1,0 +1,181 @@
+// pt_trace2.h — persistent-wave BVH2 traversal for gfx950 (wave64).
+//
+// What the first kernel (k_trace, pt_kernels.h) left on the table, from rocprofv3 PMC on MI355X:
+// VALU lane utilisation 26 % (rays of one wave finish at very different times and node/leaf work
+// serialises), 60 % of wave-cycles in s_waitcnt at 2.5 waves/SIMD (the 64-deep LDS stack capped
+// occupancy).  This kernel:
+//   * one wave per workgroup, waves are persistent: a wave pulls rays from a global work counter
+//     and REFILLS idle lanes as soon as fewer than PT2_REFILL lanes are busy (one atomic per refill);
+//   * majority-vote scheduling: each iteration the wave executes either one inner-node step or one
+//     leaf step, whichever has more lanes waiting for it, so the two code paths never run with
+//     complementary half-empty masks;
+//   * traversal stack: PT2_LDS_DEPTH entries in LDS ([level][lane], conflict-free) and the rare
+//     deeper levels in a per-lane global spill area → 6 KB LDS per wave instead of 16 KB.
+// Results are independent of traversal order (closest hit + lowest-primitive tie-break), so this
+// kernel is bit-identical to k_trace and to the CPU checker.
+#pragma once
+#include "pt_kernels.h"
+
+#define PT2_LDS_DEPTH 24
+#define PT2_OVF_DEPTH 48
+#define PT2_REFILL 40
+
+enum { TR_CLOSEST = 0, TR_SHADOW_APPLY = 1, TR_ANY_QUERY = 2 };
+
+struct Trace2Args {
+    PathState st;
+    BvhDev bvh;
+    const uint32_t* queue; // nullptr = identity
+    const uint32_t* count;
+    uint32_t* work;  // global work counter, zero before launch
+    uint32_t* ovf;   // spill stack: [PT2_OVF_DEPTH][gridDim.x * 64]
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(64) k_trace2(Trace2Args a) {
+    __shared__ uint32_t s_stack[PT2_LDS_DEPTH * 64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t gtid = blockIdx.x * 64u + lane;
+    const uint32_t gstride = gridDim.x * 64u;
+    const uint32_t n = *a.count;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    bool active = false, exhausted = false;
+    RaySetup r;
+    r.o = r.d = r.idir = r.dn = mk3(0.f);
+    float tmin = 0.f, tmax = 0.f, best = 0.f;
+    int32_t bprim = -1, node = 0;
+    int sp = 0;
+    uint32_t slot = 0;
+
+    auto push = [&](uint32_t v) {
+        if (sp < PT2_LDS_DEPTH) s_stack[sp * 64 + lane] = v;
+        else if (sp < PT2_LDS_DEPTH + PT2_OVF_DEPTH) a.ovf[(size_t)(sp - PT2_LDS_DEPTH) * gstride + gtid] = v;
+        ++sp;
+    };
+    auto pop = [&]() -> uint32_t {
+        --sp;
+        return sp < PT2_LDS_DEPTH ? s_stack[sp * 64 + lane] : a.ovf[(size_t)(sp - PT2_LDS_DEPTH) * gstride + gtid];
+    };
+    auto finish = [&]() {
+        if (MODE == TR_CLOSEST) {
+            a.st.hit[slot] = make_float2(best, __int_as_float(bprim));
+        } else if (MODE == TR_ANY_QUERY) {
+            a.st.hit[slot] = make_float2(best, __int_as_float(bprim)); // bprim = 1 occluded / 0
+        } else {
+            const float4 pe = a.st.pend[slot];
+            const int kind = __float_as_int(pe.w);
+            const bool occluded = bprim != 0;
+            if (kind == PEND_ALPHA) {
+                if (occluded) {
+                    const float4 x = a.st.alpha[slot];
+                    a.st.alpha[slot] = make_float4(x.x + pe.x, x.y + pe.y, x.z + pe.z, 0.f);
+                }
+            } else if (!occluded) {
+                float4* acc = (kind == PEND_DIRECT) ? a.st.direct : a.st.indirect;
+                const float4 x = acc[slot];
+                acc[slot] = make_float4(x.x + pe.x, x.y + pe.y, x.z + pe.z, 0.f);
+            }
+        }
+        active = false;
+    };
+
+    for (;;) {
+        // ---------------- refill idle lanes
+        const unsigned long long idle = __ballot(!active);
+        if (idle != 0ull && !exhausted) {
+            const uint32_t cnt = (uint32_t)__popcll(idle);
+            const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(a.work, cnt);
+            base = __shfl(base, (int)leader);
+            if (base + cnt >= n) exhausted = true;
+            if (!active) {
+                const uint32_t i = base + (uint32_t)__popcll(idle & lt_mask);
+                if (i < n) {
+                    slot = a.queue ? a.queue[i] : i;
+                    const float4 o4 = a.st.rayO[slot];
+                    float4 d4;
+                    if (MODE == TR_SHADOW_APPLY) {
+                        d4 = a.st.srayD[slot];
+                        tmin = 0.01f;
+                        tmax = 1e16f;
+                    } else {
+                        d4 = a.st.rayD[slot];
+                        tmin = o4.w;
+                        tmax = d4.w;
+                    }
+                    r = ray_setup(mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z));
+                    best = tmax;
+                    bprim = (MODE == TR_CLOSEST) ? -1 : 0;
+                    sp = 0;
+                    node = a.bvh.root;
+                    active = true;
+                }
+            }
+        }
+        unsigned long long act = __ballot(active);
+        if (act == 0ull) break;
+        const uint32_t thresh = exhausted ? 1u : (uint32_t)PT2_REFILL;
+        // ---------------- traverse until too few lanes are busy
+        do {
+            const bool inner = active && node >= 0;
+            const bool leaf = active && node < 0;
+            const unsigned long long m_in = __ballot(inner), m_lf = __ballot(leaf);
+            if (__popcll(m_in) >= __popcll(m_lf)) {
+                if (inner) {
+                    bool need_pop = true;
+                    if (node != PT_REF_EMPTY) {
+                        const Node2* nd = &a.bvh.nodes[node];
+                        const float4 na = nd->a, nb = nd->b, nc = nd->c, nx = nd->d;
+                        float t0, t1;
+                        const bool h0 = box_test(na.x, na.y, na.z, na.w, nb.x, nb.y, r, tmin, best, t0);
+                        const bool h1 = box_test(nb.z, nb.w, nc.x, nc.y, nc.z, nc.w, r, tmin, best, t1);
+                        const int32_t c0 = __float_as_int(nx.x), c1 = __float_as_int(nx.y);
+                        if (h0 && h1) {
+                            const bool sw = t1 < t0;
+                            push((uint32_t)(sw ? c0 : c1));
+                            node = sw ? c1 : c0;
+                            need_pop = false;
+                        } else if (h0 || h1) {
+                            node = h0 ? c0 : c1;
+                            need_pop = false;
+                        }
+                    }
+                    if (need_pop) {
+                        if (sp == 0) finish();
+                        else node = (int32_t)pop();
+                    }
+                }
+            } else {
+                if (leaf) {
+                    const uint32_t code = ~(uint32_t)node;
+                    const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+                    bool done = false;
+                    for (uint32_t k = 0; k < cnt; ++k) {
+                        const LeafTri* tp = &a.bvh.tris[first + k];
+                        const float4 ta = tp->t0, tb = tp->t1, tc = tp->t2;
+                        float t;
+                        if (tri_test(r, mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), t)) {
+                            const int32_t prim = __float_as_int(tc.y);
+                            if (MODE != TR_CLOSEST) {
+                                if (t > tmin && t < tmax) {
+                                    bprim = 1;
+                                    best = t;
+                                    done = true;
+                                    break;
+                                }
+                            } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim))) {
+                                best = t;
+                                bprim = prim;
+                            }
+                        }
+                    }
+                    if (done || sp == 0) finish();
+                    else node = (int32_t)pop();
+                }
+            }
+            act = __ballot(active);
+        } while ((uint32_t)__popcll(act) >= thresh);
+    }
+}

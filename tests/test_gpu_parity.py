@@ -291,6 +291,16 @@ def test_render_cornell_disney_4spp_depth8(ptlib, orc_det, small_probe):
     assert g["stats"]["radiance_rays"] > 0.8 * o["radiance_rays"]
 
 
+def test_both_traversal_kernels_agree(ptlib, orc_det, small_probe):
+    """The persistent-wave kernel (default) and the first grid-stride kernel give the same bits."""
+    m = scenes.voxel_terrain(n=96, target_tris=70000)
+    w, h = 128, 72
+    o = _oracle_render(orc_det, m, small_probe, scenes.TERRAIN_CAMERA, w, h, 2)
+    for tk in (0, 1):
+        r = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h, trace_kernel=tk)
+        _compare(_gpu_render(r, 2), o)
+
+
 def test_render_progressive_subframes(ptlib, orc_det, small_probe):
     """deviceProgram.cu:460-467: clamp + running lerp over subframes 0..3."""
     m = scenes.cornell_box()

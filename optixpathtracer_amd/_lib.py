@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libptamd.so")
+LIB_PATH = os.environ.get("PT_LIB") or os.path.join(HERE, "libptamd.so")  # PT_LIB: experiment builds (tools/variants.sh)
 
 # every symbol include/pt_amd.h declares
 EXPORTS = [

@@ -50,7 +50,8 @@ struct pt_ctx {
     bool cap_catcher = false;
     PathState st{};
     uint32_t *queueA = nullptr, *queueB = nullptr, *squeue = nullptr;
-    uint32_t* counters = nullptr; // [0..nq) radiance queue counts per bounce, [nq..2nq) shadow counts, [2nq..4nq) work counters
+    uint32_t* counters = nullptr; // [nq][PT_NSUB*PT_CSTRIDE] radiance sub-queue counts, the same for shadow queues, then 2*nq work counters
+    uint32_t sub_cap = 0;         // capacity of one sub-queue
     uint32_t* ovf = nullptr;      // spill stacks of the persistent traversal waves
     int trace_grid = 0;
     int nq = 0;
@@ -390,8 +391,12 @@ static int ensure_path_state(pt_ctx* ctx, uint32_t cap, uint32_t pix_cap) {
         CK(dalloc(&s.direct, cap)); CK(dalloc(&s.indirect, cap)); CK(dalloc(&s.alpha, cap)); CK(dalloc(&s.nrm, cap)); CK(dalloc(&s.alb, cap));
         if (ctx->has_catcher) { CK(dalloc(&s.prdN, cap)); CK(dalloc(&s.prdA, cap)); }
         ctx->cap_catcher = ctx->has_catcher;
-        CK(dalloc(&ctx->queueA, cap)); CK(dalloc(&ctx->queueB, cap)); CK(dalloc(&ctx->squeue, cap));
-        CK(dalloc(&ctx->counters, (size_t)4 * nq));
+        // 64 sub-queues; a producer workgroup b appends to sub-queue b % 64, 32 workgroups of k_shade's 2048 share one:
+        // a sub-queue receives at most cap/64 + 32*256 entries
+        ctx->sub_cap = cap / PT_NSUB + 8192 + 1;
+        const size_t qsize = (size_t)PT_NSUB * ctx->sub_cap;
+        CK(dalloc(&ctx->queueA, qsize)); CK(dalloc(&ctx->queueB, qsize)); CK(dalloc(&ctx->squeue, qsize));
+        CK(dalloc(&ctx->counters, (size_t)2 * nq * PT_NSUB * PT_CSTRIDE + 2 * nq));
         ctx->nq = nq;
         ctx->cap = cap;
     }
@@ -470,29 +475,34 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
             const uint32_t Sc = std::min(S, spp - s0);
             BatchParams bp{ctx->d_pixels + pix0, npix, s0, Sc, ctx->has_catcher ? 1 : 0,
                            ctx->pixResult, ctx->pixAlpha, ctx->pixNormal, ctx->pixAlbedo};
-            CK(hipMemsetAsync(ctx->counters, 0, sizeof(uint32_t) * 4 * nq, ctx->stream));
+            CK(hipMemsetAsync(ctx->counters, 0, sizeof(uint32_t) * ((size_t)2 * nq * PT_NSUB * PT_CSTRIDE + 2 * nq), ctx->stream));
             {
                 SpanGuard g(ctx, CLS_OTHER);
                 hipLaunchKernelGGL(k_generate, dim3(GRID), dim3(256), 0, ctx->stream, ctx->st, fp, bp, ctx->counters + 0);
             }
-            uint32_t* qcur = nullptr; // identity for bounce 0
-            uint32_t* qnext = ctx->queueA;
+            const size_t CS = (size_t)PT_NSUB * PT_CSTRIDE;
+            uint32_t* cntA = ctx->counters;                       // radiance queue counters, per bounce
+            uint32_t* cntS = ctx->counters + (size_t)nq * CS;     // shadow queue counters, per bounce
+            uint32_t* work = ctx->counters + (size_t)2 * nq * CS; // work counters of the persistent traversal
+            QView qcur{nullptr, cntA, ctx->sub_cap}; // identity for bounce 0 (k_generate wrote the count)
+            uint32_t* qnext_base = ctx->queueA;
             // depth d = 0..max_depth traces in the reference (the trace at depth == max_depth can only matter
             // through a shadow-catcher pass-through or alpha; without catcher materials it is provably dead and skipped)
             const int last_bounce = ctx->has_catcher ? ctx->opt.max_depth : ctx->opt.max_depth - 1;
             for (int b = 0; b <= last_bounce; ++b) {
+                QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
+                QView qshadow{ctx->squeue, cntS + (size_t)b * CS, ctx->sub_cap};
                 {
                     SpanGuard g(ctx, CLS_TRACE);
                     if (ctx->opt.trace_kernel == 1) {
-                        hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, qcur, ctx->counters + b);
+                        hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, qcur);
                     } else {
-                        Trace2Args ta{ctx->st, bvh, qcur, ctx->counters + b, ctx->counters + 2 * nq + b, ctx->ovf};
+                        Trace2Args ta{ctx->st, bvh, qcur, work + b, ctx->ovf};
                         hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
                     }
                     ++trace_launches;
                 }
-                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->probe, ctx->opt.max_depth, qcur, ctx->counters + b,
-                               qnext, ctx->counters + b + 1, ctx->squeue, ctx->counters + nq + b};
+                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->probe, ctx->opt.max_depth, qcur, qnext, qshadow};
                 {
                     SpanGuard g(ctx, CLS_SHADE);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, sp);
@@ -502,15 +512,15 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
                 {
                     SpanGuard g(ctx, CLS_SHADOW);
                     if (ctx->opt.trace_kernel == 1) {
-                        hipLaunchKernelGGL((k_trace<1>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, ctx->squeue, ctx->counters + nq + b);
+                        hipLaunchKernelGGL((k_trace<1>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, qshadow);
                     } else {
-                        Trace2Args ta{ctx->st, bvh, ctx->squeue, ctx->counters + nq + b, ctx->counters + 3 * nq + b, ctx->ovf};
+                        Trace2Args ta{ctx->st, bvh, qshadow, work + nq + b, ctx->ovf};
                         hipLaunchKernelGGL((k_trace2<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
                     }
                     ++shadow_launches;
                 }
                 qcur = qnext;
-                qnext = (qnext == ctx->queueA) ? ctx->queueB : ctx->queueA;
+                qnext_base = (qnext_base == ctx->queueA) ? ctx->queueB : ctx->queueA;
             }
             {
                 SpanGuard g(ctx, CLS_OTHER);
@@ -702,9 +712,9 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
             if (any_hit)
                 hipLaunchKernelGGL(k_query_any, dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, dO, dD, bvh, n, dOcc);
             else
-                hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, st, bvh, (const uint32_t*)nullptr, dCount);
+                hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, st, bvh, QView{nullptr, dCount, 0});
         } else {
-            Trace2Args ta{st, bvh, nullptr, dCount, dWork + it, ctx->ovf};
+            Trace2Args ta{st, bvh, QView{nullptr, dCount, 0}, dWork + it, ctx->ovf};
             if (any_hit) hipLaunchKernelGGL((k_trace2<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         }

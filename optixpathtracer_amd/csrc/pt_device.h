@@ -371,9 +371,14 @@ PT_DEV int lower_bound(const float* __restrict__ array, int lower, int upper, fl
 PT_DEV void probe_sample(const DevProbe& p, v3& dir, v3& color, float& pdf, Rng& rand) {
     float r1, r2;
     sample2d(rand, r1, r2);
+#ifdef PT_EXP_NO_SEARCH
+    int row = (int)(r1 * p.height);
+    int col = (int)(r2 * p.width);
+#else
     int row = lower_bound(p.cdfY, 0, p.height, r1);
     if (row > p.height - 1) row = p.height - 1;
     int col = lower_bound(p.cdfX, row * p.width, (row + 1) * p.width, r2) - row * p.width;
+#endif
     if (col > p.width - 1) col = p.width - 1;
     float4 px = p.data[(size_t)row * p.width + col];
     color = mk3(px.x, px.y, px.z);

@@ -19,25 +19,34 @@
 #define PT2_LDS_DEPTH 24
 #define PT2_OVF_DEPTH 48
 #define PT2_REFILL 40
+#define PT2_CHUNK 512
 
 enum { TR_CLOSEST = 0, TR_SHADOW_APPLY = 1, TR_ANY_QUERY = 2 };
 
 struct Trace2Args {
     PathState st;
     BvhDev bvh;
-    const uint32_t* queue; // nullptr = identity
-    const uint32_t* count;
-    uint32_t* work;  // global work counter, zero before launch
+    QView queue;
+    uint32_t* work;  // global work counter, zero before launch (waves take PT2_CHUNK entries per atomic)
     uint32_t* ovf;   // spill stack: [PT2_OVF_DEPTH][gridDim.x * 64]
 };
 
 template <int MODE>
 __global__ void __launch_bounds__(64) k_trace2(Trace2Args a) {
     __shared__ uint32_t s_stack[PT2_LDS_DEPTH * 64];
+    __shared__ uint32_t s_prefix[PT_NSUB + 1];
     const uint32_t lane = threadIdx.x;
     const uint32_t gtid = blockIdx.x * 64u + lane;
     const uint32_t gstride = gridDim.x * 64u;
-    const uint32_t n = *a.count;
+    const uint32_t n = qreader_init(a.queue, s_prefix);
+    // work distribution: the queue is cut into chunks of `chunk` rays (64..PT2_CHUNK, sized so that every wave
+    // gets about two); chunk number blockIdx.x is this wave's first one (no atomic), later ones come from the
+    // global counter — same-address atomics cost ≈10 ns each on MI355X, so they are kept to one per chunk.
+    uint32_t chunk = (n / (gridDim.x * 2u)) & ~63u;
+    chunk = chunk < 64u ? 64u : (chunk > (uint32_t)PT2_CHUNK ? (uint32_t)PT2_CHUNK : chunk);
+    if ((unsigned long long)blockIdx.x * chunk >= n) return;
+    uint32_t chunk_next = blockIdx.x * chunk; // wave-uniform: the part of the work range this wave still owns
+    uint32_t chunk_end = (chunk_next + chunk < n) ? chunk_next + chunk : n;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     bool active = false, exhausted = false;
@@ -85,15 +94,24 @@ __global__ void __launch_bounds__(64) k_trace2(Trace2Args a) {
         const unsigned long long idle = __ballot(!active);
         if (idle != 0ull && !exhausted) {
             const uint32_t cnt = (uint32_t)__popcll(idle);
-            const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(a.work, cnt);
-            base = __shfl(base, (int)leader);
-            if (base + cnt >= n) exhausted = true;
-            if (!active) {
-                const uint32_t i = base + (uint32_t)__popcll(idle & lt_mask);
-                if (i < n) {
-                    slot = a.queue ? a.queue[i] : i;
+            if (chunk_next == chunk_end) { // take the next chunk of the queue: one atomic per PT2_CHUNK rays
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(a.work, 1u);
+                c = __shfl(c, 0) + gridDim.x;
+                const unsigned long long b0 = (unsigned long long)c * chunk;
+                chunk_next = b0 < n ? (uint32_t)b0 : n;
+                chunk_end = (b0 + chunk < n) ? (uint32_t)(b0 + chunk) : n;
+                if (chunk_next >= chunk_end) exhausted = true;
+            }
+            const uint32_t take = (chunk_end - chunk_next) < cnt ? (chunk_end - chunk_next) : cnt;
+            const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+            const uint32_t first = chunk_next;
+            chunk_next += take;
+            if (!active && rank < take) {
+                const uint32_t i = first + rank;
+                {
+                    slot = qreader_get(a.queue, s_prefix, i);
+
                     const float4 o4 = a.st.rayO[slot];
                     float4 d4;
                     if (MODE == TR_SHADOW_APPLY) {

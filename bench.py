@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--workload", default="c3_terrain1M_1080p_4spp_d8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0)
+    ap.add_argument("--bvh-kind", type=int, default=0, help="0 = 8-wide compressed BVH (default), 1 = binary BVH")
     ap.add_argument("--trace-kernel", type=int, default=0, help="0 = persistent-wave traversal (default), 1 = first grid-stride kernel")
     args = ap.parse_args()
 
@@ -71,7 +72,7 @@ def main():
 
     r = R.SampleRenderer(model, device=local_rank)
     r.setProbe(probe)
-    r.setOptions(max_depth=depth, max_paths=args.max_paths, trace_kernel=args.trace_kernel)
+    r.setOptions(max_depth=depth, max_paths=args.max_paths, trace_kernel=args.trace_kernel, bvh_kind=args.bvh_kind)
     if world > 1:
         r.setPartition(rank, world, 64, 16)
     r.resize((w, h))
@@ -154,7 +155,7 @@ def main():
             "bvh": {"nodes": st["bvh_nodes"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2)},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "roofline": {
-                "kernel": ("k_trace<0>" if args.trace_kernel == 1 else "k_trace2<0>") + " (closest-hit BVH traversal)", "bound": "hbm", "achieved": round(achieved, 2),
+                "kernel": ("k_trace<0>" if args.trace_kernel == 1 else ("k_trace2<0>" if args.bvh_kind == 1 else "k_trace8<0>")) + " (closest-hit BVH traversal)", "bound": "hbm", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes),
             },

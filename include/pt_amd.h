@@ -70,7 +70,7 @@ typedef struct pt_options {
     int32_t bsdf_mode;      /* pt_bsdf_mode */
     uint32_t max_paths;     /* paths in flight per wavefront batch (0 = default 8Mi) */
     int32_t sort_rays;      /* reserved: per-bounce ray sort (0 = off) */
-    int32_t bvh_kind;       /* 0 = default */
+    int32_t bvh_kind;       /* 0 = default: 8-wide compressed BVH (k_trace8); 1 = binary BVH (k_trace2) */
     int32_t trace_kernel;   /* 0 = default (persistent-wave k_trace2), 1 = first grid-stride kernel (A/B) */
     int32_t reserved[2];
 } pt_options;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -13,6 +14,7 @@
 #include "pt_host.h"
 #include "pt_kernels.h"
 #include "pt_trace2.h"
+#include "pt_bvh8.h"
 
 static thread_local std::string g_create_error;
 
@@ -175,8 +177,10 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
     {
         hipDeviceProp_t prop;
         CKC(hipGetDeviceProperties(&prop, device));
-        ctx->trace_grid = prop.multiProcessorCount * 24; // persistent waves: 6 per SIMD (VGPR/LDS budget of k_trace2)
-        CKC(dalloc(&ctx->ovf, (size_t)ctx->trace_grid * 64 * PT2_OVF_DEPTH));
+        int wpe = PT8_WAVES_PER_EU; // persistent waves per SIMD = the occupancy the traversal kernels are compiled for
+        if (const char* e = getenv("PT_TRACE_WAVES")) wpe = atoi(e);
+        ctx->trace_grid = prop.multiProcessorCount * 4 * wpe;
+        CKC(dalloc(&ctx->ovf, (size_t)ctx->trace_grid * 64 * (PT8_OVF_DEPTH * 2 > PT2_OVF_DEPTH ? PT8_OVF_DEPTH * 2 : PT2_OVF_DEPTH)));
     }
     *out_ctx = ctx;
     return PT_OK;
@@ -466,6 +470,7 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     hipEvent_t ev_begin = next_event(ctx);
     CK(hipEventRecord(ev_begin, ctx->stream));
     BvhDev bvh{ctx->bvh.nodes, ctx->bvh.tris, ctx->bvh.root};
+    Bvh8Dev bvh8{ctx->bvh.nodes8, ctx->bvh.tris8};
     FrameParams fp{ctx->accum, ctx->frame, ctx->color, ctx->normal, ctx->albedo, ctx->width, ctx->height, subframe_index,
                    ctx->eye, ctx->U, ctx->V, ctx->W, spp, ctx->probe};
     uint32_t trace_launches = 0, shadow_launches = 0, shade_launches = 0;
@@ -496,9 +501,12 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
                     SpanGuard g(ctx, CLS_TRACE);
                     if (ctx->opt.trace_kernel == 1) {
                         hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, qcur);
-                    } else {
-                        Trace2Args ta{ctx->st, bvh, qcur, work + b, ctx->ovf};
+                    } else if (ctx->opt.bvh_kind == 1) {
+                        Trace2Args ta{ctx->st, bvh, qcur, work + b, ctx->ovf, nullptr};
                         hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
+                    } else {
+                        Trace8Args ta{ctx->st, bvh8, qcur, work + b, ctx->ovf, nullptr};
+                        hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
                     }
                     ++trace_launches;
                 }
@@ -513,9 +521,12 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
                     SpanGuard g(ctx, CLS_SHADOW);
                     if (ctx->opt.trace_kernel == 1) {
                         hipLaunchKernelGGL((k_trace<1>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, qshadow);
-                    } else {
-                        Trace2Args ta{ctx->st, bvh, qshadow, work + nq + b, ctx->ovf};
+                    } else if (ctx->opt.bvh_kind == 1) {
+                        Trace2Args ta{ctx->st, bvh, qshadow, work + nq + b, ctx->ovf, nullptr};
                         hipLaunchKernelGGL((k_trace2<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
+                    } else {
+                        Trace8Args ta{ctx->st, bvh8, qshadow, work + nq + b, ctx->ovf, nullptr};
+                        hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
                     }
                     ++shadow_launches;
                 }
@@ -557,9 +568,6 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     st.trace_launches = trace_launches;
     st.shadow_launches = shadow_launches;
     st.shade_launches = shade_launches;
-    st.bvh_nodes = ctx->bvh.num_nodes;
-    st.bvh_bytes = (uint64_t)ctx->bvh.num_nodes * sizeof(Node2) + (uint64_t)ctx->bvh.num_tris * sizeof(LeafTri);
-    st.bvh_build_ms = ctx->bvh_build_ms;
     if (host_rgba8) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)ctx->width * ctx->height);
     return PT_OK;
 }
@@ -656,8 +664,10 @@ extern "C" int pt_unpack(pt_ctx* ctx, int which, const void* dev_src_all) {
 extern "C" int pt_get_stats(const pt_ctx* ctx, pt_stats* out) {
     if (!ctx || !out) return PT_ERR_INVALID;
     *out = ctx->stats;
-    out->bvh_nodes = ctx->bvh.num_nodes;
-    out->bvh_bytes = (uint64_t)ctx->bvh.num_nodes * sizeof(Node2) + (uint64_t)ctx->bvh.num_tris * sizeof(LeafTri);
+    const bool wide = ctx->opt.bvh_kind != 1 && ctx->opt.trace_kernel != 1;
+    out->bvh_nodes = wide ? ctx->bvh.num_nodes8 : ctx->bvh.num_nodes;
+    out->bvh_bytes = wide ? (uint64_t)ctx->bvh.num_nodes8 * sizeof(Node8) + (uint64_t)ctx->bvh.num_tris8 * sizeof(LeafTri)
+                          : (uint64_t)ctx->bvh.num_nodes * sizeof(Node2) + (uint64_t)ctx->bvh.num_tris * sizeof(LeafTri);
     out->bvh_build_ms = ctx->bvh_build_ms;
     return PT_OK;
 }
@@ -703,6 +713,11 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     hipEventCreate(&e1);
     int32_t* dOcc = nullptr;
     if (any_hit) CK(dalloc(&dOcc, n));
+    unsigned long long* dDbg = nullptr;
+    if (getenv("PT_DEBUG_COUNTS")) {
+        CK(dalloc(&dDbg, 4));
+        CK(hipMemset(dDbg, 0, 32));
+    }
     uint32_t* dWork = nullptr;
     CK(dalloc(&dWork, (size_t)iters));
     CK(hipMemsetAsync(dWork, 0, sizeof(uint32_t) * iters, ctx->stream));
@@ -713,10 +728,14 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
                 hipLaunchKernelGGL(k_query_any, dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, dO, dD, bvh, n, dOcc);
             else
                 hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, st, bvh, QView{nullptr, dCount, 0});
-        } else {
-            Trace2Args ta{st, bvh, QView{nullptr, dCount, 0}, dWork + it, ctx->ovf};
+        } else if (ctx->opt.bvh_kind == 1) {
+            Trace2Args ta{st, bvh, QView{nullptr, dCount, 0}, dWork + it, ctx->ovf, dDbg};
             if (any_hit) hipLaunchKernelGGL((k_trace2<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
+        } else {
+            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8}, QView{nullptr, dCount, 0}, dWork + it, ctx->ovf, dDbg};
+            if (any_hit) hipLaunchKernelGGL((k_trace8<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
+            else hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         }
     }
     CK(hipEventRecord(e1, ctx->stream));
@@ -725,6 +744,13 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     if (kernel_ms) *kernel_ms = ms / iters;
+    if (dDbg) {
+        unsigned long long h[4];
+        CK(hipMemcpy(h, dDbg, 32, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pt_trace] rays %u x %d: node steps/ray %.2f, tri tests/ray %.2f, pushes/ray %.2f, max stack %llu\n", n, iters,
+                (double)h[0] / n / iters, (double)h[1] / n / iters, (double)h[3] / n / iters, h[2]);
+        dfree(dDbg);
+    }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     if (any_hit && ctx->opt.trace_kernel == 1) {

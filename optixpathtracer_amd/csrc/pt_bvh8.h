@@ -1,0 +1,284 @@
+// pt_bvh8.h — 8-wide compressed BVH ("CWBVH", after Ylitie, Karras, Laine 2017) and its persistent-wave
+// traversal kernel for gfx950.  Why: with the binary tree the traversal kernel is bound by the per-CU
+// texture-address/L1 path — every lane's 16-byte load of a different cache line costs that path a cycle,
+// and a ray touches ≈205 such loads (≈40 nodes x 4 + ≈15 triangles x 3, rocprofv3 PMC: 9.2 TB/s of L1
+// requests against a ≈9.8 TB/s ceiling for fully divergent 16-byte loads).  An 80-byte node holding 8
+// quantised child boxes needs 5 loads and a third of the tree depth.
+//
+// Node (80 B = 5 x 16 B):
+//   n0: origin.xyz (f32)                       | ex, ey, ez (biased exponents of the grid step), imask
+//   n1: child_base | tri_base | meta[0..3] | meta[4..7]     meta = tri offset (5 bits) | (tri count-1) << 5
+//   n2: qlo.x[8] (2 dwords) | qlo.y[8]   n3: qlo.z[8] | qhi.x[8]   n4: qhi.y[8] | qhi.z[8]
+// Child box s = origin + q * 2^(e-127) per axis, rounded outward at build from the padded float box, so
+// the box test stays conservative; empty slots hold an inverted box (qlo=255, qhi=0).  Internal children
+// are contiguous (child_base + rank of the slot among the set bits of imask), the triangles of all leaf
+// children are contiguous from tri_base.  Children sit in the slot whose octant (sign bits of
+// centroid - node centre) best matches them (greedy assignment at build), so visiting hit slots in
+// increasing (slot XOR ray-octant) order is an approximate front-to-back order without sorting.
+// The triangle test is pt_bvh.h's tri_test, bit-identical to the CPU checker; closest hit + lowest
+// primitive tie-break make the result independent of the tree.
+#pragma once
+#ifdef PT_BVH8_NODE_ONLY
+#include "pt_bvh.h"
+#else
+#include "pt_kernels.h"
+#endif
+
+struct Node8 {
+    float4 n0, n1, n2, n3, n4;
+};
+#define PT8_LEAF_MAX 3
+
+struct Bvh8Dev {
+    const Node8* nodes;
+    const LeafTri* tris;
+};
+
+#ifndef PT_BVH8_NODE_ONLY
+#define PT8_LDS_DEPTH 12
+#define PT8_OVF_DEPTH 52
+#define PT8_REFILL 40
+#define PT8_CHUNK 512
+#ifndef PT8_WAVES_PER_EU
+#define PT8_WAVES_PER_EU 5
+#endif
+
+struct Trace8Args {
+    PathState st;
+    Bvh8Dev bvh;
+    QView queue;
+    uint32_t* work;
+    uint32_t* ovf; // spill stack: [PT8_OVF_DEPTH][2][gridDim.x * 64]
+    unsigned long long* dbg; // optional: [0] node steps, [1] triangle tests, [2] max stack depth, [3] pushes (pt_trace + PT_DEBUG_COUNTS)
+};
+
+PT_DEV float u8f(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
+
+template <int MODE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT8_WAVES_PER_EU, PT8_WAVES_PER_EU)))
+k_trace8(Trace8Args a) {
+    __shared__ uint32_t s_stack[PT8_LDS_DEPTH * 2 * 64];
+    __shared__ uint32_t s_prefix[PT_NSUB + 1];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t gtid = blockIdx.x * 64u + lane;
+    const uint32_t gstride = gridDim.x * 64u;
+    const uint32_t n = qreader_init(a.queue, s_prefix);
+    uint32_t chunk = (n / (gridDim.x * 2u)) & ~63u;
+    chunk = chunk < 64u ? 64u : (chunk > (uint32_t)PT8_CHUNK ? (uint32_t)PT8_CHUNK : chunk);
+    if ((unsigned long long)blockIdx.x * chunk >= n) return;
+    uint32_t chunk_next = blockIdx.x * chunk;
+    uint32_t chunk_end = (chunk_next + chunk < n) ? chunk_next + chunk : n;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    bool active = false, exhausted = false;
+    RaySetup r;
+    r.o = r.d = r.idir = r.dn = mk3(0.f);
+    float tmin = 0.f, tmax = 0.f, best = 0.f;
+    int32_t bprim = -1;
+    uint32_t oct = 0;                          // ray octant: bit set where the direction is negative
+    uint32_t g_base = 0, g_imask = 0, g_hits = 0; // current node group: hits in (slot ^ oct) bit positions
+    uint32_t t_base = 0, t_mask = 0;             // current triangle group
+    int sp = 0;
+    uint32_t slot = 0;
+    uint32_t c_nodes = 0, c_tris = 0, c_maxsp = 0, c_push = 0;
+
+    auto push = [&](uint32_t v0, uint32_t v1) {
+        ++c_push;
+        if ((uint32_t)sp + 1 > c_maxsp) c_maxsp = sp + 1;
+        if (sp < PT8_LDS_DEPTH) {
+            s_stack[(sp * 2) * 64 + lane] = v0;
+            s_stack[(sp * 2 + 1) * 64 + lane] = v1;
+        } else if (sp < PT8_LDS_DEPTH + PT8_OVF_DEPTH) {
+            a.ovf[(size_t)((sp - PT8_LDS_DEPTH) * 2) * gstride + gtid] = v0;
+            a.ovf[(size_t)((sp - PT8_LDS_DEPTH) * 2 + 1) * gstride + gtid] = v1;
+        }
+        ++sp;
+    };
+    auto pop = [&](uint32_t& v0, uint32_t& v1) {
+        --sp;
+        if (sp < PT8_LDS_DEPTH) {
+            v0 = s_stack[(sp * 2) * 64 + lane];
+            v1 = s_stack[(sp * 2 + 1) * 64 + lane];
+        } else {
+            v0 = a.ovf[(size_t)((sp - PT8_LDS_DEPTH) * 2) * gstride + gtid];
+            v1 = a.ovf[(size_t)((sp - PT8_LDS_DEPTH) * 2 + 1) * gstride + gtid];
+        }
+    };
+    auto finish = [&]() {
+        if (MODE == TR_SHADOW_APPLY) {
+            const float4 pe = a.st.pend[slot];
+            const int kind = __float_as_int(pe.w);
+            const bool occluded = bprim != 0;
+            if (kind == PEND_ALPHA) {
+                if (occluded) {
+                    const float4 x = a.st.alpha[slot];
+                    a.st.alpha[slot] = make_float4(x.x + pe.x, x.y + pe.y, x.z + pe.z, 0.f);
+                }
+            } else if (!occluded) {
+                float4* acc = (kind == PEND_DIRECT) ? a.st.direct : a.st.indirect;
+                const float4 x = acc[slot];
+                acc[slot] = make_float4(x.x + pe.x, x.y + pe.y, x.z + pe.z, 0.f);
+            }
+        } else {
+            a.st.hit[slot] = make_float2(best, __int_as_float(bprim));
+        }
+        active = false;
+    };
+
+    for (;;) {
+        // ---------------- refill idle lanes
+        const unsigned long long idle = __ballot(!active);
+        if (idle != 0ull && !exhausted) {
+            const uint32_t cnt = (uint32_t)__popcll(idle);
+            if (chunk_next == chunk_end) {
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(a.work, 1u);
+                c = __shfl(c, 0) + gridDim.x;
+                const unsigned long long b0 = (unsigned long long)c * chunk;
+                chunk_next = b0 < n ? (uint32_t)b0 : n;
+                chunk_end = (b0 + chunk < n) ? (uint32_t)(b0 + chunk) : n;
+                if (chunk_next >= chunk_end) exhausted = true;
+            }
+            const uint32_t take = (chunk_end - chunk_next) < cnt ? (chunk_end - chunk_next) : cnt;
+            const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+            const uint32_t first = chunk_next;
+            chunk_next += take;
+            if (!active && rank < take) {
+                slot = qreader_get(a.queue, s_prefix, first + rank);
+                const float4 o4 = a.st.rayO[slot];
+                float4 d4;
+                if (MODE == TR_SHADOW_APPLY) {
+                    d4 = a.st.srayD[slot];
+                    tmin = 0.01f;
+                    tmax = 1e16f;
+                } else {
+                    d4 = a.st.rayD[slot];
+                    tmin = o4.w;
+                    tmax = d4.w;
+                }
+                r = ray_setup(mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z));
+                // The box test below evaluates q*(step*idir) + (origin-o)*idir: with idir = ±inf (a direction component that
+                // is exactly ±0) that is inf-inf = NaN, the axis constraint is dropped and the ray visits every node of a
+                // whole slab (measured: 0.05 % of the shadow rays — probe column 0 — cost milliseconds of tail).  A huge
+                // finite reciprocal keeps the slab test meaningful and conservative.
+                if (!(fabsf(d4.x) > 1e-30f)) r.idir.x = copysignf(1e30f, d4.x);
+                if (!(fabsf(d4.y) > 1e-30f)) r.idir.y = copysignf(1e30f, d4.y);
+                if (!(fabsf(d4.z) > 1e-30f)) r.idir.z = copysignf(1e30f, d4.z);
+                // sign BITS (so that -0.0, whose reciprocal is -inf, picks the matching near/far planes)
+                oct = (__float_as_uint(d4.x) >> 31) | ((__float_as_uint(d4.y) >> 31) << 1) | ((__float_as_uint(d4.z) >> 31) << 2);
+                best = tmax;
+                bprim = (MODE == TR_CLOSEST) ? -1 : 0;
+                sp = 0;
+                // the root is node 0: a group whose only internal child is slot 0 of a virtual parent
+                g_base = 0;
+                g_imask = 1u;
+                g_hits = 1u << (0u ^ oct);
+                t_mask = 0;
+                active = true;
+            }
+        }
+        unsigned long long act = __ballot(active);
+        if (act == 0ull) break;
+        const uint32_t thresh = exhausted ? 1u : (uint32_t)PT8_REFILL;
+        // ---------------- traverse
+        do {
+            const bool want_tri = active && t_mask != 0u;
+            const bool want_node = active && t_mask == 0u; // node step also covers "group empty → pop"
+            const unsigned long long m_tri = __ballot(want_tri), m_node = __ballot(want_node);
+            if (__popcll(m_node) >= __popcll(m_tri)) {
+                if (want_node) {
+                    if (g_hits == 0u) {
+                        if (sp == 0) {
+                            finish();
+                        } else {
+                            uint32_t v0, v1;
+                            pop(v0, v1);
+                            g_base = v0;
+                            g_imask = v1 & 0xffu;
+                            g_hits = v1 >> 8;
+                        }
+                    }
+                    if (active) {
+                        // next child of the group in (slot ^ oct) order
+                        const uint32_t bit = (uint32_t)__ffs((int)g_hits) - 1u;
+                        g_hits &= g_hits - 1u;
+                        const uint32_t cs = bit ^ oct;
+                        const uint32_t idx = g_base + (uint32_t)__popc(g_imask & ((1u << cs) - 1u));
+                        if (g_hits != 0u) push(g_base, g_imask | (g_hits << 8));
+                        ++c_nodes;
+                        const Node8* nd = &a.bvh.nodes[idx];
+                        const float4 n0 = nd->n0, n1 = nd->n1, n2 = nd->n2, n3 = nd->n3, n4 = nd->n4;
+                        const uint32_t em = __float_as_uint(n0.w);
+                        const float sx = __uint_as_float((em & 0xffu) << 23), sy = __uint_as_float(((em >> 8) & 0xffu) << 23),
+                                    sz = __uint_as_float(((em >> 16) & 0xffu) << 23);
+                        const uint32_t imask = em >> 24;
+                        const float ax = sx * r.idir.x, ay = sy * r.idir.y, az = sz * r.idir.z;
+                        const float bx = (n0.x - r.o.x) * r.idir.x, by = (n0.y - r.o.y) * r.idir.y, bz = (n0.z - r.o.z) * r.idir.z;
+                        // near/far planes per axis follow the direction sign
+                        const bool nx = (oct & 1u) != 0u, ny = (oct & 2u) != 0u, nz = (oct & 4u) != 0u;
+                        const uint32_t lox0 = __float_as_uint(n2.x), lox1 = __float_as_uint(n2.y), loy0 = __float_as_uint(n2.z), loy1 = __float_as_uint(n2.w);
+                        const uint32_t loz0 = __float_as_uint(n3.x), loz1 = __float_as_uint(n3.y), hix0 = __float_as_uint(n3.z), hix1 = __float_as_uint(n3.w);
+                        const uint32_t hiy0 = __float_as_uint(n4.x), hiy1 = __float_as_uint(n4.y), hiz0 = __float_as_uint(n4.z), hiz1 = __float_as_uint(n4.w);
+                        const uint32_t nearx[2] = {nx ? hix0 : lox0, nx ? hix1 : lox1}, farx[2] = {nx ? lox0 : hix0, nx ? lox1 : hix1};
+                        const uint32_t neary[2] = {ny ? hiy0 : loy0, ny ? hiy1 : loy1}, fary[2] = {ny ? loy0 : hiy0, ny ? loy1 : hiy1};
+                        const uint32_t nearz[2] = {nz ? hiz0 : loz0, nz ? hiz1 : loz1}, farz[2] = {nz ? loz0 : hiz0, nz ? loz1 : hiz1};
+                        const uint32_t meta[2] = {__float_as_uint(n1.z), __float_as_uint(n1.w)};
+                        uint32_t hits = 0u, tm = 0u;
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) {
+                            const int w = s >> 2, k = s & 3;
+                            const float tnx = __builtin_fmaf(u8f(nearx[w], k), ax, bx), tfx = __builtin_fmaf(u8f(farx[w], k), ax, bx);
+                            const float tny = __builtin_fmaf(u8f(neary[w], k), ay, by), tfy = __builtin_fmaf(u8f(fary[w], k), ay, by);
+                            const float tnz = __builtin_fmaf(u8f(nearz[w], k), az, bz), tfz = __builtin_fmaf(u8f(farz[w], k), az, bz);
+                            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+                            const float tf = fminf(fminf(fminf(tfx, tfy), tfz) * 1.0000004f, best);
+                            if (tn <= tf) {
+                                if (imask & (1u << s)) {
+                                    hits |= 1u << ((uint32_t)s ^ oct);
+                                } else {
+                                    const uint32_t m = (meta[w] >> (8 * k)) & 0xffu;
+                                    tm |= ((2u << (m >> 5)) - 1u) << (m & 31u);
+                                }
+                            }
+                        }
+                        g_base = __float_as_uint(n1.x);
+                        g_imask = imask;
+                        g_hits = hits;
+                        t_base = __float_as_uint(n1.y);
+                        t_mask = tm;
+                    }
+                }
+            } else {
+                if (want_tri) {
+                    const uint32_t bit = (uint32_t)__ffs((int)t_mask) - 1u;
+                    t_mask &= t_mask - 1u;
+                    ++c_tris;
+                    const LeafTri* tp = &a.bvh.tris[t_base + bit];
+                    const float4 ta = tp->t0, tb = tp->t1, tc = tp->t2;
+                    float t;
+                    if (tri_test(r, mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), t)) {
+                        const int32_t prim = __float_as_int(tc.y);
+                        if (MODE != TR_CLOSEST) {
+                            if (t > tmin && t < tmax) {
+                                bprim = 1;
+                                best = t;
+                                finish();
+                            }
+                        } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim))) {
+                            best = t;
+                            bprim = prim;
+                        }
+                    }
+                }
+            }
+            act = __ballot(active);
+        } while ((uint32_t)__popcll(act) >= thresh);
+    }
+    if (a.dbg) {
+        atomicAdd(&a.dbg[0], (unsigned long long)c_nodes);
+        atomicAdd(&a.dbg[1], (unsigned long long)c_tris);
+        atomicMax(&a.dbg[2], (unsigned long long)c_maxsp);
+        atomicAdd(&a.dbg[3], (unsigned long long)c_push);
+    }
+}
+#endif // PT_BVH8_NODE_ONLY

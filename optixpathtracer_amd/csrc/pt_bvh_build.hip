@@ -10,7 +10,8 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
-#include "pt_bvh.h"
+#define PT_BVH8_NODE_ONLY
+#include "pt_bvh8.h"
 #include "pt_host.h"
 
 namespace {
@@ -202,6 +203,173 @@ __global__ void k_emit_tris(const float* __restrict__ verts, const uint32_t* __r
     tris[i] = t;
 }
 
+// ------------------------------------------------------------------ BVH2 → compressed BVH8 (pt_bvh8.h)
+struct Task8 {
+    int bnode;     // binary node (Karras numbering: internal 0..n-2, leaf n-1+i)
+    uint32_t widx; // index of the wide node to emit
+};
+
+__device__ __forceinline__ float box_area(const float* b) {
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+__device__ __forceinline__ int node_tris(int c, int n, const int* rfirst, const int* rlast) {
+    return c >= n - 1 ? 1 : (rlast[c] - rfirst[c] + 1);
+}
+__device__ __forceinline__ int node_first(int c, int n, const int* rfirst) { return c >= n - 1 ? c - (n - 1) : rfirst[c]; }
+
+// One thread per wide node: open the binary subtree (largest surface area first) until 8 children,
+// place children in octant-matching slots, quantise, emit the node, its leaf triangles and the next tasks.
+__global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* __restrict__ tout, uint32_t* __restrict__ counters /*0 next tasks,1 nodes,2 tris*/,
+                            int n, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ rfirst,
+                            const int* __restrict__ rlast, const float* __restrict__ box, float pad,
+                            const LeafTri* __restrict__ tris_sorted, Node8* __restrict__ nodes, LeafTri* __restrict__ tris_out) {
+    const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ti >= nin) return;
+    const Task8 task = tin[ti];
+    int ch[8];
+    int nch = 2;
+    ch[0] = left[task.bnode];
+    ch[1] = right[task.bnode];
+    for (;;) {
+        if (nch == 8) break;
+        int bestj = -1;
+        float besta = -1.f;
+        for (int j = 0; j < nch; ++j) {
+            const int c = ch[j];
+            if (c >= n - 1 || node_tris(c, n, rfirst, rlast) <= PT8_LEAF_MAX) continue; // stays a leaf child
+            const float ar = box_area(&box[(size_t)c * 6]);
+            if (ar > besta) {
+                besta = ar;
+                bestj = j;
+            }
+        }
+        if (bestj < 0) break;
+        const int c = ch[bestj];
+        ch[bestj] = left[c];
+        ch[nch++] = right[c];
+    }
+    // node box (padded)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int j = 0; j < nch; ++j)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], box[(size_t)ch[j] * 6 + a] - pad);
+            hi[a] = fmaxf(hi[a], box[(size_t)ch[j] * 6 + 3 + a] + pad);
+        }
+    // greedy octant slot assignment: cost(child j, slot s) = dot(centroid_j - centre, signs(s))
+    float cen[3] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+    int slot_of[8], child_in[8];
+    for (int s = 0; s < 8; ++s) child_in[s] = -1;
+    for (int j = 0; j < nch; ++j) slot_of[j] = -1;
+    for (int it = 0; it < nch; ++it) {
+        float bc = -INFINITY;
+        int bj = -1, bs = -1;
+        for (int j = 0; j < nch; ++j) {
+            if (slot_of[j] >= 0) continue;
+            const float* b = &box[(size_t)ch[j] * 6];
+            const float dx = 0.5f * (b[0] + b[3]) - cen[0], dy = 0.5f * (b[1] + b[4]) - cen[1], dz = 0.5f * (b[2] + b[5]) - cen[2];
+            for (int s = 0; s < 8; ++s) {
+                if (child_in[s] >= 0) continue;
+                const float c = ((s & 1) ? dx : -dx) + ((s & 2) ? dy : -dy) + ((s & 4) ? dz : -dz);
+                if (c > bc) {
+                    bc = c;
+                    bj = j;
+                    bs = s;
+                }
+            }
+        }
+        slot_of[bj] = bs;
+        child_in[bs] = bj;
+    }
+    // classify, count
+    uint32_t imask = 0, nint = 0, ntri = 0;
+    for (int s = 0; s < 8; ++s) {
+        const int j = child_in[s];
+        if (j < 0) continue;
+        const int c = ch[j];
+        const int cnt = node_tris(c, n, rfirst, rlast);
+        if (c < n - 1 && cnt > PT8_LEAF_MAX) {
+            imask |= 1u << s;
+            ++nint;
+        } else {
+            ntri += (uint32_t)cnt;
+        }
+    }
+    const uint32_t child_base = nint ? atomicAdd(&counters[1], nint) : 0u;
+    const uint32_t tri_base = ntri ? atomicAdd(&counters[2], ntri) : 0u;
+    const uint32_t task_base = nint ? atomicAdd(&counters[0], nint) : 0u;
+    // grid step per axis: smallest power of two with 255 steps covering the extent
+    uint32_t eb[3];
+    float step[3];
+    for (int a = 0; a < 3; ++a) {
+        const float ext = hi[a] - lo[a];
+        int e;
+        frexpf(ext / 255.0f, &e); // ext/255 = m * 2^e, m in [0.5,1) → 2^e >= ext/255
+        if (e < -125) e = -125;
+        if (e > 127) e = 127;
+        eb[a] = (uint32_t)(e + 127);
+        step[a] = __uint_as_float(eb[a] << 23);
+    }
+    uint32_t q[6][2] = {{0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+    uint32_t meta[2] = {0u, 0u};
+    uint32_t toff = 0, irank = 0;
+    for (int s = 0; s < 8; ++s) {
+        const int j = child_in[s];
+        if (j < 0) continue; // empty slot keeps the inverted box
+        const int c = ch[j];
+        const float* b = &box[(size_t)c * 6];
+        for (int a = 0; a < 3; ++a) {
+            float ql = floorf(((b[a] - pad) - lo[a]) / step[a]);
+            float qh = ceilf(((b[3 + a] + pad) - lo[a]) / step[a]);
+            ql = fminf(fmaxf(ql, 0.f), 255.f);
+            qh = fminf(fmaxf(qh, 0.f), 255.f);
+            const int w = s >> 2, k = s & 3;
+            q[a][w] = (q[a][w] & ~(0xffu << (8 * k))) | ((uint32_t)ql << (8 * k));
+            q[3 + a][w] = (q[3 + a][w] & ~(0xffu << (8 * k))) | ((uint32_t)qh << (8 * k));
+        }
+        if (imask & (1u << s)) {
+            tout[task_base + irank] = Task8{c, child_base + irank};
+            ++irank;
+        } else {
+            const int cnt = node_tris(c, n, rfirst, rlast), first = node_first(c, n, rfirst);
+            for (int k = 0; k < cnt; ++k) tris_out[tri_base + toff + k] = tris_sorted[first + k];
+            meta[s >> 2] |= ((toff & 31u) | ((uint32_t)(cnt - 1) << 5)) << (8 * (s & 3));
+            toff += (uint32_t)cnt;
+        }
+    }
+    Node8 nd;
+    nd.n0 = make_float4(lo[0], lo[1], lo[2], __uint_as_float(eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24)));
+    nd.n1 = make_float4(__uint_as_float(child_base), __uint_as_float(tri_base), __uint_as_float(meta[0]), __uint_as_float(meta[1]));
+    nd.n2 = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
+    nd.n3 = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
+    nd.n4 = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
+    nodes[task.widx] = nd;
+}
+
+// scenes with <= PT8_LEAF_MAX triangles: one node, one leaf child
+__global__ void k_single_node8(int n, const float* __restrict__ bounds6, float pad, Node8* __restrict__ nodes) {
+    if (threadIdx.x || blockIdx.x) return;
+    float lo[3], hi[3];
+    uint32_t eb[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = bounds6[a] - pad;
+        hi[a] = bounds6[3 + a] + pad;
+        int e;
+        frexpf((hi[a] - lo[a]) / 255.0f, &e);
+        if (e < -125) e = -125;
+        if (e > 127) e = 127;
+        eb[a] = (uint32_t)(e + 127);
+    }
+    Node8 nd;
+    nd.n0 = make_float4(lo[0], lo[1], lo[2], __uint_as_float(eb[0] | (eb[1] << 8) | (eb[2] << 16)));
+    nd.n1 = make_float4(__uint_as_float(0u), __uint_as_float(0u), __uint_as_float(0u | ((uint32_t)(n - 1) << 5)), __uint_as_float(0u));
+    const uint32_t qlo = 0xffffff00u, qhi = 0x000000ffu; // slot 0 = whole grid, others inverted
+    nd.n2 = make_float4(__uint_as_float(qlo), __uint_as_float(0xffffffffu), __uint_as_float(qlo), __uint_as_float(0xffffffffu));
+    nd.n3 = make_float4(__uint_as_float(qlo), __uint_as_float(0xffffffffu), __uint_as_float(qhi), __uint_as_float(0u));
+    nd.n4 = make_float4(__uint_as_float(qhi), __uint_as_float(0u), __uint_as_float(qhi), __uint_as_float(0u));
+    nodes[0] = nd;
+}
+
 } // namespace
 
 #define HIPCHK(x)                         \
@@ -209,6 +377,46 @@ __global__ void k_emit_tris(const float* __restrict__ verts, const uint32_t* __r
         hipError_t e_ = (x);              \
         if (e_ != hipSuccess) return e_;  \
     } while (0)
+
+// wide BVH from the LBVH temporaries; nodes/tris are sized for the worst case and trimmed logically
+static hipError_t build_bvh8(int n, const int* left, const int* right, const int* rfirst, const int* rlast, const float* box, float pad,
+                             const LeafTri* tris_sorted, hipStream_t stream, PtBvh* out) {
+    Node8* nodes = nullptr;
+    LeafTri* tris8 = nullptr;
+    Task8 *ta = nullptr, *tb = nullptr;
+    uint32_t* counters = nullptr;
+    const size_t max_nodes = (size_t)n + 1; // every wide node has >= 2 children, so < n nodes
+    HIPCHK(hipMalloc(&nodes, sizeof(Node8) * max_nodes));
+    HIPCHK(hipMalloc(&tris8, sizeof(LeafTri) * (size_t)n));
+    HIPCHK(hipMalloc(&ta, sizeof(Task8) * max_nodes));
+    HIPCHK(hipMalloc(&tb, sizeof(Task8) * max_nodes));
+    HIPCHK(hipMalloc(&counters, sizeof(uint32_t) * 4));
+    uint32_t hc[4] = {0u, 1u, 0u, 0u}; // node 0 = root is taken
+    HIPCHK(hipMemcpyAsync(counters, hc, sizeof(hc), hipMemcpyHostToDevice, stream));
+    Task8 root{0, 0u};
+    HIPCHK(hipMemcpyAsync(ta, &root, sizeof(root), hipMemcpyHostToDevice, stream));
+    uint32_t nin = 1;
+    int levels = 0;
+    while (nin) {
+        hipLaunchKernelGGL(k_collapse8, dim3((nin + 63) / 64), dim3(64), 0, stream, ta, nin, tb, counters, n, left, right, rfirst, rlast, box, pad,
+                           tris_sorted, nodes, tris8);
+        HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        nin = hc[0];
+        const uint32_t zero = 0;
+        HIPCHK(hipMemcpyAsync(counters, &zero, 4, hipMemcpyHostToDevice, stream));
+        Task8* t = ta; ta = tb; tb = t;
+        if (++levels > 128) return hipErrorUnknown;
+    }
+    HIPCHK(hipGetLastError());
+    out->nodes8 = nodes;
+    out->tris8 = tris8;
+    out->num_nodes8 = hc[1];
+    out->num_tris8 = hc[2];
+    out->levels8 = levels;
+    hipFree(ta); hipFree(tb); hipFree(counters);
+    return hipSuccess;
+}
 
 // Builds the traversal structure for (verts, idx) already resident on the device.
 hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t ntri, hipStream_t stream, PtBvh* out) {
@@ -255,7 +463,18 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t nt
 
     if (n <= PT_LEAF_MAX) { // the whole scene is one leaf
         out->root = (int32_t)~((0u << 3) | (uint32_t)(n - 1));
+        Node8* nodes8 = nullptr;
+        LeafTri* tris8 = nullptr;
+        float* dbounds = nullptr;
+        HIPCHK(hipMalloc(&nodes8, sizeof(Node8)));
+        HIPCHK(hipMalloc(&tris8, sizeof(LeafTri) * (size_t)n));
+        HIPCHK(hipMalloc(&dbounds, sizeof(float) * 6));
+        HIPCHK(hipMemcpyAsync(dbounds, out->bounds, sizeof(float) * 6, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(tris8, tris, sizeof(LeafTri) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(k_single_node8, dim3(1), dim3(64), 0, stream, n, dbounds, pad, nodes8);
+        out->nodes8 = nodes8; out->tris8 = tris8; out->num_nodes8 = 1; out->num_tris8 = (uint32_t)n; out->levels8 = 1;
         HIPCHK(hipStreamSynchronize(stream));
+        hipFree(dbounds);
         hipFree(keys); hipFree(keys_sorted); hipFree(bounds); hipFree(tmp);
         return hipSuccess;
     }
@@ -294,6 +513,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t nt
     out->nodes = nodes;
     out->num_nodes = nnodes;
     out->root = 0; // node 0 (range = everything) always stays internal when n > PT_LEAF_MAX, and remap[0] = 0
+    HIPCHK(build_bvh8(n, left, right, rfirst, rlast, box, pad, tris, stream, out));
     hipFree(keys); hipFree(keys_sorted); hipFree(bounds); hipFree(tmp); hipFree(tmp2);
     hipFree(left); hipFree(right); hipFree(parent); hipFree(rfirst); hipFree(rlast); hipFree(visits);
     hipFree(box); hipFree(keep); hipFree(remap);
@@ -303,6 +523,10 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t nt
 void pt_bvh_free(PtBvh* b) {
     if (b->nodes) hipFree((void*)b->nodes);
     if (b->tris) hipFree((void*)b->tris);
+    if (b->nodes8) hipFree((void*)b->nodes8);
+    if (b->tris8) hipFree((void*)b->tris8);
+    b->nodes8 = nullptr;
+    b->tris8 = nullptr;
     b->nodes = nullptr;
     b->tris = nullptr;
 }

@@ -8,6 +8,7 @@
 #include "../../include/pt_amd.h"
 
 struct Node2;
+struct Node8;
 struct LeafTri;
 
 struct PtBvh {
@@ -17,6 +18,11 @@ struct PtBvh {
     int32_t root = 0;
     float bounds[6] = {0, 0, 0, 0, 0, 0};
     float pad = 0.f;
+    // 8-wide compressed form of the same tree (pt_bvh8.h)
+    const Node8* nodes8 = nullptr;
+    const LeafTri* tris8 = nullptr;
+    uint32_t num_nodes8 = 0, num_tris8 = 0;
+    int levels8 = 0;
 };
 
 hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t ntri, hipStream_t stream, PtBvh* out);

@@ -17,6 +17,7 @@
 
 enum { FLAG_DONE = 1, FLAG_SECONDARY = 2 }; // RAY_STATE_FLAGS_* deviceProgram.cu:46-48
 enum { PEND_DIRECT = 1, PEND_INDIRECT = 2, PEND_ALPHA = 3 };
+enum { TR_CLOSEST = 0, TR_SHADOW_APPLY = 1, TR_ANY_QUERY = 2 }; // modes of the persistent traversal kernels
 
 // 48-byte triangle in PRIMITIVE order for shading (what sbtData.vertex[index[prim]] gave, :485-489)
 struct PrimTri {

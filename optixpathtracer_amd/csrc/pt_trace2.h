@@ -21,7 +21,6 @@
 #define PT2_REFILL 40
 #define PT2_CHUNK 512
 
-enum { TR_CLOSEST = 0, TR_SHADOW_APPLY = 1, TR_ANY_QUERY = 2 };
 
 struct Trace2Args {
     PathState st;
@@ -29,10 +28,14 @@ struct Trace2Args {
     QView queue;
     uint32_t* work;  // global work counter, zero before launch (waves take PT2_CHUNK entries per atomic)
     uint32_t* ovf;   // spill stack: [PT2_OVF_DEPTH][gridDim.x * 64]
+    unsigned long long* dbg; // optional debug counters (see pt_bvh8.h)
 };
 
+#ifndef PT2_WAVES_PER_EU
+#define PT2_WAVES_PER_EU 5
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(64) k_trace2(Trace2Args a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT2_WAVES_PER_EU, PT2_WAVES_PER_EU))) k_trace2(Trace2Args a) {
     __shared__ uint32_t s_stack[PT2_LDS_DEPTH * 64];
     __shared__ uint32_t s_prefix[PT_NSUB + 1];
     const uint32_t lane = threadIdx.x;
@@ -56,8 +59,11 @@ __global__ void __launch_bounds__(64) k_trace2(Trace2Args a) {
     int32_t bprim = -1, node = 0;
     int sp = 0;
     uint32_t slot = 0;
+    uint32_t c_nodes = 0, c_tris = 0, c_maxsp = 0, c_push = 0;
 
     auto push = [&](uint32_t v) {
+        ++c_push;
+        if ((uint32_t)sp + 1 > c_maxsp) c_maxsp = sp + 1;
         if (sp < PT2_LDS_DEPTH) s_stack[sp * 64 + lane] = v;
         else if (sp < PT2_LDS_DEPTH + PT2_OVF_DEPTH) a.ovf[(size_t)(sp - PT2_LDS_DEPTH) * gstride + gtid] = v;
         ++sp;
@@ -144,6 +150,7 @@ __global__ void __launch_bounds__(64) k_trace2(Trace2Args a) {
                 if (inner) {
                     bool need_pop = true;
                     if (node != PT_REF_EMPTY) {
+                        ++c_nodes;
                         const Node2* nd = &a.bvh.nodes[node];
                         const float4 na = nd->a, nb = nd->b, nc = nd->c, nx = nd->d;
                         float t0, t1;
@@ -171,6 +178,7 @@ __global__ void __launch_bounds__(64) k_trace2(Trace2Args a) {
                     const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
                     bool done = false;
                     for (uint32_t k = 0; k < cnt; ++k) {
+                        ++c_tris;
                         const LeafTri* tp = &a.bvh.tris[first + k];
                         const float4 ta = tp->t0, tb = tp->t1, tc = tp->t2;
                         float t;
@@ -195,5 +203,11 @@ __global__ void __launch_bounds__(64) k_trace2(Trace2Args a) {
             }
             act = __ballot(active);
         } while ((uint32_t)__popcll(act) >= thresh);
+    }
+    if (a.dbg) {
+        atomicAdd(&a.dbg[0], (unsigned long long)c_nodes);
+        atomicAdd(&a.dbg[1], (unsigned long long)c_tris);
+        atomicMax(&a.dbg[2], (unsigned long long)c_maxsp);
+        atomicAdd(&a.dbg[3], (unsigned long long)c_push);
     }
 }

@@ -296,8 +296,8 @@ def test_both_traversal_kernels_agree(ptlib, orc_det, small_probe):
     m = scenes.voxel_terrain(n=96, target_tris=70000)
     w, h = 128, 72
     o = _oracle_render(orc_det, m, small_probe, scenes.TERRAIN_CAMERA, w, h, 2)
-    for tk in (0, 1):
-        r = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h, trace_kernel=tk)
+    for tk, bk in ((0, 0), (0, 1), (1, 1)):  # k_trace8 (default), k_trace2, k_trace
+        r = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h, trace_kernel=tk, bvh_kind=bk)
         _compare(_gpu_render(r, 2), o)
 
 

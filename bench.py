@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--workload", default="c3_terrain1M_1080p_4spp_d8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0)
+    ap.add_argument("--simulate-world", type=int, default=0, help="single process: render only rank 0's tiles of an N-way partition (predicts per-GPU time at N GPUs)")
+    ap.add_argument("--split-shadow", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=0, help="concurrent pixel chunks per frame (0 = library default)")
     ap.add_argument("--bvh-kind", type=int, default=0, help="0 = 8-wide compressed BVH (default), 1 = binary BVH")
     ap.add_argument("--trace-kernel", type=int, default=0, help="0 = persistent-wave traversal (default), 1 = first grid-stride kernel")
     args = ap.parse_args()
@@ -72,9 +75,11 @@ def main():
 
     r = R.SampleRenderer(model, device=local_rank)
     r.setProbe(probe)
-    r.setOptions(max_depth=depth, max_paths=args.max_paths, trace_kernel=args.trace_kernel, bvh_kind=args.bvh_kind)
+    r.setOptions(max_depth=depth, max_paths=args.max_paths, trace_kernel=args.trace_kernel, bvh_kind=args.bvh_kind, streams=args.streams, split_shadow=args.split_shadow)
     if world > 1:
         r.setPartition(rank, world, 64, 16)
+    elif args.simulate_world > 1:
+        r.setPartition(0, args.simulate_world, 64, 16)
     r.resize((w, h))
     r.setCamera(R.make_camera(cam, w / h))
     r.launchParams.samples_per_launch = spp

@@ -47,19 +47,23 @@ struct pt_ctx {
     uint32_t owned = 0, padded = 0;
     uint32_t* d_pixels = nullptr;     // this rank's pixel list
     uint32_t* d_all_pixels = nullptr; // world * padded, rank-major (0xffffffff = pad)
-    // path state
-    uint32_t cap = 0;
+    // path state: NSETS independent batch sets; pixel chunks of one frame are dealt round-robin to the sets and each
+    // set runs on its own pair of streams, so one chunk's kernel tails overlap with the other chunks' bulk work
+    struct BatchSet {
+        hipStream_t stream = nullptr, stream2 = nullptr;
+        PathState st{};
+        uint32_t *queueA = nullptr, *queueB = nullptr, *squeue = nullptr;
+        uint32_t* counters = nullptr; // [nq][PT_NSUB*PT_CSTRIDE] radiance sub-queue counts, same for shadow, then 2*nq work counters
+        uint32_t *ovf = nullptr, *ovf2 = nullptr;
+        float4 *pixResult = nullptr, *pixAlpha = nullptr, *pixNormal = nullptr, *pixAlbedo = nullptr;
+    };
+    std::vector<BatchSet> sets;
+    uint32_t set_cap = 0, set_pix_cap = 0, sub_cap = 0;
     bool cap_catcher = false;
-    PathState st{};
-    uint32_t *queueA = nullptr, *queueB = nullptr, *squeue = nullptr;
-    uint32_t* counters = nullptr; // [nq][PT_NSUB*PT_CSTRIDE] radiance sub-queue counts, the same for shadow queues, then 2*nq work counters
-    uint32_t sub_cap = 0;         // capacity of one sub-queue
-    uint32_t* ovf = nullptr;      // spill stacks of the persistent traversal waves
-    int trace_grid = 0;
     int nq = 0;
     unsigned long long* d_totals = nullptr;
-    float4 *pixResult = nullptr, *pixAlpha = nullptr, *pixNormal = nullptr, *pixAlbedo = nullptr;
-    uint32_t pix_cap = 0;
+    uint32_t* ovf = nullptr; // spill stacks for pt_trace queries
+    int trace_grid = 0;
     // stats + timing
     pt_stats stats{};
     std::vector<hipEvent_t> ev_pool;
@@ -102,6 +106,8 @@ static void default_options(pt_options* o) {
     o->bsdf_mode = PT_BSDF_DISNEY;
     o->max_paths = 8u << 20;
 }
+
+static size_t ovf_words(const pt_ctx* ctx);
 
 extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ctx) {
     if (!scene || !out_ctx || scene->num_meshes == 0 || !scene->meshes) return fail(nullptr, PT_ERR_INVALID, "pt_create: null or empty scene");
@@ -180,7 +186,7 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
         int wpe = PT8_WAVES_PER_EU; // persistent waves per SIMD = the occupancy the traversal kernels are compiled for
         if (const char* e = getenv("PT_TRACE_WAVES")) wpe = atoi(e);
         ctx->trace_grid = prop.multiProcessorCount * 4 * wpe;
-        CKC(dalloc(&ctx->ovf, (size_t)ctx->trace_grid * 64 * (PT8_OVF_DEPTH * 2 > PT2_OVF_DEPTH ? PT8_OVF_DEPTH * 2 : PT2_OVF_DEPTH)));
+        CKC(dalloc(&ctx->ovf, ovf_words(ctx)));
     }
     *out_ctx = ctx;
     return PT_OK;
@@ -188,17 +194,23 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
 }
 
 static void free_path_state(pt_ctx* ctx) {
-    PathState& s = ctx->st;
-    dfree(s.rayO); dfree(s.rayD); dfree(s.srayD); dfree(s.pend); dfree(s.hit); dfree(s.thr); dfree(s.rng); dfree(s.fd);
-    dfree(s.direct); dfree(s.indirect); dfree(s.alpha); dfree(s.nrm); dfree(s.alb); dfree(s.prdN); dfree(s.prdA);
-    dfree(ctx->queueA); dfree(ctx->queueB); dfree(ctx->squeue); dfree(ctx->counters);
-    ctx->cap = 0;
+    for (auto& b : ctx->sets) {
+        if (b.stream) hipStreamSynchronize(b.stream);
+        if (b.stream2) hipStreamSynchronize(b.stream2);
+        PathState& s = b.st;
+        dfree(s.rayO); dfree(s.rayD); dfree(s.srayD); dfree(s.pend); dfree(s.hit); dfree(s.thr); dfree(s.rng); dfree(s.fd);
+        dfree(s.direct); dfree(s.indirect); dfree(s.alpha); dfree(s.nrm); dfree(s.alb); dfree(s.prdN); dfree(s.prdA);
+        dfree(b.queueA); dfree(b.queueB); dfree(b.squeue); dfree(b.counters); dfree(b.ovf); dfree(b.ovf2);
+        dfree(b.pixResult); dfree(b.pixAlpha); dfree(b.pixNormal); dfree(b.pixAlbedo);
+        if (b.stream) hipStreamDestroy(b.stream);
+        if (b.stream2) hipStreamDestroy(b.stream2);
+    }
+    ctx->sets.clear();
+    ctx->set_cap = ctx->set_pix_cap = 0;
 }
 static void free_frame(pt_ctx* ctx) {
     dfree(ctx->accum); dfree(ctx->color); dfree(ctx->normal); dfree(ctx->albedo); dfree(ctx->frame);
     dfree(ctx->d_pixels); dfree(ctx->d_all_pixels);
-    dfree(ctx->pixResult); dfree(ctx->pixAlpha); dfree(ctx->pixNormal); dfree(ctx->pixAlbedo);
-    ctx->pix_cap = 0;
 }
 
 extern "C" int pt_destroy(pt_ctx* ctx) {
@@ -385,30 +397,36 @@ extern "C" int pt_resize(pt_ctx* ctx, int width, int height) {
     return PT_OK;
 }
 
-static int ensure_path_state(pt_ctx* ctx, uint32_t cap, uint32_t pix_cap) {
+static size_t ovf_words(const pt_ctx* ctx) {
+    return (size_t)ctx->trace_grid * 64 * (PT8_OVF_DEPTH * 2 > PT2_OVF_DEPTH ? PT8_OVF_DEPTH * 2 : PT2_OVF_DEPTH);
+}
+
+static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_cap) {
     const int nq = ctx->opt.max_depth + 2;
-    if (cap > ctx->cap || (ctx->has_catcher && !ctx->cap_catcher) || nq > ctx->nq) {
-        free_path_state(ctx);
-        PathState& s = ctx->st;
+    if ((int)ctx->sets.size() == nsets && cap <= ctx->set_cap && pix_cap <= ctx->set_pix_cap && nq <= ctx->nq &&
+        (!ctx->has_catcher || ctx->cap_catcher))
+        return PT_OK;
+    free_path_state(ctx);
+    ctx->sets.resize(nsets);
+    ctx->sub_cap = cap / PT_NSUB + 8192 + 1; // a sub-queue receives at most cap/64 + 32 workgroups * 256 entries
+    const size_t qsize = (size_t)PT_NSUB * ctx->sub_cap;
+    for (auto& b : ctx->sets) {
+        CK(hipStreamCreate(&b.stream));
+        CK(hipStreamCreate(&b.stream2));
+        PathState& s = b.st;
         CK(dalloc(&s.rayO, cap)); CK(dalloc(&s.rayD, cap)); CK(dalloc(&s.srayD, cap)); CK(dalloc(&s.pend, cap));
         CK(dalloc(&s.hit, cap)); CK(dalloc(&s.thr, cap)); CK(dalloc(&s.rng, cap)); CK(dalloc(&s.fd, cap));
         CK(dalloc(&s.direct, cap)); CK(dalloc(&s.indirect, cap)); CK(dalloc(&s.alpha, cap)); CK(dalloc(&s.nrm, cap)); CK(dalloc(&s.alb, cap));
         if (ctx->has_catcher) { CK(dalloc(&s.prdN, cap)); CK(dalloc(&s.prdA, cap)); }
-        ctx->cap_catcher = ctx->has_catcher;
-        // 64 sub-queues; a producer workgroup b appends to sub-queue b % 64, 32 workgroups of k_shade's 2048 share one:
-        // a sub-queue receives at most cap/64 + 32*256 entries
-        ctx->sub_cap = cap / PT_NSUB + 8192 + 1;
-        const size_t qsize = (size_t)PT_NSUB * ctx->sub_cap;
-        CK(dalloc(&ctx->queueA, qsize)); CK(dalloc(&ctx->queueB, qsize)); CK(dalloc(&ctx->squeue, qsize));
-        CK(dalloc(&ctx->counters, (size_t)2 * nq * PT_NSUB * PT_CSTRIDE + 2 * nq));
-        ctx->nq = nq;
-        ctx->cap = cap;
+        CK(dalloc(&b.queueA, qsize)); CK(dalloc(&b.queueB, qsize)); CK(dalloc(&b.squeue, qsize));
+        CK(dalloc(&b.counters, (size_t)2 * nq * PT_NSUB * PT_CSTRIDE + 2 * nq));
+        CK(dalloc(&b.ovf, ovf_words(ctx))); CK(dalloc(&b.ovf2, ovf_words(ctx)));
+        CK(dalloc(&b.pixResult, pix_cap)); CK(dalloc(&b.pixAlpha, pix_cap)); CK(dalloc(&b.pixNormal, pix_cap)); CK(dalloc(&b.pixAlbedo, pix_cap));
     }
-    if (pix_cap > ctx->pix_cap) {
-        dfree(ctx->pixResult); dfree(ctx->pixAlpha); dfree(ctx->pixNormal); dfree(ctx->pixAlbedo);
-        CK(dalloc(&ctx->pixResult, pix_cap)); CK(dalloc(&ctx->pixAlpha, pix_cap)); CK(dalloc(&ctx->pixNormal, pix_cap)); CK(dalloc(&ctx->pixAlbedo, pix_cap));
-        ctx->pix_cap = pix_cap;
-    }
+    ctx->cap_catcher = ctx->has_catcher;
+    ctx->nq = nq;
+    ctx->set_cap = cap;
+    ctx->set_pix_cap = pix_cap;
     return PT_OK;
 }
 
@@ -426,13 +444,14 @@ struct SpanGuard {
     pt_ctx* ctx;
     size_t a;
     int cls;
-    SpanGuard(pt_ctx* c, int cl) : ctx(c), cls(cl) {
+    hipStream_t s;
+    SpanGuard(pt_ctx* c, int cl, hipStream_t st = nullptr) : ctx(c), cls(cl), s(st ? st : c->stream) {
         a = ctx->ev_used;
-        hipEventRecord(next_event(ctx), ctx->stream);
+        hipEventRecord(next_event(ctx), s);
     }
     ~SpanGuard() {
         size_t b = ctx->ev_used;
-        hipEventRecord(next_event(ctx), ctx->stream);
+        hipEventRecord(next_event(ctx), s);
         ctx->spans.push_back({a, b, cls});
     }
 };
@@ -440,11 +459,132 @@ struct SpanGuard {
 static const int GRID = 256 * 8;
 
 template <int MODE>
-static void launch_shade(pt_ctx* ctx, const ShadeParams& sp) {
+static void launch_shade(pt_ctx* ctx, pt_ctx::BatchSet& bs, const ShadeParams& sp) {
     if (ctx->has_catcher)
-        hipLaunchKernelGGL((k_shade<MODE, true>), dim3(GRID), dim3(256), 0, ctx->stream, ctx->st, sp);
+        hipLaunchKernelGGL((k_shade<MODE, true>), dim3(GRID), dim3(256), 0, bs.stream, bs.st, sp);
     else
-        hipLaunchKernelGGL((k_shade<MODE, false>), dim3(GRID), dim3(256), 0, ctx->stream, ctx->st, sp);
+        hipLaunchKernelGGL((k_shade<MODE, false>), dim3(GRID), dim3(256), 0, bs.stream, bs.st, sp);
+}
+
+struct LaunchCounts {
+    uint32_t trace = 0, shadow = 0, shade = 0;
+};
+
+// enqueue every kernel of one pixel chunk (all its samples) on the streams of one batch set
+static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& fp, uint32_t pix0, uint32_t npix, uint32_t spp, uint32_t S,
+                          LaunchCounts& lc) {
+    const int nq = ctx->nq;
+    BvhDev bvh{ctx->bvh.nodes, ctx->bvh.tris, ctx->bvh.root};
+    Bvh8Dev bvh8{ctx->bvh.nodes8, ctx->bvh.tris8};
+    const size_t CS = (size_t)PT_NSUB * PT_CSTRIDE;
+    for (uint32_t s0 = 0; s0 < spp; s0 += S) {
+        const uint32_t Sc = std::min(S, spp - s0);
+        BatchParams bp{ctx->d_pixels + pix0, npix, s0, Sc, ctx->has_catcher ? 1 : 0, bs.pixResult, bs.pixAlpha, bs.pixNormal, bs.pixAlbedo};
+        hipMemsetAsync(bs.counters, 0, sizeof(uint32_t) * ((size_t)2 * nq * CS + 2 * nq), bs.stream);
+        {
+            SpanGuard g(ctx, CLS_OTHER, bs.stream);
+            hipLaunchKernelGGL(k_generate, dim3(GRID), dim3(256), 0, bs.stream, bs.st, fp, bp, bs.counters + 0);
+        }
+        uint32_t* cntA = bs.counters;                       // radiance queue counters, per bounce
+        uint32_t* cntS = bs.counters + (size_t)nq * CS;     // shadow queue counters, per bounce
+        uint32_t* work = bs.counters + (size_t)2 * nq * CS; // work counters of the persistent traversal
+        QView qcur{nullptr, cntA, ctx->sub_cap};            // identity for bounce 0 (k_generate wrote the count)
+        uint32_t* qnext_base = bs.queueA;
+        // depth d = 0..max_depth traces in the reference (the trace at depth == max_depth can only matter
+        // through a shadow-catcher pass-through or alpha; without catcher materials it is provably dead and skipped)
+        const int last_bounce = ctx->has_catcher ? ctx->opt.max_depth : ctx->opt.max_depth - 1;
+        hipEvent_t ev_shadow_done = nullptr;
+        const bool unified = ctx->opt.trace_kernel == 0 && ctx->opt.bvh_kind == 0 && ctx->opt.split_shadow == 0;
+        if (unified) {
+            // One traversal launch per bounce: the closest-hit rays of bounce b+1 and the shadow rays of bounce b share
+            // a persistent kernel (per-lane ray type), so the long-ray tail of one kind is filled with rays of the other
+            // and a frame has max_depth+1 traversal launches instead of 2*max_depth.
+            {
+                SpanGuard g(ctx, CLS_TRACE, bs.stream);
+                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, nullptr};
+                hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                ++lc.trace;
+            }
+            for (int b = 0; b <= last_bounce; ++b) {
+                QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
+                QView qshadow{bs.squeue, cntS + (size_t)b * CS, ctx->sub_cap};
+                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->probe, ctx->opt.max_depth, qcur, qnext, qshadow};
+                {
+                    SpanGuard g(ctx, CLS_SHADE, bs.stream);
+                    if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
+                    else launch_shade<PT_BSDF_DISNEY>(ctx, bs, sp);
+                    ++lc.shade;
+                }
+                if (b < last_bounce) {
+                    SpanGuard g(ctx, CLS_TRACE, bs.stream);
+                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, nullptr};
+                    hipLaunchKernelGGL((k_trace8<TR_UNIFIED>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                    ++lc.trace;
+                } else {
+                    SpanGuard g(ctx, CLS_SHADOW, bs.stream);
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf, nullptr};
+                    hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                    ++lc.shadow;
+                }
+                qcur = qnext;
+                qnext_base = (qnext_base == bs.queueA) ? bs.queueB : bs.queueA;
+            }
+        } else
+        for (int b = 0; b <= last_bounce; ++b) {
+            QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
+            QView qshadow{bs.squeue, cntS + (size_t)b * CS, ctx->sub_cap};
+            {
+                SpanGuard g(ctx, CLS_TRACE, bs.stream);
+                if (ctx->opt.trace_kernel == 1) {
+                    hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, bs.stream, bs.st, bvh, qcur);
+                } else if (ctx->opt.bvh_kind == 1) {
+                    Trace2Args ta{bs.st, bvh, qcur, work + b, bs.ovf, nullptr};
+                    hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                } else {
+                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, nullptr};
+                    hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                }
+                ++lc.trace;
+            }
+            ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->probe, ctx->opt.max_depth, qcur, qnext, qshadow};
+            if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0); // shade overwrites what shadow(b-1) reads
+            {
+                SpanGuard g(ctx, CLS_SHADE, bs.stream);
+                if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
+                else launch_shade<PT_BSDF_DISNEY>(ctx, bs, sp);
+                ++lc.shade;
+            }
+            {
+                // shadow rays of this bounce run on the set's second stream, concurrently with the next bounce's
+                // closest-hit traversal (both only read the ray arrays); the next shade waits for both
+                hipEvent_t ev_shaded = next_event(ctx);
+                hipEventRecord(ev_shaded, bs.stream);
+                hipStreamWaitEvent(bs.stream2, ev_shaded, 0);
+                SpanGuard g(ctx, CLS_SHADOW, bs.stream2);
+                if (ctx->opt.trace_kernel == 1) {
+                    hipLaunchKernelGGL((k_trace<1>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, bs.stream2, bs.st, bvh, qshadow);
+                } else if (ctx->opt.bvh_kind == 1) {
+                    Trace2Args ta{bs.st, bvh, qshadow, work + nq + b, bs.ovf2, nullptr};
+                    hipLaunchKernelGGL((k_trace2<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
+                } else {
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, nullptr};
+                    hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
+                }
+                ++lc.shadow;
+            }
+            ev_shadow_done = next_event(ctx);
+            hipEventRecord(ev_shadow_done, bs.stream2);
+            qcur = qnext;
+            qnext_base = (qnext_base == bs.queueA) ? bs.queueB : bs.queueA;
+        }
+        if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0);
+        {
+            SpanGuard g(ctx, CLS_OTHER, bs.stream);
+            // counters[last_bounce+1] holds paths that would have continued: not traced, not counted
+            hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters, nq, last_bounce + 1, ctx->d_totals);
+            hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, bs.stream, bs.st, fp, bp, (int)(s0 == 0), (int)(s0 + Sc >= spp));
+        }
+    }
 }
 
 extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8) {
@@ -454,92 +594,37 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     if (!ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_render: no probe set (setProbe)");
     CK(hipSetDevice(ctx->device));
     const uint32_t owned = ctx->owned;
-    // chunking: all samples of a pixel stay in one pixel chunk; samples are split when spp*pixels > max_paths;
-    // shadow-catcher scenes run one sample per pass so that per-pixel normal/albedo sums keep the reference order
+    // Chunking.  All samples of a pixel stay in one pixel chunk.  The frame is cut into (at least) `streams` pixel
+    // chunks that run concurrently on separate stream pairs; a chunk holds at most max_paths/streams paths, so
+    // samples are split when spp*pixels exceed that; shadow-catcher scenes run one sample per pass so that the
+    // per-pixel normal/albedo sums keep the reference order.  None of this changes a bit of the result.
+    const int nsets = std::max(1, std::min(16, ctx->opt.streams > 0 ? ctx->opt.streams : 1));
     const uint32_t max_paths = std::max<uint32_t>(ctx->opt.max_paths, 64u);
-    const uint32_t Np = std::min(owned, max_paths);
-    uint32_t S = ctx->has_catcher ? 1u : std::max(1u, std::min(spp, Np ? max_paths / Np : 1u));
+    const uint32_t cap = std::max<uint32_t>(64u, max_paths / nsets);
+    uint32_t Np = (owned + nsets - 1) / nsets;        // pixels per chunk ...
+    Np = std::min(cap, std::max(64u, (Np + 63u) & ~63u)); // ... whole 8x8 blocks, within the set capacity
+    const uint32_t S = ctx->has_catcher ? 1u : std::max(1u, std::min(spp, cap / Np));
     if (owned) {
-        int rc = ensure_path_state(ctx, Np * S, Np);
+        int rc = ensure_path_state(ctx, nsets, Np * S, Np);
         if (rc) return rc;
     }
-    const int nq = ctx->nq;
     ctx->ev_used = 0;
     ctx->spans.clear();
     CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 2, ctx->stream));
     hipEvent_t ev_begin = next_event(ctx);
     CK(hipEventRecord(ev_begin, ctx->stream));
-    BvhDev bvh{ctx->bvh.nodes, ctx->bvh.tris, ctx->bvh.root};
-    Bvh8Dev bvh8{ctx->bvh.nodes8, ctx->bvh.tris8};
     FrameParams fp{ctx->accum, ctx->frame, ctx->color, ctx->normal, ctx->albedo, ctx->width, ctx->height, subframe_index,
                    ctx->eye, ctx->U, ctx->V, ctx->W, spp, ctx->probe};
-    uint32_t trace_launches = 0, shadow_launches = 0, shade_launches = 0;
-    for (uint32_t pix0 = 0; pix0 < owned; pix0 += Np) {
-        const uint32_t npix = std::min(Np, owned - pix0);
-        for (uint32_t s0 = 0; s0 < spp; s0 += S) {
-            const uint32_t Sc = std::min(S, spp - s0);
-            BatchParams bp{ctx->d_pixels + pix0, npix, s0, Sc, ctx->has_catcher ? 1 : 0,
-                           ctx->pixResult, ctx->pixAlpha, ctx->pixNormal, ctx->pixAlbedo};
-            CK(hipMemsetAsync(ctx->counters, 0, sizeof(uint32_t) * ((size_t)2 * nq * PT_NSUB * PT_CSTRIDE + 2 * nq), ctx->stream));
-            {
-                SpanGuard g(ctx, CLS_OTHER);
-                hipLaunchKernelGGL(k_generate, dim3(GRID), dim3(256), 0, ctx->stream, ctx->st, fp, bp, ctx->counters + 0);
-            }
-            const size_t CS = (size_t)PT_NSUB * PT_CSTRIDE;
-            uint32_t* cntA = ctx->counters;                       // radiance queue counters, per bounce
-            uint32_t* cntS = ctx->counters + (size_t)nq * CS;     // shadow queue counters, per bounce
-            uint32_t* work = ctx->counters + (size_t)2 * nq * CS; // work counters of the persistent traversal
-            QView qcur{nullptr, cntA, ctx->sub_cap}; // identity for bounce 0 (k_generate wrote the count)
-            uint32_t* qnext_base = ctx->queueA;
-            // depth d = 0..max_depth traces in the reference (the trace at depth == max_depth can only matter
-            // through a shadow-catcher pass-through or alpha; without catcher materials it is provably dead and skipped)
-            const int last_bounce = ctx->has_catcher ? ctx->opt.max_depth : ctx->opt.max_depth - 1;
-            for (int b = 0; b <= last_bounce; ++b) {
-                QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
-                QView qshadow{ctx->squeue, cntS + (size_t)b * CS, ctx->sub_cap};
-                {
-                    SpanGuard g(ctx, CLS_TRACE);
-                    if (ctx->opt.trace_kernel == 1) {
-                        hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, qcur);
-                    } else if (ctx->opt.bvh_kind == 1) {
-                        Trace2Args ta{ctx->st, bvh, qcur, work + b, ctx->ovf, nullptr};
-                        hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
-                    } else {
-                        Trace8Args ta{ctx->st, bvh8, qcur, work + b, ctx->ovf, nullptr};
-                        hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
-                    }
-                    ++trace_launches;
-                }
-                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->probe, ctx->opt.max_depth, qcur, qnext, qshadow};
-                {
-                    SpanGuard g(ctx, CLS_SHADE);
-                    if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, sp);
-                    else launch_shade<PT_BSDF_DISNEY>(ctx, sp);
-                    ++shade_launches;
-                }
-                {
-                    SpanGuard g(ctx, CLS_SHADOW);
-                    if (ctx->opt.trace_kernel == 1) {
-                        hipLaunchKernelGGL((k_trace<1>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, ctx->st, bvh, qshadow);
-                    } else if (ctx->opt.bvh_kind == 1) {
-                        Trace2Args ta{ctx->st, bvh, qshadow, work + nq + b, ctx->ovf, nullptr};
-                        hipLaunchKernelGGL((k_trace2<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
-                    } else {
-                        Trace8Args ta{ctx->st, bvh8, qshadow, work + nq + b, ctx->ovf, nullptr};
-                        hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
-                    }
-                    ++shadow_launches;
-                }
-                qcur = qnext;
-                qnext_base = (qnext_base == ctx->queueA) ? ctx->queueB : ctx->queueA;
-            }
-            {
-                SpanGuard g(ctx, CLS_OTHER);
-                // counters[last_bounce+1] holds paths that would have continued: not traced, not counted
-                hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, ctx->stream, ctx->counters, nq, last_bounce + 1, ctx->d_totals);
-                hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, ctx->st, fp, bp,
-                                   (int)(s0 == 0), (int)(s0 + Sc >= spp));
-            }
+    LaunchCounts lc;
+    if (owned) {
+        for (auto& b : ctx->sets) hipStreamWaitEvent(b.stream, ev_begin, 0);
+        uint32_t k = 0;
+        for (uint32_t pix0 = 0; pix0 < owned; pix0 += Np, ++k)
+            enqueue_chunk(ctx, ctx->sets[k % nsets], fp, pix0, std::min(Np, owned - pix0), spp, S, lc);
+        for (auto& b : ctx->sets) {
+            hipEvent_t e = next_event(ctx);
+            hipEventRecord(e, b.stream);
+            hipStreamWaitEvent(ctx->stream, e, 0);
         }
     }
     hipEvent_t ev_end = next_event(ctx);
@@ -548,6 +633,21 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     CK(hipGetLastError());
     unsigned long long totals[2] = {0, 0};
     CK(hipMemcpy(totals, ctx->d_totals, sizeof(totals), hipMemcpyDeviceToHost));
+    if (getenv("PT_DEBUG_COUNTS") && owned) { // per-bounce queue sizes of the last chunk of set 0
+        const size_t CS = (size_t)PT_NSUB * PT_CSTRIDE;
+        std::vector<uint32_t> hc((size_t)2 * ctx->nq * CS);
+        CK(hipMemcpy(hc.data(), ctx->sets[0].counters, sizeof(uint32_t) * hc.size(), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pt_render] rays per bounce (radiance/shadow):");
+        for (int b = 0; b < ctx->nq; ++b) {
+            unsigned long long r = 0, sh = 0;
+            for (int q = 0; q < PT_NSUB; ++q) {
+                r += hc[(size_t)b * CS + q * PT_CSTRIDE];
+                sh += hc[(size_t)(ctx->nq + b) * CS + q * PT_CSTRIDE];
+            }
+            fprintf(stderr, " %llu/%llu", r, sh);
+        }
+        fprintf(stderr, "\n");
+    }
     pt_stats& st = ctx->stats;
     st.radiance_rays = totals[0];
     st.shadow_rays = totals[1];
@@ -561,13 +661,13 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
         hipEventElapsedTime(&m, ctx->ev_pool[sp.a], ctx->ev_pool[sp.b]);
         cls_ms[sp.cls] += m;
     }
-    st.trace_ms = cls_ms[CLS_TRACE];
+    st.trace_ms = cls_ms[CLS_TRACE]; // sums over concurrent streams: they overlap, so they can exceed render_ms
     st.shadow_ms = cls_ms[CLS_SHADOW];
     st.shade_ms = cls_ms[CLS_SHADE];
     st.other_ms = cls_ms[CLS_OTHER];
-    st.trace_launches = trace_launches;
-    st.shadow_launches = shadow_launches;
-    st.shade_launches = shade_launches;
+    st.trace_launches = lc.trace;
+    st.shadow_launches = lc.shadow;
+    st.shade_launches = lc.shade;
     if (host_rgba8) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)ctx->width * ctx->height);
     return PT_OK;
 }
@@ -715,8 +815,8 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     if (any_hit) CK(dalloc(&dOcc, n));
     unsigned long long* dDbg = nullptr;
     if (getenv("PT_DEBUG_COUNTS")) {
-        CK(dalloc(&dDbg, 4));
-        CK(hipMemset(dDbg, 0, 32));
+        CK(dalloc(&dDbg, 8));
+        CK(hipMemset(dDbg, 0, 64));
     }
     uint32_t* dWork = nullptr;
     CK(dalloc(&dWork, (size_t)iters));
@@ -733,7 +833,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
             if (any_hit) hipLaunchKernelGGL((k_trace2<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         } else {
-            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8}, QView{nullptr, dCount, 0}, dWork + it, ctx->ovf, dDbg};
+            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8}, QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, dDbg};
             if (any_hit) hipLaunchKernelGGL((k_trace8<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         }
@@ -745,10 +845,11 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     hipEventElapsedTime(&ms, e0, e1);
     if (kernel_ms) *kernel_ms = ms / iters;
     if (dDbg) {
-        unsigned long long h[4];
-        CK(hipMemcpy(h, dDbg, 32, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[pt_trace] rays %u x %d: node steps/ray %.2f, tri tests/ray %.2f, pushes/ray %.2f, max stack %llu\n", n, iters,
-                (double)h[0] / n / iters, (double)h[1] / n / iters, (double)h[3] / n / iters, h[2]);
+        unsigned long long h[8];
+        CK(hipMemcpy(h, dDbg, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pt_trace] rays %u x %d: node steps/ray %.2f, tri tests/ray %.2f, pushes/ray %.2f, max stack %llu, max steps of one ray %llu, "
+                "wave loop iterations max %llu mean %.1f (waves %llu)\n", n, iters,
+                (double)h[0] / n / iters, (double)h[1] / n / iters, (double)h[3] / n / iters, h[2], h[4], h[5], h[7] ? (double)h[6] / h[7] : 0.0, h[7] / iters);
         dfree(dDbg);
     }
     hipEventDestroy(e0);

@@ -37,7 +37,12 @@ struct Bvh8Dev {
 #ifndef PT_BVH8_NODE_ONLY
 #define PT8_LDS_DEPTH 12
 #define PT8_OVF_DEPTH 52
-#define PT8_REFILL 40
+#ifndef PT8_REFILL
+#define PT8_REFILL 24
+#endif
+#ifndef PT8_MIN_CHUNK
+#define PT8_MIN_CHUNK 64
+#endif
 #define PT8_CHUNK 512
 #ifndef PT8_WAVES_PER_EU
 #define PT8_WAVES_PER_EU 5
@@ -47,6 +52,7 @@ struct Trace8Args {
     PathState st;
     Bvh8Dev bvh;
     QView queue;
+    QView queue2; // TR_UNIFIED only: the shadow queue of the previous bounce, traced in the same launch
     uint32_t* work;
     uint32_t* ovf; // spill stack: [PT8_OVF_DEPTH][2][gridDim.x * 64]
     unsigned long long* dbg; // optional: [0] node steps, [1] triangle tests, [2] max stack depth, [3] pushes (pt_trace + PT_DEBUG_COUNTS)
@@ -59,16 +65,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT8_WAV
 k_trace8(Trace8Args a) {
     __shared__ uint32_t s_stack[PT8_LDS_DEPTH * 2 * 64];
     __shared__ uint32_t s_prefix[PT_NSUB + 1];
+    __shared__ uint32_t s_prefix2[PT_NSUB + 1];
     const uint32_t lane = threadIdx.x;
     const uint32_t gtid = blockIdx.x * 64u + lane;
     const uint32_t gstride = gridDim.x * 64u;
-    const uint32_t n = qreader_init(a.queue, s_prefix);
-    uint32_t chunk = (n / (gridDim.x * 2u)) & ~63u;
-    chunk = chunk < 64u ? 64u : (chunk > (uint32_t)PT8_CHUNK ? (uint32_t)PT8_CHUNK : chunk);
+    // index space of the launch: [0,n1) = rays of `queue`, [n1, n) = shadow rays of `queue2` (TR_UNIFIED)
+    const uint32_t n1 = qreader_init(a.queue, s_prefix);
+    const uint32_t n2 = (MODE == TR_UNIFIED) ? qreader_init(a.queue2, s_prefix2) : 0u;
+    const uint32_t n = n1 + n2;
+    uint32_t chunk = (n / (gridDim.x * 2u)) & ~(uint32_t)(PT8_MIN_CHUNK < 64 ? PT8_MIN_CHUNK - 1 : 63);
+    chunk = chunk < (uint32_t)PT8_MIN_CHUNK ? (uint32_t)PT8_MIN_CHUNK : (chunk > (uint32_t)PT8_CHUNK ? (uint32_t)PT8_CHUNK : chunk);
     if ((unsigned long long)blockIdx.x * chunk >= n) return;
     uint32_t chunk_next = blockIdx.x * chunk;
     uint32_t chunk_end = (chunk_next + chunk < n) ? chunk_next + chunk : n;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    bool shadow_lane = (MODE == TR_SHADOW_APPLY); // TR_UNIFIED: per lane, set at refill
 
     bool active = false, exhausted = false;
     RaySetup r;
@@ -80,7 +91,7 @@ k_trace8(Trace8Args a) {
     uint32_t t_base = 0, t_mask = 0;             // current triangle group
     int sp = 0;
     uint32_t slot = 0;
-    uint32_t c_nodes = 0, c_tris = 0, c_maxsp = 0, c_push = 0;
+    uint32_t c_nodes = 0, c_tris = 0, c_maxsp = 0, c_push = 0, c_ray = 0, c_raymax = 0, c_iters = 0;
 
     auto push = [&](uint32_t v0, uint32_t v1) {
         ++c_push;
@@ -105,7 +116,7 @@ k_trace8(Trace8Args a) {
         }
     };
     auto finish = [&]() {
-        if (MODE == TR_SHADOW_APPLY) {
+        if (MODE == TR_SHADOW_APPLY || (MODE == TR_UNIFIED && shadow_lane)) {
             const float4 pe = a.st.pend[slot];
             const int kind = __float_as_int(pe.w);
             const bool occluded = bprim != 0;
@@ -123,6 +134,8 @@ k_trace8(Trace8Args a) {
             a.st.hit[slot] = make_float2(best, __int_as_float(bprim));
         }
         active = false;
+        if (c_ray > c_raymax) c_raymax = c_ray;
+        c_ray = 0;
     };
 
     for (;;) {
@@ -144,10 +157,16 @@ k_trace8(Trace8Args a) {
             const uint32_t first = chunk_next;
             chunk_next += take;
             if (!active && rank < take) {
-                slot = qreader_get(a.queue, s_prefix, first + rank);
+                const uint32_t gi = first + rank;
+                if (MODE == TR_UNIFIED) {
+                    shadow_lane = gi >= n1;
+                    slot = shadow_lane ? qreader_get(a.queue2, s_prefix2, gi - n1) : qreader_get(a.queue, s_prefix, gi);
+                } else {
+                    slot = qreader_get(a.queue, s_prefix, gi);
+                }
                 const float4 o4 = a.st.rayO[slot];
                 float4 d4;
-                if (MODE == TR_SHADOW_APPLY) {
+                if (MODE == TR_SHADOW_APPLY || (MODE == TR_UNIFIED && shadow_lane)) {
                     d4 = a.st.srayD[slot];
                     tmin = 0.01f;
                     tmax = 1e16f;
@@ -167,7 +186,7 @@ k_trace8(Trace8Args a) {
                 // sign BITS (so that -0.0, whose reciprocal is -inf, picks the matching near/far planes)
                 oct = (__float_as_uint(d4.x) >> 31) | ((__float_as_uint(d4.y) >> 31) << 1) | ((__float_as_uint(d4.z) >> 31) << 2);
                 best = tmax;
-                bprim = (MODE == TR_CLOSEST) ? -1 : 0;
+                bprim = (MODE == TR_CLOSEST || (MODE == TR_UNIFIED && !shadow_lane)) ? -1 : 0;
                 sp = 0;
                 // the root is node 0: a group whose only internal child is slot 0 of a virtual parent
                 g_base = 0;
@@ -206,6 +225,7 @@ k_trace8(Trace8Args a) {
                         const uint32_t idx = g_base + (uint32_t)__popc(g_imask & ((1u << cs) - 1u));
                         if (g_hits != 0u) push(g_base, g_imask | (g_hits << 8));
                         ++c_nodes;
+                        ++c_ray;
                         const Node8* nd = &a.bvh.nodes[idx];
                         const float4 n0 = nd->n0, n1 = nd->n1, n2 = nd->n2, n3 = nd->n3, n4 = nd->n4;
                         const uint32_t em = __float_as_uint(n0.w);
@@ -223,7 +243,7 @@ k_trace8(Trace8Args a) {
                         const uint32_t neary[2] = {ny ? hiy0 : loy0, ny ? hiy1 : loy1}, fary[2] = {ny ? loy0 : hiy0, ny ? loy1 : hiy1};
                         const uint32_t nearz[2] = {nz ? hiz0 : loz0, nz ? hiz1 : loz1}, farz[2] = {nz ? loz0 : hiz0, nz ? loz1 : hiz1};
                         const uint32_t meta[2] = {__float_as_uint(n1.z), __float_as_uint(n1.w)};
-                        uint32_t hits = 0u, tm = 0u;
+                        uint32_t hm = 0u; // hit mask in slot positions (branch-free: one compare + select + or per child)
 #pragma unroll
                         for (int s = 0; s < 8; ++s) {
                             const int w = s >> 2, k = s & 3;
@@ -232,13 +252,22 @@ k_trace8(Trace8Args a) {
                             const float tnz = __builtin_fmaf(u8f(nearz[w], k), az, bz), tfz = __builtin_fmaf(u8f(farz[w], k), az, bz);
                             const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
                             const float tf = fminf(fminf(fminf(tfx, tfy), tfz) * 1.0000004f, best);
-                            if (tn <= tf) {
-                                if (imask & (1u << s)) {
-                                    hits |= 1u << ((uint32_t)s ^ oct);
-                                } else {
-                                    const uint32_t m = (meta[w] >> (8 * k)) & 0xffu;
-                                    tm |= ((2u << (m >> 5)) - 1u) << (m & 31u);
-                                }
+                            hm |= (tn <= tf) ? (1u << s) : 0u;
+                        }
+                        // internal hits, moved to (slot ^ oct) bit positions: XOR of the index = conditional swaps of bit groups
+                        uint32_t hits = hm & imask;
+                        hits = (oct & 1u) ? (((hits & 0x55u) << 1) | ((hits >> 1) & 0x55u)) : hits;
+                        hits = (oct & 2u) ? (((hits & 0x33u) << 2) | ((hits >> 2) & 0x33u)) : hits;
+                        hits = (oct & 4u) ? (((hits & 0x0fu) << 4) | ((hits >> 4) & 0x0fu)) : hits;
+                        // triangles of the leaf children that were hit
+                        uint32_t tm = 0u;
+                        const uint32_t lm = hm & ~imask;
+                        if (lm != 0u) {
+#pragma unroll
+                            for (int s = 0; s < 8; ++s) {
+                                const uint32_t m = (meta[s >> 2] >> (8 * (s & 3))) & 0xffu;
+                                const uint32_t bits = ((2u << (m >> 5)) - 1u) << (m & 31u);
+                                tm |= (lm & (1u << s)) ? bits : 0u;
                             }
                         }
                         g_base = __float_as_uint(n1.x);
@@ -253,12 +282,13 @@ k_trace8(Trace8Args a) {
                     const uint32_t bit = (uint32_t)__ffs((int)t_mask) - 1u;
                     t_mask &= t_mask - 1u;
                     ++c_tris;
+                    ++c_ray;
                     const LeafTri* tp = &a.bvh.tris[t_base + bit];
                     const float4 ta = tp->t0, tb = tp->t1, tc = tp->t2;
                     float t;
                     if (tri_test(r, mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), t)) {
                         const int32_t prim = __float_as_int(tc.y);
-                        if (MODE != TR_CLOSEST) {
+                        if (MODE == TR_SHADOW_APPLY || MODE == TR_ANY_QUERY || (MODE == TR_UNIFIED && shadow_lane)) {
                             if (t > tmin && t < tmax) {
                                 bprim = 1;
                                 best = t;
@@ -271,6 +301,7 @@ k_trace8(Trace8Args a) {
                     }
                 }
             }
+            ++c_iters;
             act = __ballot(active);
         } while ((uint32_t)__popcll(act) >= thresh);
     }
@@ -279,6 +310,10 @@ k_trace8(Trace8Args a) {
         atomicAdd(&a.dbg[1], (unsigned long long)c_tris);
         atomicMax(&a.dbg[2], (unsigned long long)c_maxsp);
         atomicAdd(&a.dbg[3], (unsigned long long)c_push);
+        atomicMax(&a.dbg[4], (unsigned long long)c_raymax);
+        atomicMax(&a.dbg[5], (unsigned long long)c_iters);
+        if (lane == 0) atomicAdd(&a.dbg[6], (unsigned long long)c_iters);
+        if (lane == 0) atomicAdd(&a.dbg[7], 1ull);
     }
 }
 #endif // PT_BVH8_NODE_ONLY

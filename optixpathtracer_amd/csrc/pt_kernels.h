@@ -17,7 +17,7 @@
 
 enum { FLAG_DONE = 1, FLAG_SECONDARY = 2 }; // RAY_STATE_FLAGS_* deviceProgram.cu:46-48
 enum { PEND_DIRECT = 1, PEND_INDIRECT = 2, PEND_ALPHA = 3 };
-enum { TR_CLOSEST = 0, TR_SHADOW_APPLY = 1, TR_ANY_QUERY = 2 }; // modes of the persistent traversal kernels
+enum { TR_CLOSEST = 0, TR_SHADOW_APPLY = 1, TR_ANY_QUERY = 2, TR_UNIFIED = 3 /* closest-hit queue + shadow queue in one launch */ }; // modes of the persistent traversal kernels
 
 // 48-byte triangle in PRIMITIVE order for shading (what sbtData.vertex[index[prim]] gave, :485-489)
 struct PrimTri {
@@ -444,9 +444,9 @@ __global__ void k_accum_stats(const uint32_t* __restrict__ counters, int nq, int
         r += __shfl_xor(r, off);
         s += __shfl_xor(s, off);
     }
-    if (q == 0) {
-        totals[0] += r;
-        totals[1] += s;
+    if (q == 0) { // several batch sets finish concurrently
+        atomicAdd(&totals[0], r);
+        atomicAdd(&totals[1], s);
     }
 }
 

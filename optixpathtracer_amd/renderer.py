@@ -128,8 +128,8 @@ class SampleRenderer:
         self._ck(self._L.pt_set_probe(self._ctx, *[a.ctypes.data for a in arrs], probe.width, probe.height), "pt_set_probe")
 
     # -- beyond the reference (runtime versions of its compile-time constants, multi-GPU, stats)
-    def setOptions(self, max_depth=8, bsdf_mode=PT_BSDF_DISNEY, max_paths=0, sort_rays=0, bvh_kind=0, trace_kernel=0):
-        o = Options(max_depth, bsdf_mode, max_paths, sort_rays, bvh_kind, trace_kernel)
+    def setOptions(self, max_depth=8, bsdf_mode=PT_BSDF_DISNEY, max_paths=0, sort_rays=0, bvh_kind=0, trace_kernel=0, streams=0, split_shadow=0):
+        o = Options(max_depth, bsdf_mode, max_paths, sort_rays, bvh_kind, trace_kernel, streams, split_shadow)
         self._ck(self._L.pt_set_options(self._ctx, C.byref(o)), "pt_set_options")
 
     def setPartition(self, rank, world, tile_w=64, tile_h=16):

@@ -296,8 +296,9 @@ def test_both_traversal_kernels_agree(ptlib, orc_det, small_probe):
     m = scenes.voxel_terrain(n=96, target_tris=70000)
     w, h = 128, 72
     o = _oracle_render(orc_det, m, small_probe, scenes.TERRAIN_CAMERA, w, h, 2)
-    for tk, bk in ((0, 0), (0, 1), (1, 1)):  # k_trace8 (default), k_trace2, k_trace
-        r = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h, trace_kernel=tk, bvh_kind=bk)
+    # k_trace8 unified launches (default), k_trace8 split + 2 streams, 3 concurrent pixel chunks, k_trace2, k_trace
+    for opt in (dict(), dict(split_shadow=1), dict(streams=3), dict(bvh_kind=1), dict(bvh_kind=1, trace_kernel=1)):
+        r = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h, **opt)
         _compare(_gpu_render(r, 2), o)
 
 

@@ -5,8 +5,9 @@ A "step" is one frame: one pt_render of the workload (the reference's one optixL
 SimplePathtracer.cpp:73-97) with scene, BVH and probe already resident in HBM.  Default workload is
 BASELINE config C3: the procedural 1,000,000-triangle voxel terrain, 1920x1080, 4 spp, depth 8,
 Disney BSDF, 2048x1024 sky+sun probe.  N>1: the image is tile-partitioned (interleaved 64x16 tiles,
-no data-path collective; weak/strong is 'strong' — the frame is fixed and split over ranks) and
-`value` = rays traced by all ranks / max-over-ranks time.  One RCCL all-gather of the packed frame
+no data-path collective).  Default for N>1 is WEAK scaling: per-GPU work is fixed, the image grows to N x the
+pixels (N=4: 3840x2160, config C4's size) so each rank renders one 1080p frame's worth of paths; `--scaling strong`
+splits the fixed 1080p frame N ways instead.  `value` = rays traced by all ranks / max-over-ranks time.  One RCCL all-gather of the packed frame
 runs after the timed region as the display hand-off (reported as gather_ms).
 
 Prints ONE JSON line on rank 0.
@@ -30,7 +31,8 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BYTES_PER_RADIANCE_RAY_TRACE = 32 + 4 + 8  # k_trace<0>: rayO+rayD (32) + queue entry (4) + hit write (8)
+BYTES_PER_RADIANCE_RAY_TRACE = 32 + 4 + 8  # closest-hit ray: rayO+rayD (32) + queue entry (4) + hit write (8)
+BYTES_PER_SHADOW_RAY_TRACE = 32 + 4 + 16  # shadow ray: origin+direction (32) + queue entry (4) + pending contribution (16)
 
 
 def main():
@@ -41,6 +43,7 @@ def main():
     ap.add_argument("--workload", default="c3_terrain1M_1080p_4spp_d8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N>1: weak = per-GPU work fixed (image area grows with N, C4-style); strong = the fixed frame split N ways")
     ap.add_argument("--simulate-world", type=int, default=0, help="single process: render only rank 0's tiles of an N-way partition (predicts per-GPU time at N GPUs)")
     ap.add_argument("--split-shadow", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="concurrent pixel chunks per frame (0 = library default)")
@@ -69,6 +72,11 @@ def main():
     from optixpathtracer_amd import scenes
 
     scene_name, cam_name, w, h, spp, depth = WORKLOADS[args.workload]
+    if world > 1 and args.scaling == "weak":
+        # per-GPU work fixed: the image grows to N x the pixels (same aspect, multiples of 8; N=4 is exactly 3840x2160,
+        # BASELINE config C4's size) and is tile-partitioned, so every rank still renders one 1080p frame's worth of paths
+        f = world ** 0.5
+        w, h = int(round(w * f / 8)) * 8, int(round(h * f / 8)) * 8
     model = scenes.voxel_terrain() if scene_name == "terrain" else scenes.cornell_box()
     probe = scenes.sky_probe(2048, 1024).BuildCDF()
     cam = getattr(scenes, cam_name)
@@ -95,7 +103,7 @@ def main():
         r.render()
     barrier()
     rays = 0
-    agg = dict(trace_ms=0.0, shadow_ms=0.0, shade_ms=0.0, other_ms=0.0, render_ms=0.0, trace_launches=0, radiance_rays=0, shadow_rays=0)
+    agg = dict(trace_ms=0.0, shadow_ms=0.0, shade_ms=0.0, other_ms=0.0, render_ms=0.0, trace_launches=0, shadow_launches=0, radiance_rays=0, shadow_rays=0)
     t0 = time.perf_counter()
     for k in range(args.steps):
         r.launchParams.frame.subframe_index = args.warmup + k  # progressive accumulation, like the reference's loop
@@ -132,12 +140,15 @@ def main():
 
     if rank == 0:
         mrays = rays_all / dt_max / 1e6
-        # roofline of the dominant kernel, k_trace<0> (closest-hit traversal): algorithmic bytes per launch
-        # = radiance rays of the launch x 44 B (DESIGN.md "roofline"), duration = HIP-event time on the render stream
-        n_launch = max(1, agg["trace_launches"])
-        avg_ms = agg["trace_ms"] / n_launch
-        alg_bytes = agg["radiance_rays"] / n_launch * BYTES_PER_RADIANCE_RAY_TRACE
+        # roofline of the dominant kernels, the BVH traversal launches (k_trace8<0> for the camera rays, then one
+        # k_trace8<3> per bounce tracing that bounce's closest-hit rays together with the previous bounce's shadow
+        # rays): algorithmic bytes per launch = (radiance rays x 44 B + shadow rays x 52 B) / launches,
+        # duration = mean HIP-event time of those launches on their own streams (pt_stats)
+        n_launch = max(1, agg["trace_launches"] + agg["shadow_launches"])
+        avg_ms = (agg["trace_ms"] + agg["shadow_ms"]) / n_launch
+        alg_bytes = (agg["radiance_rays"] * BYTES_PER_RADIANCE_RAY_TRACE + agg["shadow_rays"] * BYTES_PER_SHADOW_RAY_TRACE) / n_launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        kname = {(1, 0): "k_trace2", (1, 1): "k_trace", (0, 1): "k_trace"}.get((args.bvh_kind, args.trace_kernel), "k_trace8<3>/<0>")
         out = {
             "metric": "Mrays/s (and ms/frame) at 1080p 4spp depth8; 1/2/4/8 MI355X scaling",
             "value": round(mrays, 2),
@@ -147,7 +158,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": ("strong" if (world == 1 or args.scaling == "strong") else "weak"),
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -160,7 +171,7 @@ def main():
             "bvh": {"nodes": st["bvh_nodes"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2)},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "roofline": {
-                "kernel": ("k_trace<0>" if args.trace_kernel == 1 else ("k_trace2<0>" if args.bvh_kind == 1 else "k_trace8<0>")) + " (closest-hit BVH traversal)", "bound": "hbm", "achieved": round(achieved, 2),
+                "kernel": kname + " (BVH traversal: closest-hit + shadow rays)", "bound": "hbm", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes),
             },

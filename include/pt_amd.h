@@ -72,7 +72,7 @@ typedef struct pt_options {
     int32_t sort_rays;      /* reserved: per-bounce ray sort (0 = off) */
     int32_t bvh_kind;       /* 0 = default: 8-wide compressed BVH (k_trace8); 1 = binary BVH (k_trace2) */
     int32_t trace_kernel;   /* 0 = default (persistent-wave k_trace2), 1 = first grid-stride kernel (A/B) */
-    int32_t streams;        /* pixel chunks of a frame run concurrently on this many stream pairs (0 = default 1; more measured slower) */
+    int32_t streams;        /* pixel chunks of a frame run concurrently on this many stream pairs (0 = default 3, the measured optimum: tails of one chunk overlap the bulk of the others) */
     int32_t split_shadow;   /* 0 = default: shadow rays of bounce b share a launch with the closest-hit rays of b+1; 1 = separate kernels */
 } pt_options;
 

@@ -63,6 +63,7 @@ struct pt_ctx {
     int nq = 0;
     unsigned long long* d_totals = nullptr;
     uint32_t* ovf = nullptr; // spill stacks for pt_trace queries
+    unsigned long long* dbg = nullptr; // PT_DEBUG_COUNTS: traversal step counters of the last frame
     int trace_grid = 0;
     // stats + timing
     pt_stats stats{};
@@ -224,6 +225,7 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
     dfree(ctx->d_totals);
     dfree(ctx->ovf);
+    dfree(ctx->dbg);
     for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -501,7 +503,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             // and a frame has max_depth+1 traversal launches instead of 2*max_depth.
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, nullptr};
+                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, ctx->dbg};
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
@@ -517,7 +519,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, nullptr};
+                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, ctx->dbg};
                     hipLaunchKernelGGL((k_trace8<TR_UNIFIED>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 } else {
@@ -598,7 +600,7 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     // chunks that run concurrently on separate stream pairs; a chunk holds at most max_paths/streams paths, so
     // samples are split when spp*pixels exceed that; shadow-catcher scenes run one sample per pass so that the
     // per-pixel normal/albedo sums keep the reference order.  None of this changes a bit of the result.
-    const int nsets = std::max(1, std::min(16, ctx->opt.streams > 0 ? ctx->opt.streams : 1));
+    const int nsets = std::max(1, std::min(16, ctx->opt.streams > 0 ? ctx->opt.streams : 3));
     const uint32_t max_paths = std::max<uint32_t>(ctx->opt.max_paths, 64u);
     const uint32_t cap = std::max<uint32_t>(64u, max_paths / nsets);
     uint32_t Np = (owned + nsets - 1) / nsets;        // pixels per chunk ...
@@ -607,6 +609,10 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     if (owned) {
         int rc = ensure_path_state(ctx, nsets, Np * S, Np);
         if (rc) return rc;
+    }
+    if (getenv("PT_DEBUG_COUNTS")) {
+        if (!ctx->dbg) CK(dalloc(&ctx->dbg, 8));
+        CK(hipMemset(ctx->dbg, 0, 64));
     }
     ctx->ev_used = 0;
     ctx->spans.clear();
@@ -633,6 +639,11 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     CK(hipGetLastError());
     unsigned long long totals[2] = {0, 0};
     CK(hipMemcpy(totals, ctx->d_totals, sizeof(totals), hipMemcpyDeviceToHost));
+    if (ctx->dbg) {
+        unsigned long long h[8];
+        CK(hipMemcpy(h, ctx->dbg, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pt_render] traversal: node steps %llu, tri tests %llu, max steps of one ray %llu, max wave loop iterations %llu, mean %.1f\n", h[0], h[1], h[4], h[5], h[7] ? (double)h[6] / h[7] : 0.0);
+    }
     if (getenv("PT_DEBUG_COUNTS") && owned) { // per-bounce queue sizes of the last chunk of set 0
         const size_t CS = (size_t)PT_NSUB * PT_CSTRIDE;
         std::vector<uint32_t> hc((size_t)2 * ctx->nq * CS);

@@ -148,6 +148,22 @@ def main():
         avg_ms = (agg["trace_ms"] + agg["shadow_ms"]) / n_launch
         alg_bytes = (agg["radiance_rays"] * BYTES_PER_RADIANCE_RAY_TRACE + agg["shadow_rays"] * BYTES_PER_SHADOW_RAY_TRACE) / n_launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic per traversal launch from the committed rocprofv3 PMC passes of this same command
+        # (tools/profile.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the guide); PMC cannot be
+        # collected inside an unprofiled run, so the figure is read from profiles/ when the workload matches
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if os.path.exists(tj) and args.workload == "c3_terrain1M_1080p_4spp_d8" and world == 1 and args.bvh_kind == 0 and args.trace_kernel == 0:
+            try:
+                T = json.load(open(tj))
+                num = den = 0.0
+                for k, v in T.items():
+                    if k.startswith("k_trace8"):
+                        num += (v["fetch_bytes_per_dispatch_x2"] + v["write_bytes_per_dispatch"]) * v["dispatches"]
+                        den += v["dispatches"]
+                traffic = int(num / den) if den else None
+            except Exception:
+                traffic = None
         kname = {(1, 0): "k_trace2", (1, 1): "k_trace", (0, 1): "k_trace"}.get((args.bvh_kind, args.trace_kernel), "k_trace8<3>/<0>")
         out = {
             "metric": "Mrays/s (and ms/frame) at 1080p 4spp depth8; 1/2/4/8 MI355X scaling",
@@ -172,7 +188,7 @@ def main():
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "roofline": {
                 "kernel": kname + " (BVH traversal: closest-hit + shadow rays)", "bound": "hbm", "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes),
             },
         }

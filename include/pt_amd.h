@@ -118,6 +118,13 @@ int pt_get_options(const pt_ctx* ctx, pt_options* opt);
 int pt_set_probe(pt_ctx* ctx, const float* data_rgba, const float* pdfX, const float* cdfX, const float* pdfY,
                  const float* cdfY, int width, int height);
 
+/* main.cpp:146-156 loadProbe + ProbeData::BuildCDF (Probe.h:29-77) + setProbe in one call, with the CDF built ON THE
+ * GPU: one thread per row performs the reference's sequential float running sum (so the
+ * arrays are bit-identical to the host BuildCDF), one thread accumulates the row totals.  data = w*h float4. */
+int pt_set_probe_image(pt_ctx* ctx, const float* data_rgba, int width, int height);
+/* read back the device CDF arrays (pdfX,cdfX: w*h floats; pdfY,cdfY: h floats); any pointer may be NULL */
+int pt_get_probe_cdf(pt_ctx* ctx, float* pdfX, float* cdfX, float* pdfY, float* cdfY);
+
 /* ProbeData::BuildCDF (Probe.h:29-77), host side like the reference. Pure function, no context. */
 int pt_build_cdf(const float* data_rgba, int width, int height, float* pdfX, float* cdfX, float* pdfY, float* cdfY);
 

@@ -15,7 +15,7 @@ EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_options", "pt_get_options", "pt_set_probe", "pt_build_cdf",
     "pt_resize", "pt_set_camera", "pt_uvw_frame", "pt_set_partition", "pt_render", "pt_download", "pt_upload_accum",
     "pt_device_buffer", "pt_tonemap_sqrt", "pt_owned_pixels", "pt_pack", "pt_unpack", "pt_get_stats", "pt_trace",
-    "pt_eval_table", "pt_version",
+    "pt_eval_table", "pt_version", "pt_set_probe_image", "pt_get_probe_cdf",
 ]
 
 
@@ -103,6 +103,8 @@ def load_library() -> C.CDLL:
     L.pt_get_options.argtypes = [vp, C.POINTER(Options)]
     L.pt_set_probe.argtypes = [vp, vp, vp, vp, vp, vp, i, i]
     L.pt_build_cdf.argtypes = [vp, i, i, vp, vp, vp, vp]
+    L.pt_set_probe_image.argtypes = [vp, vp, i, i]
+    L.pt_get_probe_cdf.argtypes = [vp, vp, vp, vp, vp]
     L.pt_resize.argtypes = [vp, i, i]
     L.pt_set_camera.argtypes = [vp, C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3)]
     L.pt_uvw_frame.argtypes = [C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3), f, f, C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3)]

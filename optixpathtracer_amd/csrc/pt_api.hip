@@ -328,6 +328,43 @@ extern "C" int pt_set_probe(pt_ctx* ctx, const float* data, const float* pdfX, c
     return PT_OK;
 }
 
+extern "C" int pt_set_probe_image(pt_ctx* ctx, const float* data, int w, int h) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!data || w <= 0 || h <= 0) return fail(ctx, PT_ERR_INVALID, "pt_set_probe_image: Probe Data is not valid");
+    if ((long long)w * h >= (1ll << 31)) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_set_probe_image: probe too large");
+    CK(hipSetDevice(ctx->device));
+    CK(hipStreamSynchronize(ctx->stream));
+    dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
+    const size_t n = (size_t)w * h;
+    float* rowTotal = nullptr;
+    CK(dalloc(&ctx->d_probe_data, n));
+    CK(dalloc(&ctx->d_pdfX, n));
+    CK(dalloc(&ctx->d_cdfX, n));
+    CK(dalloc(&ctx->d_pdfY, (size_t)h));
+    CK(dalloc(&ctx->d_cdfY, (size_t)h));
+    CK(dalloc(&rowTotal, (size_t)h));
+    CK(hipMemcpy(ctx->d_probe_data, data, sizeof(float4) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_cdf_rows, dim3((h + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_probe_data, w, h, ctx->d_pdfX, ctx->d_cdfX, rowTotal);
+    hipLaunchKernelGGL(k_cdf_marginal, dim3(1), dim3(64), 0, ctx->stream, rowTotal, h, ctx->d_pdfY, ctx->d_cdfY);
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipGetLastError());
+    dfree(rowTotal);
+    ctx->probe = DevProbe{w, h, ctx->d_probe_data, ctx->d_pdfX, ctx->d_cdfX, ctx->d_pdfY, ctx->d_cdfY};
+    return PT_OK;
+}
+
+extern "C" int pt_get_probe_cdf(pt_ctx* ctx, float* pdfX, float* cdfX, float* pdfY, float* cdfY) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_get_probe_cdf: no probe set");
+    CK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->probe.width * ctx->probe.height;
+    if (pdfX) CK(hipMemcpy(pdfX, ctx->d_pdfX, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (cdfX) CK(hipMemcpy(cdfX, ctx->d_cdfX, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (pdfY) CK(hipMemcpy(pdfY, ctx->d_pdfY, sizeof(float) * ctx->probe.height, hipMemcpyDeviceToHost));
+    if (cdfY) CK(hipMemcpy(cdfY, ctx->d_cdfY, sizeof(float) * ctx->probe.height, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 extern "C" int pt_set_camera(pt_ctx* ctx, const float eye[3], const float U[3], const float V[3], const float W[3]) {
     if (!ctx || !eye || !U || !V || !W) return PT_ERR_INVALID;
     ctx->eye = v3{eye[0], eye[1], eye[2]};

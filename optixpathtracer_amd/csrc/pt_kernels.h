@@ -464,6 +464,42 @@ __global__ void k_emit_prims(const float* __restrict__ verts, const uint32_t* __
     prims[p] = t;
 }
 
+// ------------------------------------------------------------------ probe CDF on the GPU (Probe.h:29-77)
+// One thread per row keeps the reference's sequential float accumulation order, so the arrays equal the host
+// BuildCDF bit for bit (a parallel scan would reassociate the float sums).
+__global__ void k_cdf_rows(const float4* __restrict__ data, int width, int height, float* __restrict__ pdfX,
+                           float* __restrict__ cdfX, float* __restrict__ rowTotal) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= height) return;
+    float totalWeightX = 0.0f;
+    for (int i = 0; i < width; ++i) {
+        const float4 c = data[(size_t)j * width + i];
+        const float weight = c.x * 0.3f + c.y * 0.6f + c.z * 0.1f; // Luminance, maths.h:165-168
+        totalWeightX += weight;
+        pdfX[(size_t)j * width + i] = weight;
+        cdfX[(size_t)j * width + i] = totalWeightX;
+    }
+    const float invTotalWeightX = 1.0f / totalWeightX;
+    for (int i = 0; i < width; ++i) {
+        pdfX[(size_t)j * width + i] *= invTotalWeightX;
+        cdfX[(size_t)j * width + i] *= invTotalWeightX;
+    }
+    rowTotal[j] = totalWeightX;
+}
+__global__ void k_cdf_marginal(const float* __restrict__ rowTotal, int height, float* __restrict__ pdfY, float* __restrict__ cdfY) {
+    if (threadIdx.x || blockIdx.x) return;
+    float totalWeightY = 0.0f;
+    for (int j = 0; j < height; ++j) {
+        totalWeightY += rowTotal[j];
+        pdfY[j] = rowTotal[j];
+        cdfY[j] = totalWeightY;
+    }
+    for (int j = 0; j < height; ++j) {
+        cdfY[j] /= totalWeightY;
+        pdfY[j] /= totalWeightY;
+    }
+}
+
 // ------------------------------------------------------------------ function tables (tests)
 template <int MODE>
 __global__ void k_table_bsdf(pt_material mat, const float* __restrict__ in, uint32_t n, float* __restrict__ out) {

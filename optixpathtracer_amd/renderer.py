@@ -126,6 +126,21 @@ class SampleRenderer:
             raise RuntimeError("Probe Data is not valid")  # Probe.h:104-105
         arrs = [np.ascontiguousarray(a, np.float32) for a in (probe.data, probe.pdfValuesX, probe.cdfValuesX, probe.pdfValuesY, probe.cdfValuesY)]
         self._ck(self._L.pt_set_probe(self._ctx, *[a.ctypes.data for a in arrs], probe.width, probe.height), "pt_set_probe")
+        self._probe_wh = (probe.width, probe.height)
+
+    def setProbeImage(self, data: np.ndarray):
+        """loadProbe + BuildCDF + setProbe with the CDF built on the GPU (bit-identical to the host BuildCDF)."""
+        d = np.ascontiguousarray(data, np.float32)
+        h, w = d.shape[0], d.shape[1]
+        self._ck(self._L.pt_set_probe_image(self._ctx, d.ctypes.data, w, h), "pt_set_probe_image")
+        self._probe_wh = (w, h)
+
+    def probeCDF(self):
+        w, h = self._probe_wh
+        pdfX = np.empty((h, w), np.float32); cdfX = np.empty((h, w), np.float32)
+        pdfY = np.empty(h, np.float32); cdfY = np.empty(h, np.float32)
+        self._ck(self._L.pt_get_probe_cdf(self._ctx, pdfX.ctypes.data, cdfX.ctypes.data, pdfY.ctypes.data, cdfY.ctypes.data), "pt_get_probe_cdf")
+        return pdfX, cdfX, pdfY, cdfY
 
     # -- beyond the reference (runtime versions of its compile-time constants, multi-GPU, stats)
     def setOptions(self, max_depth=8, bsdf_mode=PT_BSDF_DISNEY, max_paths=0, sort_rays=0, bvh_kind=0, trace_kernel=0, streams=0, split_shadow=0):

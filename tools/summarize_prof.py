@@ -39,6 +39,7 @@ def main():
         for r in rows[:14]:
             print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
         print()
+    traffic = {}
     for cname, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         cc = find(os.path.join(out, sub), "*counter_collection.csv")
         if not cc:
@@ -55,7 +56,18 @@ def main():
         print("|---|---|---|---|")
         for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:10]:
             print(f"| {k} | {n} | {v/1024:.1f} | {v/1024/max(n,1):.2f} |")
+            traffic.setdefault(k, {})[cname] = {"dispatches": n, "KiB": v}
         print()
+    # machine-readable per-kernel traffic for bench.py's roofline.traffic (bytes per dispatch; FETCH_SIZE doubled as
+    # MI355X_MICROARCH.md §HBM prescribes for 16-B-per-lane loads, WRITE_SIZE as is; KiB -> bytes)
+    import json
+    out_t = {}
+    for k, d in traffic.items():
+        f, w_ = d.get("FETCH_SIZE"), d.get("WRITE_SIZE")
+        if f and w_:
+            out_t[k] = {"dispatches": f["dispatches"], "fetch_bytes_per_dispatch_x2": 2 * f["KiB"] * 1024 / f["dispatches"],
+                        "write_bytes_per_dispatch": w_["KiB"] * 1024 / w_["dispatches"]}
+    json.dump(out_t, open(os.path.join(out, f"traffic_{tag}.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -152,6 +152,35 @@ int pt_set_partition(pt_ctx* ctx, int rank, int world, int tile_w, int tile_h);
  * buffer is copied into it (render(CUDAOutputBuffer&) + downloadPixels, :99-107,149-153). */
 int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8);
 
+/* Foveated variants (the HelloPathtracing_sv, _sv2, _sv3, _sv4_vmv23 directories).  One pt_region = one optixLaunch of the sv4 raygen
+ * (HelloPathtracing_sv4_vmv23/deviceProgram.cu:388-590): LaunchParams.frame.{factor,fillSize,c,r_inner,r_outer,offset,
+ * redraw} (sv4 LaunchParams.h:62-70) + the launch dimensions, samples_per_launch and subframe_index of that launch. */
+typedef struct pt_region {
+    uint32_t launch_w, launch_h;  /* optixLaunch width/height */
+    uint32_t factor_x, factor_y;  /* frame.factor */
+    int32_t fill_size;            /* frame.fillSize: the result is splatted over fill_size^2 pixels */
+    uint32_t cx, cy;              /* frame.c: gaze point in pixels */
+    float r_inner, r_outer;       /* pixels whose distance to c is outside [r_inner, r_outer] are skipped */
+    uint32_t offset_x, offset_y;  /* frame.offset */
+    uint32_t redraw;              /* 1: never blend with accum_buffer */
+    uint32_t spp;                 /* samples_per_launch */
+    uint32_t subframe_index;
+} pt_region;
+
+/* what the sv3/sv4 device code changed relative to the canonical variant */
+typedef struct pt_variant {
+    float radiance_tmin;          /* 0.001 canonical (deviceProgram.cu:420); 0.01 sv4 (global tmin, sv4 :41,485) */
+    int32_t cull_back_occlusion;  /* 0 canonical (TERMINATE_ON_FIRST_HIT); 1 sv3/sv4 (CULL_BACK_FACING_TRIANGLES, sv4 :240) */
+    int32_t tonemap;              /* 0: make_color(accum); 1: make_color(reinhard(accum * exposure, white)) (sv4 :555-569) */
+    float exposure;               /* sv4: pow(2,2) = 4 */
+    float white;                  /* sv4: 1 */
+} pt_variant;
+
+/* SampleRenderer::render() of the foveated variants (HelloPathtracing_sv4_vmv23/SimplePathtracer.cpp:77-216): the
+ * given launches in order (later ones overwrite earlier pixels).  Depth cutoff = pt_options.max_depth (sv4: 4).
+ * Writes accum_buffer and frame_buffer only, like sv4.  variant may be NULL (canonical settings). */
+int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t n, const pt_variant* variant, uint32_t* host_rgba8);
+
 /* SampleRenderer::downloadPixels (SimplePathtracer.cpp:149-153), generalised to all five buffers.
  * bytes must equal width*height*(16 or 4). */
 int pt_download(pt_ctx* ctx, int which /* pt_buffer */, void* host, size_t bytes);

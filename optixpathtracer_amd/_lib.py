@@ -15,7 +15,7 @@ EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_options", "pt_get_options", "pt_set_probe", "pt_build_cdf",
     "pt_resize", "pt_set_camera", "pt_uvw_frame", "pt_set_partition", "pt_render", "pt_download", "pt_upload_accum",
     "pt_device_buffer", "pt_tonemap_sqrt", "pt_owned_pixels", "pt_pack", "pt_unpack", "pt_get_stats", "pt_trace",
-    "pt_eval_table", "pt_version", "pt_set_probe_image", "pt_get_probe_cdf",
+    "pt_eval_table", "pt_version", "pt_set_probe_image", "pt_get_probe_cdf", "pt_render_regions",
 ]
 
 
@@ -45,6 +45,18 @@ class Options(C.Structure):
         ("max_depth", C.c_int32), ("bsdf_mode", C.c_int32), ("max_paths", C.c_uint32), ("sort_rays", C.c_int32),
         ("bvh_kind", C.c_int32), ("trace_kernel", C.c_int32), ("streams", C.c_int32), ("split_shadow", C.c_int32),
     ]
+
+
+class Region(C.Structure):  # pt_region
+    _fields_ = [
+        ("launch_w", C.c_uint32), ("launch_h", C.c_uint32), ("factor_x", C.c_uint32), ("factor_y", C.c_uint32),
+        ("fill_size", C.c_int32), ("cx", C.c_uint32), ("cy", C.c_uint32), ("r_inner", C.c_float), ("r_outer", C.c_float),
+        ("offset_x", C.c_uint32), ("offset_y", C.c_uint32), ("redraw", C.c_uint32), ("spp", C.c_uint32), ("subframe_index", C.c_uint32),
+    ]
+
+
+class Variant(C.Structure):  # pt_variant
+    _fields_ = [("radiance_tmin", C.c_float), ("cull_back_occlusion", C.c_int32), ("tonemap", C.c_int32), ("exposure", C.c_float), ("white", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -110,6 +122,7 @@ def load_library() -> C.CDLL:
     L.pt_uvw_frame.argtypes = [C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3), f, f, C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3)]
     L.pt_set_partition.argtypes = [vp, i, i, i, i]
     L.pt_render.argtypes = [vp, u32, u32, vp]
+    L.pt_render_regions.argtypes = [vp, C.POINTER(Region), u32, C.POINTER(Variant), vp]
     L.pt_download.argtypes = [vp, i, vp, C.c_size_t]
     L.pt_upload_accum.argtypes = [vp, vp, C.c_size_t]
     L.pt_device_buffer.restype = vp

@@ -510,9 +510,17 @@ struct LaunchCounts {
 };
 
 // enqueue every kernel of one pixel chunk (all its samples) on the streams of one batch set
+struct RegionJob { // non-null: one launch-index range of a foveated launch instead of a pixel chunk
+    RegionParams rg;
+    VariantParams var;
+    uint32_t l0, nl;
+};
+
 static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& fp, uint32_t pix0, uint32_t npix, uint32_t spp, uint32_t S,
-                          LaunchCounts& lc) {
+                          LaunchCounts& lc, const RegionJob* job = nullptr) {
     const int nq = ctx->nq;
+    const float tmin_rad = job ? job->var.radiance_tmin : 0.001f;
+    const int cull = job ? job->var.cull_back_occlusion : 0;
     BvhDev bvh{ctx->bvh.nodes, ctx->bvh.tris, ctx->bvh.root};
     Bvh8Dev bvh8{ctx->bvh.nodes8, ctx->bvh.tris8};
     const size_t CS = (size_t)PT_NSUB * PT_CSTRIDE;
@@ -520,14 +528,18 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
         const uint32_t Sc = std::min(S, spp - s0);
         BatchParams bp{ctx->d_pixels + pix0, npix, s0, Sc, ctx->has_catcher ? 1 : 0, bs.pixResult, bs.pixAlpha, bs.pixNormal, bs.pixAlbedo};
         hipMemsetAsync(bs.counters, 0, sizeof(uint32_t) * ((size_t)2 * nq * CS + 2 * nq), bs.stream);
-        {
-            SpanGuard g(ctx, CLS_OTHER, bs.stream);
-            hipLaunchKernelGGL(k_generate, dim3(GRID), dim3(256), 0, bs.stream, bs.st, fp, bp, bs.counters + 0);
-        }
         uint32_t* cntA = bs.counters;                       // radiance queue counters, per bounce
         uint32_t* cntS = bs.counters + (size_t)nq * CS;     // shadow queue counters, per bounce
         uint32_t* work = bs.counters + (size_t)2 * nq * CS; // work counters of the persistent traversal
         QView qcur{nullptr, cntA, ctx->sub_cap};            // identity for bounce 0 (k_generate wrote the count)
+        if (job) qcur.base = bs.queueB;                     // foveated launch: only the paths inside the annulus are queued
+        {
+            SpanGuard g(ctx, CLS_OTHER, bs.stream);
+            if (job)
+                hipLaunchKernelGGL(k_generate_region, dim3(GRID), dim3(256), 0, bs.stream, bs.st, fp, job->rg, tmin_rad, job->l0, job->nl, qcur);
+            else
+                hipLaunchKernelGGL(k_generate, dim3(GRID), dim3(256), 0, bs.stream, bs.st, fp, bp, bs.counters + 0);
+        }
         uint32_t* qnext_base = bs.queueA;
         // depth d = 0..max_depth traces in the reference (the trace at depth == max_depth can only matter
         // through a shadow-catcher pass-through or alpha; without catcher materials it is provably dead and skipped)
@@ -540,14 +552,14 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             // and a frame has max_depth+1 traversal launches instead of 2*max_depth.
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, ctx->dbg};
+                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg};
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeue, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->probe, ctx->opt.max_depth, qcur, qnext, qshadow};
+                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
@@ -556,12 +568,12 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, ctx->dbg};
+                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, cull, ctx->dbg};
                     hipLaunchKernelGGL((k_trace8<TR_UNIFIED>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 } else {
                     SpanGuard g(ctx, CLS_SHADOW, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf, nullptr};
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf, cull, nullptr};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.shadow;
                 }
@@ -580,12 +592,12 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     Trace2Args ta{bs.st, bvh, qcur, work + b, bs.ovf, nullptr};
                     hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 } else {
-                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, nullptr};
+                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr};
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 }
                 ++lc.trace;
             }
-            ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->probe, ctx->opt.max_depth, qcur, qnext, qshadow};
+            ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow};
             if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0); // shade overwrites what shadow(b-1) reads
             {
                 SpanGuard g(ctx, CLS_SHADE, bs.stream);
@@ -606,7 +618,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     Trace2Args ta{bs.st, bvh, qshadow, work + nq + b, bs.ovf2, nullptr};
                     hipLaunchKernelGGL((k_trace2<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
                 } else {
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, nullptr};
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
                 }
                 ++lc.shadow;
@@ -621,7 +633,10 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             SpanGuard g(ctx, CLS_OTHER, bs.stream);
             // counters[last_bounce+1] holds paths that would have continued: not traced, not counted
             hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters, nq, last_bounce + 1, ctx->d_totals);
-            hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, bs.stream, bs.st, fp, bp, (int)(s0 == 0), (int)(s0 + Sc >= spp));
+            if (job)
+                hipLaunchKernelGGL(k_resolve_region, dim3((job->nl + 255) / 256), dim3(256), 0, bs.stream, bs.st, fp, job->rg, job->var, job->l0, job->nl);
+            else
+                hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, bs.stream, bs.st, fp, bp, (int)(s0 == 0), (int)(s0 + Sc >= spp));
         }
     }
 }
@@ -710,6 +725,93 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
         cls_ms[sp.cls] += m;
     }
     st.trace_ms = cls_ms[CLS_TRACE]; // sums over concurrent streams: they overlap, so they can exceed render_ms
+    st.shadow_ms = cls_ms[CLS_SHADOW];
+    st.shade_ms = cls_ms[CLS_SHADE];
+    st.other_ms = cls_ms[CLS_OTHER];
+    st.trace_launches = lc.trace;
+    st.shadow_launches = lc.shadow;
+    st.shade_launches = lc.shade;
+    if (host_rgba8) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)ctx->width * ctx->height);
+    return PT_OK;
+}
+
+// The foveated variants' render() (HelloPathtracing_sv4_vmv23/SimplePathtracer.cpp:132-216) issues up to three
+// optixLaunch calls per frame with different LaunchParams.frame.{factor,fillSize,c,r_inner,r_outer,offset,redraw},
+// samples_per_launch and subframe_index; later launches overwrite the pixels of earlier ones, so the launches run
+// in order on one stream.
+extern "C" int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t n, const pt_variant* variant, uint32_t* host_rgba8) {
+    if (!ctx || (!regions && n)) return PT_ERR_INVALID;
+    if (ctx->width == 0) return PT_OK;
+    if (!ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_render_regions: no probe set (setProbe)");
+    if (ctx->opt.bvh_kind != 0 || ctx->opt.trace_kernel != 0) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_regions: needs the default traversal (bvh_kind 0, trace_kernel 0)");
+    if (ctx->has_catcher) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_regions: shadow-catcher materials are not supported in foveated launches");
+    if (ctx->world != 1) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_regions: single-GPU only");
+    CK(hipSetDevice(ctx->device));
+    VariantParams var{0.001f, 0, 0, 1.0f, 1.0f};
+    if (variant) var = VariantParams{variant->radiance_tmin, variant->cull_back_occlusion, variant->tonemap, variant->exposure, variant->white};
+    const uint32_t max_paths = std::max<uint32_t>(ctx->opt.max_paths, 64u);
+    uint32_t need = 64;
+    for (uint32_t r = 0; r < n; ++r) {
+        const pt_region& g = regions[r];
+        if (g.spp == 0 || g.spp > 4096 || g.launch_w == 0 || g.launch_h == 0 || g.fill_size < 0 || g.fill_size > 64 ||
+            (unsigned long long)g.launch_w * g.launch_h >= (1ull << 31))
+            return fail(ctx, PT_ERR_INVALID, "pt_render_regions: bad region");
+        if (g.spp > max_paths) return fail(ctx, PT_ERR_INVALID, "pt_render_regions: samples_per_launch exceeds max_paths");
+        const unsigned long long total = (unsigned long long)g.launch_w * g.launch_h * g.spp;
+        need = (uint32_t)std::max<unsigned long long>(need, std::min<unsigned long long>(total, max_paths));
+    }
+    {
+        int rc = ensure_path_state(ctx, std::max<int>(1, (int)ctx->sets.size()), need, 64);
+        if (rc) return rc;
+    }
+    ctx->ev_used = 0;
+    ctx->spans.clear();
+    CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 2, ctx->stream));
+    hipEvent_t ev_begin = next_event(ctx);
+    CK(hipEventRecord(ev_begin, ctx->stream));
+    pt_ctx::BatchSet& bs = ctx->sets[0];
+    hipStreamWaitEvent(bs.stream, ev_begin, 0);
+    LaunchCounts lc;
+    uint64_t paths = 0;
+    for (uint32_t r = 0; r < n; ++r) {
+        const pt_region& g = regions[r];
+        FrameParams fp{ctx->accum, ctx->frame, ctx->color, ctx->normal, ctx->albedo, ctx->width, ctx->height, g.subframe_index,
+                       ctx->eye, ctx->U, ctx->V, ctx->W, g.spp, ctx->probe};
+        RegionJob job;
+        job.rg = RegionParams{g.launch_w, g.launch_h, g.factor_x, g.factor_y, g.fill_size, g.cx, g.cy, g.r_inner, g.r_outer, g.offset_x, g.offset_y, g.redraw, g.spp, g.subframe_index};
+        job.var = var;
+        const uint32_t nlaunch = g.launch_w * g.launch_h;
+        const uint32_t per = std::max(1u, ctx->set_cap / g.spp); // launch indices per pass (all their samples together)
+        for (uint32_t l0 = 0; l0 < nlaunch; l0 += per) {
+            job.l0 = l0;
+            job.nl = std::min(per, nlaunch - l0);
+            enqueue_chunk(ctx, bs, fp, 0, 0, g.spp, g.spp, lc, &job);
+        }
+        paths += (uint64_t)nlaunch * g.spp;
+    }
+    hipEvent_t e = next_event(ctx);
+    hipEventRecord(e, bs.stream);
+    hipStreamWaitEvent(ctx->stream, e, 0);
+    hipEvent_t ev_end = next_event(ctx);
+    CK(hipEventRecord(ev_end, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipGetLastError());
+    unsigned long long totals[2] = {0, 0};
+    CK(hipMemcpy(totals, ctx->d_totals, sizeof(totals), hipMemcpyDeviceToHost));
+    pt_stats& st = ctx->stats;
+    st.radiance_rays = totals[0];
+    st.shadow_rays = totals[1];
+    st.paths = paths;
+    float ms = 0;
+    hipEventElapsedTime(&ms, ev_begin, ev_end);
+    st.render_ms = ms;
+    double cls_ms[4] = {0, 0, 0, 0};
+    for (auto& sp : ctx->spans) {
+        float m = 0;
+        hipEventElapsedTime(&m, ctx->ev_pool[sp.a], ctx->ev_pool[sp.b]);
+        cls_ms[sp.cls] += m;
+    }
+    st.trace_ms = cls_ms[CLS_TRACE];
     st.shadow_ms = cls_ms[CLS_SHADOW];
     st.shade_ms = cls_ms[CLS_SHADE];
     st.other_ms = cls_ms[CLS_OTHER];
@@ -881,7 +983,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
             if (any_hit) hipLaunchKernelGGL((k_trace2<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         } else {
-            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8}, QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, dDbg};
+            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8}, QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, 0, dDbg};
             if (any_hit) hipLaunchKernelGGL((k_trace8<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         }

@@ -46,7 +46,13 @@ PT_DEV RaySetup ray_setup(v3 o, v3 d) {
 }
 
 // returns true with t if the supporting ray (t > 0) hits the triangle; the caller applies (tmin,tmax)
+PT_DEV bool tri_test_det(const RaySetup& r, v3 v0, v3 v1, v3 v2, float& t, float& det_out);
 PT_DEV bool tri_test(const RaySetup& r, v3 v0, v3 v1, v3 v2, float& t) {
+    float det;
+    return tri_test_det(r, v0, v1, v2, t, det);
+}
+// det > 0: the ray meets the triangle's front (counter-clockwise) side — what OPTIX_RAY_FLAG_CULL_BACK_FACING keeps
+PT_DEV bool tri_test_det(const RaySetup& r, v3 v0, v3 v1, v3 v2, float& t, float& det_out) {
     const v3 A = sub3(v0, r.o), B = sub3(v1, r.o), C = sub3(v2, r.o);
     const v3 CxB = cross3(C, B), AxC = cross3(A, C), BxA = cross3(B, A);
     const float U = dot3(r.d, CxB), V = dot3(r.d, AxC), W = dot3(r.d, BxA);
@@ -57,6 +63,7 @@ PT_DEV bool tri_test(const RaySetup& r, v3 v0, v3 v1, v3 v2, float& t) {
     const float T = U * Ad + V * Bd + W * Cd;
     if (T == 0.0f || ((T < 0.0f) != (det < 0.0f))) return false;
     t = T / det;
+    det_out = det;
     return true;
 }
 

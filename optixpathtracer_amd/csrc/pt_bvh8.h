@@ -55,6 +55,7 @@ struct Trace8Args {
     QView queue2; // TR_UNIFIED only: the shadow queue of the previous bounce, traced in the same launch
     uint32_t* work;
     uint32_t* ovf; // spill stack: [PT8_OVF_DEPTH][2][gridDim.x * 64]
+    int cull_back; // shadow rays ignore back-facing triangles (sv3/sv4 occlusion ray flag)
     unsigned long long* dbg; // optional: [0] node steps, [1] triangle tests, [2] max stack depth, [3] pushes (pt_trace + PT_DEBUG_COUNTS)
 };
 
@@ -285,11 +286,11 @@ k_trace8(Trace8Args a) {
                     ++c_ray;
                     const LeafTri* tp = &a.bvh.tris[t_base + bit];
                     const float4 ta = tp->t0, tb = tp->t1, tc = tp->t2;
-                    float t;
-                    if (tri_test(r, mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), t)) {
+                    float t, det;
+                    if (tri_test_det(r, mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), t, det)) {
                         const int32_t prim = __float_as_int(tc.y);
                         if (MODE == TR_SHADOW_APPLY || MODE == TR_ANY_QUERY || (MODE == TR_UNIFIED && shadow_lane)) {
-                            if (t > tmin && t < tmax) {
+                            if (t > tmin && t < tmax && (!a.cull_back || det > 0.0f)) {
                                 bprim = 1;
                                 best = t;
                                 finish();

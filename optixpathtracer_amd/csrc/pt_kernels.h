@@ -15,7 +15,7 @@
 #pragma once
 #include "pt_bvh.h"
 
-enum { FLAG_DONE = 1, FLAG_SECONDARY = 2 }; // RAY_STATE_FLAGS_* deviceProgram.cu:46-48
+enum { FLAG_DONE = 1, FLAG_SECONDARY = 2, FLAG_CULLED = 4 /* outside the foveation annulus */ }; // RAY_STATE_FLAGS_* deviceProgram.cu:46-48
 enum { PEND_DIRECT = 1, PEND_INDIRECT = 2, PEND_ALPHA = 3 };
 enum { TR_CLOSEST = 0, TR_SHADOW_APPLY = 1, TR_ANY_QUERY = 2, TR_UNIFIED = 3 /* closest-hit queue + shadow queue in one launch */ }; // modes of the persistent traversal kernels
 
@@ -178,6 +178,7 @@ struct ShadeParams {
     const pt_material* mats;
     DevProbe probe;
     int max_depth;
+    float tmin_radiance; // 0.001 (deviceProgram.cu:420); 0.01 in the sv4 variant
     QView queue;        // paths to shade (identity at bounce 0)
     QView next_queue;   // paths that continue
     QView shadow_queue; // paths with a live shadow ray
@@ -229,7 +230,7 @@ __global__ void __launch_bounds__(256) k_shade(PathState st, ShadeParams sp) {
                 const v3 N_0 = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
                 const v3 N = faceforward3(N_0, neg3(ray_dir), N_0);
                 const v3 P = add3(ray_o, scl3(ray_dir, h.x));
-                st.rayO[p] = make_float4(P.x, P.y, P.z, 0.001f);
+                st.rayO[p] = make_float4(P.x, P.y, P.z, sp.tmin_radiance);
                 const bool is_catcher = (mat.flags & 1) != 0;
                 if (CATCHER && is_catcher && (flags & FLAG_SECONDARY)) {
                     // pass-through (:503-508): origin = P, direction unchanged, --depth; then raygen (:424-439)
@@ -401,6 +402,127 @@ __global__ void __launch_bounds__(256) k_resolve(PathState st, FrameParams fp, B
     fp.normal[image_index] = make_float4(normal.x, normal.y, normal.z, 1.0f);
     fp.color[image_index] = make_float4(accum_color.x, accum_color.y, accum_color.z, 1.0f);
     fp.albedo[image_index] = make_float4(albedo.x, albedo.y, albedo.z, 1.0f);
+}
+
+// ------------------------------------------------------------------ foveated variant (HelloPathtracing_sv4_vmv23/)
+// One optixLaunch of the sv4 raygen (deviceProgram.cu:388-590): launch index → pixel = index*factor + offset, early
+// return outside the annulus [r_inner,r_outer] around c, splat over fillSize^2 pixels, blend only when
+// subframe_index > 0 && !redraw, write accum_buffer + frame_buffer (exposure, Reinhard, make_color) only.
+struct RegionParams { // LaunchParams.frame.{factor,fillSize,c,r_inner,r_outer,offset,redraw} (sv4 LaunchParams.h:62-70)
+    uint32_t launch_w, launch_h;
+    uint32_t factor_x, factor_y;
+    int32_t fill_size;
+    uint32_t cx, cy;
+    float r_inner, r_outer;
+    uint32_t offset_x, offset_y;
+    uint32_t redraw;
+    uint32_t spp;
+    uint32_t subframe_index;
+};
+struct VariantParams {
+    float radiance_tmin;
+    int cull_back_occlusion;
+    int tonemap;
+    float exposure, white;
+};
+
+// paths: i = sample * nl + (launch index - l0); culled launch indices are flagged and never queued
+__global__ void __launch_bounds__(256) k_generate_region(PathState st, FrameParams fp, RegionParams rg, float tmin, uint32_t l0, uint32_t nl, QView qgen) {
+    const uint32_t total = nl * rg.spp;
+    const uint32_t nround = (total + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += gridDim.x * blockDim.x) {
+        bool live = false;
+        if (i < total) {
+            const uint32_t sl = i / nl, li = l0 + (i - sl * nl);
+            const uint32_t lx = li % rg.launch_w, ly = li / rg.launch_w;
+            uint32_t seed = tea4(ly * (uint32_t)fp.width + lx, rg.subframe_index); // the LAUNCH index seeds (:406)
+            const uint32_t ix = lx * rg.factor_x + rg.offset_x, iy = ly * rg.factor_y + rg.offset_y;
+            const v3 dv = sub3(mk3((float)ix, (float)iy, 0.0f), mk3((float)rg.cx, (float)rg.cy, 0.0f));
+            const float range = sqrtf(dot3(dv, dv));
+            if (range < rg.r_inner || range > rg.r_outer) {
+                st.fd[i] = (uint32_t)FLAG_CULLED << 8;
+            } else {
+                for (uint32_t k = 0; k < 2u * sl; ++k) lcg(seed);
+                Rng r;
+                r.init(seed);
+                const float jx = rnd(seed), jy = rnd(seed);
+                const float dx = 2.0f * (((float)ix + jx) / (float)fp.width) - 1.0f;
+                const float dy = 2.0f * (((float)iy + jy) / (float)fp.height) - 1.0f;
+                const v3 dir = normalize3(add3(add3(scl3(fp.U, dx), scl3(fp.V, dy)), fp.W));
+                st.rayO[i] = make_float4(fp.eye.x, fp.eye.y, fp.eye.z, tmin);
+                st.rayD[i] = make_float4(dir.x, dir.y, dir.z, 1e16f);
+                st.thr[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+                st.rng[i] = make_uint2(r.seed1, r.seed2);
+                st.fd[i] = 0u;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                st.direct[i] = z;
+                st.indirect[i] = z;
+                st.alpha[i] = z;
+                st.nrm[i] = z;
+                st.alb[i] = z;
+                if (st.prdN) {
+                    st.prdN[i] = z;
+                    st.prdA[i] = z;
+                }
+                live = true;
+            }
+        }
+        queue_push(live, i, qgen);
+    }
+}
+
+PT_DEV v3 reinhard_tonemap(v3 color, float white) { // sv4 deviceProgram.cu:124-128
+    const float luminance = 0.2126f * color.x + 0.7152f * color.y + 0.0722f * color.z;
+    return div3s(scl3(color, 1.0f), 1.0f + luminance / white);
+}
+
+__global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParams fp, RegionParams rg, VariantParams var, uint32_t l0, uint32_t nl) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nl) return;
+    if ((st.fd[k] >> 8) & FLAG_CULLED) return;
+    const uint32_t li = l0 + k;
+    const uint32_t lx = li % rg.launch_w, ly = li / rg.launch_w;
+    v3 result = mk3(0.f), alpha = mk3(0.f);
+    for (uint32_t sl = 0; sl < rg.spp; ++sl) {
+        const uint32_t i = sl * nl + k;
+        const float4 d = st.direct[i], in = st.indirect[i], a = st.alpha[i];
+        result = add3(result, add3(mk3(d.x, d.y, d.z), mk3(in.x, in.y, in.z)));
+        alpha = add3(alpha, mk3(a.x, a.y, a.z));
+    }
+    const float spp = (float)rg.spp;
+    alpha = div3s(alpha, spp);
+    // backplate of the last sample's camera ray
+    uint32_t seed = tea4(ly * (uint32_t)fp.width + lx, rg.subframe_index);
+    for (uint32_t q = 0; q < 2u * (rg.spp - 1u); ++q) lcg(seed);
+    const uint32_t ix = lx * rg.factor_x + rg.offset_x, iy = ly * rg.factor_y + rg.offset_y;
+    const float jx = rnd(seed), jy = rnd(seed);
+    const float dx = 2.0f * (((float)ix + jx) / (float)fp.width) - 1.0f;
+    const float dy = 2.0f * (((float)iy + jy) / (float)fp.height) - 1.0f;
+    const v3 dir = normalize3(add3(add3(scl3(fp.U, dx), scl3(fp.V, dy)), fp.W));
+    float pu, pv;
+    probe_dir_to_uv(dir, pu, pv);
+    const float4 bpx = probe_eval(fp.probe, pu, pv);
+    const v3 backplate = mk3(bpx.x, bpx.y, bpx.z);
+    for (int fi = 0; fi < rg.fill_size; ++fi) {
+        for (int fj = 0; fj < rg.fill_size; ++fj) {
+            uint32_t px = lx * rg.factor_x + (uint32_t)fi + rg.offset_x, py = ly * rg.factor_y + (uint32_t)fj + rg.offset_y;
+            px = px > (uint32_t)(fp.width - 1) ? (uint32_t)(fp.width - 1) : px;
+            py = py > (uint32_t)(fp.height - 1) ? (uint32_t)(fp.height - 1) : py;
+            const size_t image_index = (size_t)py * fp.width + px;
+            const v3 color = add3(mul3(scl3(backplate, spp), sub3(mk3(1.0f), alpha)), result);
+            v3 accum_color = div3s(color, spp);
+            if (rg.subframe_index > 0 && !rg.redraw) {
+                accum_color = mk3(clampf(accum_color.x, 0.0f, 10.0f), clampf(accum_color.y, 0.0f, 10.0f), clampf(accum_color.z, 0.0f, 10.0f));
+                const float a = 1.0f / (float)(rg.subframe_index + 1);
+                const float4 prev = fp.accum[image_index];
+                accum_color = lerp3(mk3(prev.x, prev.y, prev.z), accum_color, a);
+            }
+            fp.accum[image_index] = make_float4(accum_color.x, accum_color.y, accum_color.z, 1.0f);
+            v3 shown = accum_color;
+            if (var.tonemap) shown = reinhard_tonemap(scl3(accum_color, var.exposure), var.white);
+            fp.frame[image_index] = make_color(shown);
+        }
+    }
 }
 
 // toneMap.cu:41-58 computeFinalPixelColorsKernel

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import Material as CMaterial
-from ._lib import MeshDesc, Options, SceneDesc, Stats
+from ._lib import MeshDesc, Options, Region, SceneDesc, Stats, Variant
 from .scenes import Model, ProbeData, uvw_frame
 
 PT_BUF_ACCUM, PT_BUF_FRAME, PT_BUF_COLOR, PT_BUF_NORMAL, PT_BUF_ALBEDO = range(5)
@@ -141,6 +141,45 @@ class SampleRenderer:
         pdfY = np.empty(h, np.float32); cdfY = np.empty(h, np.float32)
         self._ck(self._L.pt_get_probe_cdf(self._ctx, pdfX.ctypes.data, cdfX.ctypes.data, pdfY.ctypes.data, cdfY.ctypes.data), "pt_get_probe_cdf")
         return pdfX, cdfX, pdfY, cdfY
+
+    # -- the foveated variants' render() (HelloPathtracing_sv4_vmv23/SimplePathtracer.cpp:77-216)
+    SV4_VARIANT = dict(radiance_tmin=0.01, cull_back_occlusion=1, tonemap=1, exposure=4.0, white=1.0)
+
+    def renderRegions(self, regions, variant=None, out: np.ndarray | None = None):
+        """regions: list of dicts with pt_region's fields; variant: dict with pt_variant's fields (None = canonical)."""
+        arr = (Region * len(regions))()
+        for k, g in enumerate(regions):
+            for name, _ in Region._fields_:
+                setattr(arr[k], name, g[name])
+        vp = None
+        if variant is not None:
+            v = Variant(**variant)
+            vp = C.byref(v)
+        ptr = out.ctypes.data if out is not None else None
+        self._ck(self._L.pt_render_regions(self._ctx, arr, len(regions), vp, ptr), "pt_render_regions")
+
+    @staticmethod
+    def foveatedRegions(size, c, subframe_index, inner_radius=157, outer_radius=515, spp=(1, 2, 8)):
+        """The three launches of sv4's FOV_ON render(): periphery at 1/4 resolution (accumulating), an annulus at 1/2
+        resolution and the fovea at full resolution (both redrawn every frame with subframe_index 0)."""
+        w, h = size
+        cx, cy = c
+        u32 = lambda v: int(v) & 0xFFFFFFFF  # uint2 arithmetic wraps like the reference's
+        return [
+            dict(launch_w=w // 4, launch_h=h // 4, factor_x=4, factor_y=4, fill_size=4, cx=cx, cy=cy, r_inner=float(outer_radius), r_outer=1000000000.0,
+                 offset_x=0, offset_y=0, redraw=0, spp=spp[0], subframe_index=subframe_index),
+            dict(launch_w=outer_radius + 2, launch_h=outer_radius + 2, factor_x=2, factor_y=2, fill_size=2, cx=cx, cy=cy, r_inner=float(inner_radius),
+                 r_outer=float(outer_radius + 2), offset_x=u32(cx - (outer_radius + 2)), offset_y=u32(cy - (outer_radius + 2)), redraw=1, spp=spp[1], subframe_index=0),
+            dict(launch_w=(inner_radius + 1) * 2, launch_h=(inner_radius + 1) * 2, factor_x=1, factor_y=1, fill_size=1, cx=cx, cy=cy, r_inner=0.0,
+                 r_outer=float(inner_radius + 1), offset_x=u32(cx - (inner_radius + 1)), offset_y=u32(cy - (inner_radius + 1)), redraw=1, spp=spp[2], subframe_index=0),
+        ]
+
+    def renderFoveated(self, c, inner_radius=157, outer_radius=515, spp=(1, 2, 8), out=None):
+        """sv4 SampleRenderer::render() with FOV_ON: three launches around the gaze point c (launchParams.frame.c),
+        then launchParams.frame.subframe_index++ (SimplePathtracer.cpp:132-216)."""
+        regs = self.foveatedRegions(self.launchParams.frame.size, c, int(self.launchParams.frame.subframe_index), inner_radius, outer_radius, spp)
+        self.renderRegions(regs, self.SV4_VARIANT, out)
+        self.launchParams.frame.subframe_index += 1
 
     # -- beyond the reference (runtime versions of its compile-time constants, multi-GPU, stats)
     def setOptions(self, max_depth=8, bsdf_mode=PT_BSDF_DISNEY, max_paths=0, sort_rays=0, bvh_kind=0, trace_kernel=0, streams=0, split_shadow=0):

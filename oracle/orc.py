@@ -38,6 +38,18 @@ class Params(C.Structure):
     ]
 
 
+class Region(C.Structure):
+    _fields_ = [
+        ("launch_w", C.c_uint32), ("launch_h", C.c_uint32), ("factor_x", C.c_uint32), ("factor_y", C.c_uint32),
+        ("fill_size", C.c_int32), ("cx", C.c_uint32), ("cy", C.c_uint32), ("r_inner", C.c_float), ("r_outer", C.c_float),
+        ("offset_x", C.c_uint32), ("offset_y", C.c_uint32), ("redraw", C.c_uint32), ("spp", C.c_uint32), ("subframe_index", C.c_uint32),
+    ]
+
+
+class Variant(C.Structure):
+    _fields_ = [("radiance_tmin", C.c_float), ("cull_back_occlusion", C.c_int), ("tonemap", C.c_int), ("exposure", C.c_float), ("white", C.c_float)]
+
+
 class Stats(C.Structure):
     _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64)]
 
@@ -89,6 +101,7 @@ class Oracle:
         L.orc_cosine_sample_hemisphere.argtypes = [C.c_float, C.c_float, f32p]
         L.orc_math_table.argtypes = [C.c_int, f32p, f32p, C.c_int, f32p]
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(Probe), C.POINTER(Params), f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Stats)]
+        L.orc_render_region.argtypes = [C.c_void_p, C.POINTER(Probe), C.POINTER(Params), C.POINTER(Region), C.POINTER(Variant), f32p, u32p, C.POINTER(Stats)]
         L.orc_sizeof_material.restype = C.c_size_t
         assert L.orc_sizeof_material() == 104
 
@@ -136,6 +149,23 @@ class Oracle:
             nthreads = min(os.cpu_count() or 1, 64)
         self.lib.orc_render(scene.h, C.byref(probe), C.byref(prm), accum.reshape(-1), frame.ctypes.data, normal.ctypes.data, color.ctypes.data, albedo.ctypes.data, nthreads, C.byref(st))
         return dict(accum=accum, frame=frame, normal=normal, color=color, albedo=albedo, radiance_rays=int(st.radiance_rays), shadow_rays=int(st.shadow_rays), n=n)
+
+    def render_regions(self, scene, probe, cam_uvw, eye, width, height, regions, variant, max_depth, accum, frame, bsdf_mode=BSDF_DISNEY):
+        """The foveated variants' launches, in order, in place on (accum, frame). Returns total rays."""
+        prm = Params()
+        prm.width, prm.height, prm.max_depth, prm.bsdf_mode = width, height, max_depth, bsdf_mode
+        U, V, W = cam_uvw
+        for dst, src in ((prm.eye, eye), (prm.U, U), (prm.V, V), (prm.W, W)):
+            for k in range(3):
+                dst[k] = float(src[k])
+        var = Variant(**variant)
+        rays = 0
+        for g in regions:
+            rg = Region(**g)
+            st = Stats()
+            self.lib.orc_render_region(scene.h, C.byref(probe), C.byref(prm), C.byref(rg), C.byref(var), accum.reshape(-1), frame.reshape(-1), C.byref(st))
+            rays += int(st.radiance_rays) + int(st.shadow_rays)
+        return rays
 
     def trace_closest(self, scene, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

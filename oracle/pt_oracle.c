@@ -583,7 +583,7 @@ static inline void wray_init(wray* r, f3 o, f3 d) {
  * Returns 1 and *t_out if the supporting ray hits at some t > 0 (caller applies (tmin,tmax)).
  * Every operation is a single rounded IEEE op; the HIP kernel (pt_bvh.h tri_test) performs the
  * same ones in the same order, so t is bit-identical on both sides. */
-static inline int wtri(const wray* r, const float* p0, const float* p1, const float* p2, float* t_out) {
+static inline int wtri2(const wray* r, const float* p0, const float* p1, const float* p2, float* t_out, float* det_out) {
     const f3 A = sub3(mk3(p0[0], p0[1], p0[2]), r->o);
     const f3 B = sub3(mk3(p1[0], p1[1], p1[2]), r->o);
     const f3 C = sub3(mk3(p2[0], p2[1], p2[2]), r->o);
@@ -596,7 +596,12 @@ static inline int wtri(const wray* r, const float* p0, const float* p1, const fl
     const float T = U * Ad + V * Bd + W * Cd;
     if (T == 0.0f || ((T < 0.0f) != (det < 0.0f))) return 0;
     *t_out = T / det;
+    *det_out = det;
     return 1;
+}
+static inline int wtri(const wray* r, const float* p0, const float* p1, const float* p2, float* t_out) {
+    float det;
+    return wtri2(r, p0, p1, p2, t_out, &det);
 }
 
 static inline void tri_verts(const orc_scene* s, uint32_t prim, const float** v0, const float** v1, const float** v2) {
@@ -666,15 +671,18 @@ static int64_t closest_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tma
     return bp;
 }
 
-static int any_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tmax) {
+/* cull_back: OPTIX_RAY_FLAG_CULL_BACK_FACING_TRIANGLES (the sv3/sv4 occlusion ray, HelloPathtracing_sv4_vmv23/
+ * deviceProgram.cu:240): only triangles whose front (counter-clockwise) side faces the ray origin count, i.e.
+ * dot(d, (v1-v0)x(v2-v0)) < 0, which is det > 0 in wtri's convention (det = -d.n). */
+static int any_hit_c(const orc_scene* s, f3 o, f3 d, float tmin, float tmax, int cull_back) {
     wray r;
     wray_init(&r, o, d);
     if (!s->use_bvh) {
         for (uint32_t p = 0; p < s->ntri; ++p) {
             const float *v0, *v1, *v2;
-            float t;
+            float t, det;
             tri_verts(s, p, &v0, &v1, &v2);
-            if (wtri(&r, v0, v1, v2, &t) && t > tmin && t < tmax) return 1;
+            if (wtri2(&r, v0, v1, v2, &t, &det) && t > tmin && t < tmax && (!cull_back || det > 0.0f)) return 1;
         }
         return 0;
     }
@@ -689,9 +697,9 @@ static int any_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tmax) {
             for (uint32_t k = 0; k < n->count; ++k) {
                 uint32_t p = s->order[n->left + k];
                 const float *v0, *v1, *v2;
-                float t;
+                float t, det;
                 tri_verts(s, p, &v0, &v1, &v2);
-                if (wtri(&r, v0, v1, v2, &t) && t > tmin && t < tmax) return 1;
+                if (wtri2(&r, v0, v1, v2, &t, &det) && t > tmin && t < tmax && (!cull_back || det > 0.0f)) return 1;
             }
         } else {
             stack[sp++] = n->left;
@@ -700,6 +708,8 @@ static int any_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tmax) {
     }
     return 0;
 }
+
+static int any_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tmax) { return any_hit_c(s, o, d, tmin, tmax, 0); }
 
 /* --- median-split BVH2 (the oracle's own; unrelated to the product's LBVH) */
 typedef struct { float c[3]; uint32_t prim; } cent;
@@ -885,6 +895,15 @@ typedef struct {
 
 typedef struct { uint64_t radiance_rays, shadow_rays; } orc_stats;
 
+/* Knobs that differ between the canonical variant and the foveated sv3/sv4 variants */
+typedef struct {
+    float radiance_tmin;      /* 0.001 original (deviceProgram.cu:420); 0.01 in sv4 (global tmin, sv4 deviceProgram.cu:41,485) */
+    int cull_back_occlusion;  /* 0 original (TERMINATE_ON_FIRST_HIT); 1 sv3/sv4 (CULL_BACK_FACING_TRIANGLES, :240) */
+    int tonemap;              /* 0 = make_color(accum) ; 1 = make_color(reinhard(accum * exposure, white)) (sv4 :555-569) */
+    float exposure, white;
+} orc_variant;
+static __thread orc_variant g_var = {0.001f, 0, 0, 1.0f, 1.0f};
+
 /* deviceProgram.cu:252-334 SampleLights / SampleShadow (want_occluded selects) */
 static f3 sample_lights(const orc_scene* s, const orc_probe* probe, int mode, const orc_material* mat, f3 albedo, float etaI,
                         float etaO, f3 P, f3 N, f3 wo, orc_random* rand, int want_occluded, orc_stats* st) {
@@ -893,7 +912,7 @@ static f3 sample_lights(const orc_scene* s, const orc_probe* probe, int mode, co
     float skyPdf;
     probe_sample(probe, &wi, &skyColor, &skyPdf, rand);
     st->shadow_rays++;
-    const int occluded = any_hit(s, P, wi, 0.01f, 1e16f);
+    const int occluded = any_hit_c(s, P, wi, 0.01f, 1e16f, g_var.cull_back_occlusion);
     if (occluded == want_occluded) {
         float bsdfPdf = bsdf_pdf(mode, mat, etaI, etaO, N, wo, wi);
         f3 f = bsdf_eval(mode, mat, albedo, etaI, etaO, N, wo, wi);
@@ -1116,6 +1135,131 @@ void orc_render_rows(const orc_scene* s, const orc_probe* probe, const orc_param
         pthread_create(&th[t], NULL, rowjob_main, &jobs[t]);
     }
     for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+}
+
+/* ---------------------------------------------------------------- foveated variant (HelloPathtracing_sv4_vmv23/)
+ * One optixLaunch of the sv4 raygen (deviceProgram.cu:388-590): the launch index is remapped by
+ * factor/offset, pixels outside the annulus [r_inner, r_outer] around c return early, the result is
+ * splatted over fillSize^2 pixels, blended only when (subframe_index > 0 && !redraw), and only accum_buffer and
+ * frame_buffer are written, the latter through exposure + Reinhard + make_color. */
+typedef struct {
+    uint32_t launch_w, launch_h;
+    uint32_t factor_x, factor_y;
+    int32_t fill_size;
+    uint32_t cx, cy;
+    float r_inner, r_outer;
+    uint32_t offset_x, offset_y;
+    uint32_t redraw;
+    uint32_t spp;
+    uint32_t subframe_index;
+} orc_region;
+
+static inline f3 reinhard(f3 color, float white) { /* sv4 deviceProgram.cu:124-128 */
+    const float luminance = 0.2126f * color.x + 0.7152f * color.y + 0.0722f * color.z;
+    return div3s(scl3(color, 1.0f), 1.0f + luminance / white);
+}
+
+static void raygen_region_thread(const orc_scene* s, const orc_probe* probe, const orc_params* prm, const orc_region* rg, uint32_t lx,
+                                 uint32_t ly, float* accum, uint32_t* frame, orc_stats* st) {
+    const int w = prm->width, h = prm->height;
+    const f3 eye = mk3(prm->eye[0], prm->eye[1], prm->eye[2]);
+    const f3 U = mk3(prm->U[0], prm->U[1], prm->U[2]), V = mk3(prm->V[0], prm->V[1], prm->V[2]), W = mk3(prm->W[0], prm->W[1], prm->W[2]);
+    const int spp = (int)rg->spp;
+    int i = spp;
+    uint32_t seed = orc_tea4(ly * (uint32_t)w + lx, rg->subframe_index); /* seeded with the LAUNCH index (:406) */
+    f3 result = mk3s(0.0f);
+    const uint32_t ix = lx * rg->factor_x + rg->offset_x, iy = ly * rg->factor_y + rg->offset_y; /* :419, u32 wrap */
+    {
+        const f3 dv = sub3(mk3((float)ix, (float)iy, 0.0f), mk3((float)rg->cx, (float)rg->cy, 0.0f));
+        const float range = sqrtf(dot3(dv, dv));
+        if (range < rg->r_inner || range > rg->r_outer) return; /* :421-426 */
+    }
+    f3 alpha = mk3s(0.f), backplate = mk3s(0.f);
+    do {
+        f3 directLight = mk3s(0.0f), indirectLight = mk3s(0.0f);
+        prd_t prd;
+        prd.radiance = mk3s(0.f);
+        prd.alpha = mk3s(0.f);
+        orc_random_init(&prd.rand, seed);
+        prd.rayEta = 1.0f;
+        prd.throughput = mk3s(1.f);
+        prd.bsdfPdf = 1.0f;
+        prd.normal = mk3s(0.0f);
+        prd.albedo = mk3s(0.0f);
+        prd.flags = 0;
+        prd.depth = 0;
+        prd.origin = eye;
+        prd.direction = mk3s(0.f);
+        float jx = orc_rnd(&seed), jy = orc_rnd(&seed);
+        float dx = 2.0f * (((float)ix + jx) / (float)w) - 1.0f;
+        float dy = 2.0f * (((float)iy + jy) / (float)h) - 1.0f;
+        f3 ray_direction = normalize3(add3(add3(scl3(U, dx), scl3(V, dy)), W));
+        f3 ray_origin = eye;
+        {
+            float dir[3] = {ray_direction.x, ray_direction.y, ray_direction.z}, uv[2], px[4];
+            orc_probe_dir_to_uv(dir, uv);
+            orc_probe_eval(probe, uv, px);
+            backplate = mk3(px[0], px[1], px[2]);
+        }
+        for (;;) {
+            prd.radiance = mk3s(0.f);
+            float t;
+            st->radiance_rays++;
+            int64_t prim = closest_hit(s, ray_origin, ray_direction, g_var.radiance_tmin, 1e16f, &t);
+            if (prim >= 0) {
+                closest_hit_program(s, probe, prm->bsdf_mode, (uint32_t)prim, ray_origin, ray_direction, t, &prd, st);
+            } else {
+                prd.albedo = mk3s(0.f);
+                prd.normal = mk3s(0.f);
+                prd.flags |= FLAG_DONE;
+            }
+            if ((prd.flags & FLAG_DONE) || prd.depth >= prm->max_depth) break;
+            if (prd.depth == 0)
+                directLight = add3(directLight, prd.radiance);
+            else
+                indirectLight = add3(indirectLight, prd.radiance);
+            ++prd.depth;
+            ray_origin = prd.origin;
+            ray_direction = prd.direction;
+        }
+        result = add3(result, add3(directLight, indirectLight));
+        alpha = add3(alpha, prd.alpha);
+    } while (--i);
+    alpha = div3s(alpha, (float)spp);
+    for (int fi = 0; fi < rg->fill_size; ++fi) {
+        for (int fj = 0; fj < rg->fill_size; ++fj) {
+            uint32_t px = lx * rg->factor_x + (uint32_t)fi + rg->offset_x, py = ly * rg->factor_y + (uint32_t)fj + rg->offset_y;
+            if (px > (uint32_t)(w - 1)) px = (uint32_t)(w - 1); /* clamp(index, 0, (w-1,h-1)) on unsigned */
+            if (py > (uint32_t)(h - 1)) py = (uint32_t)(h - 1);
+            const size_t image_index = (size_t)py * w + px;
+            f3 color = add3(mul3(scl3(backplate, (float)spp), sub3(mk3s(1.0f), alpha)), result);
+            f3 accum_color = div3s(color, (float)spp);
+            if (rg->subframe_index > 0 && !rg->redraw) {
+                accum_color = mk3(clampf(accum_color.x, 0.0f, 10.0f), clampf(accum_color.y, 0.0f, 10.0f), clampf(accum_color.z, 0.0f, 10.0f));
+                const float a = 1.0f / (float)(rg->subframe_index + 1);
+                const f3 prev = mk3(accum[4 * image_index], accum[4 * image_index + 1], accum[4 * image_index + 2]);
+                accum_color = lerp3(prev, accum_color, a);
+            }
+            float* o = &accum[4 * image_index];
+            o[0] = accum_color.x; o[1] = accum_color.y; o[2] = accum_color.z; o[3] = 1.0f;
+            f3 shown = accum_color;
+            if (g_var.tonemap) shown = reinhard(scl3(accum_color, g_var.exposure), g_var.white);
+            float c[3] = {shown.x, shown.y, shown.z};
+            frame[image_index] = orc_make_color(c);
+        }
+    }
+}
+
+/* sequential over the launch grid (launches with overlapping splats are order-dependent in the reference too) */
+void orc_render_region(const orc_scene* s, const orc_probe* probe, const orc_params* prm, const orc_region* rg, const orc_variant* var,
+                       float* accum, uint32_t* frame, orc_stats* stats) {
+    g_var = *var;
+    orc_stats st = {0, 0};
+    for (uint32_t ly = 0; ly < rg->launch_h; ++ly)
+        for (uint32_t lx = 0; lx < rg->launch_w; ++lx) raygen_region_thread(s, probe, prm, rg, lx, ly, accum, frame, &st);
+    if (stats) *stats = st;
+    orc_variant def = {0.001f, 0, 0, 1.0f, 1.0f};
+    g_var = def;
 }
 
 size_t orc_sizeof_material(void) { return sizeof(orc_material); }

@@ -509,3 +509,43 @@ def test_gpu_cdf_build_bit_exact(ptlib, orc_det, small_probe):
     g = _gpu_render(r, 2)
     o = _oracle_render(orc_det, m, small_probe, scenes.CORNELL_CAMERA, w, h, 2)
     _compare(g, o)
+
+
+def test_foveated_sv4_three_launches(ptlib, orc_det):
+    """SURVEY §8f row 1 — the foveated variants' render() (HelloPathtracing_sv4_vmv23/SimplePathtracer.cpp:132-216):
+    periphery at 1/4 resolution accumulating over subframes, annulus at 1/2 resolution and fovea at full
+    resolution redrawn every frame; sv4 device semantics (seed from the launch index, annulus early-out, fillSize^2
+    splat, tmin .01, back-face-culled occlusion rays, depth 4, exposure 4 + Reinhard + make_color).  Several frames
+    with a moving gaze point, bit-exact accum_buffer and frame_buffer against the checker."""
+    from optixpathtracer_amd.renderer import SampleRenderer, make_camera
+
+    m = scenes.voxel_terrain(n=64, target_tris=30000)
+    probe = scenes.sky_probe(256, 128).BuildCDF()
+    w, h = 192, 128
+    r = SampleRenderer(m)
+    r.setProbe(probe)
+    r.setOptions(max_depth=4)
+    r.resize((w, h))
+    r.setCamera(make_camera(scenes.TERRAIN_CAMERA, w / h))
+    sc = orc_det.make_scene(m, True)
+    pr = orc_det.make_probe(probe)
+    U, V, W = scenes.uvw_frame(**scenes.TERRAIN_CAMERA, aspect=w / h)
+    accum = np.zeros((h, w, 4), np.float32)
+    frame = np.zeros((h, w), np.uint32)
+    for k, gaze in enumerate([(96, 64), (100, 60), (70, 80)]):
+        assert r.launchParams.frame.subframe_index == k
+        regs = r.foveatedRegions((w, h), gaze, k, inner_radius=14, outer_radius=44, spp=(1, 2, 4))
+        r.renderFoveated(gaze, inner_radius=14, outer_radius=44, spp=(1, 2, 4))
+        orc_det.render_regions(sc, pr, (U, V, W), scenes.TERRAIN_CAMERA["eye"], w, h, regs, r.SV4_VARIANT, 4, accum, frame)
+        g_acc = r.download(R_ACCUM)
+        g_frm = r.download(R_FRAME)
+        assert_bits_equal(g_acc, accum, f"foveated accum_buffer, frame {k}")
+        assert np.array_equal(g_frm, frame), f"foveated frame_buffer, frame {k}"
+    # the three regions really differ in sampling density: fovea pixels are all distinct renders, periphery is 4x4 blocks
+    blk = g_acc[0:4, 0:4, :3].reshape(-1, 3)
+    assert (blk == blk[0]).all()
+    st = r.stats()
+    assert st["radiance_rays"] > 0 and st["paths"] == (w // 4) * (h // 4) * 1 + 46 * 46 * 2 + 30 * 30 * 4
+
+
+R_ACCUM, R_FRAME = 0, 1

@@ -28,6 +28,10 @@ WORKLOADS = {
     "c3_terrain1M_1080p_4spp_d8": ("terrain", "TERRAIN_CAMERA", 1920, 1080, 4, 8),
     "c2_cornell_1080p_4spp_d8": ("cornell", "CORNELL_CAMERA", 1920, 1080, 4, 8),
     "c4_terrain1M_4k_16spp_d8": ("terrain", "TERRAIN_CAMERA", 3840, 2160, 16, 8),
+    # the reference's only published runs (HelloPathtracing_sv4_vmv23, 3840x2160, depth cutoff 4):
+    # uniform 8 spp without accumulation, and the 3-region foveated schedule (radii 157/515, 1/2/8 spp)
+    "sv4_uniform_terrain1M_4k_8spp_d4": ("terrain", "TERRAIN_CAMERA", 3840, 2160, 8, 4),
+    "sv4_foveated_terrain1M_4k_d4": ("terrain", "TERRAIN_CAMERA", 3840, 2160, 8, 4),
 }
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -98,16 +102,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sv4 = args.workload.startswith("sv4_")
+    foveated = "foveated" in args.workload
+
+    def render_frame(k):
+        if not sv4:
+            r.launchParams.frame.subframe_index = k  # progressive accumulation, like the reference's loop
+            r.render()
+        elif foveated:  # sv4 FOV_ON render(): gaze = cursor; here it circles the image centre
+            import math
+            gaze = (w // 2 + int(300 * math.cos(0.3 * k)), h // 2 + int(200 * math.sin(0.3 * k)))
+            r.renderFoveated(gaze)
+        else:  # sv4 FOV_OFF render(): one full-resolution launch, 8 spp, accumulation off
+            r.renderRegions([dict(launch_w=w, launch_h=h, factor_x=1, factor_y=1, fill_size=1, cx=w // 2, cy=h // 2, r_inner=0.0,
+                                  r_outer=1000000000.0, offset_x=0, offset_y=0, redraw=0, spp=spp, subframe_index=0)], r.SV4_VARIANT)
+
     for k in range(args.warmup):
-        r.launchParams.frame.subframe_index = k
-        r.render()
+        render_frame(k)
     barrier()
     rays = 0
     agg = dict(trace_ms=0.0, shadow_ms=0.0, shade_ms=0.0, other_ms=0.0, render_ms=0.0, trace_launches=0, shadow_launches=0, radiance_rays=0, shadow_rays=0)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        r.launchParams.frame.subframe_index = args.warmup + k  # progressive accumulation, like the reference's loop
-        r.render()
+        render_frame(args.warmup + k)
         st = r.stats()
         rays += st["radiance_rays"] + st["shadow_rays"]
         for key in agg:
@@ -183,6 +200,7 @@ def main():
                 "max_depth": depth, "bsdf": "disney", "probe": "sky2048x1024+sun", "partition": f"tiles64x16/{world}",
             },
             "rays_per_frame": int(rays_all / args.steps),
+            "fps": round(args.steps / dt_max, 2),
             "kernel_ms_per_frame": {k: round(agg[k] / args.steps, 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
             "bvh": {"nodes": st["bvh_nodes"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2)},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),

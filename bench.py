@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--workload", default="c3_terrain1M_1080p_4spp_d8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --share-device rehearses the N>1 path on a 1-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use HIP device 0 (rehearsal only)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N>1: weak = per-GPU work fixed (image area grows with N, C4-style); strong = the fixed frame split N ways")
     ap.add_argument("--simulate-world", type=int, default=0, help="single process: render only rank 0's tiles of an N-way partition (predicts per-GPU time at N GPUs)")
     ap.add_argument("--split-shadow", type=int, default=0)
@@ -68,9 +70,15 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.share_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     torch.cuda.set_device(local_rank)
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"  # device of the tensors handed to collectives
 
     from optixpathtracer_amd import renderer as R
     from optixpathtracer_amd import scenes
@@ -132,7 +140,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    tot = torch.tensor([dt, float(rays)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([dt, float(rays)], dtype=torch.float64, device=red_dev)
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -148,12 +156,25 @@ def main():
         from optixpathtracer_amd import multigpu
 
         packer = multigpu.DevicePacker(r)
-        multigpu.exchange_frame(packer, R.PT_BUF_FRAME, world, dist.all_gather_into_tensor)  # warm RCCL
+
+        def all_gather(dst, src):
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(dst, src)
+            else:  # rehearsal: stage through host memory
+                d = torch.empty(dst.shape, dtype=dst.dtype)
+                dist.all_gather_into_tensor(d, src.cpu())
+                dst.copy_(d)
+
+        multigpu.exchange_frame(packer, R.PT_BUF_FRAME, world, all_gather)  # warm RCCL
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        multigpu.exchange_frame(packer, R.PT_BUF_ACCUM, world, dist.all_gather_into_tensor)
+        multigpu.exchange_frame(packer, R.PT_BUF_ACCUM, world, all_gather)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        # the assembled frame must be complete: every pixel of accum_buffer was written by exactly one rank (alpha = 1)
+        full = r.download(R.PT_BUF_ACCUM)
+        if not (full[..., 3] == 1.0).all():
+            raise SystemExit(f"rank {rank}: assembled frame has unwritten pixels")
 
     if rank == 0:
         mrays = rays_all / dt_max / 1e6
@@ -196,7 +217,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": args.workload, "triangles": model.num_triangles, "width": w, "height": h, "spp": spp,
+                "workload": args.workload + (f"_weak_x{world}_area" if (world > 1 and args.scaling == "weak") else ""), "triangles": model.num_triangles, "width": w, "height": h, "spp": spp,
                 "max_depth": depth, "bsdf": "disney", "probe": "sky2048x1024+sun", "partition": f"tiles64x16/{world}",
             },
             "rays_per_frame": int(rays_all / args.steps),

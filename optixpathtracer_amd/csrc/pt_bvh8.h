@@ -27,7 +27,9 @@
 struct Node8 {
     float4 n0, n1, n2, n3, n4;
 };
+#ifndef PT8_LEAF_MAX
 #define PT8_LEAF_MAX 3
+#endif
 
 struct Bvh8Dev {
     const Node8* nodes;

@@ -42,6 +42,9 @@ struct Bvh8Dev {
 #ifndef PT8_REFILL
 #define PT8_REFILL 24
 #endif
+#ifndef PT8_TRI_BIAS
+#define PT8_TRI_BIAS 3 // a triangle step runs when tri-waiting lanes * bias > node-waiting lanes
+#endif
 #ifndef PT8_MIN_CHUNK
 #define PT8_MIN_CHUNK 64
 #endif
@@ -207,7 +210,7 @@ k_trace8(Trace8Args a) {
             const bool want_tri = active && t_mask != 0u;
             const bool want_node = active && t_mask == 0u; // node step also covers "group empty → pop"
             const unsigned long long m_tri = __ballot(want_tri), m_node = __ballot(want_node);
-            if (__popcll(m_node) >= __popcll(m_tri)) {
+            if (__popcll(m_node) >= PT8_TRI_BIAS * __popcll(m_tri)) {
                 if (want_node) {
                     if (g_hits == 0u) {
                         if (sp == 0) {
@@ -247,6 +250,9 @@ k_trace8(Trace8Args a) {
                         const uint32_t nearz[2] = {nz ? hiz0 : loz0, nz ? hiz1 : loz1}, farz[2] = {nz ? loz0 : hiz0, nz ? loz1 : hiz1};
                         const uint32_t meta[2] = {__float_as_uint(n1.z), __float_as_uint(n1.w)};
                         uint32_t hm = 0u; // hit mask in slot positions (branch-free: one compare + select + or per child)
+                        // No extra widening of the far plane here: the 8-bit grid (rounded outward from boxes already padded
+                        // by 2^-16 of the scene size) is orders of magnitude coarser than the rounding of these products.
+                        // (Measured and rejected: 2-wide vectors → v_pk_fma_f32; the packing moves and VGPR pairs cost more.)
 #pragma unroll
                         for (int s = 0; s < 8; ++s) {
                             const int w = s >> 2, k = s & 3;
@@ -254,7 +260,7 @@ k_trace8(Trace8Args a) {
                             const float tny = __builtin_fmaf(u8f(neary[w], k), ay, by), tfy = __builtin_fmaf(u8f(fary[w], k), ay, by);
                             const float tnz = __builtin_fmaf(u8f(nearz[w], k), az, bz), tfz = __builtin_fmaf(u8f(farz[w], k), az, bz);
                             const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-                            const float tf = fminf(fminf(fminf(tfx, tfy), tfz) * 1.0000004f, best);
+                            const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best));
                             hm |= (tn <= tf) ? (1u << s) : 0u;
                         }
                         // internal hits, moved to (slot ^ oct) bit positions: XOR of the index = conditional swaps of bit groups

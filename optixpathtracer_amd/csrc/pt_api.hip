@@ -36,7 +36,7 @@ struct pt_ctx {
     // probe
     DevProbe probe{};
     float4* d_probe_data = nullptr;
-    float *d_pdfX = nullptr, *d_cdfX = nullptr, *d_pdfY = nullptr, *d_cdfY = nullptr;
+    float *d_pdfX = nullptr, *d_cdfX = nullptr, *d_pdfY = nullptr, *d_cdfY = nullptr, *d_c64X = nullptr, *d_c8X = nullptr, *d_c64Y = nullptr, *d_c8Y = nullptr;
     // frame
     int width = 0, height = 0;
     float4 *accum = nullptr, *color = nullptr, *normal = nullptr, *albedo = nullptr;
@@ -223,6 +223,7 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     dfree(ctx->d_verts); dfree(ctx->d_idx); dfree(ctx->d_tri_mesh); dfree(ctx->d_mats); dfree(ctx->d_prims);
     pt_bvh_free(&ctx->bvh);
     dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
+    dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y);
     dfree(ctx->d_totals);
     dfree(ctx->ovf);
     dfree(ctx->dbg);
@@ -306,6 +307,32 @@ extern "C" int pt_uvw_frame(const float eye[3], const float lookat[3], const flo
     return PT_OK;
 }
 
+// finish a probe upload: build the block-search accelerators and publish the device view
+static int finish_probe(pt_ctx* ctx, int w, int h) {
+    dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y);
+    const int ncx = w / PT_CDF_BLOCK, ncy = h / PT_CDF_BLOCK;
+    const int ncx_pad = (ncx + 7) & ~7, ncy_pad = (ncy + 7) & ~7;
+    const bool okx = (w % PT_CDF_BLOCK) == 0 && w >= PT_CDF_BLOCK, oky = (h % PT_CDF_BLOCK) == 0 && h >= PT_CDF_BLOCK;
+    const bool enabled = getenv("PT_NO_BLOCKED_SEARCH") == nullptr;
+    if (okx && enabled) {
+        CK(dalloc(&ctx->d_c64X, (size_t)h * ncx_pad));
+        CK(dalloc(&ctx->d_c8X, (size_t)h * (w / 8)));
+        hipLaunchKernelGGL(k_probe_coarse, dim3((h * ncx_pad + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_cdfX, h, w, PT_CDF_BLOCK, ncx_pad, ctx->d_c64X);
+        hipLaunchKernelGGL(k_probe_coarse, dim3((h * (w / 8) + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_cdfX, h, w, 8, w / 8, ctx->d_c8X);
+    }
+    if (oky && enabled) {
+        CK(dalloc(&ctx->d_c64Y, (size_t)ncy_pad));
+        CK(dalloc(&ctx->d_c8Y, (size_t)(h / 8)));
+        hipLaunchKernelGGL(k_probe_coarse, dim3((ncy_pad + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_cdfY, 1, h, PT_CDF_BLOCK, ncy_pad, ctx->d_c64Y);
+        hipLaunchKernelGGL(k_probe_coarse, dim3((h / 8 + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_cdfY, 1, h, 8, h / 8, ctx->d_c8Y);
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipGetLastError());
+    ctx->probe = DevProbe{w, h, ctx->d_probe_data, ctx->d_pdfX, ctx->d_cdfX, ctx->d_pdfY, ctx->d_cdfY,
+                          ctx->d_c64X, ctx->d_c8X, ctx->d_c64Y, ctx->d_c8Y, ncx, ncx_pad, ncy};
+    return PT_OK;
+}
+
 extern "C" int pt_set_probe(pt_ctx* ctx, const float* data, const float* pdfX, const float* cdfX, const float* pdfY,
                             const float* cdfY, int w, int h) {
     if (!ctx) return PT_ERR_INVALID;
@@ -324,8 +351,7 @@ extern "C" int pt_set_probe(pt_ctx* ctx, const float* data, const float* pdfX, c
     CK(hipMemcpy(ctx->d_cdfX, cdfX, sizeof(float) * n, hipMemcpyHostToDevice));
     CK(hipMemcpy(ctx->d_pdfY, pdfY, sizeof(float) * h, hipMemcpyHostToDevice));
     CK(hipMemcpy(ctx->d_cdfY, cdfY, sizeof(float) * h, hipMemcpyHostToDevice));
-    ctx->probe = DevProbe{w, h, ctx->d_probe_data, ctx->d_pdfX, ctx->d_cdfX, ctx->d_pdfY, ctx->d_cdfY};
-    return PT_OK;
+    return finish_probe(ctx, w, h);
 }
 
 extern "C" int pt_set_probe_image(pt_ctx* ctx, const float* data, int w, int h) {
@@ -349,8 +375,7 @@ extern "C" int pt_set_probe_image(pt_ctx* ctx, const float* data, int w, int h) 
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipGetLastError());
     dfree(rowTotal);
-    ctx->probe = DevProbe{w, h, ctx->d_probe_data, ctx->d_pdfX, ctx->d_cdfX, ctx->d_pdfY, ctx->d_cdfY};
-    return PT_OK;
+    return finish_probe(ctx, w, h);
 }
 
 extern "C" int pt_get_probe_cdf(pt_ctx* ctx, float* pdfX, float* cdfX, float* pdfY, float* cdfY) {

@@ -327,10 +327,14 @@ PT_DEV v3 bsdf_eval(const pt_material& mat, v3 albedo, float etaI, float etaO, v
 }
 
 // ------------------------------------------------------------------ probe (Probe.cuh)
+#define PT_CDF_BLOCK 64
 struct DevProbe {
     int width, height;
     const float4* data;
     const float *pdfX, *cdfX, *pdfY, *cdfY;
+    // search accelerators built at setProbe: the last CDF value of every PT_CDF_BLOCK-entry block, per row / of cdfY
+    const float *c64X, *c8X, *c64Y, *c8Y; // [height][ncx_pad], [height][width/8], [ncy_pad], [height/8]; null = binary search
+    int ncx, ncx_pad, ncy;
 };
 
 // :38-46
@@ -367,6 +371,33 @@ PT_DEV int lower_bound(const float* __restrict__ array, int lower, int upper, fl
     }
     return lower;
 }
+// LowerBound (:119-136) in three dependent memory steps instead of log2(n).  For a non-decreasing array the lower
+// bound equals the number of entries < value, so: (1) count the 64-entry blocks whose LAST entry is < value in the
+// compact array c64, (2) inside that block count the 8-entry groups whose last entry is < value in c8, (3) count the
+// entries < value of the one remaining group.  Same index as the binary search for every array BuildCDF can produce
+// (also an all-NaN row of an all-black probe row: every `<` is false → 0, like the reference's loop).  Each step reads
+// one or two 64-byte lines with 16-byte loads; the binary search reads 10-11 different lines one after the other.
+// (Measured and rejected: scanning the whole 64-entry block instead of steps 2+3 — more VALU work than it saves.)
+PT_DEV int count_lt8(const float* __restrict__ p, float v) { // p is 16-byte aligned, 8 floats
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    return (a.x < v ? 1 : 0) + (a.y < v ? 1 : 0) + (a.z < v ? 1 : 0) + (a.w < v ? 1 : 0) + (b.x < v ? 1 : 0) + (b.y < v ? 1 : 0) +
+           (b.z < v ? 1 : 0) + (b.w < v ? 1 : 0);
+}
+PT_DEV int lower_bound_blocked(const float* __restrict__ row, int n, const float* __restrict__ c64, int nc64,
+                               const float* __restrict__ c8, float value) {
+    // requires n % 64 == 0 (checked on the host; otherwise the plain binary search is used)
+    int b = 0;
+    if (nc64 <= 32) {
+        for (int k = 0; k < nc64; k += 8) b += count_lt8(c64 + k, value); // c64 rows are padded to a multiple of 8 with +inf
+    } else {
+        b = lower_bound(c64, 0, nc64, value);
+    }
+    if (b >= nc64) return n;
+    const int g = count_lt8(c8 + b * 8, value); // 0..7: the block's last entry is >= value, so g <= 7
+    const int base = b * PT_CDF_BLOCK + (g < 7 ? g : 7) * 8;
+    return base + count_lt8(row + base, value);
+}
+
 // :138-169 (row/col clamped: unreachable for a valid CDF, guards a degenerate probe)
 PT_DEV void probe_sample(const DevProbe& p, v3& dir, v3& color, float& pdf, Rng& rand) {
     float r1, r2;
@@ -375,9 +406,11 @@ PT_DEV void probe_sample(const DevProbe& p, v3& dir, v3& color, float& pdf, Rng&
     int row = (int)(r1 * p.height);
     int col = (int)(r2 * p.width);
 #else
-    int row = lower_bound(p.cdfY, 0, p.height, r1);
+    int row = p.c64Y ? lower_bound_blocked(p.cdfY, p.height, p.c64Y, p.ncy, p.c8Y, r1) : lower_bound(p.cdfY, 0, p.height, r1);
     if (row > p.height - 1) row = p.height - 1;
-    int col = lower_bound(p.cdfX, row * p.width, (row + 1) * p.width, r2) - row * p.width;
+    int col = p.c64X ? lower_bound_blocked(p.cdfX + (size_t)row * p.width, p.width, p.c64X + (size_t)row * p.ncx_pad, p.ncx,
+                                           p.c8X + (size_t)row * (p.width / 8), r2)
+                     : lower_bound(p.cdfX, row * p.width, (row + 1) * p.width, r2) - row * p.width;
 #endif
     if (col > p.width - 1) col = p.width - 1;
     float4 px = p.data[(size_t)row * p.width + col];

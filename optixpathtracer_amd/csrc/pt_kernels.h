@@ -622,6 +622,14 @@ __global__ void k_cdf_marginal(const float* __restrict__ rowTotal, int height, f
     }
 }
 
+// out[r][k] = cdf[r][(k+1)*stride - 1] for k < n/stride, +inf for the padding up to row_pitch (see lower_bound_blocked)
+__global__ void k_probe_coarse(const float* __restrict__ cdf, int rows, int n, int stride, int row_pitch, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * row_pitch) return;
+    const int r = i / row_pitch, k = i - r * row_pitch;
+    out[i] = (k < n / stride) ? cdf[(size_t)r * n + (size_t)(k + 1) * stride - 1] : INFINITY;
+}
+
 // ------------------------------------------------------------------ function tables (tests)
 template <int MODE>
 __global__ void k_table_bsdf(pt_material mat, const float* __restrict__ in, uint32_t n, float* __restrict__ out) {

@@ -5,6 +5,7 @@
 // Deterministic: keys are (morton30 << 32 | primitive) so they are unique.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <cstring>
@@ -213,16 +214,32 @@ __device__ __forceinline__ float box_area(const float* b) {
     const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
     return dx * dy + dy * dz + dz * dx;
 }
-__device__ __forceinline__ int node_tris(int c, int n, const int* rfirst, const int* rlast) {
-    return c >= n - 1 ? 1 : (rlast[c] - rfirst[c] + 1);
+// leaves (sorted-order triangle indices) of a small binary subtree, left to right
+__device__ __forceinline__ int gather_leaves(int c, int n, const int* left, const int* right, int* out, int cap) {
+    int stack[8], sp = 0, k = 0;
+    stack[sp++] = c;
+    while (sp && k < cap) {
+        const int x = stack[--sp];
+        if (x >= n - 1) {
+            out[k++] = x - (n - 1);
+        } else if (sp + 2 <= 8) {
+            stack[sp++] = right[x];
+            stack[sp++] = left[x];
+        }
+    }
+    return k;
 }
-__device__ __forceinline__ int node_first(int c, int n, const int* rfirst) { return c >= n - 1 ? c - (n - 1) : rfirst[c]; }
+__global__ void k_counts_from_ranges(int n, const int* __restrict__ rfirst, const int* __restrict__ rlast, int* __restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n - 1) return;
+    cnt[i] = i < n - 1 ? (rlast[i] - rfirst[i] + 1) : 1;
+}
 
 // One thread per wide node: open the binary subtree (largest surface area first) until 8 children,
 // place children in octant-matching slots, quantise, emit the node, its leaf triangles and the next tasks.
 __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* __restrict__ tout, uint32_t* __restrict__ counters /*0 next tasks,1 nodes,2 tris*/,
-                            int n, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ rfirst,
-                            const int* __restrict__ rlast, const float* __restrict__ box, float pad,
+                            int n, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ cnt_of,
+                            const float* __restrict__ box, float pad,
                             const LeafTri* __restrict__ tris_sorted, Node8* __restrict__ nodes, LeafTri* __restrict__ tris_out) {
     const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
     if (ti >= nin) return;
@@ -237,7 +254,7 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
         float besta = -1.f;
         for (int j = 0; j < nch; ++j) {
             const int c = ch[j];
-            if (c >= n - 1 || node_tris(c, n, rfirst, rlast) <= PT8_LEAF_MAX) continue; // stays a leaf child
+            if (c >= n - 1 || cnt_of[c] <= PT8_LEAF_MAX) continue; // stays a leaf child
             const float ar = box_area(&box[(size_t)c * 6]);
             if (ar > besta) {
                 besta = ar;
@@ -287,7 +304,7 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
         const int j = child_in[s];
         if (j < 0) continue;
         const int c = ch[j];
-        const int cnt = node_tris(c, n, rfirst, rlast);
+        const int cnt = cnt_of[c];
         if (c < n - 1 && cnt > PT8_LEAF_MAX) {
             imask |= 1u << s;
             ++nint;
@@ -331,8 +348,9 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
             tout[task_base + irank] = Task8{c, child_base + irank};
             ++irank;
         } else {
-            const int cnt = node_tris(c, n, rfirst, rlast), first = node_first(c, n, rfirst);
-            for (int k = 0; k < cnt; ++k) tris_out[tri_base + toff + k] = tris_sorted[first + k];
+            int ids[PT8_LEAF_MAX > 4 ? PT8_LEAF_MAX : 4];
+            const int cnt = gather_leaves(c, n, left, right, ids, PT8_LEAF_MAX > 4 ? PT8_LEAF_MAX : 4);
+            for (int k = 0; k < cnt; ++k) tris_out[tri_base + toff + k] = tris_sorted[ids[k]];
             meta[s >> 2] |= ((toff & 31u) | ((uint32_t)(cnt - 1) << 5)) << (8 * (s & 3));
             toff += (uint32_t)cnt;
         }
@@ -344,6 +362,67 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
     nd.n3 = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
     nd.n4 = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
     nodes[task.widx] = nd;
+}
+
+// ------------------------------------------------------------------ PLOC (Meister & Bittner 2018)
+// Bottom-up agglomerative clustering over the Morton-sorted leaves: every cluster looks PLOC_R positions left and
+// right for the partner that minimises the surface area of the merged box; mutual nearest neighbours merge; repeat.
+// Much closer to a SAH tree than the LBVH split-at-Morton-bit hierarchy, still fully parallel.
+#define PLOC_R 25
+__global__ void k_ploc_nn(const int* __restrict__ cl, int N, const float* __restrict__ box, int* __restrict__ nn) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float* bi = &box[(size_t)cl[i] * 6];
+    const float l0 = bi[0], l1 = bi[1], l2 = bi[2], h0 = bi[3], h1 = bi[4], h2 = bi[5];
+    float best = INFINITY;
+    int bj = -1;
+    const int j0 = i - PLOC_R < 0 ? 0 : i - PLOC_R, j1 = i + PLOC_R > N - 1 ? N - 1 : i + PLOC_R;
+    for (int j = j0; j <= j1; ++j) {
+        if (j == i) continue;
+        const float* bjp = &box[(size_t)cl[j] * 6];
+        const float dx = fmaxf(h0, bjp[3]) - fminf(l0, bjp[0]), dy = fmaxf(h1, bjp[4]) - fminf(l1, bjp[1]), dz = fmaxf(h2, bjp[5]) - fminf(l2, bjp[2]);
+        const float a = dx * dy + dy * dz + dz * dx;
+        if (a < best) { // strict: the lowest index wins ties → deterministic
+            best = a;
+            bj = j;
+        }
+    }
+    nn[i] = bj;
+}
+// flags: merge[i] = 1 if i starts a merged pair (i < nn[i], mutual); valid[i] = 0 if i is the absorbed partner
+__global__ void k_ploc_flags(const int* __restrict__ nn, int N, uint32_t* __restrict__ merge, uint32_t* __restrict__ valid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int j = nn[i];
+    const bool mutual = j >= 0 && nn[j] == i;
+    merge[i] = (mutual && i < j) ? 1u : 0u;
+    valid[i] = (mutual && i > j) ? 0u : 1u;
+}
+__global__ void k_ploc_merge(const int* __restrict__ cl, const int* __restrict__ nn, int N, const uint32_t* __restrict__ merge,
+                             const uint32_t* __restrict__ merge_rank, const uint32_t* __restrict__ valid, const uint32_t* __restrict__ valid_rank,
+                             int next_id, int* __restrict__ left, int* __restrict__ right, float* __restrict__ box, int* __restrict__ cnt,
+                             int* __restrict__ cl_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N || !valid[i]) return;
+    int node = cl[i];
+    if (merge[i]) {
+        const int a = cl[i], b = cl[nn[i]];
+        node = next_id + (int)merge_rank[i];
+        left[node] = a;
+        right[node] = b;
+        const float *ba = &box[(size_t)a * 6], *bb = &box[(size_t)b * 6];
+        float* bo = &box[(size_t)node * 6];
+        for (int k = 0; k < 3; ++k) {
+            bo[k] = fminf(ba[k], bb[k]);
+            bo[3 + k] = fmaxf(ba[3 + k], bb[3 + k]);
+        }
+        cnt[node] = cnt[a] + cnt[b];
+    }
+    cl_out[valid_rank[i]] = node;
+}
+__global__ void k_ploc_init(int n, int* __restrict__ cl) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cl[i] = n - 1 + i; // leaf node ids, Morton order
 }
 
 // scenes with <= PT8_LEAF_MAX triangles: one node, one leaf child
@@ -379,7 +458,7 @@ __global__ void k_single_node8(int n, const float* __restrict__ bounds6, float p
     } while (0)
 
 // wide BVH from the LBVH temporaries; nodes/tris are sized for the worst case and trimmed logically
-static hipError_t build_bvh8(int n, const int* left, const int* right, const int* rfirst, const int* rlast, const float* box, float pad,
+static hipError_t build_bvh8(int n, int root, const int* left, const int* right, const int* cnt, const float* box, float pad,
                              const LeafTri* tris_sorted, hipStream_t stream, PtBvh* out) {
     Node8* nodes = nullptr;
     LeafTri* tris8 = nullptr;
@@ -393,12 +472,12 @@ static hipError_t build_bvh8(int n, const int* left, const int* right, const int
     HIPCHK(hipMalloc(&counters, sizeof(uint32_t) * 4));
     uint32_t hc[4] = {0u, 1u, 0u, 0u}; // node 0 = root is taken
     HIPCHK(hipMemcpyAsync(counters, hc, sizeof(hc), hipMemcpyHostToDevice, stream));
-    Task8 root{0, 0u};
-    HIPCHK(hipMemcpyAsync(ta, &root, sizeof(root), hipMemcpyHostToDevice, stream));
+    Task8 root_task{root, 0u};
+    HIPCHK(hipMemcpyAsync(ta, &root_task, sizeof(root_task), hipMemcpyHostToDevice, stream));
     uint32_t nin = 1;
     int levels = 0;
     while (nin) {
-        hipLaunchKernelGGL(k_collapse8, dim3((nin + 63) / 64), dim3(64), 0, stream, ta, nin, tb, counters, n, left, right, rfirst, rlast, box, pad,
+        hipLaunchKernelGGL(k_collapse8, dim3((nin + 63) / 64), dim3(64), 0, stream, ta, nin, tb, counters, n, left, right, cnt, box, pad,
                            tris_sorted, nodes, tris8);
         HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -415,6 +494,44 @@ static hipError_t build_bvh8(int n, const int* left, const int* right, const int
     out->num_tris8 = hc[2];
     out->levels8 = levels;
     hipFree(ta); hipFree(tb); hipFree(counters);
+    return hipSuccess;
+}
+
+// PLOC hierarchy over the sorted leaves (leaf boxes at box[n-1+i] come from the refit pass); overwrites the
+// internal-node arrays left/right/box/cnt (ids 0..n-2, root = the last one created)
+static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt, hipStream_t stream, int* root_out) {
+    int *cl_a = nullptr, *cl_b = nullptr, *nn = nullptr;
+    uint32_t *merge = nullptr, *valid = nullptr, *merge_rank = nullptr, *valid_rank = nullptr;
+    HIPCHK(hipMalloc(&cl_a, sizeof(int) * (size_t)n)); HIPCHK(hipMalloc(&cl_b, sizeof(int) * (size_t)n)); HIPCHK(hipMalloc(&nn, sizeof(int) * (size_t)n));
+    HIPCHK(hipMalloc(&merge, 4 * (size_t)n)); HIPCHK(hipMalloc(&valid, 4 * (size_t)n));
+    HIPCHK(hipMalloc(&merge_rank, 4 * (size_t)n)); HIPCHK(hipMalloc(&valid_rank, 4 * (size_t)n));
+    size_t tmp_bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, merge, merge_rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    void* tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    const int B = 256;
+    hipLaunchKernelGGL(k_ploc_init, dim3((n + B - 1) / B), dim3(B), 0, stream, n, cl_a);
+    int N = n, next_id = 0, iters = 0;
+    while (N > 1) {
+        hipLaunchKernelGGL(k_ploc_nn, dim3((N + B - 1) / B), dim3(B), 0, stream, cl_a, N, box, nn);
+        hipLaunchKernelGGL(k_ploc_flags, dim3((N + B - 1) / B), dim3(B), 0, stream, nn, N, merge, valid);
+        HIPCHK(rocprim::exclusive_scan(tmp, tmp_bytes, merge, merge_rank, 0u, (size_t)N, rocprim::plus<uint32_t>(), stream));
+        HIPCHK(rocprim::exclusive_scan(tmp, tmp_bytes, valid, valid_rank, 0u, (size_t)N, rocprim::plus<uint32_t>(), stream));
+        hipLaunchKernelGGL(k_ploc_merge, dim3((N + B - 1) / B), dim3(B), 0, stream, cl_a, nn, N, merge, merge_rank, valid, valid_rank, next_id, left, right, box, cnt, cl_b);
+        uint32_t lm[2], lv[2];
+        HIPCHK(hipMemcpyAsync(&lm[0], merge + (N - 1), 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(&lm[1], merge_rank + (N - 1), 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(&lv[0], valid + (N - 1), 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(&lv[1], valid_rank + (N - 1), 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        const int merged = (int)(lm[0] + lm[1]);
+        if (merged == 0 || ++iters > 4096) return hipErrorUnknown; // cannot happen: the global closest pair is always mutual
+        next_id += merged;
+        N = (int)(lv[0] + lv[1]);
+        int* t = cl_a; cl_a = cl_b; cl_b = t;
+    }
+    HIPCHK(hipMemcpy(root_out, cl_a, sizeof(int), hipMemcpyDeviceToHost));
+    hipFree(cl_a); hipFree(cl_b); hipFree(nn); hipFree(merge); hipFree(valid); hipFree(merge_rank); hipFree(valid_rank); hipFree(tmp);
     return hipSuccess;
 }
 
@@ -513,7 +630,20 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t nt
     out->nodes = nodes;
     out->num_nodes = nnodes;
     out->root = 0; // node 0 (range = everything) always stays internal when n > PT_LEAF_MAX, and remap[0] = 0
-    HIPCHK(build_bvh8(n, left, right, rfirst, rlast, box, pad, tris, stream, out));
+    {
+        // hierarchy for the wide tree: the LBVH itself (default) or PLOC (PT_BVH_BUILDER=ploc).  Measured on the C3 voxel
+        // terrain: PLOC gives MORE node visits per ray (13.3 vs 12.5 primary, 15.9 vs 13.6 diffuse bounce) and 5 % lower
+        // Mrays/s — on a scene of uniform, evenly spread quads the Morton split is already near the SAH optimum and
+        // balances the 8-wide collapse better; PLOC stays selectable for irregular scenes.
+        int* cnt = nullptr;
+        HIPCHK(hipMalloc(&cnt, sizeof(int) * (size_t)(2 * n)));
+        hipLaunchKernelGGL(k_counts_from_ranges, dim3((2 * n + B - 1) / B), dim3(B), 0, stream, n, rfirst, rlast, cnt);
+        int root = 0;
+        const char* builder = getenv("PT_BVH_BUILDER");
+        if (builder && strcmp(builder, "ploc") == 0) HIPCHK(build_ploc(n, left, right, box, cnt, stream, &root));
+        HIPCHK(build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, out));
+        hipFree(cnt);
+    }
     hipFree(keys); hipFree(keys_sorted); hipFree(bounds); hipFree(tmp); hipFree(tmp2);
     hipFree(left); hipFree(right); hipFree(parent); hipFree(rfirst); hipFree(rlast); hipFree(visits);
     hipFree(box); hipFree(keep); hipFree(remap);

@@ -53,13 +53,22 @@ typedef struct pt_mesh_desc {
     const uint32_t* index; /* num_triangles * 3, local to this mesh */
     uint32_t num_triangles;
     pt_material material;
-    int32_t diffuse_texture_id; /* must be -1: texture sampling is a later row */
+    int32_t diffuse_texture_id; /* index into pt_scene_desc.textures or -1 (TriangleMesh::diffuseTextureID) */
+    const float* texcoord;      /* num_vertices * 2 (TriangleMesh::texcoord) or NULL */
 } pt_mesh_desc;
+
+/* Texture (Model.h:21-29): RGBA8 pixels, row 0 first (loadTexture already mirrored them in y, Model.cpp:112-121) */
+typedef struct pt_texture_desc {
+    const uint32_t* pixel;
+    int32_t width, height;
+} pt_texture_desc;
 
 /* Model (Model.h:31-42) */
 typedef struct pt_scene_desc {
     const pt_mesh_desc* meshes;
     uint32_t num_meshes;
+    const pt_texture_desc* textures; /* may be NULL when num_textures == 0 */
+    uint32_t num_textures;
 } pt_scene_desc;
 
 enum pt_bsdf_mode { PT_BSDF_DISNEY = 0, PT_BSDF_LAMBERT = 1 /* Disney.cuh:125-147 */ };
@@ -100,7 +109,8 @@ typedef struct pt_stats {
 } pt_stats;
 
 /* SampleRenderer::SampleRenderer(const Model*) (SimplePathtracer.cpp:39-71): uploads the meshes
- * (buildAccel :481-489), builds the acceleration structure ON THE GPU (replaces optixAccelBuild +
+ * (buildAccel :481-489) and textures (createTextures :603-654; sampled in software: wrap, bilinear, normalised
+ * float, no sRGB), builds the acceleration structure ON THE GPU (replaces optixAccelBuild +
  * optixAccelCompact :561-591) and the per-mesh material table (replaces buildSBT :390-455).
  * `device` is the HIP device ordinal.  The scene is deep-copied; the caller keeps its arrays. */
 int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ctx);
@@ -223,6 +233,7 @@ int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit, float* t_o
  *  which = 4: make_color in: n x rgb[3] out: n x {packed bits} (1)
  *  which = 5: detmath in: n x {fn, x, y} (3) out: n x 1   fn: 0 sin 1 cos 2 acos 3 atan2(x,y) 4 log 5 pow(x,y) 6 x/y 7 sqrt(x)
  *  which = 6: tea4/lcg/Random in: n x {a bits, b bits} out: n x {tea4(a,b), lcg state, rnd, Randf bits...} (8)
+ *  which = 7: tex2D of scene texture 0 in: n x {s,t} (2) out: n x rgba (4)
  * material applies to which 0,1; the context's probe to 2,3. All arrays are host memory. */
 int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material, int bsdf_mode, const float* in, uint32_t n,
                   float* out);

@@ -32,12 +32,16 @@ class Material(C.Structure):  # pt_material == Material.h:47-68
 class MeshDesc(C.Structure):
     _fields_ = [
         ("vertex", C.c_void_p), ("num_vertices", C.c_uint32), ("index", C.c_void_p), ("num_triangles", C.c_uint32),
-        ("material", Material), ("diffuse_texture_id", C.c_int32),
+        ("material", Material), ("diffuse_texture_id", C.c_int32), ("texcoord", C.c_void_p),
     ]
 
 
+class TextureDesc(C.Structure):
+    _fields_ = [("pixel", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
 class SceneDesc(C.Structure):
-    _fields_ = [("meshes", C.POINTER(MeshDesc)), ("num_meshes", C.c_uint32)]
+    _fields_ = [("meshes", C.POINTER(MeshDesc)), ("num_meshes", C.c_uint32), ("textures", C.POINTER(TextureDesc)), ("num_textures", C.c_uint32)]
 
 
 class Options(C.Structure):

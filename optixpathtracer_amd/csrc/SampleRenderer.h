@@ -48,15 +48,21 @@ static_assert(sizeof(Material) == sizeof(pt_material), "Material must stay layou
 // Model.h:10-42
 struct TriangleMesh {
     std::vector<float3> vertex;
-    std::vector<float3> normal;   // carried like the reference; the hot path shades with geometric normals
-    std::vector<float2> texcoord; // (deviceProgram.cu:490), so these are not uploaded
+    std::vector<float3> normal;   // carried like the reference; the hot path shades with geometric normals (deviceProgram.cu:490)
+    std::vector<float2> texcoord; // uploaded when the mesh has a diffuse texture
     std::vector<uint3> index;
     Material material;
     int diffuseTextureID{-1};
 };
+struct Texture { // Model.h:21-29
+    ~Texture() { delete[] pixel; }
+    uint32_t* pixel{nullptr};
+    int2 resolution{-1, -1};
+};
 struct Model {
-    ~Model() { for (auto m : meshes) delete m; }
+    ~Model() { for (auto m : meshes) delete m; for (auto t : textures) delete t; }
     std::vector<TriangleMesh*> meshes;
+    std::vector<Texture*> textures;
 };
 
 // Probe.h:8-88
@@ -99,8 +105,11 @@ class SampleRenderer {
             static_assert(sizeof(pt_material) == 104, "");
             md[i].material = *reinterpret_cast<const pt_material*>(&m->material);
             md[i].diffuse_texture_id = m->diffuseTextureID;
+            md[i].texcoord = m->texcoord.size() == m->vertex.size() && !m->texcoord.empty() ? &m->texcoord[0].x : nullptr;
         }
-        pt_scene_desc sd{md.data(), (uint32_t)md.size()};
+        std::vector<pt_texture_desc> td(model->textures.size());
+        for (size_t i = 0; i < td.size(); ++i) td[i] = pt_texture_desc{model->textures[i]->pixel, model->textures[i]->resolution.x, model->textures[i]->resolution.y};
+        pt_scene_desc sd{md.data(), (uint32_t)md.size(), td.data(), (uint32_t)td.size()};
         if (pt_create(&sd, device, &ctx) != PT_OK) throw std::runtime_error(std::string("SampleRenderer: ") + pt_last_error(nullptr));
     }
     ~SampleRenderer() { pt_destroy(ctx); }

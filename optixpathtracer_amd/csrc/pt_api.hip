@@ -31,6 +31,12 @@ struct pt_ctx {
     pt_material* d_mats = nullptr;
     PrimTri* d_prims = nullptr;
     bool has_catcher = false;
+    // textures
+    int32_t* d_mesh_tex = nullptr;
+    PrimUV* d_uvs = nullptr;
+    DevTex* d_textures = nullptr;
+    std::vector<uint32_t*> d_tex_pixels;
+    DevTex tex0{};
     PtBvh bvh;
     double bvh_build_ms = 0;
     // probe
@@ -119,13 +125,16 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
     for (uint32_t m = 0; m < scene->num_meshes; ++m) {
         const pt_mesh_desc& md = scene->meshes[m];
         if (!md.vertex || !md.index || md.num_triangles == 0) return fail(nullptr, PT_ERR_INVALID, "pt_create: empty mesh");
-        if (md.diffuse_texture_id >= 0) return fail(nullptr, PT_ERR_UNSUPPORTED, "pt_create: textured meshes are not supported yet");
+        if (md.diffuse_texture_id >= (int32_t)scene->num_textures) return fail(nullptr, PT_ERR_INVALID, "pt_create: diffuse_texture_id out of range");
         for (size_t k = 0; k < 3 * (size_t)md.num_triangles; ++k)
             if (md.index[k] >= md.num_vertices) return fail(nullptr, PT_ERR_INVALID, "pt_create: vertex index out of range");
         nv += md.num_vertices;
         nt += md.num_triangles;
     }
     if (nt >= (1u << 28)) return fail(nullptr, PT_ERR_UNSUPPORTED, "pt_create: more than 2^28 triangles");
+    for (uint32_t t = 0; t < scene->num_textures; ++t)
+        if (!scene->textures || !scene->textures[t].pixel || scene->textures[t].width <= 0 || scene->textures[t].height <= 0)
+            return fail(nullptr, PT_ERR_INVALID, "pt_create: bad texture");
     pt_ctx* ctx = new pt_ctx();
     default_options(&ctx->opt);
     ctx->device = device;
@@ -168,6 +177,47 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
     CKC(hipMemcpy(ctx->d_mats, mats.data(), sizeof(pt_material) * mats.size(), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_emit_prims, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_verts, ctx->d_idx,
                        ctx->d_tri_mesh, (uint32_t)nt, ctx->d_prims);
+    {   // textures (createTextures, SimplePathtracer.cpp:603-654) and per-primitive texcoords (buildSBT :430-447)
+        std::vector<int32_t> mesh_tex(scene->num_meshes, -1);
+        bool any = false;
+        for (uint32_t m = 0; m < scene->num_meshes; ++m)
+            if (scene->meshes[m].diffuse_texture_id >= 0 && scene->meshes[m].texcoord) { // hasTexture && sbtData.texcoord (:512)
+                mesh_tex[m] = scene->meshes[m].diffuse_texture_id;
+                any = true;
+            }
+        if (any) {
+            std::vector<float> tc(2 * nv, 0.f);
+            size_t vb2 = 0;
+            for (uint32_t m = 0; m < scene->num_meshes; ++m) {
+                const pt_mesh_desc& md = scene->meshes[m];
+                if (md.texcoord) memcpy(&tc[2 * vb2], md.texcoord, sizeof(float) * 2 * md.num_vertices);
+                vb2 += md.num_vertices;
+            }
+            float* d_tc = nullptr;
+            CKC(dalloc(&d_tc, 2 * nv));
+            CKC(hipMemcpy(d_tc, tc.data(), sizeof(float) * 2 * nv, hipMemcpyHostToDevice));
+            CKC(dalloc(&ctx->d_uvs, nt));
+            hipLaunchKernelGGL(k_emit_uvs, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, d_tc, ctx->d_idx, (uint32_t)nt, ctx->d_uvs);
+            CKC(hipStreamSynchronize(ctx->stream));
+            dfree(d_tc);
+            CKC(dalloc(&ctx->d_mesh_tex, mesh_tex.size()));
+            CKC(hipMemcpy(ctx->d_mesh_tex, mesh_tex.data(), sizeof(int32_t) * mesh_tex.size(), hipMemcpyHostToDevice));
+        }
+        std::vector<DevTex> tex(scene->num_textures);
+        for (uint32_t t = 0; t < scene->num_textures; ++t) {
+            const pt_texture_desc& td = scene->textures[t];
+            uint32_t* px = nullptr;
+            CKC(dalloc(&px, (size_t)td.width * td.height));
+            ctx->d_tex_pixels.push_back(px);
+            CKC(hipMemcpy(px, td.pixel, sizeof(uint32_t) * (size_t)td.width * td.height, hipMemcpyHostToDevice));
+            tex[t] = DevTex{px, td.width, td.height};
+        }
+        if (!tex.empty()) {
+            CKC(dalloc(&ctx->d_textures, tex.size()));
+            CKC(hipMemcpy(ctx->d_textures, tex.data(), sizeof(DevTex) * tex.size(), hipMemcpyHostToDevice));
+            ctx->tex0 = tex[0];
+        }
+    }
     hipEvent_t e0, e1;
     CKC(hipEventCreate(&e0));
     CKC(hipEventCreate(&e1));
@@ -221,6 +271,8 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     free_path_state(ctx);
     free_frame(ctx);
     dfree(ctx->d_verts); dfree(ctx->d_idx); dfree(ctx->d_tri_mesh); dfree(ctx->d_mats); dfree(ctx->d_prims);
+    dfree(ctx->d_mesh_tex); dfree(ctx->d_uvs); dfree(ctx->d_textures);
+    for (uint32_t*& px : ctx->d_tex_pixels) dfree(px);
     pt_bvh_free(&ctx->bvh);
     dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
     dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y);
@@ -584,7 +636,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeue, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow};
+                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
@@ -622,7 +674,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 ++lc.trace;
             }
-            ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow};
+            ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow};
             if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0); // shade overwrites what shadow(b-1) reads
             {
                 SpanGuard g(ctx, CLS_SHADE, bs.stream);
@@ -1050,10 +1102,11 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
 extern "C" int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material, int bsdf_mode, const float* in, uint32_t n, float* out) {
     if (!ctx || !in || !out) return PT_ERR_INVALID;
     if (n == 0) return PT_OK;
-    static const int in_w[7] = {11, 9, 1, 3, 3, 3, 2}, out_w[7] = {4, 6, 9, 6, 1, 1, 8};
-    if (which < 0 || which > 6) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: unknown table");
+    static const int in_w[8] = {11, 9, 1, 3, 3, 3, 2, 2}, out_w[8] = {4, 6, 9, 6, 1, 1, 8, 4};
+    if (which < 0 || which > 7) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: unknown table");
     if (which <= 1 && !material) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: material required");
     if ((which == 2 || which == 3) && !ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: no probe set");
+    if (which == 7 && !ctx->tex0.pixel) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: the scene has no texture");
     CK(hipSetDevice(ctx->device));
     float *dIn = nullptr, *dOut = nullptr;
     CK(dalloc(&dIn, (size_t)n * in_w[which]));
@@ -1076,6 +1129,7 @@ extern "C" int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material
         case 4: hipLaunchKernelGGL(k_table_color, g, b, 0, ctx->stream, dIn, n, dOut); break;
         case 5: hipLaunchKernelGGL(k_table_math, g, b, 0, ctx->stream, dIn, n, dOut); break;
         case 6: hipLaunchKernelGGL(k_table_rng, g, b, 0, ctx->stream, dIn, n, dOut); break;
+        case 7: hipLaunchKernelGGL(k_table_tex, g, b, 0, ctx->stream, ctx->tex0, dIn, n, dOut); break;
     }
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipGetLastError());

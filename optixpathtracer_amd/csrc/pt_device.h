@@ -426,6 +426,35 @@ PT_DEV void probe_sample(const DevProbe& p, v3& dir, v3& color, float& pdf, Rng&
     dir = probe_uv_to_dir(u, v);
 }
 
+// ------------------------------------------------------------------ software tex2D (SimplePathtracer.cpp:603-654 settings)
+// uchar4 array, wrap addressing, bilinear filter, normalised float read, normalised coordinates, no sRGB — the formula of
+// the CUDA C Programming Guide appendix "Texture Fetching" (weights in 1.8 fixed point; rounding to nearest assumed).
+struct DevTex {
+    const uint32_t* pixel;
+    int w, h;
+};
+PT_DEV float texel_ch(uint32_t p, int k) { return (float)((p >> (8 * k)) & 0xffu) / 255.0f; }
+PT_DEV float4 tex2d_wrap_linear(const DevTex& tx, float s, float t) {
+    const int W = tx.w, H = tx.h;
+    const float x = (s - floorf(s)) * (float)W, y = (t - floorf(t)) * (float)H;
+    const float xB = x - 0.5f, yB = y - 0.5f;
+    const float fi = floorf(xB), fj = floorf(yB);
+    const float alpha = floorf((xB - fi) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    const float beta = floorf((yB - fj) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    int i0 = (int)fi, j0 = (int)fj;
+    int i1 = i0 + 1, j1 = j0 + 1;
+    i0 = ((i0 % W) + W) % W; i1 = ((i1 % W) + W) % W;
+    j0 = ((j0 % H) + H) % H; j1 = ((j1 % H) + H) % H;
+    const uint32_t t00 = tx.pixel[(size_t)j0 * W + i0], t10 = tx.pixel[(size_t)j0 * W + i1], t01 = tx.pixel[(size_t)j1 * W + i0],
+                   t11 = tx.pixel[(size_t)j1 * W + i1];
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        o[k] = (1.0f - alpha) * (1.0f - beta) * texel_ch(t00, k) + alpha * (1.0f - beta) * texel_ch(t10, k) +
+               (1.0f - alpha) * beta * texel_ch(t01, k) + alpha * beta * texel_ch(t11, k);
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // ------------------------------------------------------------------ output transforms
 // cuda/helpers.h:34-61
 PT_DEV uint32_t quantize8(float x) {

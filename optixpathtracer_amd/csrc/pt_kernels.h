@@ -173,9 +173,15 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace(PathState st, BvhDev b
 }
 
 // ------------------------------------------------------------------ shade
+struct PrimUV { // texcoords of the three vertices of a primitive (sbtData.texcoord[index.*])
+    float2 c0, c1, c2;
+};
 struct ShadeParams {
     const PrimTri* prims;
     const pt_material* mats;
+    const int32_t* mesh_tex; // per mesh: texture id when the mesh has a texture AND texcoords, else -1 (null: no textures)
+    const PrimUV* uvs;
+    const DevTex* textures;
     DevProbe probe;
     int max_depth;
     float tmin_radiance; // 0.001 (deviceProgram.cu:420); 0.01 in the sv4 variant
@@ -243,7 +249,24 @@ __global__ void __launch_bounds__(256) k_shade(PathState st, ShadeParams sp) {
                     ++depth;
                     push_next = true;
                 } else {
-                    const v3 albedo = mk3(mat.color[0], mat.color[1], mat.color[2]);
+                    v3 albedo = mk3(mat.color[0], mat.color[1], mat.color[2]);
+                    if (sp.mesh_tex) { // deviceProgram.cu:512-523: a textured mesh's albedo is REPLACED by tex2D at the hit's texcoord
+                        const int tid = sp.mesh_tex[__float_as_int(tri.t2.y)];
+                        if (tid >= 0) {
+                            // optixGetTriangleBarycentrics = (weight of vertex 1, weight of vertex 2): the hit test's own weights
+                            const v3 A = sub3(v0, ray_o), B = sub3(v1, ray_o), C = sub3(v2, ray_o);
+                            const v3 CxB = cross3(C, B), AxC = cross3(A, C), BxA = cross3(B, A);
+                            const float Uw = dot3(ray_dir, CxB), Vw = dot3(ray_dir, AxC), Ww = dot3(ray_dir, BxA);
+                            const float det = Uw + Vw + Ww;
+                            const float bu = Vw / det, bv = Ww / det;
+                            const PrimUV uv = sp.uvs[prim];
+                            const float w0 = 1.f - bu - bv;
+                            const float tcx = w0 * uv.c0.x + bu * uv.c1.x + bv * uv.c2.x;
+                            const float tcy = w0 * uv.c0.y + bu * uv.c1.y + bv * uv.c2.y;
+                            const float4 tx = tex2d_wrap_linear(sp.textures[tid], tcx, tcy);
+                            albedo = mk3(tx.x, tx.y, tx.z);
+                        }
+                    }
                     const float4 th = st.thr[p];
                     const v3 T_old = mk3(th.x, th.y, th.z);
                     float rayEta = th.w;
@@ -707,6 +730,22 @@ __global__ void k_table_math(const float* __restrict__ in, uint32_t n, float* __
         default: r = sqrtf(x); break;
     }
     out[i] = r;
+}
+__global__ void k_table_tex(DevTex tex, const float* __restrict__ in, uint32_t n, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = tex2d_wrap_linear(tex, in[2 * (size_t)i], in[2 * (size_t)i + 1]);
+    out[4 * (size_t)i] = c.x; out[4 * (size_t)i + 1] = c.y; out[4 * (size_t)i + 2] = c.z; out[4 * (size_t)i + 3] = c.w;
+}
+__global__ void k_emit_uvs(const float* __restrict__ texcoord, const uint32_t* __restrict__ idx, uint32_t ntri, PrimUV* __restrict__ uvs) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= ntri) return;
+    const uint32_t a = idx[3 * (size_t)p], b = idx[3 * (size_t)p + 1], c = idx[3 * (size_t)p + 2];
+    PrimUV u;
+    u.c0 = make_float2(texcoord[2 * (size_t)a], texcoord[2 * (size_t)a + 1]);
+    u.c1 = make_float2(texcoord[2 * (size_t)b], texcoord[2 * (size_t)b + 1]);
+    u.c2 = make_float2(texcoord[2 * (size_t)c], texcoord[2 * (size_t)c + 1]);
+    uvs[p] = u;
 }
 __global__ void k_table_rng(const float* __restrict__ in, uint32_t n, float* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import Material as CMaterial
-from ._lib import MeshDesc, Options, Region, SceneDesc, Stats, Variant
+from ._lib import MeshDesc, Options, Region, SceneDesc, Stats, TextureDesc, Variant
 from .scenes import Model, ProbeData, uvw_frame
 
 PT_BUF_ACCUM, PT_BUF_FRAME, PT_BUF_COLOR, PT_BUF_NORMAL, PT_BUF_ALBEDO = range(5)
@@ -72,7 +72,19 @@ class SampleRenderer:
             meshes[k].num_triangles = len(ix)
             C.memmove(C.byref(meshes[k].material), np.asarray(m.material).tobytes(), 104)
             meshes[k].diffuse_texture_id = m.diffuseTextureID
-        sd = SceneDesc(meshes, len(model.meshes))
+            if m.texcoord is not None and len(m.texcoord):
+                tc = np.ascontiguousarray(m.texcoord, np.float32)
+                assert tc.shape == (len(v), 2)
+                self._keep.append(tc)
+                meshes[k].texcoord = tc.ctypes.data
+        textures = getattr(model, "textures", []) or []
+        tdesc = (TextureDesc * max(1, len(textures)))()
+        for k, t in enumerate(textures):
+            px = np.ascontiguousarray(t.pixel, np.uint32)
+            self._keep.append(px)
+            tdesc[k].pixel = px.ctypes.data
+            tdesc[k].height, tdesc[k].width = px.shape
+        sd = SceneDesc(meshes, len(model.meshes), tdesc, len(textures))
         rc = L.pt_create(C.byref(sd), device, C.byref(self._ctx))
         if rc:
             self._ctx = C.c_void_p()

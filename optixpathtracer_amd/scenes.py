@@ -65,11 +65,36 @@ class TriangleMesh:  # Model.h:10-19
     index: np.ndarray  # (nt,3) u32, local to this mesh
     material: np.ndarray  # MATERIAL_DTYPE scalar
     diffuseTextureID: int = -1
+    texcoord: np.ndarray = None  # (nv,2) f32 or None
+
+
+@dataclass
+class Texture:  # Model.h:21-29: RGBA8 pixels (h,w) uint32, row 0 first (after loadTexture's y mirror)
+    pixel: np.ndarray
+
+    @property
+    def resolution(self):
+        return (self.pixel.shape[1], self.pixel.shape[0])
 
 
 @dataclass
 class Model:  # Model.h:31-42
     meshes: list = field(default_factory=list)
+    textures: list = field(default_factory=list)
+
+    def flatten_textures(self):
+        """Global texcoords (nv,2) or None, per-mesh texture id, per-mesh has-texcoord flag."""
+        any_uv = any(m.texcoord is not None and len(m.texcoord) for m in self.meshes)
+        tcs = []
+        for m in self.meshes:
+            if m.texcoord is not None and len(m.texcoord):
+                tcs.append(np.ascontiguousarray(m.texcoord, np.float32))
+            else:
+                tcs.append(np.zeros((len(m.vertex), 2), np.float32))
+        tc = np.ascontiguousarray(np.concatenate(tcs)) if any_uv else None
+        mesh_tex = np.array([m.diffuseTextureID for m in self.meshes], np.int32)
+        has_uv = np.array([1 if (m.texcoord is not None and len(m.texcoord)) else 0 for m in self.meshes], np.uint8)
+        return tc, mesh_tex, has_uv
 
     @property
     def num_triangles(self) -> int:
@@ -150,6 +175,33 @@ def cornell_box() -> Model:
     L = [[(343, 548.6, 227), (343, 548.6, 332), (213, 548.6, 332), (213, 548.6, 227)]]
     m = Model([_quads_to_mesh(W, white), _quads_to_mesh(R, red), _quads_to_mesh(G, green), _quads_to_mesh(L, light)])
     assert m.num_triangles == 32
+    return m
+
+
+def checker_texture(w=64, h=32, cells=8, c0=(220, 40, 40), c1=(240, 240, 200)) -> Texture:
+    """RGBA8 checkerboard with a per-pixel ramp so bilinear filtering and wrap are exercised."""
+    ys, xs = np.mgrid[0:h, 0:w]
+    sel = ((xs * cells // w) + (ys * cells // h)) % 2
+    rgb = np.where(sel[..., None] == 0, np.array(c0), np.array(c1)).astype(np.uint32)
+    rgb[..., 2] = (rgb[..., 2] + xs * 3 + ys * 5) % 256
+    pix = rgb[..., 0] | (rgb[..., 1] << 8) | (rgb[..., 2] << 16) | (np.uint32(255) << 24)
+    return Texture(np.ascontiguousarray(pix.astype(np.uint32)))
+
+
+def textured_scene() -> Model:
+    """A textured ground quad (texcoords run past [0,1] → wrap), a textured tilted quad, an untextured box and a mesh
+    that names a texture but has no texcoords (hasTexture && texcoord is false → material colour, deviceProgram.cu:512)."""
+    m = Model()
+    ground = _quads_to_mesh([[(-4, 0, -4), (4, 0, -4), (4, 0, 4), (-4, 0, 4)]], Material(color=(0.1, 0.9, 0.1)))
+    ground.texcoord = np.array([[-1.5, -1.5], [2.5, -1.5], [2.5, 2.5], [-1.5, 2.5]], np.float32)
+    ground.diffuseTextureID = 0
+    wall = _quads_to_mesh([[(-2, 0, 2), (2, 0, 2.5), (2, 2.5, 3), (-2, 2.5, 2.5)]], Material(color=(0.9, 0.1, 0.1), roughness=0.4))
+    wall.texcoord = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    wall.diffuseTextureID = 1
+    m.meshes += [ground, wall]
+    add_box(m, Material(color=(0.3, 0.4, 0.8)), (0.0, 0.5, 0.0), (0.5, 0.5, 0.5))
+    m.meshes[-1].diffuseTextureID = 0  # named texture, no texcoords
+    m.textures = [checker_texture(), checker_texture(48, 40, 6, (30, 60, 200), (250, 250, 60))]
     return m
 
 

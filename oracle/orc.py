@@ -102,6 +102,8 @@ class Oracle:
         L.orc_math_table.argtypes = [C.c_int, f32p, f32p, C.c_int, f32p]
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(Probe), C.POINTER(Params), f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_render_region.argtypes = [C.c_void_p, C.POINTER(Probe), C.POINTER(Params), C.POINTER(Region), C.POINTER(Variant), f32p, u32p, C.POINTER(Stats)]
+        L.orc_tex2d.argtypes = [u32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p]
+        L.orc_scene_set_textures.argtypes = [C.c_void_p, C.c_void_p, i32p, u8p, C.c_uint32, C.c_void_p, i32p, i32p]
         L.orc_sizeof_material.restype = C.c_size_t
         assert L.orc_sizeof_material() == 104
 
@@ -127,6 +129,14 @@ class Oracle:
         if use_bvh is None:
             use_bvh = len(idx) > 256
         h = self.lib.orc_scene_create(verts.reshape(-1), len(verts), idx.reshape(-1), len(idx), tri_mesh, mats.ctypes.data, len(mats), int(use_bvh))
+        textures = getattr(model, "textures", []) or []
+        if textures or any(m.diffuseTextureID >= 0 for m in model.meshes):
+            tc, mesh_tex, has_uv = model.flatten_textures()
+            pix = [np.ascontiguousarray(t.pixel, np.uint32) for t in textures]
+            ptrs = (C.c_void_p * max(1, len(pix)))(*[p.ctypes.data for p in pix])
+            ws = np.array([p.shape[1] for p in pix] or [0], np.int32)
+            hs = np.array([p.shape[0] for p in pix] or [0], np.int32)
+            self.lib.orc_scene_set_textures(h, tc.ctypes.data if tc is not None else None, mesh_tex, has_uv, len(pix), ptrs, ws, hs)
         return SceneHandle(self, h)
 
     def render(self, scene, probe, cam_uvw, eye, width, height, spp, max_depth=8, subframe=0, bsdf_mode=BSDF_DISNEY, accum=None, nthreads=None):

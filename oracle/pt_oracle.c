@@ -555,6 +555,12 @@ typedef struct {
     uint32_t* tri_mesh; /* ntri */
     orc_material* mats; /* nmesh */
     int has_catcher;
+    /* textures: per-vertex texcoords (or NULL), per-mesh texture id (-1 none) and uv flag */
+    float* texcoord;    /* nv*2 or NULL */
+    int32_t* mesh_tex;  /* nmesh */
+    uint8_t* mesh_has_uv;
+    struct { uint32_t* pixel; int w, h; }* tex;
+    uint32_t ntex;
     /* optional BVH */
     int use_bvh;
     onode* nodes;
@@ -801,7 +807,52 @@ orc_scene* orc_scene_create(const float* verts, uint32_t nv, const uint32_t* idx
 void orc_scene_destroy(orc_scene* s) {
     if (!s) return;
     free(s->verts); free(s->idx); free(s->tri_mesh); free(s->mats); free(s->nodes); free(s->order);
+    free(s->texcoord); free(s->mesh_tex); free(s->mesh_has_uv);
+    for (uint32_t k = 0; k < s->ntex; ++k) free(s->tex[k].pixel);
+    free(s->tex);
     free(s);
+}
+
+/* tex2D<float4> of a uchar4 CUDA array with addressMode Wrap, filterMode Linear, readMode NormalizedFloat,
+ * normalizedCoords, no sRGB (SimplePathtracer.cpp:603-654), restated from the CUDA C Programming Guide appendix
+ * "Texture Fetching" (linear filtering: xB = x - 0.5, i = floor(xB), alpha = frac(xB) kept in 9-bit fixed point with 8
+ * fractional bits; wrap: x = frac(s) * N).  The hardware's exact rounding of alpha is not documented: round to nearest
+ * is used.  PARITY UNPINNED (no CUDA hardware, no fixture in the reference). */
+static inline float texel_ch(uint32_t p, int k) { return (float)((p >> (8 * k)) & 0xffu) / 255.0f; }
+static void tex2d_wrap_linear(const uint32_t* pix, int W, int H, float s, float t, float out[4]) {
+    const float x = (s - floorf(s)) * (float)W, y = (t - floorf(t)) * (float)H;
+    const float xB = x - 0.5f, yB = y - 0.5f;
+    const float fi = floorf(xB), fj = floorf(yB);
+    const float alpha = floorf((xB - fi) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    const float beta = floorf((yB - fj) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    int i0 = (int)fi, j0 = (int)fj;
+    int i1 = i0 + 1, j1 = j0 + 1;
+    i0 = ((i0 % W) + W) % W; i1 = ((i1 % W) + W) % W;
+    j0 = ((j0 % H) + H) % H; j1 = ((j1 % H) + H) % H;
+    const uint32_t t00 = pix[(size_t)j0 * W + i0], t10 = pix[(size_t)j0 * W + i1], t01 = pix[(size_t)j1 * W + i0], t11 = pix[(size_t)j1 * W + i1];
+    for (int k = 0; k < 4; ++k)
+        out[k] = (1.0f - alpha) * (1.0f - beta) * texel_ch(t00, k) + alpha * (1.0f - beta) * texel_ch(t10, k) +
+                 (1.0f - alpha) * beta * texel_ch(t01, k) + alpha * beta * texel_ch(t11, k);
+}
+void orc_tex2d(const uint32_t* pix, int W, int H, float s, float t, float out[4]) { tex2d_wrap_linear(pix, W, H, s, t, out); }
+
+void orc_scene_set_textures(orc_scene* s, const float* texcoord, const int32_t* mesh_tex, const uint8_t* mesh_has_uv, uint32_t ntex,
+                            const uint32_t* const* pixels, const int32_t* widths, const int32_t* heights) {
+    if (texcoord) {
+        s->texcoord = (float*)malloc(sizeof(float) * 2 * (size_t)s->nv);
+        memcpy(s->texcoord, texcoord, sizeof(float) * 2 * (size_t)s->nv);
+    }
+    s->mesh_tex = (int32_t*)malloc(sizeof(int32_t) * s->nmesh);
+    memcpy(s->mesh_tex, mesh_tex, sizeof(int32_t) * s->nmesh);
+    s->mesh_has_uv = (uint8_t*)malloc(s->nmesh);
+    memcpy(s->mesh_has_uv, mesh_has_uv, s->nmesh);
+    s->ntex = ntex;
+    s->tex = calloc(ntex ? ntex : 1, sizeof(*s->tex));
+    for (uint32_t k = 0; k < ntex; ++k) {
+        s->tex[k].w = widths[k]; s->tex[k].h = heights[k];
+        s->tex[k].pixel = (uint32_t*)malloc(4 * (size_t)widths[k] * heights[k]);
+        memcpy(s->tex[k].pixel, pixels[k], 4 * (size_t)widths[k] * heights[k]);
+    }
 }
 
 /* batch ray queries for kernel-level tests: rays = n*8 floats (o.xyz,tmin,d.xyz,tmax) */
@@ -948,6 +999,28 @@ static void closest_hit_program(const orc_scene* s, const orc_probe* probe, int 
     }
     prd->normal = N;
     prd->albedo = mk3(mat->color[0], mat->color[1], mat->color[2]);
+    {   /* deviceProgram.cu:512-523: hasTexture && texcoord → albedo REPLACED by tex2D at the interpolated texcoord */
+        const uint32_t mesh = s->tri_mesh[prim];
+        if (s->mesh_tex && s->mesh_tex[mesh] >= 0 && s->mesh_has_uv[mesh] && s->texcoord) {
+            /* optixGetTriangleBarycentrics: (weight of vertex 1, weight of vertex 2) — from the hit test's own weights */
+            wray r;
+            wray_init(&r, ray_o, ray_dir);
+            const f3 A = sub3(v0, r.o), B = sub3(v1, r.o), C = sub3(v2, r.o);
+            const f3 CxB = cross3(C, B), AxC = cross3(A, C), BxA = cross3(B, A);
+            const float Uw = dot3(r.d, CxB), Vw = dot3(r.d, AxC), Ww = dot3(r.d, BxA);
+            const float det = Uw + Vw + Ww;
+            const float bu = Vw / det, bv = Ww / det;
+            const uint32_t* ix = &s->idx[3 * (size_t)prim];
+            const float *c0 = &s->texcoord[2 * (size_t)ix[0]], *c1 = &s->texcoord[2 * (size_t)ix[1]], *c2 = &s->texcoord[2 * (size_t)ix[2]];
+            const float w0 = 1.f - bu - bv;
+            const float tcx = w0 * c0[0] + bu * c1[0] + bv * c2[0];
+            const float tcy = w0 * c0[1] + bu * c1[1] + bv * c2[1];
+            float tx[4];
+            const int tid = s->mesh_tex[mesh];
+            tex2d_wrap_linear(s->tex[tid].pixel, s->tex[tid].w, s->tex[tid].h, tcx, tcy, tx);
+            prd->albedo = mk3(tx[0], tx[1], tx[2]);
+        }
+    }
     if (prd->rayEta == 1.0f)
         outEta = orc_material_ior(mat);
     else

@@ -549,3 +549,38 @@ def test_foveated_sv4_three_launches(ptlib, orc_det):
 
 
 R_ACCUM, R_FRAME = 0, 1
+
+
+def test_textured_meshes(ptlib, orc_det):
+    """deviceProgram.cu:512-523 + createTextures (SimplePathtracer.cpp:603-654): albedo replaced by a wrap/bilinear
+    tex2D of an RGBA8 texture at the barycentric texcoord; a mesh with a texture id but no texcoords keeps its colour."""
+    import ctypes as C
+
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    m = scenes.textured_scene()
+    probe = scenes.sky_probe(256, 128).BuildCDF()
+    # the sampler itself
+    r = SampleRenderer(m)
+    rng = np.random.default_rng(21)
+    st = rng.uniform(-3, 3, (20000, 2)).astype(np.float32)
+    st[:8] = [[0, 0], [1, 1], [0.5, 0.5], [-0.25, 1.75], [1.0 / 128, 1.0 / 64], [0.999999, 0.000001], [-1, -1], [2, -3]]
+    g = r.evalTable(7, st, 4)
+    tex = m.textures[0].pixel
+    ref = np.zeros((len(st), 4), np.float32)
+    out = np.zeros(4, np.float32)
+    for i in range(len(st)):
+        orc_det.lib.orc_tex2d(tex.reshape(-1), tex.shape[1], tex.shape[0], float(st[i, 0]), float(st[i, 1]), out)
+        ref[i] = out
+    assert_bits_equal(g, ref, "tex2D wrap/bilinear")
+    assert 0.0 <= g.min() and g.max() <= 1.0
+    # whole render
+    w, h = 160, 100
+    cam = dict(eye=(3.0, 2.5, -4.5), lookat=(0.0, 0.6, 0.5), up=(0.0, 1.0, 0.0), fovY=45.0)
+    rr = _renderer(m, probe, cam, w, h)
+    gg = _gpu_render(rr, 3, subframes=2)
+    oo = _oracle_render(orc_det, m, probe, cam, w, h, 3, subframes=2, use_bvh=False)
+    _compare(gg, oo)
+    # the texture really shows up in the first-hit albedo buffer: many distinct albedos, not 3 material colours
+    alb = gg["albedo"][..., :3].reshape(-1, 3)
+    assert len(np.unique(alb.round(4), axis=0)) > 100

@@ -77,6 +77,7 @@ struct pt_ctx {
     size_t ev_used = 0;
     struct Span { size_t a, b; int cls; };
     std::vector<Span> spans;
+    bool span_timing = true; // per-kernel-class HIP-event timing (PT_TIMING=0 turns it off: ~2 events per launch less)
 };
 
 #define CK(call)                                                                                   \
@@ -138,6 +139,7 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
     pt_ctx* ctx = new pt_ctx();
     default_options(&ctx->opt);
     ctx->device = device;
+    if (const char* e = getenv("PT_TIMING")) ctx->span_timing = atoi(e) != 0;
     auto bail = [&](int code) { g_create_error = ctx->err; pt_destroy(ctx); return code; };
 #define CKC(call)                                                           \
     do {                                                                    \
@@ -562,10 +564,12 @@ struct SpanGuard {
     int cls;
     hipStream_t s;
     SpanGuard(pt_ctx* c, int cl, hipStream_t st = nullptr) : ctx(c), cls(cl), s(st ? st : c->stream) {
+        if (!ctx->span_timing) return;
         a = ctx->ev_used;
         hipEventRecord(next_event(ctx), s);
     }
     ~SpanGuard() {
+        if (!ctx->span_timing) return;
         size_t b = ctx->ev_used;
         hipEventRecord(next_event(ctx), s);
         ctx->spans.push_back({a, b, cls});

@@ -744,8 +744,8 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
         if (rc) return rc;
     }
     if (getenv("PT_DEBUG_COUNTS")) {
-        if (!ctx->dbg) CK(dalloc(&ctx->dbg, 8));
-        CK(hipMemset(ctx->dbg, 0, 64));
+        if (!ctx->dbg) CK(dalloc(&ctx->dbg, 16));
+        CK(hipMemset(ctx->dbg, 0, 128));
     }
     ctx->ev_used = 0;
     ctx->spans.clear();
@@ -773,9 +773,11 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     unsigned long long totals[2] = {0, 0};
     CK(hipMemcpy(totals, ctx->d_totals, sizeof(totals), hipMemcpyDeviceToHost));
     if (ctx->dbg) {
-        unsigned long long h[8];
-        CK(hipMemcpy(h, ctx->dbg, 64, hipMemcpyDeviceToHost));
+        unsigned long long h[16];
+        CK(hipMemcpy(h, ctx->dbg, 128, hipMemcpyDeviceToHost));
         fprintf(stderr, "[pt_render] traversal: node steps %llu, tri tests %llu, max steps of one ray %llu, max wave loop iterations %llu, mean %.1f\n", h[0], h[1], h[4], h[5], h[7] ? (double)h[6] / h[7] : 0.0);
+        fprintf(stderr, "[pt_render] per loop iteration: lanes holding a ray %.1f / 64, lanes executing the chosen step %.1f / 64, node-step iterations %.1f %%\n",
+                h[6] ? (double)h[8] / h[6] : 0.0, h[6] ? (double)h[9] / h[6] : 0.0, h[6] ? 100.0 * h[10] / h[6] : 0.0);
     }
     if (getenv("PT_DEBUG_COUNTS") && owned) { // per-bounce queue sizes of the last chunk of set 0
         const size_t CS = (size_t)PT_NSUB * PT_CSTRIDE;
@@ -1046,8 +1048,8 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     if (any_hit) CK(dalloc(&dOcc, n));
     unsigned long long* dDbg = nullptr;
     if (getenv("PT_DEBUG_COUNTS")) {
-        CK(dalloc(&dDbg, 8));
-        CK(hipMemset(dDbg, 0, 64));
+        CK(dalloc(&dDbg, 16));
+        CK(hipMemset(dDbg, 0, 128));
     }
     uint32_t* dWork = nullptr;
     CK(dalloc(&dWork, (size_t)iters));

@@ -53,6 +53,12 @@ struct Bvh8Dev {
 #define PT8_WAVES_PER_EU 5
 #endif
 
+#ifdef PT_DEBUG_STATS
+#define PT_STAT(x) x
+#else
+#define PT_STAT(x)
+#endif
+
 struct Trace8Args {
     PathState st;
     Bvh8Dev bvh;
@@ -96,12 +102,12 @@ k_trace8(Trace8Args a) {
     uint32_t g_base = 0, g_imask = 0, g_hits = 0; // current node group: hits in (slot ^ oct) bit positions
     uint32_t t_base = 0, t_mask = 0;             // current triangle group
     int sp = 0;
-    uint32_t slot = 0;
-    uint32_t c_nodes = 0, c_tris = 0, c_maxsp = 0, c_push = 0, c_ray = 0, c_raymax = 0, c_iters = 0;
+    uint32_t slot = 0, hint1 = 0, hint2 = 0;
+    PT_STAT(uint32_t c_nodes = 0; uint32_t c_tris = 0; uint32_t c_maxsp = 0; uint32_t c_push = 0; uint32_t c_ray = 0; uint32_t c_raymax = 0; uint32_t c_iters = 0;
+            uint32_t c_act = 0; uint32_t c_exec = 0; uint32_t c_nodeit = 0;)
 
     auto push = [&](uint32_t v0, uint32_t v1) {
-        ++c_push;
-        if ((uint32_t)sp + 1 > c_maxsp) c_maxsp = sp + 1;
+        PT_STAT(++c_push; if ((uint32_t)sp + 1 > c_maxsp) c_maxsp = sp + 1;)
         if (sp < PT8_LDS_DEPTH) {
             s_stack[(sp * 2) * 64 + lane] = v0;
             s_stack[(sp * 2 + 1) * 64 + lane] = v1;
@@ -140,8 +146,7 @@ k_trace8(Trace8Args a) {
             a.st.hit[slot] = make_float2(best, __int_as_float(bprim));
         }
         active = false;
-        if (c_ray > c_raymax) c_raymax = c_ray;
-        c_ray = 0;
+        PT_STAT(if (c_ray > c_raymax) c_raymax = c_ray; c_ray = 0;)
     };
 
     for (;;) {
@@ -166,9 +171,9 @@ k_trace8(Trace8Args a) {
                 const uint32_t gi = first + rank;
                 if (MODE == TR_UNIFIED) {
                     shadow_lane = gi >= n1;
-                    slot = shadow_lane ? qreader_get(a.queue2, s_prefix2, gi - n1) : qreader_get(a.queue, s_prefix, gi);
+                    slot = shadow_lane ? qreader_get_hint(a.queue2, s_prefix2, gi - n1, hint2) : qreader_get_hint(a.queue, s_prefix, gi, hint1);
                 } else {
-                    slot = qreader_get(a.queue, s_prefix, gi);
+                    slot = qreader_get_hint(a.queue, s_prefix, gi, hint1);
                 }
                 const float4 o4 = a.st.rayO[slot];
                 float4 d4;
@@ -181,11 +186,20 @@ k_trace8(Trace8Args a) {
                     tmin = o4.w;
                     tmax = d4.w;
                 }
-                r = ray_setup(mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z));
-                // The box test below evaluates q*(step*idir) + (origin-o)*idir: with idir = ±inf (a direction component that
-                // is exactly ±0) that is inf-inf = NaN, the axis constraint is dropped and the ray visits every node of a
-                // whole slab (measured: 0.05 % of the shadow rays — probe column 0 — cost milliseconds of tail).  A huge
-                // finite reciprocal keeps the slab test meaningful and conservative.
+                // Refilling a lane runs with few lanes active, so it is kept short: the reciprocal direction only feeds the
+                // conservative box tests and uses v_rcp_f32 (1 ulp); dn = d / dot(d,d) feeds t and keeps the IEEE division.
+                // With idir = ±inf (a direction component that is exactly ±0) the box test's q*(step*idir) + (origin-o)*idir
+                // is inf-inf = NaN, the axis constraint is dropped and the ray visits every node of a whole slab (measured:
+                // 0.05 % of the shadow rays — probe column 0 — cost milliseconds of tail): a huge finite reciprocal keeps the
+                // slab test meaningful and conservative.
+                r.o = mk3(o4.x, o4.y, o4.z);
+                r.d = mk3(d4.x, d4.y, d4.z);
+#ifdef PT8_IEEE_IDIR
+                r.idir = mk3(1.0f / d4.x, 1.0f / d4.y, 1.0f / d4.z);
+#else
+                r.idir = mk3(__builtin_amdgcn_rcpf(d4.x), __builtin_amdgcn_rcpf(d4.y), __builtin_amdgcn_rcpf(d4.z));
+#endif
+                r.dn = scl3(r.d, 1.0f / dot3(r.d, r.d));
                 if (!(fabsf(d4.x) > 1e-30f)) r.idir.x = copysignf(1e30f, d4.x);
                 if (!(fabsf(d4.y) > 1e-30f)) r.idir.y = copysignf(1e30f, d4.y);
                 if (!(fabsf(d4.z) > 1e-30f)) r.idir.z = copysignf(1e30f, d4.z);
@@ -230,8 +244,7 @@ k_trace8(Trace8Args a) {
                         const uint32_t cs = bit ^ oct;
                         const uint32_t idx = g_base + (uint32_t)__popc(g_imask & ((1u << cs) - 1u));
                         if (g_hits != 0u) push(g_base, g_imask | (g_hits << 8));
-                        ++c_nodes;
-                        ++c_ray;
+                        PT_STAT(++c_nodes; ++c_ray;)
                         const Node8* nd = &a.bvh.nodes[idx];
                         const float4 n0 = nd->n0, n1 = nd->n1, n2 = nd->n2, n3 = nd->n3, n4 = nd->n4;
                         const uint32_t em = __float_as_uint(n0.w);
@@ -290,8 +303,7 @@ k_trace8(Trace8Args a) {
                 if (want_tri) {
                     const uint32_t bit = (uint32_t)__ffs((int)t_mask) - 1u;
                     t_mask &= t_mask - 1u;
-                    ++c_tris;
-                    ++c_ray;
+                    PT_STAT(++c_tris; ++c_ray;)
                     const LeafTri* tp = &a.bvh.tris[t_base + bit];
                     const float4 ta = tp->t0, tb = tp->t1, tc = tp->t2;
                     float t, det;
@@ -310,19 +322,29 @@ k_trace8(Trace8Args a) {
                     }
                 }
             }
-            ++c_iters;
+            PT_STAT(++c_iters; if (a.dbg && lane == 0) {
+                const bool node_step = __popcll(m_node) >= PT8_TRI_BIAS * __popcll(m_tri);
+                c_act += (uint32_t)__popcll(m_node | m_tri);
+                c_exec += (uint32_t)__popcll(node_step ? m_node : m_tri);
+                c_nodeit += node_step ? 1u : 0u;
+            })
             act = __ballot(active);
         } while ((uint32_t)__popcll(act) >= thresh);
     }
-    if (a.dbg) {
+    PT_STAT(if (a.dbg) {
         atomicAdd(&a.dbg[0], (unsigned long long)c_nodes);
         atomicAdd(&a.dbg[1], (unsigned long long)c_tris);
         atomicMax(&a.dbg[2], (unsigned long long)c_maxsp);
         atomicAdd(&a.dbg[3], (unsigned long long)c_push);
         atomicMax(&a.dbg[4], (unsigned long long)c_raymax);
         atomicMax(&a.dbg[5], (unsigned long long)c_iters);
-        if (lane == 0) atomicAdd(&a.dbg[6], (unsigned long long)c_iters);
-        if (lane == 0) atomicAdd(&a.dbg[7], 1ull);
-    }
+        if (lane == 0) {
+            atomicAdd(&a.dbg[6], (unsigned long long)c_iters);
+            atomicAdd(&a.dbg[7], 1ull);
+            atomicAdd(&a.dbg[8], (unsigned long long)c_act);
+            atomicAdd(&a.dbg[9], (unsigned long long)c_exec);
+            atomicAdd(&a.dbg[10], (unsigned long long)c_nodeit);
+        }
+    })
 }
 #endif // PT_BVH8_NODE_ONLY

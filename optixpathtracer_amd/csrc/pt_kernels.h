@@ -86,6 +86,22 @@ PT_DEV uint32_t qreader_init(const QView& q, uint32_t* s_prefix) {
     __syncthreads();
     return s_prefix[PT_NSUB];
 }
+// same, trying the sub-queue of the lane's previous lookup first (consecutive work indices mostly share it)
+PT_DEV uint32_t qreader_get_hint(const QView& q, const uint32_t* s_prefix, uint32_t i, uint32_t& hint) {
+    if (q.base == nullptr) return i;
+    uint32_t lo = hint;
+    if (!(s_prefix[lo] <= i && i < s_prefix[lo + 1])) {
+        lo = 0;
+        uint32_t hi = PT_NSUB;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_prefix[mid] <= i) lo = mid; else hi = mid;
+        }
+        hint = lo;
+    }
+    return q.base[(size_t)lo * q.sub_cap + (i - s_prefix[lo])];
+}
 PT_DEV uint32_t qreader_get(const QView& q, const uint32_t* s_prefix, uint32_t i) {
     if (q.base == nullptr) return i;
     uint32_t lo = 0, hi = PT_NSUB; // find lo with s_prefix[lo] <= i < s_prefix[lo+1]

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT2_WAV
     int32_t bprim = -1, node = 0;
     int sp = 0;
     uint32_t slot = 0;
-    uint32_t c_nodes = 0, c_tris = 0, c_maxsp = 0, c_push = 0;
+    uint32_t c_nodes = 0, c_tris = 0, c_maxsp = 0, c_push = 0; // step counters, reported only when a.dbg is set (pt_trace + PT_DEBUG_COUNTS)
 
     auto push = [&](uint32_t v) {
         ++c_push;

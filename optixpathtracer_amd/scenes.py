@@ -380,6 +380,13 @@ class ProbeData:  # Probe.h:8-88
             self.pdfValuesX, self.cdfValuesX, self.pdfValuesY, self.cdfValuesY = builder(self.data, self.width, self.height)
         else:
             d = self.data.astype(np.float32)
+            with np.errstate(divide="ignore", invalid="ignore"):  # an all-black row gives 1/0 and NaN entries, like Probe.h:53
+                return self._build_numpy(d)
+        self.valid = True
+        return self
+
+    def _build_numpy(self, d):
+        if True:  # (kept as one block: the arithmetic order below mirrors Probe.h line by line)
             lum = (d[..., 0] * np.float32(0.3) + d[..., 1] * np.float32(0.6)) + d[..., 2] * np.float32(0.1)
             cx = np.cumsum(lum, axis=1, dtype=np.float32)
             tot = cx[:, -1].copy()

@@ -584,3 +584,33 @@ def test_textured_meshes(ptlib, orc_det):
     # the texture really shows up in the first-hit albedo buffer: many distinct albedos, not 3 material colours
     alb = gg["albedo"][..., :3].reshape(-1, 3)
     assert len(np.unique(alb.round(4), axis=0)) > 100
+
+
+def test_fullsize_c5_progressive_rows(ptlib, orc_det):
+    """C5 at full size: 1 M triangles, 1920x1080, 12 subframes x 4 spp of progressive accumulation; five rows of the
+    final accum_buffer are re-rendered by the checker through all 12 subframes and must match bit for bit."""
+    import ctypes as C
+
+    from oracle import orc as orc_mod
+
+    m = scenes.voxel_terrain()
+    probe = scenes.sky_probe(2048, 1024).BuildCDF()
+    w, h, nsub = 1920, 1080, 12
+    r = _renderer(m, probe, scenes.TERRAIN_CAMERA, w, h)
+    g = _gpu_render(r, 4, subframes=nsub)
+    sc = orc_det.make_scene(m, True)
+    pr = orc_det.make_probe(probe)
+    U, V, W = scenes.uvw_frame(**scenes.TERRAIN_CAMERA, aspect=w / h)
+    rows = np.array([0, 271, 540, 803, 1079], np.int32)
+    accum = np.zeros((h, w, 4), np.float32)
+    orc_det.lib.orc_render_rows.argtypes = [C.c_void_p, C.POINTER(orc_mod.Probe), C.POINTER(orc_mod.Params), orc_mod.f32p, orc_mod.i32p, C.c_int, C.c_int]
+    for sf in range(nsub):
+        prm = orc_mod.Params()
+        prm.width, prm.height, prm.subframe_index, prm.samples_per_launch, prm.max_depth, prm.bsdf_mode = w, h, sf, 4, 8, 0
+        for dst, src in ((prm.eye, scenes.TERRAIN_CAMERA["eye"]), (prm.U, U), (prm.V, V), (prm.W, W)):
+            for k in range(3):
+                dst[k] = float(src[k])
+        orc_det.lib.orc_render_rows(sc.h, C.byref(pr), C.byref(prm), accum.reshape(-1), rows, len(rows), 8)
+    for y in rows:
+        assert_bits_equal(g["accum"][y], accum[y], f"row {y} after {nsub} subframes")
+    assert (g["accum"][..., :3] <= 50.0 + 1e-3).all()  # subframe 0 is unclamped (sun radiance 50), later ones clamp to 10

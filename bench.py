@@ -202,6 +202,18 @@ def main():
                 traffic = int(num / den) if den else None
             except Exception:
                 traffic = None
+        # what actually bounds the path (committed PMC pass, profiles/r1_04_pmc_valu.md): VALU issue slots used by the
+        # frame = VALU wave-instructions x 4 SIMD cycles / (SIMDs x clock x frame time), and the lane utilisation
+        valu = None
+        vj = os.path.join(ROOT, "profiles", "r1_pmc_valu.json")
+        if traffic is not None and os.path.exists(vj):
+            try:
+                P = json.load(open(vj))
+                frame_s = dt_max / args.steps
+                valu = {"issue_frac": round(P["valu_insts_per_frame"] * P["simd_cycles_per_valu_inst"] / (P["simds"] * P["clock_ghz"] * 1e9 * frame_s), 3),
+                        "lane_util_traversal": P["valu_lane_util"]["k_trace8<3>"], "source": P["source"]}
+            except Exception:
+                valu = None
         kname = {(1, 0): "k_trace2", (1, 1): "k_trace", (0, 1): "k_trace"}.get((args.bvh_kind, args.trace_kernel), "k_trace8<3>/<0>")
         out = {
             "metric": "Mrays/s (and ms/frame) at 1080p 4spp depth8; 1/2/4/8 MI355X scaling",
@@ -212,7 +224,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": ("strong" if (world == 1 or args.scaling == "strong") else "weak"),
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -228,7 +240,7 @@ def main():
             "roofline": {
                 "kernel": kname + " (BVH traversal: closest-hit + shadow rays)", "bound": "hbm", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes),
+                "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes), "valu": valu,
             },
         }
         if not args.no_cpu_baseline and world == 1:

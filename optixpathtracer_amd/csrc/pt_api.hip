@@ -104,6 +104,27 @@ static void dfree(T*& p) {
     p = nullptr;
 }
 
+// frees temporaries of the query entry points on every exit path
+struct DevScope {
+    std::vector<void*> ptrs;
+    std::vector<hipEvent_t> events;
+    template <typename T>
+    hipError_t alloc(T** p, size_t n) {
+        hipError_t e = dalloc(p, n);
+        if (e == hipSuccess) ptrs.push_back((void*)*p);
+        return e;
+    }
+    hipError_t event(hipEvent_t* ev) {
+        hipError_t e = hipEventCreate(ev);
+        if (e == hipSuccess) events.push_back(*ev);
+        return e;
+    }
+    ~DevScope() {
+        for (void* p : ptrs) hipFree(p);
+        for (hipEvent_t e : events) hipEventDestroy(e);
+    }
+};
+
 extern "C" const char* pt_version(void) { return "ptamd 0.1 (gfx950 wavefront path tracer)"; }
 
 extern "C" const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -149,6 +170,7 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
             return bail(PT_ERR_HIP);                                        \
         }                                                                   \
     } while (0)
+    DevScope tmp;
     CKC(hipSetDevice(device));
     CKC(hipStreamCreate(&ctx->stream));
     // flatten like buildAccel (SimplePathtracer.cpp:481-489) — one global vertex/index space
@@ -196,12 +218,11 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
                 vb2 += md.num_vertices;
             }
             float* d_tc = nullptr;
-            CKC(dalloc(&d_tc, 2 * nv));
+            CKC(tmp.alloc(&d_tc, 2 * nv));
             CKC(hipMemcpy(d_tc, tc.data(), sizeof(float) * 2 * nv, hipMemcpyHostToDevice));
             CKC(dalloc(&ctx->d_uvs, nt));
             hipLaunchKernelGGL(k_emit_uvs, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, d_tc, ctx->d_idx, (uint32_t)nt, ctx->d_uvs);
             CKC(hipStreamSynchronize(ctx->stream));
-            dfree(d_tc);
             CKC(dalloc(&ctx->d_mesh_tex, mesh_tex.size()));
             CKC(hipMemcpy(ctx->d_mesh_tex, mesh_tex.data(), sizeof(int32_t) * mesh_tex.size(), hipMemcpyHostToDevice));
         }
@@ -221,8 +242,8 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
         }
     }
     hipEvent_t e0, e1;
-    CKC(hipEventCreate(&e0));
-    CKC(hipEventCreate(&e1));
+    CKC(tmp.event(&e0));
+    CKC(tmp.event(&e1));
     CKC(hipEventRecord(e0, ctx->stream));
     CKC(pt_bvh_build(ctx->d_verts, ctx->d_idx, (uint32_t)nt, ctx->stream, &ctx->bvh));
     CKC(hipEventRecord(e1, ctx->stream));
@@ -230,8 +251,6 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     ctx->bvh_build_ms = ms;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     CKC(dalloc(&ctx->d_totals, 2));
     {
         hipDeviceProp_t prop;
@@ -416,19 +435,19 @@ extern "C" int pt_set_probe_image(pt_ctx* ctx, const float* data, int w, int h) 
     CK(hipStreamSynchronize(ctx->stream));
     dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
     const size_t n = (size_t)w * h;
+    DevScope tmp;
     float* rowTotal = nullptr;
     CK(dalloc(&ctx->d_probe_data, n));
     CK(dalloc(&ctx->d_pdfX, n));
     CK(dalloc(&ctx->d_cdfX, n));
     CK(dalloc(&ctx->d_pdfY, (size_t)h));
     CK(dalloc(&ctx->d_cdfY, (size_t)h));
-    CK(dalloc(&rowTotal, (size_t)h));
+    CK(tmp.alloc(&rowTotal, (size_t)h));
     CK(hipMemcpy(ctx->d_probe_data, data, sizeof(float4) * n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_cdf_rows, dim3((h + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_probe_data, w, h, ctx->d_pdfX, ctx->d_cdfX, rowTotal);
     hipLaunchKernelGGL(k_cdf_marginal, dim3(1), dim3(64), 0, ctx->stream, rowTotal, h, ctx->d_pdfY, ctx->d_cdfY);
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipGetLastError());
-    dfree(rowTotal);
     return finish_probe(ctx, w, h);
 }
 
@@ -1023,10 +1042,18 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     CK(hipSetDevice(ctx->device));
     if (iters < 1) iters = 1;
     // temporary state just for the query
+    DevScope tmp;
     float4 *dO = nullptr, *dD = nullptr;
     float2* dHit = nullptr;
-    uint32_t* dCount = nullptr;
-    CK(dalloc(&dO, n)); CK(dalloc(&dD, n)); CK(dalloc(&dHit, n)); CK(dalloc(&dCount, 1));
+    uint32_t *dCount = nullptr, *dWork = nullptr;
+    int32_t* dOcc = nullptr;
+    unsigned long long* dDbg = nullptr;
+    hipEvent_t e0, e1;
+    CK(tmp.alloc(&dO, n)); CK(tmp.alloc(&dD, n)); CK(tmp.alloc(&dHit, n)); CK(tmp.alloc(&dCount, 1));
+    CK(tmp.alloc(&dWork, (size_t)iters));
+    if (any_hit) CK(tmp.alloc(&dOcc, n));
+    CK(tmp.event(&e0));
+    CK(tmp.event(&e1));
     std::vector<float4> hO(n), hD(n);
     for (uint32_t i = 0; i < n; ++i) {
         const float* r = &rays[8 * (size_t)i];
@@ -1041,18 +1068,10 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     st.rayO = dO;
     st.rayD = dD;
     st.hit = dHit;
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    int32_t* dOcc = nullptr;
-    if (any_hit) CK(dalloc(&dOcc, n));
-    unsigned long long* dDbg = nullptr;
     if (getenv("PT_DEBUG_COUNTS")) {
-        CK(dalloc(&dDbg, 16));
+        CK(tmp.alloc(&dDbg, 16));
         CK(hipMemset(dDbg, 0, 128));
     }
-    uint32_t* dWork = nullptr;
-    CK(dalloc(&dWork, (size_t)iters));
     CK(hipMemsetAsync(dWork, 0, sizeof(uint32_t) * iters, ctx->stream));
     CK(hipEventRecord(e0, ctx->stream));
     for (int it = 0; it < iters; ++it) {
@@ -1083,10 +1102,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
         fprintf(stderr, "[pt_trace] rays %u x %d: node steps/ray %.2f, tri tests/ray %.2f, pushes/ray %.2f, max stack %llu, max steps of one ray %llu, "
                 "wave loop iterations max %llu mean %.1f (waves %llu)\n", n, iters,
                 (double)h[0] / n / iters, (double)h[1] / n / iters, (double)h[3] / n / iters, h[2], h[4], h[5], h[7] ? (double)h[6] / h[7] : 0.0, h[7] / iters);
-        dfree(dDbg);
     }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     if (any_hit && ctx->opt.trace_kernel == 1) {
         CK(hipMemcpy(prim_out, dOcc, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     } else if (any_hit) {
@@ -1101,7 +1117,6 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
             memcpy(&prim_out[i], &hh[i].y, 4);
         }
     }
-    dfree(dO); dfree(dD); dfree(dHit); dfree(dCount); dfree(dOcc); dfree(dWork);
     return PT_OK;
 }
 
@@ -1114,9 +1129,10 @@ extern "C" int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material
     if ((which == 2 || which == 3) && !ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: no probe set");
     if (which == 7 && !ctx->tex0.pixel) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: the scene has no texture");
     CK(hipSetDevice(ctx->device));
+    DevScope tmp;
     float *dIn = nullptr, *dOut = nullptr;
-    CK(dalloc(&dIn, (size_t)n * in_w[which]));
-    CK(dalloc(&dOut, (size_t)n * out_w[which]));
+    CK(tmp.alloc(&dIn, (size_t)n * in_w[which]));
+    CK(tmp.alloc(&dOut, (size_t)n * out_w[which]));
     CK(hipMemcpy(dIn, in, sizeof(float) * (size_t)n * in_w[which], hipMemcpyHostToDevice));
     const dim3 g((n + 127) / 128), b(128);
     pt_material mat{};
@@ -1140,7 +1156,5 @@ extern "C" int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipGetLastError());
     CK(hipMemcpy(out, dOut, sizeof(float) * (size_t)n * out_w[which], hipMemcpyDeviceToHost));
-    dfree(dIn);
-    dfree(dOut);
     return PT_OK;
 }

@@ -220,8 +220,13 @@ PT_DEV void queue_push(bool pred, uint32_t value, const QView& q) {
     if (pred) queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
 
+#ifdef PT_SHADE_WAVES
+#define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, PT_SHADE_WAVES)))
+#else
+#define PT_SHADE_ATTR
+#endif
 template <int MODE, bool CATCHER>
-__global__ void __launch_bounds__(256) k_shade(PathState st, ShadeParams sp) {
+__global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, ShadeParams sp) {
     __shared__ uint32_t s_prefix[PT_NSUB + 1];
     const uint32_t n = qreader_init(sp.queue, s_prefix);
     const uint32_t nround = (n + 63u) & ~63u; // whole waves stay in the loop so ballots see every lane

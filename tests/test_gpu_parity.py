@@ -267,6 +267,72 @@ def test_trace_terrain_vs_oracle(ptlib, orc_det):
     assert_bits_equal(t2, to2, "closest-hit t (surface origins)")
 
 
+def _soup_model(rng):
+    """Triangle soup with the cases a regular scene never has: sizes over five decades, zero-area and duplicated
+    triangles (ties → lowest primitive index), coplanar overlaps, scene-spanning and far-away triangles."""
+    def tris(n, lo, hi, size):
+        c = rng.uniform(lo, hi, (n, 1, 3))
+        return (c + rng.standard_normal((n, 3, 3)) * size).astype(np.float32)
+
+    parts = [tris(3000, -100, 100, np.exp(rng.uniform(np.log(1e-3), np.log(50.0), (3000, 1, 1))))]
+    deg = tris(200, -100, 100, 5.0)
+    deg[:100, 2] = deg[:100, 1]                      # two equal vertices
+    deg[100:, 2] = 0.5 * (deg[100:, 0] + deg[100:, 1])  # collinear
+    parts.append(deg)
+    parts.append(parts[0][rng.integers(0, 3000, 100)])  # exact duplicates
+    parts.append(tris(100, -20, 20, 300.0))              # scene-spanning
+    parts.append(tris(50, 9000, 11000, 40.0))            # far away: stretches the root box and the 8-bit grids
+    cop = tris(60, -50, 50, 20.0)
+    cop[:, :, 1] = 7.0                                    # coplanar overlapping triangles in the plane y = 7
+    parts.append(cop)
+    tri = np.concatenate(parts).astype(np.float32)
+    perm = rng.permutation(len(tri))
+    tri = tri[perm]
+    mesh = scenes.TriangleMesh(vertex=tri.reshape(-1, 3).copy(), index=np.arange(3 * len(tri), dtype=np.uint32).reshape(-1, 3), material=scenes.Material())
+    return scenes.Model(meshes=[mesh]), tri
+
+
+def test_trace_triangle_soup_adversarial(ptlib, orc_det):
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    rng = np.random.default_rng(77)
+    m, tri = _soup_model(rng)
+    sc = orc_det.make_scene(m, use_bvh=False)
+    rays = [_random_rays(rng, 30000, -120, 120)]
+    ax = _random_rays(rng, 6000, -110, 110)                # axis-parallel rays: exact +0 / -0 direction components
+    k = rng.integers(0, 3, len(ax))
+    sgn = rng.choice([-1.0, 1.0], len(ax)).astype(np.float32)
+    ax[:, 4:7] = np.where(rng.random((len(ax), 3)) < 0.5, 0.0, -0.0).astype(np.float32)
+    ax[np.arange(len(ax)), 4 + k] = sgn
+    rays.append(ax)
+    pl = _random_rays(rng, 6000, -110, 110)                # one zero component, in the plane of the coplanar group
+    pl[:, 1] = 7.0
+    pl[:, 5] = 0.0
+    rays.append(pl)
+    sc_ = _random_rays(rng, 6000, -110, 110)               # unnormalised directions and finite [tmin, tmax] windows
+    sc_[:, 4:7] *= np.exp(rng.uniform(np.log(1e-3), np.log(1e3), (len(sc_), 1))).astype(np.float32)
+    sc_[:, 3] = rng.uniform(0, 50, len(sc_)) / np.linalg.norm(sc_[:, 4:7], axis=1)
+    sc_[:, 7] = sc_[:, 3] + rng.uniform(0, 150, len(sc_)) / np.linalg.norm(sc_[:, 4:7], axis=1)
+    rays.append(sc_)
+    tg = tri[rng.integers(0, len(tri), 6000)]               # aimed at vertices / edge midpoints of the soup
+    targets = np.where(rng.random((len(tg), 1)) < 0.5, tg[:, 0], 0.5 * (tg[:, 0] + tg[:, 1]))
+    o = rng.uniform(-150, 150, (len(tg), 3)).astype(np.float32)
+    aimed = np.concatenate([o, np.full((len(o), 1), 1e-3, np.float32), (targets - o).astype(np.float32), np.full((len(o), 1), 1e16, np.float32)], 1)
+    rays.append(aimed)
+    rays = np.concatenate(rays).astype(np.float32)
+    to, po = orc_det.trace_closest(sc, rays)
+    occ_o = orc_det.trace_any(sc, rays)
+    assert (po >= 0).mean() > 0.3
+    for kind in (0, 1):
+        r = SampleRenderer(m)
+        r.setOptions(bvh_kind=kind)
+        (t, prim), _ = r.trace(rays)
+        assert np.array_equal(prim, po), f"bvh_kind {kind}: {(prim != po).sum()} primitive ids differ"
+        assert_bits_equal(t, to, f"closest-hit t, bvh_kind {kind}")
+        occ, _ = r.trace(rays, any_hit=True)
+        assert np.array_equal(occ, occ_o)
+
+
 # ---------------------------------------------------------------- whole renders
 def test_render_cornell_c1_lambert(ptlib, orc_det, small_probe):
     """BASELINE config 1: Cornell 256x256, 1 spp, depth 4, Lambert."""

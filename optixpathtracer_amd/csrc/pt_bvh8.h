@@ -7,12 +7,12 @@
 //
 // Node (80 B = 5 x 16 B):
 //   n0: origin.xyz (f32)                       | ex, ey, ez (biased exponents of the grid step), imask
-//   n1: child_base | tri_base | meta[0..3] | meta[4..7]     meta = tri offset (5 bits) | (tri count-1) << 5
+//   n1: child_base | tri_base | leafbits | 0      leafbits bit 3*s+k: slot s is a leaf child holding more than k triangles
 //   n2: qlo.x[8] (2 dwords) | qlo.y[8]   n3: qlo.z[8] | qhi.x[8]   n4: qhi.y[8] | qhi.z[8]
 // Child box s = origin + q * 2^(e-127) per axis, rounded outward at build from the padded float box, so
 // the box test stays conservative; empty slots hold an inverted box (qlo=255, qhi=0).  Internal children
 // are contiguous (child_base + rank of the slot among the set bits of imask), the triangles of all leaf
-// children are contiguous from tri_base.  Children sit in the slot whose octant (sign bits of
+// children are contiguous from tri_base in (slot, k) order, i.e. triangle (s,k) is tri_base + rank of bit 3*s+k in leafbits.  Children sit in the slot whose octant (sign bits of
 // centroid - node centre) best matches them (greedy assignment at build), so visiting hit slots in
 // increasing (slot XOR ray-octant) order is an approximate front-to-back order without sorting.
 // The triangle test is pt_bvh.h's tri_test, bit-identical to the CPU checker; closest hit + lowest
@@ -30,6 +30,7 @@ struct Node8 {
 #ifndef PT8_LEAF_MAX
 #define PT8_LEAF_MAX 3
 #endif
+static_assert(PT8_LEAF_MAX >= 1 && PT8_LEAF_MAX <= 3, "leafbits holds 3 bits per slot");
 
 struct Bvh8Dev {
     const Node8* nodes;
@@ -100,7 +101,7 @@ k_trace8(Trace8Args a) {
     int32_t bprim = -1;
     uint32_t oct = 0;                          // ray octant: bit set where the direction is negative
     uint32_t g_base = 0, g_imask = 0, g_hits = 0; // current node group: hits in (slot ^ oct) bit positions
-    uint32_t t_base = 0, t_mask = 0;             // current triangle group
+    uint32_t t_base = 0, t_mask = 0, t_bits = 0; // current triangle group: pending bits of the node's leafbits
     int sp = 0;
     uint32_t slot = 0, hint1 = 0, hint2 = 0;
     PT_STAT(uint32_t c_nodes = 0; uint32_t c_tris = 0; uint32_t c_maxsp = 0; uint32_t c_push = 0; uint32_t c_ray = 0; uint32_t c_raymax = 0; uint32_t c_iters = 0;
@@ -261,7 +262,6 @@ k_trace8(Trace8Args a) {
                         const uint32_t nearx[2] = {nx ? hix0 : lox0, nx ? hix1 : lox1}, farx[2] = {nx ? lox0 : hix0, nx ? lox1 : hix1};
                         const uint32_t neary[2] = {ny ? hiy0 : loy0, ny ? hiy1 : loy1}, fary[2] = {ny ? loy0 : hiy0, ny ? loy1 : hiy1};
                         const uint32_t nearz[2] = {nz ? hiz0 : loz0, nz ? hiz1 : loz1}, farz[2] = {nz ? loz0 : hiz0, nz ? loz1 : hiz1};
-                        const uint32_t meta[2] = {__float_as_uint(n1.z), __float_as_uint(n1.w)};
                         uint32_t hm = 0u; // hit mask in slot positions (branch-free: one compare + select + or per child)
                         // No extra widening of the far plane here: the 8-bit grid (rounded outward from boxes already padded
                         // by 2^-16 of the scene size) is orders of magnitude coarser than the rounding of these products.
@@ -281,21 +281,17 @@ k_trace8(Trace8Args a) {
                         hits = (oct & 1u) ? (((hits & 0x55u) << 1) | ((hits >> 1) & 0x55u)) : hits;
                         hits = (oct & 2u) ? (((hits & 0x33u) << 2) | ((hits >> 2) & 0x33u)) : hits;
                         hits = (oct & 4u) ? (((hits & 0x0fu) << 4) | ((hits >> 4) & 0x0fu)) : hits;
-                        // triangles of the leaf children that were hit
-                        uint32_t tm = 0u;
-                        const uint32_t lm = hm & ~imask;
-                        if (lm != 0u) {
-#pragma unroll
-                            for (int s = 0; s < 8; ++s) {
-                                const uint32_t m = (meta[s >> 2] >> (8 * (s & 3))) & 0xffu;
-                                const uint32_t bits = ((2u << (m >> 5)) - 1u) << (m & 31u);
-                                tm |= (lm & (1u << s)) ? bits : 0u;
-                            }
-                        }
+                        // triangles of the leaf children that were hit: every hit bit s → bits 3s..3s+2, masked by the node's leafbits
+                        const uint32_t leafbits = __float_as_uint(n1.z);
+                        uint32_t sp3 = (hm | (hm << 8)) & 0x00F00Fu;
+                        sp3 = (sp3 | (sp3 << 4)) & 0x0C30C3u;
+                        sp3 = (sp3 | (sp3 << 2)) & 0x249249u;
+                        const uint32_t tm = (sp3 * 7u) & leafbits;
                         g_base = __float_as_uint(n1.x);
                         g_imask = imask;
                         g_hits = hits;
                         t_base = __float_as_uint(n1.y);
+                        t_bits = leafbits;
                         t_mask = tm;
                     }
                 }
@@ -304,7 +300,7 @@ k_trace8(Trace8Args a) {
                     const uint32_t bit = (uint32_t)__ffs((int)t_mask) - 1u;
                     t_mask &= t_mask - 1u;
                     PT_STAT(++c_tris; ++c_ray;)
-                    const LeafTri* tp = &a.bvh.tris[t_base + bit];
+                    const LeafTri* tp = &a.bvh.tris[t_base + (uint32_t)__popc(t_bits & ((1u << bit) - 1u))];
                     const float4 ta = tp->t0, tb = tp->t1, tc = tp->t2;
                     float t, det;
                     if (tri_test_det(r, mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), t, det)) {

@@ -7,6 +7,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
 
 #include <cstring>
 #include <rocprim/rocprim.hpp>
@@ -237,15 +240,100 @@ __global__ void k_counts_from_ranges(int n, const int* __restrict__ rfirst, cons
 
 // One thread per wide node: open the binary subtree (largest surface area first) until 8 children,
 // place children in octant-matching slots, quantise, emit the node, its leaf triangles and the next tasks.
+
+// ---- optimal collapse (Ylitie, Karras, Laine 2017, §3.2): for every binary node n and slot budget i = 1..7,
+// C(n,i) = least SAH cost of representing n's subtree with at most i slots of the parent wide node:
+//   C(n,1) = min(leaf: A_n * cnt * c_p (cnt <= PT8_LEAF_MAX),  internal: A_n * c_n + D(n,8))
+//   C(n,i) = min(D(n,i), C(n,i-1)),   D(n,j) = min_{0<k<j} C(left,k) + C(right,j-k)
+// dec[n][i-1] records the choice: i = 1: 0 leaf / 1 internal; i = 2..7: split k or 0 = "as for i-1"; dec[n][7] = split of D(n,8).
+__global__ void k_parents(int n, const int* __restrict__ left, const int* __restrict__ right, int root, int* __restrict__ parent) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    parent[left[i]] = i;
+    parent[right[i]] = i;
+    if (i == root) parent[i] = -1;
+}
+__device__ __forceinline__ float padded_area(const float* b, float pad) {
+    const float dx = b[3] - b[0] + 2.f * pad, dy = b[4] - b[1] + 2.f * pad, dz = b[5] - b[2] + 2.f * pad;
+    return dx * dy + dy * dz + dz * dx;
+}
+__global__ void k_collapse_cost(int n, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ parent,
+                                const int* __restrict__ cnt_of, const float* __restrict__ box, float pad, float cp,
+                                float* __restrict__ cost, uint8_t* __restrict__ dec, int* __restrict__ visits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cur = parent[n - 1 + i];
+    while (cur >= 0) {
+        if (atomicAdd(&visits[cur], 1) == 0) return; // the sibling subtree's thread finishes this node
+        __threadfence();
+        const int l = left[cur], r = right[cur];
+        float Cl[8], Cr[8];
+        const float al = padded_area(&box[(size_t)l * 6], pad) * cp, ar = padded_area(&box[(size_t)r * 6], pad) * cp;
+        for (int k = 1; k <= 7; ++k) {
+            Cl[k] = l >= n - 1 ? al : __builtin_nontemporal_load(&cost[(size_t)l * 7 + (k - 1)]);
+            Cr[k] = r >= n - 1 ? ar : __builtin_nontemporal_load(&cost[(size_t)r * 7 + (k - 1)]);
+        }
+        float dist[9];
+        int ks[9];
+        for (int j = 2; j <= 8; ++j) {
+            float best = INFINITY;
+            int bk = 1;
+            for (int k = 1; k < j; ++k) {
+                if (k > 7 || j - k > 7) continue;
+                const float c = Cl[k] + Cr[j - k];
+                if (c < best) { best = c; bk = k; }
+            }
+            dist[j] = best;
+            ks[j] = bk;
+        }
+        const float A = padded_area(&box[(size_t)cur * 6], pad);
+        const int cnt = cnt_of[cur];
+        const float c_leaf = cnt <= PT8_LEAF_MAX ? A * (float)cnt * cp : INFINITY;
+        const float c_int = A + dist[8];
+        float prev = fminf(c_leaf, c_int);
+        uint8_t* d = &dec[(size_t)cur * 8];
+        d[0] = c_leaf <= c_int ? 0 : 1;
+        cost[(size_t)cur * 7 + 0] = prev;
+        for (int b = 2; b <= 7; ++b) {
+            if (dist[b] < prev) { prev = dist[b]; d[b - 1] = (uint8_t)ks[b]; }
+            else d[b - 1] = 0;
+            cost[(size_t)cur * 7 + (b - 1)] = prev;
+        }
+        d[7] = (uint8_t)ks[8];
+        __threadfence();
+        cur = parent[cur];
+    }
+}
+
 __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* __restrict__ tout, uint32_t* __restrict__ counters /*0 next tasks,1 nodes,2 tris*/,
                             int n, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ cnt_of,
-                            const float* __restrict__ box, float pad,
+                            const float* __restrict__ box, float pad, const uint8_t* __restrict__ dec /* null: greedy by area */,
                             const LeafTri* __restrict__ tris_sorted, Node8* __restrict__ nodes, LeafTri* __restrict__ tris_out) {
     const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
     if (ti >= nin) return;
     const Task8 task = tin[ti];
     int ch[8];
-    int nch = 2;
+    bool internal[8];
+    int nch = 0;
+    if (dec) { // follow the optimal-collapse decisions: distribute the 8 slots down the binary tree
+        int sn[16], sb[16], sp = 0;
+        {
+            const int k = dec[(size_t)task.bnode * 8 + 7];
+            sn[sp] = right[task.bnode]; sb[sp++] = 8 - k;
+            sn[sp] = left[task.bnode]; sb[sp++] = k;
+        }
+        while (sp) {
+            const int x = sn[--sp];
+            int b = sb[sp];
+            if (x >= n - 1) { ch[nch] = x; internal[nch++] = false; continue; }
+            while (b > 1 && dec[(size_t)x * 8 + (b - 1)] == 0) --b;
+            if (b == 1) { ch[nch] = x; internal[nch++] = dec[(size_t)x * 8] != 0; continue; }
+            const int k = dec[(size_t)x * 8 + (b - 1)];
+            sn[sp] = right[x]; sb[sp++] = b - k;
+            sn[sp] = left[x]; sb[sp++] = k;
+        }
+    } else {
+    nch = 2;
     ch[0] = left[task.bnode];
     ch[1] = right[task.bnode];
     for (;;) {
@@ -265,6 +353,8 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
         const int c = ch[bestj];
         ch[bestj] = left[c];
         ch[nch++] = right[c];
+    }
+    for (int j = 0; j < nch; ++j) internal[j] = ch[j] < n - 1 && cnt_of[ch[j]] > PT8_LEAF_MAX;
     }
     // node box (padded)
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -305,7 +395,7 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
         if (j < 0) continue;
         const int c = ch[j];
         const int cnt = cnt_of[c];
-        if (c < n - 1 && cnt > PT8_LEAF_MAX) {
+        if (internal[j]) {
             imask |= 1u << s;
             ++nint;
         } else {
@@ -328,7 +418,7 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
         step[a] = __uint_as_float(eb[a] << 23);
     }
     uint32_t q[6][2] = {{0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
-    uint32_t meta[2] = {0u, 0u};
+    uint32_t leafbits = 0u;
     uint32_t toff = 0, irank = 0;
     for (int s = 0; s < 8; ++s) {
         const int j = child_in[s];
@@ -351,13 +441,13 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
             int ids[PT8_LEAF_MAX > 4 ? PT8_LEAF_MAX : 4];
             const int cnt = gather_leaves(c, n, left, right, ids, PT8_LEAF_MAX > 4 ? PT8_LEAF_MAX : 4);
             for (int k = 0; k < cnt; ++k) tris_out[tri_base + toff + k] = tris_sorted[ids[k]];
-            meta[s >> 2] |= ((toff & 31u) | ((uint32_t)(cnt - 1) << 5)) << (8 * (s & 3));
+            leafbits |= ((1u << cnt) - 1u) << (3 * s);
             toff += (uint32_t)cnt;
         }
     }
     Node8 nd;
     nd.n0 = make_float4(lo[0], lo[1], lo[2], __uint_as_float(eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24)));
-    nd.n1 = make_float4(__uint_as_float(child_base), __uint_as_float(tri_base), __uint_as_float(meta[0]), __uint_as_float(meta[1]));
+    nd.n1 = make_float4(__uint_as_float(child_base), __uint_as_float(tri_base), __uint_as_float(leafbits), __uint_as_float(0u));
     nd.n2 = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
     nd.n3 = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
     nd.n4 = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
@@ -441,7 +531,7 @@ __global__ void k_single_node8(int n, const float* __restrict__ bounds6, float p
     }
     Node8 nd;
     nd.n0 = make_float4(lo[0], lo[1], lo[2], __uint_as_float(eb[0] | (eb[1] << 8) | (eb[2] << 16)));
-    nd.n1 = make_float4(__uint_as_float(0u), __uint_as_float(0u), __uint_as_float(0u | ((uint32_t)(n - 1) << 5)), __uint_as_float(0u));
+    nd.n1 = make_float4(__uint_as_float(0u), __uint_as_float(0u), __uint_as_float((1u << n) - 1u), __uint_as_float(0u));
     const uint32_t qlo = 0xffffff00u, qhi = 0x000000ffu; // slot 0 = whole grid, others inverted
     nd.n2 = make_float4(__uint_as_float(qlo), __uint_as_float(0xffffffffu), __uint_as_float(qlo), __uint_as_float(0xffffffffu));
     nd.n3 = make_float4(__uint_as_float(qlo), __uint_as_float(0xffffffffu), __uint_as_float(qhi), __uint_as_float(0u));
@@ -472,12 +562,31 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
     HIPCHK(hipMalloc(&counters, sizeof(uint32_t) * 4));
     uint32_t hc[4] = {0u, 1u, 0u, 0u}; // node 0 = root is taken
     HIPCHK(hipMemcpyAsync(counters, hc, sizeof(hc), hipMemcpyHostToDevice, stream));
+    // which binary nodes become wide nodes / leaf slots: SAH-optimal collapse (default) or greedy opening of the
+    // largest child (PT_BVH_COLLAPSE=greedy)
+    uint8_t* dec = nullptr;
+    const char* collapse = getenv("PT_BVH_COLLAPSE");
+    if (!(collapse && strcmp(collapse, "greedy") == 0)) {
+        float cp = 0.3f; // cost of a triangle test relative to a wide-node step
+        if (const char* e = getenv("PT_BVH_CP")) cp = (float)atof(e);
+        int *parent = nullptr, *visits = nullptr;
+        float* cost = nullptr;
+        HIPCHK(hipMalloc(&parent, sizeof(int) * (size_t)(2 * n)));
+        HIPCHK(hipMalloc(&visits, sizeof(int) * (size_t)n));
+        HIPCHK(hipMalloc(&cost, sizeof(float) * 7 * (size_t)n));
+        HIPCHK(hipMalloc(&dec, 8 * (size_t)n));
+        HIPCHK(hipMemsetAsync(visits, 0, sizeof(int) * (size_t)n, stream));
+        hipLaunchKernelGGL(k_parents, dim3((n + 255) / 256), dim3(256), 0, stream, n, left, right, root, parent);
+        hipLaunchKernelGGL(k_collapse_cost, dim3((n + 255) / 256), dim3(256), 0, stream, n, left, right, parent, cnt, box, pad, cp, cost, dec, visits);
+        HIPCHK(hipStreamSynchronize(stream));
+        hipFree(parent); hipFree(visits); hipFree(cost);
+    }
     Task8 root_task{root, 0u};
     HIPCHK(hipMemcpyAsync(ta, &root_task, sizeof(root_task), hipMemcpyHostToDevice, stream));
     uint32_t nin = 1;
     int levels = 0;
     while (nin) {
-        hipLaunchKernelGGL(k_collapse8, dim3((nin + 63) / 64), dim3(64), 0, stream, ta, nin, tb, counters, n, left, right, cnt, box, pad,
+        hipLaunchKernelGGL(k_collapse8, dim3((nin + 63) / 64), dim3(64), 0, stream, ta, nin, tb, counters, n, left, right, cnt, box, pad, dec,
                            tris_sorted, nodes, tris8);
         HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -488,12 +597,38 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
         if (++levels > 128) return hipErrorUnknown;
     }
     HIPCHK(hipGetLastError());
+    if (getenv("PT_DEBUG_BVH")) { // slot occupancy of the wide tree
+        auto fbits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+        std::vector<Node8> h(hc[1]);
+        HIPCHK(hipMemcpy(h.data(), nodes, sizeof(Node8) * h.size(), hipMemcpyDeviceToHost));
+        unsigned long long fill[9] = {0}, leafsz[9] = {0}, nint = 0, nleaf = 0;
+        for (const Node8& nd : h) {
+            const uint32_t imask = fbits(nd.n0.w) >> 24;
+            const uint32_t qlo[2] = {fbits(nd.n2.x), fbits(nd.n2.y)}, qhi[2] = {fbits(nd.n3.z), fbits(nd.n3.w)};
+            const uint32_t leafbits = fbits(nd.n1.z);
+            int used = 0;
+            for (int s = 0; s < 8; ++s) {
+                const uint32_t lo = (qlo[s >> 2] >> (8 * (s & 3))) & 0xffu, hi = (qhi[s >> 2] >> (8 * (s & 3))) & 0xffu;
+                if (lo == 255u && hi == 0u) continue; // inverted = empty
+                ++used;
+                if (imask & (1u << s)) ++nint;
+                else { ++nleaf; ++leafsz[__builtin_popcount((leafbits >> (3 * s)) & 7u)]; }
+            }
+            ++fill[used];
+        }
+        fprintf(stderr, "[pt_bvh] wide nodes %u, levels %d, internal children %llu, leaf slots %llu; slots used per node:", hc[1], levels, nint, nleaf);
+        for (int k = 0; k <= 8; ++k) fprintf(stderr, " %d:%llu", k, fill[k]);
+        fprintf(stderr, "; triangles per leaf slot:");
+        for (int k = 1; k <= 8; ++k) if (leafsz[k]) fprintf(stderr, " %d:%llu", k, leafsz[k]);
+        fprintf(stderr, "\n");
+    }
     out->nodes8 = nodes;
     out->tris8 = tris8;
     out->num_nodes8 = hc[1];
     out->num_tris8 = hc[2];
     out->levels8 = levels;
     hipFree(ta); hipFree(tb); hipFree(counters);
+    if (dec) hipFree(dec);
     return hipSuccess;
 }
 

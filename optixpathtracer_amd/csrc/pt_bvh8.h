@@ -6,15 +6,17 @@
 // quantised child boxes needs 5 loads and a third of the tree depth.
 //
 // Node (80 B = 5 x 16 B):
-//   n0: origin.xyz (f32)                       | ex, ey, ez (biased exponents of the grid step), imask
-//   n1: child_base | tri_base | leafbits | 0      leafbits bit 3*s+k: slot s is a leaf child holding more than k triangles
+//   n0: origin.xyz (f32)                       | upper halves of the floats 2^ex, 2^ey (grid steps)
+//   n1: child_base | tri_base | leafbits | upper half of 2^ez, imask << 16
+//       leafbits bit 3*s+k: slot s is a leaf child holding more than k triangles
 //   n2: qlo.x[8] (2 dwords) | qlo.y[8]   n3: qlo.z[8] | qhi.x[8]   n4: qhi.y[8] | qhi.z[8]
 // Child box s = origin + q * 2^(e-127) per axis, rounded outward at build from the padded float box, so
 // the box test stays conservative; empty slots hold an inverted box (qlo=255, qhi=0).  Internal children
 // are contiguous (child_base + rank of the slot among the set bits of imask), the triangles of all leaf
 // children are contiguous from tri_base in (slot, k) order, i.e. triangle (s,k) is tri_base + rank of bit 3*s+k in leafbits.  Children sit in the slot whose octant (sign bits of
 // centroid - node centre) best matches them (greedy assignment at build), so visiting hit slots in
-// increasing (slot XOR ray-octant) order is an approximate front-to-back order without sorting.
+// increasing (slot XOR ray-octant) order is an approximate front-to-back order without sorting; the next slot in
+// that order is found by three mask-and-select steps (z half, y quarter, x slot on the side the ray enters first).
 // The triangle test is pt_bvh.h's tri_test, bit-identical to the CPU checker; closest hit + lowest
 // primitive tie-break make the result independent of the tree.
 #pragma once
@@ -44,14 +46,14 @@ struct Bvh8Dev {
 #define PT8_REFILL 24
 #endif
 #ifndef PT8_TRI_BIAS
-#define PT8_TRI_BIAS 3 // a triangle step runs when tri-waiting lanes * bias > node-waiting lanes
+#define PT8_TRI_BIAS 2 // a triangle step runs when tri-waiting lanes * bias > node-waiting lanes
 #endif
 #ifndef PT8_MIN_CHUNK
 #define PT8_MIN_CHUNK 64
 #endif
 #define PT8_CHUNK 512
 #ifndef PT8_WAVES_PER_EU
-#define PT8_WAVES_PER_EU 5
+#define PT8_WAVES_PER_EU 4
 #endif
 
 #ifdef PT_DEBUG_STATS
@@ -99,8 +101,8 @@ k_trace8(Trace8Args a) {
     r.o = r.d = r.idir = r.dn = mk3(0.f);
     float tmin = 0.f, tmax = 0.f, best = 0.f;
     int32_t bprim = -1;
-    uint32_t oct = 0;                          // ray octant: bit set where the direction is negative
-    uint32_t g_base = 0, g_imask = 0, g_hits = 0; // current node group: hits in (slot ^ oct) bit positions
+    uint32_t pm = 0;                           // near-side slot masks of the ray's octant: z half | y quarters << 8 | x slots << 16
+    uint32_t g_base = 0, g_imask = 0, g_hits = 0; // current node group: children still to visit (slot positions)
     uint32_t t_base = 0, t_mask = 0, t_bits = 0; // current triangle group: pending bits of the node's leafbits
     int sp = 0;
     uint32_t slot = 0, hint1 = 0, hint2 = 0;
@@ -204,15 +206,16 @@ k_trace8(Trace8Args a) {
                 if (!(fabsf(d4.x) > 1e-30f)) r.idir.x = copysignf(1e30f, d4.x);
                 if (!(fabsf(d4.y) > 1e-30f)) r.idir.y = copysignf(1e30f, d4.y);
                 if (!(fabsf(d4.z) > 1e-30f)) r.idir.z = copysignf(1e30f, d4.z);
-                // sign BITS (so that -0.0, whose reciprocal is -inf, picks the matching near/far planes)
-                oct = (__float_as_uint(d4.x) >> 31) | ((__float_as_uint(d4.y) >> 31) << 1) | ((__float_as_uint(d4.z) >> 31) << 2);
+                // sign BITS (so that -0.0 picks the same near/far planes as its -1e30 reciprocal)
+                pm = ((__float_as_uint(d4.z) >> 31) ? 0xF0u : 0x0Fu) | (((__float_as_uint(d4.y) >> 31) ? 0xCCu : 0x33u) << 8) |
+                     (((__float_as_uint(d4.x) >> 31) ? 0xAAu : 0x55u) << 16);
                 best = tmax;
                 bprim = (MODE == TR_CLOSEST || (MODE == TR_UNIFIED && !shadow_lane)) ? -1 : 0;
                 sp = 0;
                 // the root is node 0: a group whose only internal child is slot 0 of a virtual parent
                 g_base = 0;
                 g_imask = 1u;
-                g_hits = 1u << (0u ^ oct);
+                g_hits = 1u;
                 t_mask = 0;
                 active = true;
             }
@@ -239,48 +242,48 @@ k_trace8(Trace8Args a) {
                         }
                     }
                     if (active) {
-                        // next child of the group in (slot ^ oct) order
-                        const uint32_t bit = (uint32_t)__ffs((int)g_hits) - 1u;
-                        g_hits &= g_hits - 1u;
-                        const uint32_t cs = bit ^ oct;
-                        const uint32_t idx = g_base + (uint32_t)__popc(g_imask & ((1u << cs) - 1u));
+                        // next child of the group in (slot ^ octant) order
+                        uint32_t h = g_hits, t = h & pm;
+                        h = t ? t : h;
+                        t = h & (pm >> 8);
+                        h = t ? t : h;
+                        t = h & (pm >> 16);
+                        h = t ? t : h; // a single bit now
+                        g_hits ^= h;
+                        const uint32_t idx = g_base + (uint32_t)__popc(g_imask & (h - 1u));
                         if (g_hits != 0u) push(g_base, g_imask | (g_hits << 8));
                         PT_STAT(++c_nodes; ++c_ray;)
                         const Node8* nd = &a.bvh.nodes[idx];
                         const float4 n0 = nd->n0, n1 = nd->n1, n2 = nd->n2, n3 = nd->n3, n4 = nd->n4;
-                        const uint32_t em = __float_as_uint(n0.w);
-                        const float sx = __uint_as_float((em & 0xffu) << 23), sy = __uint_as_float(((em >> 8) & 0xffu) << 23),
-                                    sz = __uint_as_float(((em >> 16) & 0xffu) << 23);
-                        const uint32_t imask = em >> 24;
+                        const uint32_t e01 = __float_as_uint(n0.w), e2m = __float_as_uint(n1.w);
+                        const float sx = __uint_as_float(e01 << 16), sy = __uint_as_float(e01 & 0xffff0000u), sz = __uint_as_float(e2m << 16);
+                        const uint32_t imask = e2m >> 16;
                         const float ax = sx * r.idir.x, ay = sy * r.idir.y, az = sz * r.idir.z;
                         const float bx = (n0.x - r.o.x) * r.idir.x, by = (n0.y - r.o.y) * r.idir.y, bz = (n0.z - r.o.z) * r.idir.z;
                         // near/far planes per axis follow the direction sign
-                        const bool nx = (oct & 1u) != 0u, ny = (oct & 2u) != 0u, nz = (oct & 4u) != 0u;
+                        const bool nx = r.idir.x < 0.0f, ny = r.idir.y < 0.0f, nz = r.idir.z < 0.0f;
                         const uint32_t lox0 = __float_as_uint(n2.x), lox1 = __float_as_uint(n2.y), loy0 = __float_as_uint(n2.z), loy1 = __float_as_uint(n2.w);
                         const uint32_t loz0 = __float_as_uint(n3.x), loz1 = __float_as_uint(n3.y), hix0 = __float_as_uint(n3.z), hix1 = __float_as_uint(n3.w);
                         const uint32_t hiy0 = __float_as_uint(n4.x), hiy1 = __float_as_uint(n4.y), hiz0 = __float_as_uint(n4.z), hiz1 = __float_as_uint(n4.w);
                         const uint32_t nearx[2] = {nx ? hix0 : lox0, nx ? hix1 : lox1}, farx[2] = {nx ? lox0 : hix0, nx ? lox1 : hix1};
                         const uint32_t neary[2] = {ny ? hiy0 : loy0, ny ? hiy1 : loy1}, fary[2] = {ny ? loy0 : hiy0, ny ? loy1 : hiy1};
                         const uint32_t nearz[2] = {nz ? hiz0 : loz0, nz ? hiz1 : loz1}, farz[2] = {nz ? loz0 : hiz0, nz ? loz1 : hiz1};
-                        uint32_t hm = 0u; // hit mask in slot positions (branch-free: one compare + select + or per child)
                         // No extra widening of the far plane here: the 8-bit grid (rounded outward from boxes already padded
                         // by 2^-16 of the scene size) is orders of magnitude coarser than the rounding of these products.
                         // (Measured and rejected: 2-wide vectors → v_pk_fma_f32; the packing moves and VGPR pairs cost more.)
+                        uint32_t miss = 0u; // sign bits of tfar - tnear, slot 7 first (one subtract + one funnel shift per child)
 #pragma unroll
-                        for (int s = 0; s < 8; ++s) {
+                        for (int s = 7; s >= 0; --s) {
                             const int w = s >> 2, k = s & 3;
                             const float tnx = __builtin_fmaf(u8f(nearx[w], k), ax, bx), tfx = __builtin_fmaf(u8f(farx[w], k), ax, bx);
                             const float tny = __builtin_fmaf(u8f(neary[w], k), ay, by), tfy = __builtin_fmaf(u8f(fary[w], k), ay, by);
                             const float tnz = __builtin_fmaf(u8f(nearz[w], k), az, bz), tfz = __builtin_fmaf(u8f(farz[w], k), az, bz);
                             const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
                             const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best));
-                            hm |= (tn <= tf) ? (1u << s) : 0u;
+                            miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31u);
                         }
-                        // internal hits, moved to (slot ^ oct) bit positions: XOR of the index = conditional swaps of bit groups
-                        uint32_t hits = hm & imask;
-                        hits = (oct & 1u) ? (((hits & 0x55u) << 1) | ((hits >> 1) & 0x55u)) : hits;
-                        hits = (oct & 2u) ? (((hits & 0x33u) << 2) | ((hits >> 2) & 0x33u)) : hits;
-                        hits = (oct & 4u) ? (((hits & 0x0fu) << 4) | ((hits >> 4) & 0x0fu)) : hits;
+                        const uint32_t hm = miss ^ 0xffu; // hit mask in slot positions
+                        const uint32_t hits = hm & imask;
                         // triangles of the leaf children that were hit: every hit bit s → bits 3s..3s+2, masked by the node's leafbits
                         const uint32_t leafbits = __float_as_uint(n1.z);
                         uint32_t sp3 = (hm | (hm << 8)) & 0x00F00Fu;

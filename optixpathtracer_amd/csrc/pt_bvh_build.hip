@@ -446,8 +446,8 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
         }
     }
     Node8 nd;
-    nd.n0 = make_float4(lo[0], lo[1], lo[2], __uint_as_float(eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24)));
-    nd.n1 = make_float4(__uint_as_float(child_base), __uint_as_float(tri_base), __uint_as_float(leafbits), __uint_as_float(0u));
+    nd.n0 = make_float4(lo[0], lo[1], lo[2], __uint_as_float((eb[0] << 7) | (eb[1] << 23)));
+    nd.n1 = make_float4(__uint_as_float(child_base), __uint_as_float(tri_base), __uint_as_float(leafbits), __uint_as_float((eb[2] << 7) | (imask << 16)));
     nd.n2 = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
     nd.n3 = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
     nd.n4 = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
@@ -530,8 +530,8 @@ __global__ void k_single_node8(int n, const float* __restrict__ bounds6, float p
         eb[a] = (uint32_t)(e + 127);
     }
     Node8 nd;
-    nd.n0 = make_float4(lo[0], lo[1], lo[2], __uint_as_float(eb[0] | (eb[1] << 8) | (eb[2] << 16)));
-    nd.n1 = make_float4(__uint_as_float(0u), __uint_as_float(0u), __uint_as_float((1u << n) - 1u), __uint_as_float(0u));
+    nd.n0 = make_float4(lo[0], lo[1], lo[2], __uint_as_float((eb[0] << 7) | (eb[1] << 23)));
+    nd.n1 = make_float4(__uint_as_float(0u), __uint_as_float(0u), __uint_as_float((1u << n) - 1u), __uint_as_float(eb[2] << 7));
     const uint32_t qlo = 0xffffff00u, qhi = 0x000000ffu; // slot 0 = whole grid, others inverted
     nd.n2 = make_float4(__uint_as_float(qlo), __uint_as_float(0xffffffffu), __uint_as_float(qlo), __uint_as_float(0xffffffffu));
     nd.n3 = make_float4(__uint_as_float(qlo), __uint_as_float(0xffffffffu), __uint_as_float(qhi), __uint_as_float(0u));
@@ -603,7 +603,7 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
         HIPCHK(hipMemcpy(h.data(), nodes, sizeof(Node8) * h.size(), hipMemcpyDeviceToHost));
         unsigned long long fill[9] = {0}, leafsz[9] = {0}, nint = 0, nleaf = 0;
         for (const Node8& nd : h) {
-            const uint32_t imask = fbits(nd.n0.w) >> 24;
+            const uint32_t imask = fbits(nd.n1.w) >> 16;
             const uint32_t qlo[2] = {fbits(nd.n2.x), fbits(nd.n2.y)}, qhi[2] = {fbits(nd.n3.z), fbits(nd.n3.w)};
             const uint32_t leafbits = fbits(nd.n1.z);
             int used = 0;

@@ -4,7 +4,7 @@ set -e
 NAME=$1; DEFS=$2
 cd "$(dirname "$0")/../optixpathtracer_amd/csrc"
 mkdir -p ../variants
-FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wno-unused-result -Wno-unused-value $DEFS"
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -Wno-unused-result -Wno-unused-value $DEFS"
 /opt/rocm/bin/hipcc $FLAGS -c pt_api.hip -o /tmp/pt_api_$NAME.o &
 /opt/rocm/bin/hipcc $FLAGS -c pt_bvh_build.hip -o /tmp/pt_bvh_build_$NAME.o &
 wait

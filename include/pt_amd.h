@@ -90,7 +90,8 @@ enum pt_buffer {          /* LaunchParams.frame.* (LaunchParams.h:53-63) */
     PT_BUF_FRAME = 1,     /* uchar4 frame_buffer (make_color) */
     PT_BUF_COLOR = 2,     /* float4 color_buffer */
     PT_BUF_NORMAL = 3,    /* float4 normal_buffer */
-    PT_BUF_ALBEDO = 4     /* float4 albedo_buffer */
+    PT_BUF_ALBEDO = 4,    /* float4 albedo_buffer */
+    PT_BUF_DENOISED = 5   /* float4 denoisedBuffer (SimplePathtracer.h:149-150); allocated by the first pt_denoise */
 };
 
 typedef struct pt_stats {
@@ -205,6 +206,28 @@ void* pt_device_buffer(pt_ctx* ctx, int which);
 /* toneMap.cu:41-70 computeFinalPixelColors: rgba8 = clamp(sqrt(accum))*255.9 into the frame buffer
  * (the reference's disabled alternative epilogue, SimplePathtracer.cpp:105). */
 int pt_tonemap_sqrt(pt_ctx* ctx, uint32_t* host_rgba8 /* may be NULL */);
+
+/* The denoiser pass the reference wires up but leaves empty: OptiXDenoiser::{init,exec,finish} (OptixDenoiser.h:12-31,
+ * OptixDenoiser.cpp:15-42 — init() has no body) with DenoiseData{width,height,color,albedo,normal,output} set in
+ * resize() (SimplePathtracer.cpp:138-146) and the disabled calls "denoiser.exec(); computeFinalPixelColors(size,
+ * denoisedBuffer, result)" in render(target) (SimplePathtracer.cpp:104-105).  Here exec() is an edge-avoiding
+ * a-trous wavelet filter (Dammertz et al. 2010) guided by the first-hit normal and albedo AOVs the hot path already
+ * writes: `iterations` passes of a 5x5 B3-spline kernel with tap spacing 2^i; tap weight =
+ * k[dx]*k[dy] * exp(-|c_p-c_q|^2 / (sigma_color*2^-i)^2) * exp(-|n_p-n_q|^2 / (4^i * sigma_normal^2)) *
+ * exp(-|a_p-a_q|^2 / sigma_albedo^2); taps outside the image are skipped; alpha is carried through.
+ * input: PT_BUF_COLOR (this frame's radiance, what DenoiseData.color points at) or PT_BUF_ACCUM (the progressive
+ * average).  epilogue: 0 none, 1 computeFinalPixelColors (toneMap.cu:41-58, as in the disabled call), 2 make_color;
+ * 1 and 2 write the rgba8 frame buffer.  Works on the full-size buffers of this context (multi-GPU: after pt_unpack
+ * of the three inputs).  The reference has no behaviour to match here: the CPU checker defines the semantics. */
+typedef struct pt_denoise_params {
+    int32_t iterations;   /* 0..8; 0 copies the input */
+    float sigma_color;    /* > 0 */
+    float sigma_normal;   /* > 0 */
+    float sigma_albedo;   /* > 0 */
+    int32_t input;        /* PT_BUF_COLOR or PT_BUF_ACCUM */
+    int32_t epilogue;     /* 0, 1, 2 */
+} pt_denoise_params;
+int pt_denoise(pt_ctx* ctx, const pt_denoise_params* params, uint32_t* host_rgba8 /* may be NULL */, double* kernel_ms /* may be NULL */);
 
 /* Multi-GPU exchange helpers. pt_owned_pixels = number of pixels this rank renders (padded count is
  * the same on every rank: pt_owned_pixels_padded). pt_pack packs this rank's pixels of buffer `which`

@@ -15,8 +15,13 @@ EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_options", "pt_get_options", "pt_set_probe", "pt_build_cdf",
     "pt_resize", "pt_set_camera", "pt_uvw_frame", "pt_set_partition", "pt_render", "pt_download", "pt_upload_accum",
     "pt_device_buffer", "pt_tonemap_sqrt", "pt_owned_pixels", "pt_pack", "pt_unpack", "pt_get_stats", "pt_trace",
-    "pt_eval_table", "pt_version", "pt_set_probe_image", "pt_get_probe_cdf", "pt_render_regions",
+    "pt_eval_table", "pt_version", "pt_set_probe_image", "pt_get_probe_cdf", "pt_render_regions", "pt_denoise",
 ]
+
+
+class DenoiseParams(C.Structure):  # pt_denoise_params
+    _fields_ = [("iterations", C.c_int32), ("sigma_color", C.c_float), ("sigma_normal", C.c_float), ("sigma_albedo", C.c_float),
+                ("input", C.c_int32), ("epilogue", C.c_int32)]
 
 
 class Material(C.Structure):  # pt_material == Material.h:47-68
@@ -132,6 +137,7 @@ def load_library() -> C.CDLL:
     L.pt_device_buffer.restype = vp
     L.pt_device_buffer.argtypes = [vp, i]
     L.pt_tonemap_sqrt.argtypes = [vp, vp]
+    L.pt_denoise.argtypes = [vp, C.POINTER(DenoiseParams), vp, C.POINTER(C.c_double)]
     L.pt_owned_pixels.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.pt_pack.argtypes = [vp, i, vp]
     L.pt_unpack.argtypes = [vp, i, vp]

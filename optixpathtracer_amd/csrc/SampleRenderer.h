@@ -135,7 +135,13 @@ class SampleRenderer {
         if (!probe.valid) throw std::runtime_error("Probe Data is not valid"); // Probe.h:104-105
         ck(pt_set_probe(ctx, &probe.data[0].x, probe.pdfValuesX.data(), probe.cdfValuesX.data(), probe.pdfValuesY.data(), probe.cdfValuesY.data(), probe.width, probe.height));
     }
-    bool denoiserOn = false; // SimplePathtracer.h:63 — the reference's denoiser is a dead stub (OptixDenoiser.cpp:15-42)
+    // The pass the reference leaves disabled in render(target): "denoiser.exec(); computeFinalPixelColors(size, denoisedBuffer, result)"
+    // (SimplePathtracer.cpp:104-105).  Call after render(); h_pixels may be null.
+    void denoiseAndTonemap(uint32_t h_pixels[], int iterations = 5, float sigma_color = 1.0f, float sigma_normal = 0.25f, float sigma_albedo = 0.1f) {
+        pt_denoise_params p{iterations, sigma_color, sigma_normal, sigma_albedo, PT_BUF_COLOR, 1};
+        ck(pt_denoise(ctx, &p, h_pixels, nullptr));
+    }
+    bool denoiserOn = false; // SimplePathtracer.h:63: the flag exists in the reference but nothing reads it (OptixDenoiser.cpp:15-42 is empty)
     LaunchParams launchParams;
     pt_ctx* ctx = nullptr;
 

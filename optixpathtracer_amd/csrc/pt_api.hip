@@ -47,6 +47,7 @@ struct pt_ctx {
     int width = 0, height = 0;
     float4 *accum = nullptr, *color = nullptr, *normal = nullptr, *albedo = nullptr;
     uint32_t* frame = nullptr;
+    float4 *denoised = nullptr, *denoise_tmp = nullptr; // allocated by the first pt_denoise at the current size
     v3 eye{0, 0, 0}, U{1, 0, 0}, V{0, 1, 0}, W{0, 0, 1};
     // partition
     int rank = 0, world = 1, tile_w = 64, tile_h = 16;
@@ -282,6 +283,7 @@ static void free_path_state(pt_ctx* ctx) {
 }
 static void free_frame(pt_ctx* ctx) {
     dfree(ctx->accum); dfree(ctx->color); dfree(ctx->normal); dfree(ctx->albedo); dfree(ctx->frame);
+    dfree(ctx->denoised); dfree(ctx->denoise_tmp);
     dfree(ctx->d_pixels); dfree(ctx->d_all_pixels);
 }
 
@@ -931,6 +933,7 @@ static void* buffer_ptr(pt_ctx* ctx, int which, size_t* elem) {
         case PT_BUF_COLOR: *elem = 16; return ctx->color;
         case PT_BUF_NORMAL: *elem = 16; return ctx->normal;
         case PT_BUF_ALBEDO: *elem = 16; return ctx->albedo;
+        case PT_BUF_DENOISED: *elem = 16; return ctx->denoised;
     }
     *elem = 0;
     return nullptr;
@@ -969,6 +972,52 @@ extern "C" int pt_tonemap_sqrt(pt_ctx* ctx, uint32_t* host_rgba8) {
     hipLaunchKernelGGL(k_tonemap_sqrt, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->accum, ctx->frame, n);
     CK(hipStreamSynchronize(ctx->stream));
     if (host_rgba8) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)n);
+    return PT_OK;
+}
+
+// OptiXDenoiser::exec() + the computeFinalPixelColors call of render(target) (SimplePathtracer.cpp:104-105)
+extern "C" int pt_denoise(pt_ctx* ctx, const pt_denoise_params* prm, uint32_t* host_rgba8, double* kernel_ms) {
+    if (!ctx || !prm) return PT_ERR_INVALID;
+    if (ctx->width == 0) return PT_OK;
+    if (prm->iterations < 0 || prm->iterations > 8) return fail(ctx, PT_ERR_INVALID, "pt_denoise: iterations must be in [0,8]");
+    if (!(prm->sigma_color > 0.f) || !(prm->sigma_normal > 0.f) || !(prm->sigma_albedo > 0.f)) return fail(ctx, PT_ERR_INVALID, "pt_denoise: sigmas must be positive");
+    if (prm->input != PT_BUF_COLOR && prm->input != PT_BUF_ACCUM) return fail(ctx, PT_ERR_INVALID, "pt_denoise: input must be PT_BUF_COLOR or PT_BUF_ACCUM");
+    if (prm->epilogue < 0 || prm->epilogue > 2) return fail(ctx, PT_ERR_INVALID, "pt_denoise: unknown epilogue");
+    CK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->width * ctx->height;
+    if (!ctx->denoised) {
+        CK(dalloc(&ctx->denoised, n));
+        CK(dalloc(&ctx->denoise_tmp, n));
+    }
+    DevScope tmp;
+    hipEvent_t e0, e1;
+    CK(tmp.event(&e0));
+    CK(tmp.event(&e1));
+    const float4* src = prm->input == PT_BUF_COLOR ? ctx->color : ctx->accum;
+    CK(hipEventRecord(e0, ctx->stream));
+    if (prm->iterations == 0) CK(hipMemcpyAsync(ctx->denoised, src, sizeof(float4) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    // ping-pong so that the last pass lands in `denoised`
+    float4* bufs[2] = {ctx->denoised, ctx->denoise_tmp};
+    int cur = (prm->iterations & 1) ? 0 : 1;
+    const dim3 grid((ctx->width + 31) / 32, (ctx->height + 7) / 8), block(256);
+    for (int i = 0; i < prm->iterations; ++i) {
+        const float sc = prm->sigma_color / (float)(1 << i), sn = prm->sigma_normal * (float)(1 << i);
+        AtrousParams ap{ctx->width, ctx->height, 1 << i, 1.0f / (sc * sc), 1.0f / (sn * sn), 1.0f / (prm->sigma_albedo * prm->sigma_albedo)};
+        hipLaunchKernelGGL(k_atrous, grid, block, 0, ctx->stream, src, ctx->normal, ctx->albedo, bufs[cur], ap);
+        src = bufs[cur];
+        cur ^= 1;
+    }
+    if (prm->epilogue == 1)
+        hipLaunchKernelGGL(k_tonemap_sqrt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->denoised, ctx->frame, (uint32_t)n);
+    else if (prm->epilogue == 2)
+        hipLaunchKernelGGL(k_make_color, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->denoised, ctx->frame, (uint32_t)n);
+    CK(hipEventRecord(e1, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipGetLastError());
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (kernel_ms) *kernel_ms = ms;
+    if (host_rgba8 && prm->epilogue) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * n);
     return PT_OK;
 }
 

@@ -581,6 +581,50 @@ __global__ void k_tonemap_sqrt(const float4* __restrict__ accum, uint32_t* __res
     frame[i] = r | (g << 8) | (b << 16) | (a << 24);
 }
 
+// One a-trous pass (pt_amd.h pt_denoise): 25 taps at spacing `step`, fixed row-major summation order, expf = pt_expf
+// (include/pt_detmath.h) so that the CPU checker reproduces every bit.  inv_* are 1/sigma^2 of this pass.
+struct AtrousParams {
+    int width, height, step;
+    float inv_color, inv_normal, inv_albedo;
+};
+__global__ void __launch_bounds__(256) k_atrous(const float4* __restrict__ src, const float4* __restrict__ nrm, const float4* __restrict__ alb,
+                                                float4* __restrict__ dst, AtrousParams p) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= p.width || y >= p.height) return;
+    const size_t ip = (size_t)y * p.width + x;
+    const float4 cp = src[ip], np = nrm[ip], ap = alb[ip];
+    const float kern[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+    for (int dy = -2; dy <= 2; ++dy) {
+        const int qy = y + dy * p.step;
+        if (qy < 0 || qy >= p.height) continue;
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int qx = x + dx * p.step;
+            if (qx < 0 || qx >= p.width) continue;
+            const size_t iq = (size_t)qy * p.width + qx;
+            const float4 cq = src[iq], nq = nrm[iq], aq = alb[iq];
+            const float dcx = cp.x - cq.x, dcy = cp.y - cq.y, dcz = cp.z - cq.z;
+            const float dnx = np.x - nq.x, dny = np.y - nq.y, dnz = np.z - nq.z;
+            const float dax = ap.x - aq.x, day = ap.y - aq.y, daz = ap.z - aq.z;
+            const float ec = (dcx * dcx + dcy * dcy + dcz * dcz) * p.inv_color;
+            const float en = (dnx * dnx + dny * dny + dnz * dnz) * p.inv_normal;
+            const float ea = (dax * dax + day * day + daz * daz) * p.inv_albedo;
+            const float w = pt_expf(-fminf(ec + en + ea, 80.0f)) * (kern[dy + 2] * kern[dx + 2]); // pt_expf is defined on |x| < 80
+            sx += cq.x * w;
+            sy += cq.y * w;
+            sz += cq.z * w;
+            sw += w;
+        }
+    }
+    dst[ip] = make_float4(sx / sw, sy / sw, sz / sw, cp.w);
+}
+__global__ void k_make_color(const float4* __restrict__ src, uint32_t* __restrict__ frame, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 f = src[i];
+    frame[i] = make_color(mk3(f.x, f.y, f.z));
+}
+
 // multi-GPU exchange: gather owned pixels of a buffer into a packed array and back
 template <typename T>
 __global__ void k_pack(const T* __restrict__ buf, const uint32_t* __restrict__ pixels, uint32_t n, int width, T* __restrict__ dst) {

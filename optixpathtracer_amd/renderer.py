@@ -17,7 +17,7 @@ from ._lib import Material as CMaterial
 from ._lib import MeshDesc, Options, Region, SceneDesc, Stats, TextureDesc, Variant
 from .scenes import Model, ProbeData, uvw_frame
 
-PT_BUF_ACCUM, PT_BUF_FRAME, PT_BUF_COLOR, PT_BUF_NORMAL, PT_BUF_ALBEDO = range(5)
+PT_BUF_ACCUM, PT_BUF_FRAME, PT_BUF_COLOR, PT_BUF_NORMAL, PT_BUF_ALBEDO, PT_BUF_DENOISED = range(6)
 PT_BSDF_DISNEY, PT_BSDF_LAMBERT = 0, 1
 
 
@@ -219,6 +219,17 @@ class SampleRenderer:
         out = np.empty((h, w), np.uint32)
         self._ck(self._L.pt_tonemap_sqrt(self._ctx, out.ctypes.data), "pt_tonemap_sqrt")
         return out
+
+    def denoise(self, iterations=5, sigma_color=1.0, sigma_normal=0.25, sigma_albedo=0.1, input=PT_BUF_COLOR, epilogue=0):
+        """OptiXDenoiser::exec() as the reference wires it (SimplePathtracer.cpp:104-105,138-146; its own body is empty): an
+        a-trous filter of `input` guided by normal_buffer and albedo_buffer → PT_BUF_DENOISED; epilogue 1 = computeFinalPixelColors,
+        2 = make_color into frame_buffer.  Returns (denoised float4 image, kernel ms)."""
+        from ._lib import DenoiseParams
+
+        prm = DenoiseParams(int(iterations), float(sigma_color), float(sigma_normal), float(sigma_albedo), int(input), int(epilogue))
+        ms = C.c_double()
+        self._ck(self._L.pt_denoise(self._ctx, C.byref(prm), None, C.byref(ms)), "pt_denoise")
+        return self.download(PT_BUF_DENOISED), ms.value
 
     def stats(self) -> dict:
         s = Stats()

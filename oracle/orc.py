@@ -102,6 +102,7 @@ class Oracle:
         L.orc_math_table.argtypes = [C.c_int, f32p, f32p, C.c_int, f32p]
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(Probe), C.POINTER(Params), f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_render_region.argtypes = [C.c_void_p, C.POINTER(Probe), C.POINTER(Params), C.POINTER(Region), C.POINTER(Variant), f32p, u32p, C.POINTER(Stats)]
+        L.orc_denoise.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, f32p, f32p, f32p, f32p]
         L.orc_tex2d.argtypes = [u32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p]
         L.orc_scene_set_textures.argtypes = [C.c_void_p, C.c_void_p, i32p, u8p, C.c_uint32, C.c_void_p, i32p, i32p]
         L.orc_sizeof_material.restype = C.c_size_t
@@ -188,6 +189,14 @@ class Oracle:
         occ = np.empty(len(rays), np.uint8)
         self.lib.orc_trace_any(scene.h, rays.reshape(-1), len(rays), occ)
         return occ
+
+    def denoise(self, color, normal, albedo, iterations=5, sigma_color=1.0, sigma_normal=0.25, sigma_albedo=0.1):
+        color = np.ascontiguousarray(color, np.float32)
+        h, w = color.shape[:2]
+        out = np.empty_like(color)
+        self.lib.orc_denoise(w, h, iterations, sigma_color, sigma_normal, sigma_albedo, color.reshape(-1),
+                             np.ascontiguousarray(normal, np.float32).reshape(-1), np.ascontiguousarray(albedo, np.float32).reshape(-1), out.reshape(-1))
+        return out
 
     def math_table(self, which, x, y=None):
         x = np.ascontiguousarray(x, np.float32)

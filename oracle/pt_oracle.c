@@ -51,6 +51,7 @@
 #define M_ATAN2 pt_atan2f
 #define M_LOG pt_logf
 #define M_POW pt_powf
+#define M_EXP pt_expf
 #else
 #define M_SIN sinf
 #define M_COS cosf
@@ -58,6 +59,7 @@
 #define M_ATAN2 atan2f
 #define M_LOG logf
 #define M_POW powf
+#define M_EXP expf
 #endif
 
 /* ---------------------------------------------------------------- vec helpers
@@ -1333,6 +1335,64 @@ void orc_render_region(const orc_scene* s, const orc_probe* probe, const orc_par
     if (stats) *stats = st;
     orc_variant def = {0.001f, 0, 0, 1.0f, 1.0f};
     g_var = def;
+}
+
+/* ---------------------------------------------------------------- AOV-guided a-trous filter (include/pt_amd.h pt_denoise)
+ * The reference wires a denoiser pass (OptiXDenoiser::exec between render() and computeFinalPixelColors,
+ * SimplePathtracer.cpp:104-105,138-146) whose implementation is empty (OptixDenoiser.cpp:15-18): there is no reference
+ * behaviour to follow, so this restatement DEFINES the semantics ("parity unpinned").  One pass per iteration i with tap
+ * spacing 2^i over a 5x5 B3-spline kernel, taps outside the image skipped, row-major summation, alpha carried through. */
+static void atrous_pass(int w, int h, int step, float inv_color, float inv_normal, float inv_albedo, const float* src, const float* nrm,
+                        const float* alb, float* dst) {
+    static const float kern[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const size_t ip = 4 * ((size_t)y * w + x);
+            float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+            for (int dy = -2; dy <= 2; ++dy) {
+                const int qy = y + dy * step;
+                if (qy < 0 || qy >= h) continue;
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const int qx = x + dx * step;
+                    if (qx < 0 || qx >= w) continue;
+                    const size_t iq = 4 * ((size_t)qy * w + qx);
+                    const float dcx = src[ip] - src[iq], dcy = src[ip + 1] - src[iq + 1], dcz = src[ip + 2] - src[iq + 2];
+                    const float dnx = nrm[ip] - nrm[iq], dny = nrm[ip + 1] - nrm[iq + 1], dnz = nrm[ip + 2] - nrm[iq + 2];
+                    const float dax = alb[ip] - alb[iq], day = alb[ip + 1] - alb[iq + 1], daz = alb[ip + 2] - alb[iq + 2];
+                    const float ec = (dcx * dcx + dcy * dcy + dcz * dcz) * inv_color;
+                    const float en = (dnx * dnx + dny * dny + dnz * dnz) * inv_normal;
+                    const float ea = (dax * dax + day * day + daz * daz) * inv_albedo;
+                    const float wt = M_EXP(-fminf(ec + en + ea, 80.0f)) * (kern[dy + 2] * kern[dx + 2]);
+                    sx += src[iq] * wt;
+                    sy += src[iq + 1] * wt;
+                    sz += src[iq + 2] * wt;
+                    sw += wt;
+                }
+            }
+            dst[ip] = sx / sw;
+            dst[ip + 1] = sy / sw;
+            dst[ip + 2] = sz / sw;
+            dst[ip + 3] = src[ip + 3];
+        }
+}
+void orc_denoise(int w, int h, int iterations, float sigma_color, float sigma_normal, float sigma_albedo, const float* color, const float* normal,
+                 const float* albedo, float* out) {
+    const size_t n = 4 * (size_t)w * h;
+    if (iterations <= 0) {
+        memcpy(out, color, sizeof(float) * n);
+        return;
+    }
+    float* tmp = (float*)malloc(sizeof(float) * n);
+    float* bufs[2] = {out, tmp};
+    int cur = (iterations & 1) ? 0 : 1;
+    const float* src = color;
+    for (int i = 0; i < iterations; ++i) {
+        const float sc = sigma_color / (float)(1 << i), sn = sigma_normal * (float)(1 << i);
+        atrous_pass(w, h, 1 << i, 1.0f / (sc * sc), 1.0f / (sn * sn), 1.0f / (sigma_albedo * sigma_albedo), src, normal, albedo, bufs[cur]);
+        src = bufs[cur];
+        cur ^= 1;
+    }
+    free(tmp);
 }
 
 size_t orc_sizeof_material(void) { return sizeof(orc_material); }

@@ -680,3 +680,51 @@ def test_fullsize_c5_progressive_rows(ptlib, orc_det):
     for y in rows:
         assert_bits_equal(g["accum"][y], accum[y], f"row {y} after {nsub} subframes")
     assert (g["accum"][..., :3] <= 50.0 + 1e-3).all()  # subframe 0 is unclamped (sun radiance 50), later ones clamp to 10
+
+
+def test_denoise_atrous_bit_exact(ptlib, orc_det, small_probe):
+    """f4: the AOV-guided a-trous pass (pt_denoise) against the checker's restatement, bit for bit: rendered Cornell AOVs
+    (noisy 1-spp colour, first-hit normal and albedo), both inputs, 0..5 iterations, and the two rgba8 epilogues."""
+    from optixpathtracer_amd import renderer as R
+
+    m = scenes.cornell_box()
+    w, h = 160, 96
+    r = _renderer(m, small_probe, scenes.CORNELL_CAMERA, w, h)
+    g = _gpu_render(r, 1, subframes=3)
+    assert np.isfinite(g["color"]).all()
+    for inp, src in ((R.PT_BUF_COLOR, g["color"]), (R.PT_BUF_ACCUM, g["accum"])):
+        for it in (0, 1, 2, 5):
+            d, ms = r.denoise(iterations=it, sigma_color=0.8, sigma_normal=0.3, sigma_albedo=0.15, input=inp)
+            o = orc_det.denoise(src, g["normal"], g["albedo"], it, 0.8, 0.3, 0.15)
+            assert_bits_equal(d, o, f"denoised, input {inp}, {it} iterations")
+    d, _ = r.denoise(iterations=5, epilogue=1)
+    o = orc_det.denoise(g["color"], g["normal"], g["albedo"], 5, 1.0, 0.25, 0.1)
+    assert_bits_equal(d, o, "denoised (defaults)")
+    import ctypes as C
+    px = np.empty(w * h, np.uint32)
+    orc_det.lib.orc_tonemap_sqrt.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    orc_det.lib.orc_tonemap_sqrt(o.ctypes.data, px.ctypes.data, w * h)
+    assert np.array_equal(r.download(R.PT_BUF_FRAME).reshape(-1), px), "computeFinalPixelColors of the denoised buffer"
+    # the filter must actually do something useful: less variance inside the flat back wall, walls' colour edge kept
+    noisy, den = g["color"][..., :3], d[..., :3]
+    flat = (np.abs(g["normal"][..., 2] + 1.0) < 1e-6) & (np.abs(g["albedo"][..., 0] - g["albedo"][..., 1]) < 1e-6) & (g["albedo"][..., 0] > 0)
+    assert flat.sum() > 500 and den[flat].var(0).sum() < 0.5 * noisy[flat].var(0).sum()
+    with pytest.raises(RuntimeError):
+        r.denoise(iterations=9)
+    with pytest.raises(RuntimeError):
+        r.denoise(sigma_color=0.0)
+
+
+def test_denoise_edge_sizes_and_synthetic(ptlib, orc_det, small_probe):
+    """a-trous on tiny / odd frames (taps falling outside the image at every spacing) with synthetic AOVs."""
+    from optixpathtracer_amd import renderer as R
+
+    m = scenes.cornell_box()
+    rng = np.random.default_rng(5)
+    for (w, h) in ((1, 1), (3, 5), (33, 9), (70, 41)):
+        r = _renderer(m, small_probe, scenes.CORNELL_CAMERA, w, h)
+        g = _gpu_render(r, 2)
+        d, _ = r.denoise(iterations=5, sigma_color=2.0, sigma_normal=0.5, sigma_albedo=0.5, input=R.PT_BUF_ACCUM)
+        o = orc_det.denoise(g["accum"], g["normal"], g["albedo"], 5, 2.0, 0.5, 0.5)
+        assert_bits_equal(d, o, f"denoised {w}x{h}")
+        assert np.isfinite(d).all()

@@ -176,3 +176,33 @@ def test_closed_white_furnace_energy_bound(orc_det):
     exact = np.isclose(k, np.round(k), atol=1e-5) & np.isclose(ratio, ratio[..., :1], rtol=1e-6).all(-1) & (k <= 4)
     assert exact.mean() > 0.97 and (np.round(k[exact]) == 4).mean() > 0.25 and (np.round(k[exact]) >= 2).mean() > 0.9
     assert r["shadow_rays"] > 0
+
+
+@pytest.mark.parametrize("kind", ["libm", "det"])
+def test_atrous_filter_properties(kind, orc_libm, orc_det):
+    """The checker's a-trous restatement (pt_denoise semantics): constants are fixed points, weights are a partition of
+    unity (output within the input range), guide edges stop the blur, 0 iterations is the identity."""
+    O = orc_libm if kind == "libm" else orc_det
+    rng = np.random.default_rng(3)
+    h, w = 40, 56
+    const = np.full((h, w, 4), 0.37, np.float32)
+    zeros = np.zeros((h, w, 4), np.float32)
+    out = O.denoise(const, zeros, zeros, 5)
+    assert np.abs(out - const).max() < 1e-6
+    noisy = rng.uniform(0.2, 0.8, (h, w, 4)).astype(np.float32)
+    assert np.array_equal(O.denoise(noisy, zeros, zeros, 0), noisy)
+    out = O.denoise(noisy, zeros, zeros, 4, sigma_color=10.0)
+    assert out[..., :3].min() >= 0.2 - 1e-6 and out[..., :3].max() <= 0.8 + 1e-6
+    assert np.array_equal(out[..., 3], noisy[..., 3])  # alpha carried through
+    assert out[..., :3].var() < 0.1 * noisy[..., :3].var()
+    # two half-planes with different albedo and colour: the albedo guide keeps the step sharp
+    step = np.zeros((h, w, 4), np.float32)
+    step[:, : w // 2, :3] = 0.2
+    step[:, w // 2 :, :3] = 0.9
+    alb = step.copy()
+    noise = rng.normal(0, 0.02, (h, w, 3)).astype(np.float32)
+    col = step.copy()
+    col[..., :3] += noise
+    out = O.denoise(col, zeros, alb, 5, sigma_color=10.0, sigma_albedo=0.05)
+    assert abs(out[:, : w // 2, :3].mean() - 0.2) < 0.01 and abs(out[:, w // 2 :, :3].mean() - 0.9) < 0.01
+    assert out[:, w // 2 - 1, :3].max() < 0.3 and out[:, w // 2, :3].min() > 0.8

@@ -182,8 +182,9 @@ typedef struct pt_region {
 typedef struct pt_variant {
     float radiance_tmin;          /* 0.001 canonical (deviceProgram.cu:420); 0.01 sv4 (global tmin, sv4 :41,485) */
     int32_t cull_back_occlusion;  /* 0 canonical (TERMINATE_ON_FIRST_HIT); 1 sv3/sv4 (CULL_BACK_FACING_TRIANGLES, sv4 :240) */
-    int32_t tonemap;              /* 0: make_color(accum); 1: make_color(reinhard(accum * exposure, white)) (sv4 :555-569) */
-    float exposure;               /* sv4: pow(2,2) = 4 */
+    int32_t tonemap;              /* 0: make_color(accum); 1: make_color(reinhard(accum * exposure, white)) (sv4 :555-569);
+                                   * 2: make_color(accum * exposure) (sv3 :580-604, where the later plain write wins) */
+    float exposure;               /* sv4: pow(2,2) = 4; sv3: pow(2,3) = 8 */
     float white;                  /* sv4: 1 */
 } pt_variant;
 

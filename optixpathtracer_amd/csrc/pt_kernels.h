@@ -563,7 +563,8 @@ __global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParam
             }
             fp.accum[image_index] = make_float4(accum_color.x, accum_color.y, accum_color.z, 1.0f);
             v3 shown = accum_color;
-            if (var.tonemap) shown = reinhard_tonemap(scl3(accum_color, var.exposure), var.white);
+            if (var.tonemap == 1) shown = reinhard_tonemap(scl3(accum_color, var.exposure), var.white);
+            else if (var.tonemap == 2) shown = scl3(accum_color, var.exposure); // sv3: its Reinhard write is overwritten (sv3 :591-604)
             fp.frame[image_index] = make_color(shown);
         }
     }

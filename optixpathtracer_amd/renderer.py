@@ -156,6 +156,9 @@ class SampleRenderer:
 
     # -- the foveated variants' render() (HelloPathtracing_sv4_vmv23/SimplePathtracer.cpp:77-216)
     SV4_VARIANT = dict(radiance_tmin=0.01, cull_back_occlusion=1, tonemap=1, exposure=4.0, white=1.0)
+    # HelloPathtracing_sv3: same device code except exposure 2^3 and no Reinhard in the final write; host radii 100/200, spp 2/8/64
+    SV3_VARIANT = dict(radiance_tmin=0.01, cull_back_occlusion=1, tonemap=2, exposure=8.0, white=1.0)
+    SV3_SCHEDULE = dict(inner_radius=100, outer_radius=200, spp=(2, 8, 64))
 
     def renderRegions(self, regions, variant=None, out: np.ndarray | None = None):
         """regions: list of dicts with pt_region's fields; variant: dict with pt_variant's fields (None = canonical)."""
@@ -186,11 +189,11 @@ class SampleRenderer:
                  r_outer=float(inner_radius + 1), offset_x=u32(cx - (inner_radius + 1)), offset_y=u32(cy - (inner_radius + 1)), redraw=1, spp=spp[2], subframe_index=0),
         ]
 
-    def renderFoveated(self, c, inner_radius=157, outer_radius=515, spp=(1, 2, 8), out=None):
+    def renderFoveated(self, c, inner_radius=157, outer_radius=515, spp=(1, 2, 8), out=None, variant=None):
         """sv4 SampleRenderer::render() with FOV_ON: three launches around the gaze point c (launchParams.frame.c),
         then launchParams.frame.subframe_index++ (SimplePathtracer.cpp:132-216)."""
         regs = self.foveatedRegions(self.launchParams.frame.size, c, int(self.launchParams.frame.subframe_index), inner_radius, outer_radius, spp)
-        self.renderRegions(regs, self.SV4_VARIANT, out)
+        self.renderRegions(regs, variant or self.SV4_VARIANT, out)
         self.launchParams.frame.subframe_index += 1
 
     # -- beyond the reference (runtime versions of its compile-time constants, multi-GPU, stats)

@@ -952,7 +952,7 @@ typedef struct { uint64_t radiance_rays, shadow_rays; } orc_stats;
 typedef struct {
     float radiance_tmin;      /* 0.001 original (deviceProgram.cu:420); 0.01 in sv4 (global tmin, sv4 deviceProgram.cu:41,485) */
     int cull_back_occlusion;  /* 0 original (TERMINATE_ON_FIRST_HIT); 1 sv3/sv4 (CULL_BACK_FACING_TRIANGLES, :240) */
-    int tonemap;              /* 0 = make_color(accum) ; 1 = make_color(reinhard(accum * exposure, white)) (sv4 :555-569) */
+    int tonemap;              /* 0 = make_color(accum) ; 1 = make_color(reinhard(accum * exposure, white)) (sv4 :555-569); 2 = make_color(accum * exposure) (sv3) */
     float exposure, white;
 } orc_variant;
 static __thread orc_variant g_var = {0.001f, 0, 0, 1.0f, 1.0f};
@@ -1318,7 +1318,8 @@ static void raygen_region_thread(const orc_scene* s, const orc_probe* probe, con
             float* o = &accum[4 * image_index];
             o[0] = accum_color.x; o[1] = accum_color.y; o[2] = accum_color.z; o[3] = 1.0f;
             f3 shown = accum_color;
-            if (g_var.tonemap) shown = reinhard(scl3(accum_color, g_var.exposure), g_var.white);
+            if (g_var.tonemap == 1) shown = reinhard(scl3(accum_color, g_var.exposure), g_var.white);
+            else if (g_var.tonemap == 2) shown = scl3(accum_color, g_var.exposure); /* sv3 :580-604: the Reinhard write is overwritten by make_color(exposure-corrected) */
             float c[3] = {shown.x, shown.y, shown.z};
             frame[image_index] = orc_make_color(c);
         }

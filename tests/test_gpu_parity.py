@@ -577,12 +577,14 @@ def test_gpu_cdf_build_bit_exact(ptlib, orc_det, small_probe):
     _compare(g, o)
 
 
-def test_foveated_sv4_three_launches(ptlib, orc_det):
+@pytest.mark.parametrize("variant_name", ["SV4_VARIANT", "SV3_VARIANT"])
+def test_foveated_sv4_three_launches(ptlib, orc_det, variant_name):
     """SURVEY §8f row 1 — the foveated variants' render() (HelloPathtracing_sv4_vmv23/SimplePathtracer.cpp:132-216):
     periphery at 1/4 resolution accumulating over subframes, annulus at 1/2 resolution and fovea at full
     resolution redrawn every frame; sv4 device semantics (seed from the launch index, annulus early-out, fillSize^2
     splat, tmin .01, back-face-culled occlusion rays, depth 4, exposure 4 + Reinhard + make_color).  Several frames
-    with a moving gaze point, bit-exact accum_buffer and frame_buffer against the checker."""
+    with a moving gaze point, bit-exact accum_buffer and frame_buffer against the checker.  SV3_VARIANT = the sv3 directory's
+    epilogue (exposure 2^3, no Reinhard in the write that wins)."""
     from optixpathtracer_amd.renderer import SampleRenderer, make_camera
 
     m = scenes.voxel_terrain(n=64, target_tris=30000)
@@ -601,8 +603,9 @@ def test_foveated_sv4_three_launches(ptlib, orc_det):
     for k, gaze in enumerate([(96, 64), (100, 60), (70, 80)]):
         assert r.launchParams.frame.subframe_index == k
         regs = r.foveatedRegions((w, h), gaze, k, inner_radius=14, outer_radius=44, spp=(1, 2, 4))
-        r.renderFoveated(gaze, inner_radius=14, outer_radius=44, spp=(1, 2, 4))
-        orc_det.render_regions(sc, pr, (U, V, W), scenes.TERRAIN_CAMERA["eye"], w, h, regs, r.SV4_VARIANT, 4, accum, frame)
+        variant = getattr(r, variant_name)
+        r.renderFoveated(gaze, inner_radius=14, outer_radius=44, spp=(1, 2, 4), variant=variant)
+        orc_det.render_regions(sc, pr, (U, V, W), scenes.TERRAIN_CAMERA["eye"], w, h, regs, variant, 4, accum, frame)
         g_acc = r.download(R_ACCUM)
         g_frm = r.download(R_FRAME)
         assert_bits_equal(g_acc, accum, f"foveated accum_buffer, frame {k}")

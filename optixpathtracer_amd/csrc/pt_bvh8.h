@@ -6,11 +6,11 @@
 // quantised child boxes needs 5 loads and a third of the tree depth.
 //
 // Node (80 B = 5 x 16 B):
-//   n0: origin.xyz (f32)                       | upper halves of the floats 2^ex, 2^ey (grid steps)
-//   n1: child_base | tri_base | leafbits | upper half of 2^ez, imask << 16
+//   n0: origin.xyz (f32)                       | upper halves (sign, exponent, 7 mantissa bits) of the grid steps sx, sy
+//   n1: child_base | tri_base | leafbits | upper half of sz, imask << 16
 //       leafbits bit 3*s+k: slot s is a leaf child holding more than k triangles
 //   n2: qlo.x[8] (2 dwords) | qlo.y[8]   n3: qlo.z[8] | qhi.x[8]   n4: qhi.y[8] | qhi.z[8]
-// Child box s = origin + q * 2^(e-127) per axis, rounded outward at build from the padded float box, so
+// Child box s = origin + q * step per axis (step = extent/255 rounded up to 8 significant bits), rounded outward at build from the padded float box, so
 // the box test stays conservative; empty slots hold an inverted box (qlo=255, qhi=0).  Internal children
 // are contiguous (child_base + rank of the slot among the set bits of imask), the triangles of all leaf
 // children are contiguous from tri_base in (slot, k) order, i.e. triangle (s,k) is tri_base + rank of bit 3*s+k in leafbits.  Children sit in the slot whose octant (sign bits of

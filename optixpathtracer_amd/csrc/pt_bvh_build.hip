@@ -405,17 +405,17 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
     const uint32_t child_base = nint ? atomicAdd(&counters[1], nint) : 0u;
     const uint32_t tri_base = ntri ? atomicAdd(&counters[2], ntri) : 0u;
     const uint32_t task_base = nint ? atomicAdd(&counters[0], nint) : 0u;
-    // grid step per axis: smallest power of two with 255 steps covering the extent
-    uint32_t eb[3];
+    // grid step per axis: ext/255 rounded UP to a float with an 8-bit significand (the 16 bits the node stores), so the
+    // 255 steps cover the extent with < 1 % slack (a power-of-two step wasted up to 2x of the 8-bit resolution)
+    uint32_t eb[3]; // upper 16 bits of the step
     float step[3];
     for (int a = 0; a < 3; ++a) {
         const float ext = hi[a] - lo[a];
-        int e;
-        frexpf(ext / 255.0f, &e); // ext/255 = m * 2^e, m in [0.5,1) → 2^e >= ext/255
-        if (e < -125) e = -125;
-        if (e > 127) e = 127;
-        eb[a] = (uint32_t)(e + 127);
-        step[a] = __uint_as_float(eb[a] << 23);
+        float st = ext * (1.0f / 255.0f) * 1.015625f;
+        if (!(st >= 2.3509887e-38f)) st = 2.3509887e-38f; // 2^-125
+        if (st > 1.0e38f) st = 1.0e38f;
+        eb[a] = (__float_as_uint(st) + 0xffffu) >> 16;
+        step[a] = __uint_as_float(eb[a] << 16);
     }
     uint32_t q[6][2] = {{0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
     uint32_t leafbits = 0u;
@@ -430,6 +430,9 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
             float qh = ceilf(((b[3 + a] + pad) - lo[a]) / step[a]);
             ql = fminf(fmaxf(ql, 0.f), 255.f);
             qh = fminf(fmaxf(qh, 0.f), 255.f);
+            // the division by a non-power-of-two step rounds: make sure the grid planes still enclose the padded box
+            while (ql > 0.f && lo[a] + ql * step[a] > b[a] - pad) ql -= 1.f;
+            while (qh < 255.f && lo[a] + qh * step[a] < b[3 + a] + pad) qh += 1.f;
             const int w = s >> 2, k = s & 3;
             q[a][w] = (q[a][w] & ~(0xffu << (8 * k))) | ((uint32_t)ql << (8 * k));
             q[3 + a][w] = (q[3 + a][w] & ~(0xffu << (8 * k))) | ((uint32_t)qh << (8 * k));
@@ -446,8 +449,8 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
         }
     }
     Node8 nd;
-    nd.n0 = make_float4(lo[0], lo[1], lo[2], __uint_as_float((eb[0] << 7) | (eb[1] << 23)));
-    nd.n1 = make_float4(__uint_as_float(child_base), __uint_as_float(tri_base), __uint_as_float(leafbits), __uint_as_float((eb[2] << 7) | (imask << 16)));
+    nd.n0 = make_float4(lo[0], lo[1], lo[2], __uint_as_float(eb[0] | (eb[1] << 16)));
+    nd.n1 = make_float4(__uint_as_float(child_base), __uint_as_float(tri_base), __uint_as_float(leafbits), __uint_as_float(eb[2] | (imask << 16)));
     nd.n2 = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
     nd.n3 = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
     nd.n4 = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));

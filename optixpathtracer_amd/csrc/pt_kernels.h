@@ -220,11 +220,12 @@ PT_DEV void queue_push(bool pred, uint32_t value, const QView& q) {
     if (pred) queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
 
-#ifdef PT_SHADE_WAVES
-#define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, PT_SHADE_WAVES)))
-#else
-#define PT_SHADE_ATTR
+// k_shade is half latency-bound (dependent scattered loads: state, triangle, probe CDF search): 5 waves per SIMD at 96 VGPRs
+// (11 dwords of scratch) measured +1.5 % on C2 and C3 over the compiler's 4 waves at 109; 6 and more lose to spills
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 5
 #endif
+#define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, PT_SHADE_WAVES)))
 template <int MODE, bool CATCHER>
 __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, ShadeParams sp) {
     __shared__ uint32_t s_prefix[PT_NSUB + 1];

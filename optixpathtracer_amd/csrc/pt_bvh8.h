@@ -71,6 +71,7 @@ struct Trace8Args {
     uint32_t* ovf; // spill stack: [PT8_OVF_DEPTH][2][gridDim.x * 64]
     int cull_back; // shadow rays ignore back-facing triangles (sv3/sv4 occlusion ray flag)
     unsigned long long* dbg; // optional: [0] node steps, [1] triangle tests, [2] max stack depth, [3] pushes (pt_trace + PT_DEBUG_COUNTS)
+    int lds_skip; // test hook (PT_STACK_LDS_SKIP): keep this many fewer stack levels in LDS, so shallow trees exercise the global spill path
 };
 
 PT_DEV float u8f(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
@@ -84,6 +85,7 @@ k_trace8(Trace8Args a) {
     const uint32_t lane = threadIdx.x;
     const uint32_t gtid = blockIdx.x * 64u + lane;
     const uint32_t gstride = gridDim.x * 64u;
+    const int lds_depth = PT8_LDS_DEPTH - a.lds_skip;
     // index space of the launch: [0,n1) = rays of `queue`, [n1, n) = shadow rays of `queue2` (TR_UNIFIED)
     const uint32_t n1 = qreader_init(a.queue, s_prefix);
     const uint32_t n2 = (MODE == TR_UNIFIED) ? qreader_init(a.queue2, s_prefix2) : 0u;
@@ -111,23 +113,23 @@ k_trace8(Trace8Args a) {
 
     auto push = [&](uint32_t v0, uint32_t v1) {
         PT_STAT(++c_push; if ((uint32_t)sp + 1 > c_maxsp) c_maxsp = sp + 1;)
-        if (sp < PT8_LDS_DEPTH) {
+        if (sp < lds_depth) {
             s_stack[(sp * 2) * 64 + lane] = v0;
             s_stack[(sp * 2 + 1) * 64 + lane] = v1;
-        } else if (sp < PT8_LDS_DEPTH + PT8_OVF_DEPTH) {
-            a.ovf[(size_t)((sp - PT8_LDS_DEPTH) * 2) * gstride + gtid] = v0;
-            a.ovf[(size_t)((sp - PT8_LDS_DEPTH) * 2 + 1) * gstride + gtid] = v1;
+        } else if (sp < lds_depth + PT8_OVF_DEPTH) {
+            a.ovf[(size_t)((sp - lds_depth) * 2) * gstride + gtid] = v0;
+            a.ovf[(size_t)((sp - lds_depth) * 2 + 1) * gstride + gtid] = v1;
         }
         ++sp;
     };
     auto pop = [&](uint32_t& v0, uint32_t& v1) {
         --sp;
-        if (sp < PT8_LDS_DEPTH) {
+        if (sp < lds_depth) {
             v0 = s_stack[(sp * 2) * 64 + lane];
             v1 = s_stack[(sp * 2 + 1) * 64 + lane];
         } else {
-            v0 = a.ovf[(size_t)((sp - PT8_LDS_DEPTH) * 2) * gstride + gtid];
-            v1 = a.ovf[(size_t)((sp - PT8_LDS_DEPTH) * 2 + 1) * gstride + gtid];
+            v0 = a.ovf[(size_t)((sp - lds_depth) * 2) * gstride + gtid];
+            v1 = a.ovf[(size_t)((sp - lds_depth) * 2 + 1) * gstride + gtid];
         }
     };
     auto finish = [&]() {

@@ -731,3 +731,29 @@ def test_denoise_edge_sizes_and_synthetic(ptlib, orc_det, small_probe):
         o = orc_det.denoise(g["accum"], g["normal"], g["albedo"], 5, 2.0, 0.5, 0.5)
         assert_bits_equal(d, o, f"denoised {w}x{h}")
         assert np.isfinite(d).all()
+
+
+def test_traversal_stack_spill_path(ptlib, orc_det, small_probe, monkeypatch):
+    """The traversal stack keeps 12 levels in LDS and spills deeper ones to a per-lane global area that the test scenes
+    (depth <= 7) never reach.  PT_STACK_LDS_SKIP moves the LDS/global boundary down so that the spill path runs on
+    every ray with 2 or more pending groups; the image and the batch queries must not change by a bit."""
+    m = scenes.voxel_terrain(n=96, target_tris=70000)
+    w, h = 160, 96
+    ref = _gpu_render(_renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h), 2)
+    rng = np.random.default_rng(21)
+    rays = _random_rays(rng, 60000, -110, 110)
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    (t0, p0), _ = SampleRenderer(m).trace(rays)
+    for skip in ("11", "12"):
+        monkeypatch.setenv("PT_STACK_LDS_SKIP", skip)
+        r = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h)
+        g = _gpu_render(r, 2)
+        _compare(g, ref)
+        (t1, p1), _ = r.trace(rays)
+        assert np.array_equal(p0, p1)
+        assert_bits_equal(t0, t1, f"closest-hit t with PT_STACK_LDS_SKIP={skip}")
+        occ0, _ = SampleRenderer(m).trace(rays, any_hit=True)
+    monkeypatch.delenv("PT_STACK_LDS_SKIP")
+    o = _oracle_render(orc_det, m, small_probe, scenes.TERRAIN_CAMERA, w, h, 2, use_bvh=True)
+    _compare(ref, o)

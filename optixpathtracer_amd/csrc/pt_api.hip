@@ -448,7 +448,7 @@ extern "C" int pt_set_probe_image(pt_ctx* ctx, const float* data, int w, int h) 
     CK(dalloc(&ctx->d_cdfY, (size_t)h));
     CK(tmp.alloc(&rowTotal, (size_t)h));
     CK(hipMemcpy(ctx->d_probe_data, data, sizeof(float4) * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_cdf_rows, dim3((h + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_probe_data, w, h, ctx->d_pdfX, ctx->d_cdfX, rowTotal);
+    hipLaunchKernelGGL(k_cdf_rows, dim3(h), dim3(64), 0, ctx->stream, ctx->d_probe_data, w, h, ctx->d_pdfX, ctx->d_cdfX, rowTotal);
     hipLaunchKernelGGL(k_cdf_marginal, dim3(1), dim3(64), 0, ctx->stream, rowTotal, h, ctx->d_pdfY, ctx->d_cdfY);
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipGetLastError());

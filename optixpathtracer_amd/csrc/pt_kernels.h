@@ -677,42 +677,72 @@ __global__ void k_emit_prims(const float* __restrict__ verts, const uint32_t* __
 }
 
 // ------------------------------------------------------------------ probe CDF on the GPU (Probe.h:29-77)
-// One thread per row keeps the reference's sequential float accumulation order, so the arrays equal the host
-// BuildCDF bit for bit (a parallel scan would reassociate the float sums).
-__global__ void k_cdf_rows(const float4* __restrict__ data, int width, int height, float* __restrict__ pdfX,
-                           float* __restrict__ cdfX, float* __restrict__ rowTotal) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= height) return;
+// BuildCDF (Probe.h:29-77) on the GPU with the reference's sequential float accumulation order, so the arrays equal the host
+// loop bit for bit (a parallel scan would reassociate the sums).  One wave per row: 64 pixels are loaded coalesced and their
+// weights parked in LDS; every lane then runs the same left-to-right chain of 64 adds (broadcast LDS reads) and keeps the
+// partial sum of its own column — the dependent chain is the only serial part, and a 4096-row probe has 4096 of them in flight.
+PT_DEV float seq_prefix64(const float* s_w, uint32_t lane, uint32_t count, float& carry) {
+    float acc = carry, mine = 0.0f;
+    for (uint32_t m = 0; m < count; ++m) {
+        acc += s_w[m];
+        mine = (m == lane) ? acc : mine;
+    }
+    carry = acc;
+    return mine;
+}
+__global__ void __launch_bounds__(64) k_cdf_rows(const float4* __restrict__ data, int width, int height, float* __restrict__ pdfX,
+                                                 float* __restrict__ cdfX, float* __restrict__ rowTotal) {
+    __shared__ float s_w[64];
+    const int j = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const size_t row = (size_t)j * width;
     float totalWeightX = 0.0f;
-    for (int i = 0; i < width; ++i) {
-        const float4 c = data[(size_t)j * width + i];
-        const float weight = c.x * 0.3f + c.y * 0.6f + c.z * 0.1f; // Luminance, maths.h:165-168
-        totalWeightX += weight;
-        pdfX[(size_t)j * width + i] = weight;
-        cdfX[(size_t)j * width + i] = totalWeightX;
+    for (int i0 = 0; i0 < width; i0 += 64) {
+        const uint32_t count = (uint32_t)min(64, width - i0);
+        float weight = 0.0f;
+        if (lane < count) {
+            const float4 c = data[row + i0 + lane];
+            weight = c.x * 0.3f + c.y * 0.6f + c.z * 0.1f; // Luminance, maths.h:165-168
+        }
+        s_w[lane] = weight;
+        __syncthreads();
+        const float mine = seq_prefix64(s_w, lane, count, totalWeightX);
+        __syncthreads();
+        if (lane < count) {
+            pdfX[row + i0 + lane] = weight;
+            cdfX[row + i0 + lane] = mine;
+        }
     }
     const float invTotalWeightX = 1.0f / totalWeightX;
-    for (int i = 0; i < width; ++i) {
-        pdfX[(size_t)j * width + i] *= invTotalWeightX;
-        cdfX[(size_t)j * width + i] *= invTotalWeightX;
+    for (int i = (int)lane; i < width; i += 64) {
+        pdfX[row + i] *= invTotalWeightX;
+        cdfX[row + i] *= invTotalWeightX;
     }
-    rowTotal[j] = totalWeightX;
+    if (lane == 0) rowTotal[j] = totalWeightX;
 }
-__global__ void k_cdf_marginal(const float* __restrict__ rowTotal, int height, float* __restrict__ pdfY, float* __restrict__ cdfY) {
-    if (threadIdx.x || blockIdx.x) return;
+__global__ void __launch_bounds__(64) k_cdf_marginal(const float* __restrict__ rowTotal, int height, float* __restrict__ pdfY, float* __restrict__ cdfY) {
+    __shared__ float s_w[64];
+    if (blockIdx.x) return;
+    const uint32_t lane = threadIdx.x;
     float totalWeightY = 0.0f;
-    for (int j = 0; j < height; ++j) {
-        totalWeightY += rowTotal[j];
-        pdfY[j] = rowTotal[j];
-        cdfY[j] = totalWeightY;
+    for (int j0 = 0; j0 < height; j0 += 64) {
+        const uint32_t count = (uint32_t)min(64, height - j0);
+        const float weight = lane < count ? rowTotal[j0 + lane] : 0.0f;
+        s_w[lane] = weight;
+        __syncthreads();
+        const float mine = seq_prefix64(s_w, lane, count, totalWeightY);
+        __syncthreads();
+        if (lane < count) {
+            pdfY[j0 + lane] = weight;
+            cdfY[j0 + lane] = mine;
+        }
     }
-    for (int j = 0; j < height; ++j) {
+    for (int j = (int)lane; j < height; j += 64) {
         cdfY[j] /= totalWeightY;
         pdfY[j] /= totalWeightY;
     }
 }
 
-// out[r][k] = cdf[r][(k+1)*stride - 1] for k < n/stride, +inf for the padding up to row_pitch (see lower_bound_blocked)
 __global__ void k_probe_coarse(const float* __restrict__ cdf, int rows, int n, int stride, int row_pitch, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * row_pitch) return;

@@ -621,7 +621,7 @@ struct RegionJob { // non-null: one launch-index range of a foveated launch inst
 };
 
 static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& fp, uint32_t pix0, uint32_t npix, uint32_t spp, uint32_t S,
-                          LaunchCounts& lc, const RegionJob* job = nullptr) {
+                          LaunchCounts& lc, const RegionJob* job = nullptr, const std::vector<hipEvent_t>* before_resolve = nullptr) {
     const int nq = ctx->nq;
     const float tmin_rad = job ? job->var.radiance_tmin : 0.001f;
     const int cull = job ? job->var.cull_back_occlusion : 0;
@@ -733,6 +733,8 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             qnext_base = (qnext_base == bs.queueA) ? bs.queueB : bs.queueA;
         }
         if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0);
+        if (before_resolve) // foveated launches: this launch's pixels are written after the previous launch's (they overlap)
+            for (hipEvent_t e : *before_resolve) hipStreamWaitEvent(bs.stream, e, 0);
         {
             SpanGuard g(ctx, CLS_OTHER, bs.stream);
             // counters[last_bounce+1] holds paths that would have continued: not traced, not counted
@@ -856,18 +858,23 @@ extern "C" int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t
     VariantParams var{0.001f, 0, 0, 1.0f, 1.0f};
     if (variant) var = VariantParams{variant->radiance_tmin, variant->cull_back_occlusion, variant->tonemap, variant->exposure, variant->white};
     const uint32_t max_paths = std::max<uint32_t>(ctx->opt.max_paths, 64u);
+    // The launches of one frame are independent until they write pixels: their passes are dealt round-robin to the batch
+    // sets (separate streams, so one launch's long-ray tails overlap the others' work) and only the resolves are ordered —
+    // a launch's pixels are written after all pixels of the previous launch, as later launches overwrite earlier ones.
+    const int nsets = std::max(1, std::min(16, ctx->opt.streams > 0 ? ctx->opt.streams : 3));
+    const uint32_t cap = std::max<uint32_t>(64u, max_paths / nsets);
     uint32_t need = 64;
     for (uint32_t r = 0; r < n; ++r) {
         const pt_region& g = regions[r];
         if (g.spp == 0 || g.spp > 4096 || g.launch_w == 0 || g.launch_h == 0 || g.fill_size < 0 || g.fill_size > 64 ||
             (unsigned long long)g.launch_w * g.launch_h >= (1ull << 31))
             return fail(ctx, PT_ERR_INVALID, "pt_render_regions: bad region");
-        if (g.spp > max_paths) return fail(ctx, PT_ERR_INVALID, "pt_render_regions: samples_per_launch exceeds max_paths");
+        if (g.spp > cap) return fail(ctx, PT_ERR_INVALID, "pt_render_regions: samples_per_launch exceeds max_paths / streams");
         const unsigned long long total = (unsigned long long)g.launch_w * g.launch_h * g.spp;
-        need = (uint32_t)std::max<unsigned long long>(need, std::min<unsigned long long>(total, max_paths));
+        need = (uint32_t)std::max<unsigned long long>(need, std::min<unsigned long long>(total, cap));
     }
     {
-        int rc = ensure_path_state(ctx, std::max<int>(1, (int)ctx->sets.size()), need, 64);
+        int rc = ensure_path_state(ctx, nsets, need, 64);
         if (rc) return rc;
     }
     ctx->ev_used = 0;
@@ -875,10 +882,11 @@ extern "C" int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t
     CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 2, ctx->stream));
     hipEvent_t ev_begin = next_event(ctx);
     CK(hipEventRecord(ev_begin, ctx->stream));
-    pt_ctx::BatchSet& bs = ctx->sets[0];
-    hipStreamWaitEvent(bs.stream, ev_begin, 0);
+    for (auto& b : ctx->sets) hipStreamWaitEvent(b.stream, ev_begin, 0);
     LaunchCounts lc;
     uint64_t paths = 0;
+    uint32_t next_set = 0;
+    std::vector<hipEvent_t> prev_done, cur_done;
     for (uint32_t r = 0; r < n; ++r) {
         const pt_region& g = regions[r];
         FrameParams fp{ctx->accum, ctx->frame, ctx->color, ctx->normal, ctx->albedo, ctx->width, ctx->height, g.subframe_index,
@@ -888,16 +896,29 @@ extern "C" int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t
         job.var = var;
         const uint32_t nlaunch = g.launch_w * g.launch_h;
         const uint32_t per = std::max(1u, ctx->set_cap / g.spp); // launch indices per pass (all their samples together)
+        std::vector<bool> used(ctx->sets.size(), false);
         for (uint32_t l0 = 0; l0 < nlaunch; l0 += per) {
             job.l0 = l0;
             job.nl = std::min(per, nlaunch - l0);
-            enqueue_chunk(ctx, bs, fp, 0, 0, g.spp, g.spp, lc, &job);
+            const uint32_t si = next_set++ % (uint32_t)nsets;
+            enqueue_chunk(ctx, ctx->sets[si], fp, 0, 0, g.spp, g.spp, lc, &job, prev_done.empty() ? nullptr : &prev_done);
+            used[si] = true;
         }
+        cur_done.clear();
+        for (size_t si = 0; si < ctx->sets.size(); ++si)
+            if (used[si]) {
+                hipEvent_t e = next_event(ctx);
+                hipEventRecord(e, ctx->sets[si].stream);
+                cur_done.push_back(e);
+            }
+        prev_done = cur_done; // these resolves waited for the older launches themselves: the order is transitive
         paths += (uint64_t)nlaunch * g.spp;
     }
-    hipEvent_t e = next_event(ctx);
-    hipEventRecord(e, bs.stream);
-    hipStreamWaitEvent(ctx->stream, e, 0);
+    for (auto& b : ctx->sets) {
+        hipEvent_t e = next_event(ctx);
+        hipEventRecord(e, b.stream);
+        hipStreamWaitEvent(ctx->stream, e, 0);
+    }
     hipEvent_t ev_end = next_event(ctx);
     CK(hipEventRecord(ev_end, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));

@@ -80,3 +80,18 @@ def test_product_never_imports_the_oracle():
                 s = open(os.path.join(dirpath, f), errors="ignore").read()
                 for pat in ("import oracle", "from oracle", "oracle/", "liborc", "orc_"):
                     assert pat not in s, f"{f} references the checker ({pat})"
+
+
+def test_headers_compile_as_c99_and_cxx17(tmp_path):
+    """include/pt_amd.h is a plain C header; the C++ facade over it (the reference's SampleRenderer surface) compiles
+    with a host compiler alone — no hipcc, no torch types on the application side."""
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (shutil.which("gcc") and shutil.which("g++")):
+        pytest.skip("no host compiler")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(root, "include", "pt_amd.h")], check=True)
+    src = tmp_path / "facade.cpp"
+    src.write_text('#include "optixpathtracer_amd/csrc/SampleRenderer.h"\nint main() { return 0; }\n')
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", root, "-I", os.path.join(root, "include"), str(src)], check=True)

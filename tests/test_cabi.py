@@ -6,6 +6,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 from conftest import ROOT, assert_bits_equal
 from optixpathtracer_amd import _lib, scenes

@@ -758,3 +758,48 @@ def test_traversal_stack_spill_path(ptlib, orc_det, small_probe, monkeypatch):
     monkeypatch.delenv("PT_STACK_LDS_SKIP")
     o = _oracle_render(orc_det, m, small_probe, scenes.TERRAIN_CAMERA, w, h, 2, use_bvh=True)
     _compare(ref, o)
+
+
+def test_cxx_facade_demo_matches_python(ptlib, small_probe, tmp_path):
+    """The C++ facade (csrc/SampleRenderer.h) over the C ABI, compiled with a host compiler alone and run as its own process
+    (no Python, no torch): the reference application's call sequence on the main.cpp two-box scene gives the same bits as
+    the Python facade."""
+    import os
+    import shutil
+    import struct
+    import subprocess
+
+    from conftest import ROOT
+
+    if not shutil.which("g++"):
+        pytest.skip("no host C++ compiler")
+    m = scenes.two_box_scene(shadow_catcher=False)
+    cam = scenes.TWO_BOX_CAMERA
+    w, h, spp, nsub = 96, 64, 2, 3
+    scene = tmp_path / "scene.bin"
+    with open(scene, "wb") as f:
+        f.write(struct.pack("<I", len(m.meshes)))
+        for mesh in m.meshes:
+            v = np.ascontiguousarray(mesh.vertex, np.float32)
+            idx = np.ascontiguousarray(mesh.index, np.uint32)
+            f.write(struct.pack("<II", len(v), len(idx)))
+            f.write(np.asarray(mesh.material).tobytes())
+            f.write(v.tobytes())
+            f.write(idx.tobytes())
+        f.write(struct.pack("<II", small_probe.width, small_probe.height))
+        f.write(np.ascontiguousarray(small_probe.data, np.float32).tobytes())
+        f.write(np.asarray(list(cam["eye"]) + list(cam["lookat"]) + list(cam["up"]) + [cam["fovY"]], np.float32).tobytes())
+        f.write(struct.pack("<IIII", w, h, spp, nsub))
+    exe = tmp_path / "facade_demo"
+    libdir = os.path.join(ROOT, "optixpathtracer_amd")
+    subprocess.run(["g++", "-std=c++17", "-I", ROOT, "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "facade_demo.cpp"),
+                    "-L", libdir, "-lptamd", "-L", "/opt/rocm/lib", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    out = tmp_path / "out.bin"
+    res = subprocess.run([str(exe), str(scene), str(out)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    raw = np.fromfile(out, np.uint8)
+    frame = raw[: w * h * 4].view(np.uint32).reshape(h, w)
+    accum = raw[w * h * 4 :].view(np.float32).reshape(h, w, 4)
+    g = _gpu_render(_renderer(m, small_probe, cam, w, h), spp, subframes=nsub)
+    assert_bits_equal(accum, g["accum"], "accum_buffer from the C++ process")
+    assert np.array_equal(frame, g["frame"])

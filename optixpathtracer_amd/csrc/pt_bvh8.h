@@ -86,7 +86,7 @@ k_trace8(Trace8Args a) {
     const uint32_t gtid = blockIdx.x * 64u + lane;
     const uint32_t gstride = gridDim.x * 64u;
     const int lds_depth = PT8_LDS_DEPTH - a.lds_skip;
-    // index space of the launch: [0,n1) = rays of `queue`, [n1, n) = shadow rays of `queue2` (TR_UNIFIED)
+    // index space of the launch: TR_UNIFIED: [0,n2) = shadow rays of `queue2`, [n2, n) = rays of `queue`; else [0,n1) = rays of `queue`
     const uint32_t n1 = qreader_init(a.queue, s_prefix);
     const uint32_t n2 = (MODE == TR_UNIFIED) ? qreader_init(a.queue2, s_prefix2) : 0u;
     const uint32_t n = n1 + n2;
@@ -175,8 +175,11 @@ k_trace8(Trace8Args a) {
             if (!active && rank < take) {
                 const uint32_t gi = first + rank;
                 if (MODE == TR_UNIFIED) {
-                    shadow_lane = gi >= n1;
-                    slot = shadow_lane ? qreader_get_hint(a.queue2, s_prefix2, gi - n1, hint2) : qreader_get_hint(a.queue, s_prefix, gi, hint1);
+                    // shadow rays first: the longest rays of a launch are probe shadow rays that graze the terrain and hit nothing;
+                    // started early, their tails overlap the closest-hit bulk instead of trailing it (and within each queue the
+                    // rays flagged long by k_shade come first, pt_kernels.h queue_push)
+                    shadow_lane = gi < n2;
+                    slot = shadow_lane ? qreader_get_hint(a.queue2, s_prefix2, gi, hint2) : qreader_get_hint(a.queue, s_prefix, gi - n2, hint1);
                 } else {
                     slot = qreader_get_hint(a.queue, s_prefix, gi, hint1);
                 }

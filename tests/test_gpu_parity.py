@@ -509,6 +509,16 @@ def test_fullsize_1080p_terrain_properties(ptlib, orc_det):
     orc_det.lib.orc_render_rows(sc.h, C.byref(pr), C.byref(prm), accum.reshape(-1), np.array(rows, np.int32), len(rows), 8)
     for y in rows:
         assert_bits_equal(g1["accum"][y], accum[y], f"row {y} of the 1080p frame")
+    # the schedule never changes a bit at full size either: one stream / five streams / a third of the path slots
+    # (samples split into passes) / separate shadow launches all reproduce the default frame
+    for opt in (dict(streams=1), dict(streams=5), dict(max_paths=3_000_000), dict(split_shadow=1)):
+        r2 = _renderer(m, probe, scenes.TERRAIN_CAMERA, w, h, **opt)
+        g3 = _gpu_render(r2, 4)
+        for k in ("accum", "color", "normal", "albedo"):
+            assert np.array_equal(g3[k].view(np.uint32), g1[k].view(np.uint32)), f"{opt}: {k} differs from the default schedule"
+        assert np.array_equal(g3["frame"], g1["frame"])
+        assert g3["stats"]["radiance_rays"] == st["radiance_rays"] and g3["stats"]["shadow_rays"] == st["shadow_rays"]
+        del r2
 
 
 def test_partition_matches_host_mirror(ptlib, small_probe):

@@ -82,7 +82,9 @@ typedef struct pt_options {
     int32_t bvh_kind;       /* 0 = default: 8-wide compressed BVH (k_trace8); 1 = binary BVH (k_trace2) */
     int32_t trace_kernel;   /* 0 = default (persistent-wave k_trace2), 1 = first grid-stride kernel (A/B) */
     int32_t streams;        /* pixel chunks of a frame run concurrently on this many stream pairs (0 = default 3, the measured optimum: tails of one chunk overlap the bulk of the others) */
-    int32_t split_shadow;   /* 0 = default: shadow rays of bounce b share a launch with the closest-hit rays of b+1; 1 = separate kernels */
+    int32_t split_shadow;   /* 0 = default: shadow rays of bounce b share a launch with the closest-hit rays of b+1; 1 = separate kernels;
+                             * 2 = asynchronous: per-bounce shadow records traced on side streams, nothing waits for them before the
+                             *     resolve, which sums the visible contributions in bounce order (not with shadow-catcher materials) */
 } pt_options;
 
 enum pt_buffer {          /* LaunchParams.frame.* (LaunchParams.h:53-63) */

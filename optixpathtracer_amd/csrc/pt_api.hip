@@ -57,16 +57,18 @@ struct pt_ctx {
     // path state: NSETS independent batch sets; pixel chunks of one frame are dealt round-robin to the sets and each
     // set runs on its own pair of streams, so one chunk's kernel tails overlap with the other chunks' bulk work
     struct BatchSet {
-        hipStream_t stream = nullptr, stream2 = nullptr;
+        hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
         PathState st{};
         uint32_t *queueA = nullptr, *queueB = nullptr, *squeue = nullptr;
+        uint32_t* squeueB = nullptr; // asynchronous shadow rays: one shadow queue per bounce
+        uint32_t* ovf3 = nullptr;
         uint32_t* counters = nullptr; // [nq][PT_NSUB*PT_CSTRIDE] radiance sub-queue counts, same for shadow, then 2*nq work counters
         uint32_t *ovf = nullptr, *ovf2 = nullptr;
         float4 *pixResult = nullptr, *pixAlpha = nullptr, *pixNormal = nullptr, *pixAlbedo = nullptr;
     };
     std::vector<BatchSet> sets;
     uint32_t set_cap = 0, set_pix_cap = 0, sub_cap = 0;
-    bool cap_catcher = false;
+    bool cap_catcher = false, cap_async = false;
     int nq = 0;
     unsigned long long* d_totals = nullptr;
     uint32_t* ovf = nullptr; // spill stacks for pt_trace queries
@@ -276,6 +278,8 @@ static void free_path_state(pt_ctx* ctx) {
         dfree(s.rayO); dfree(s.rayD); dfree(s.srayD); dfree(s.pend); dfree(s.hit); dfree(s.thr); dfree(s.rng); dfree(s.fd);
         dfree(s.direct); dfree(s.indirect); dfree(s.alpha); dfree(s.nrm); dfree(s.alb); dfree(s.prdN); dfree(s.prdA);
         dfree(b.queueA); dfree(b.queueB); dfree(b.squeue); dfree(b.counters); dfree(b.ovf); dfree(b.ovf2);
+        dfree(b.squeueB); dfree(b.ovf3); dfree(s.sO); dfree(s.sD); dfree(s.pendB); dfree(s.vis);
+        if (b.stream3) { hipStreamSynchronize(b.stream3); hipStreamDestroy(b.stream3); }
         dfree(b.pixResult); dfree(b.pixAlpha); dfree(b.pixNormal); dfree(b.pixAlbedo);
         if (b.stream) hipStreamDestroy(b.stream);
         if (b.stream2) hipStreamDestroy(b.stream2);
@@ -542,10 +546,17 @@ static size_t ovf_words(const pt_ctx* ctx) {
     return (size_t)ctx->trace_grid * 64 * (PT8_OVF_DEPTH * 2 > PT2_OVF_DEPTH ? PT8_OVF_DEPTH * 2 : PT2_OVF_DEPTH);
 }
 
+// asynchronous shadow rays (split_shadow = 2): per-bounce shadow records and queues; not for shadow-catcher scenes, whose
+// alpha accumulation interleaves assignments and sums, and only with the default traversal
+static bool async_shadows(const pt_ctx* ctx) {
+    return ctx->opt.split_shadow == 2 && !ctx->has_catcher && ctx->opt.bvh_kind == 0 && ctx->opt.trace_kernel == 0 && ctx->opt.max_depth < 31;
+}
+
 static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_cap) {
     const int nq = ctx->opt.max_depth + 2;
+    const bool async = async_shadows(ctx);
     if ((int)ctx->sets.size() == nsets && cap <= ctx->set_cap && pix_cap <= ctx->set_pix_cap && nq <= ctx->nq &&
-        (!ctx->has_catcher || ctx->cap_catcher))
+        (!ctx->has_catcher || ctx->cap_catcher) && async == ctx->cap_async)
         return PT_OK;
     free_path_state(ctx);
     ctx->sets.resize(nsets);
@@ -563,7 +574,16 @@ static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_
         CK(dalloc(&b.counters, (size_t)2 * nq * PT_NSUB * PT_CSTRIDE + 2 * nq));
         CK(dalloc(&b.ovf, ovf_words(ctx))); CK(dalloc(&b.ovf2, ovf_words(ctx)));
         CK(dalloc(&b.pixResult, pix_cap)); CK(dalloc(&b.pixAlpha, pix_cap)); CK(dalloc(&b.pixNormal, pix_cap)); CK(dalloc(&b.pixAlbedo, pix_cap));
+        if (async) {
+            CK(hipStreamCreate(&b.stream3));
+            CK(dalloc(&s.sO, (size_t)nq * cap)); CK(dalloc(&s.sD, (size_t)nq * cap)); CK(dalloc(&s.pendB, (size_t)nq * cap));
+            CK(dalloc(&s.vis, cap));
+            s.bstride = cap;
+            CK(dalloc(&b.squeueB, (size_t)nq * qsize));
+            CK(dalloc(&b.ovf3, ovf_words(ctx)));
+        }
     }
+    ctx->cap_async = async;
     ctx->cap_catcher = ctx->has_catcher;
     ctx->nq = nq;
     ctx->set_cap = cap;
@@ -650,13 +670,60 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
         const int last_bounce = ctx->has_catcher ? ctx->opt.max_depth : ctx->opt.max_depth - 1;
         hipEvent_t ev_shadow_done = nullptr;
         const bool unified = ctx->opt.trace_kernel == 0 && ctx->opt.bvh_kind == 0 && ctx->opt.split_shadow == 0;
-        if (unified) {
+        const bool async = ctx->cap_async;
+        if (async) {
+            // The bounce chain holds closest-hit launches only; the shadow rays of bounce b are traced from their own records
+            // on one of two side streams as soon as k_shade(b) has written them, and nothing waits for them before k_resolve.
+            const size_t qsize = (size_t)PT_NSUB * ctx->sub_cap;
+            std::vector<hipEvent_t> shadow_done;
+            {
+                SpanGuard g(ctx, CLS_TRACE, bs.stream);
+                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip};
+                hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                ++lc.trace;
+            }
+            for (int b = 0; b <= last_bounce; ++b) {
+                QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
+                QView qshadow{bs.squeueB + (size_t)b * qsize, cntS + (size_t)b * CS, ctx->sub_cap};
+                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow};
+                {
+                    SpanGuard g(ctx, CLS_SHADE, bs.stream);
+                    if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
+                    else launch_shade<PT_BSDF_DISNEY>(ctx, bs, sp);
+                    ++lc.shade;
+                }
+                {
+                    hipEvent_t ev_shaded = next_event(ctx);
+                    hipEventRecord(ev_shaded, bs.stream);
+                    hipStream_t ss = (b & 1) ? bs.stream3 : bs.stream2;
+                    hipStreamWaitEvent(ss, ev_shaded, 0);
+                    {
+                        SpanGuard g(ctx, CLS_SHADOW, ss);
+                        Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, (b & 1) ? bs.ovf3 : bs.ovf2, cull, nullptr, b, ctx->lds_skip};
+                        hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, ss, ta);
+                        ++lc.shadow;
+                    }
+                    hipEvent_t ev = next_event(ctx);
+                    hipEventRecord(ev, ss);
+                    shadow_done.push_back(ev);
+                }
+                if (b < last_bounce) {
+                    SpanGuard g(ctx, CLS_TRACE, bs.stream);
+                    Trace8Args ta{bs.st, bvh8, qnext, QView{}, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip};
+                    hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                    ++lc.trace;
+                }
+                qcur = qnext;
+                qnext_base = (qnext_base == bs.queueA) ? bs.queueB : bs.queueA;
+            }
+            for (hipEvent_t e : shadow_done) hipStreamWaitEvent(bs.stream, e, 0);
+        } else if (unified) {
             // One traversal launch per bounce: the closest-hit rays of bounce b+1 and the shadow rays of bounce b share
             // a persistent kernel (per-lane ray type), so the long-ray tail of one kind is filled with rays of the other
             // and a frame has max_depth+1 traversal launches instead of 2*max_depth.
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, ctx->lds_skip};
+                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip};
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
@@ -672,12 +739,12 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, cull, ctx->dbg, ctx->lds_skip};
+                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip};
                     hipLaunchKernelGGL((k_trace8<TR_UNIFIED>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 } else {
                     SpanGuard g(ctx, CLS_SHADOW, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf, cull, nullptr, ctx->lds_skip};
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.shadow;
                 }
@@ -696,7 +763,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     Trace2Args ta{bs.st, bvh, qcur, work + b, bs.ovf, nullptr};
                     hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 } else {
-                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, ctx->lds_skip};
+                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip};
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 }
                 ++lc.trace;
@@ -722,7 +789,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     Trace2Args ta{bs.st, bvh, qshadow, work + nq + b, bs.ovf2, nullptr};
                     hipLaunchKernelGGL((k_trace2<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
                 } else {
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr, ctx->lds_skip};
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr, 0, ctx->lds_skip};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
                 }
                 ++lc.shadow;
@@ -1157,7 +1224,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
             if (any_hit) hipLaunchKernelGGL((k_trace2<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         } else {
-            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8}, QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, 0, dDbg, ctx->lds_skip};
+            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8}, QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, 0, dDbg, 0, ctx->lds_skip};
             if (any_hit) hipLaunchKernelGGL((k_trace8<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         }

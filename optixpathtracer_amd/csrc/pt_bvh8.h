@@ -71,6 +71,7 @@ struct Trace8Args {
     uint32_t* ovf; // spill stack: [PT8_OVF_DEPTH][2][gridDim.x * 64]
     int cull_back; // shadow rays ignore back-facing triangles (sv3/sv4 occlusion ray flag)
     unsigned long long* dbg; // optional: [0] node steps, [1] triangle tests, [2] max stack depth, [3] pushes (pt_trace + PT_DEBUG_COUNTS)
+    int bounce;   // shadow modes with asynchronous shadow records (st.vis != null): the bounce whose records this launch traces
     int lds_skip; // test hook (PT_STACK_LDS_SKIP): keep this many fewer stack levels in LDS, so shallow trees exercise the global spill path
 };
 
@@ -134,9 +135,15 @@ k_trace8(Trace8Args a) {
     };
     auto finish = [&]() {
         if (MODE == TR_SHADOW_APPLY || (MODE == TR_UNIFIED && shadow_lane)) {
+            const bool occluded = bprim != 0;
+            if (a.st.vis) { // asynchronous shadow records: only publish the visibility, k_resolve sums in bounce order
+                if (!occluded) atomicOr(&a.st.vis[slot], 1u << a.bounce);
+                active = false;
+                PT_STAT(if (c_ray > c_raymax) c_raymax = c_ray; c_ray = 0;)
+                return;
+            }
             const float4 pe = a.st.pend[slot];
             const int kind = __float_as_int(pe.w);
-            const bool occluded = bprim != 0;
             if (kind == PEND_ALPHA) {
                 if (occluded) {
                     const float4 x = a.st.alpha[slot];
@@ -183,13 +190,20 @@ k_trace8(Trace8Args a) {
                 } else {
                     slot = qreader_get_hint(a.queue, s_prefix, gi, hint1);
                 }
-                const float4 o4 = a.st.rayO[slot];
-                float4 d4;
+                float4 o4, d4;
                 if (MODE == TR_SHADOW_APPLY || (MODE == TR_UNIFIED && shadow_lane)) {
-                    d4 = a.st.srayD[slot];
+                    if (a.st.vis) {
+                        const size_t bi = (size_t)a.bounce * a.st.bstride + slot;
+                        o4 = a.st.sO[bi];
+                        d4 = a.st.sD[bi];
+                    } else {
+                        o4 = a.st.rayO[slot];
+                        d4 = a.st.srayD[slot];
+                    }
                     tmin = 0.01f;
                     tmax = 1e16f;
                 } else {
+                    o4 = a.st.rayO[slot];
                     d4 = a.st.rayD[slot];
                     tmin = o4.w;
                     tmax = d4.w;

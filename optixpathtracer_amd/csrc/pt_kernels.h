@@ -35,6 +35,14 @@ struct PathState {
     uint32_t* fd;  // depth | flags << 8
     float4 *direct, *indirect, *alpha, *nrm, *alb;
     float4 *prdN, *prdA; // prd.normal / prd.albedo, shadow-catcher scenes only (else null)
+    // asynchronous shadow rays (pt_options.split_shadow = 2; null otherwise): every bounce b has its own shadow records
+    // [b * bstride + slot] — origin, direction, pending contribution — so that the shadow rays of bounce b no longer have to
+    // finish before k_shade(b+1) overwrites the per-path slots, and a visibility bit per bounce instead of the immediate
+    // `direct/indirect += contribution`: k_resolve adds the visible contributions in bounce order, which keeps the
+    // reference's float sums whatever order the shadow launches finish in.
+    float4 *sO, *sD, *pendB;
+    uint32_t* vis;
+    uint32_t bstride;
 };
 
 struct FrameParams { // LaunchParams (LaunchParams.h:51-79) minus the OptiX handle and the dead light
@@ -134,6 +142,7 @@ __global__ void __launch_bounds__(256) k_generate(PathState st, FrameParams fp, 
         st.thr[i] = make_float4(1.f, 1.f, 1.f, 1.f);
         st.rng[i] = make_uint2(r.seed1, r.seed2);
         st.fd[i] = 0u;
+        if (st.vis) st.vis[i] = 0u;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         st.direct[i] = z;
         st.indirect[i] = z;
@@ -364,9 +373,16 @@ __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, Shade
                             st.direct[p] = make_float4(dd.x + mat.emission[0], dd.y + mat.emission[1], dd.z + mat.emission[2], 0.f);
                         }
                         if (has_val) {
-                            st.pend[p] = make_float4(contrib.x, contrib.y, contrib.z,
-                                                     __int_as_float(depth == 0 ? PEND_DIRECT : PEND_INDIRECT));
-                            st.srayD[p] = make_float4(wi.x, wi.y, wi.z, 0.f);
+                            const float4 pe = make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(depth == 0 ? PEND_DIRECT : PEND_INDIRECT));
+                            if (st.vis) { // asynchronous shadow rays: a self-contained record of this bounce
+                                const size_t bi = (size_t)depth * st.bstride + p;
+                                st.sO[bi] = make_float4(P.x, P.y, P.z, 0.f);
+                                st.sD[bi] = make_float4(wi.x, wi.y, wi.z, 0.f);
+                                st.pendB[bi] = pe;
+                            } else {
+                                st.pend[p] = pe;
+                                st.srayD[p] = make_float4(wi.x, wi.y, wi.z, 0.f);
+                            }
                             push_shadow = true;
                         }
                     }
@@ -384,6 +400,20 @@ __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, Shade
 }
 
 // ------------------------------------------------------------------ resolve
+// asynchronous shadow rays: the deferred `sum += val` of SampleLights, in bounce order (bounce 0 → direct, later → indirect)
+PT_DEV void apply_visible_contributions(const PathState& st, uint32_t i, float4& d, float4& in) {
+    if (!st.vis) return;
+    uint32_t v = st.vis[i];
+    if (v & 1u) {
+        const float4 pe = st.pendB[i];
+        d = make_float4(d.x + pe.x, d.y + pe.y, d.z + pe.z, 0.f);
+    }
+    for (uint32_t b = 1; (v >> b) != 0u; ++b)
+        if ((v >> b) & 1u) {
+            const float4 pe = st.pendB[(size_t)b * st.bstride + i];
+            in = make_float4(in.x + pe.x, in.y + pe.y, in.z + pe.z, 0.f);
+        }
+}
 __global__ void __launch_bounds__(256) k_resolve(PathState st, FrameParams fp, BatchParams bp, int first, int last) {
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= bp.npix) return;
@@ -397,7 +427,9 @@ __global__ void __launch_bounds__(256) k_resolve(PathState st, FrameParams fp, B
     }
     for (uint32_t sl = 0; sl < bp.S; ++sl) {
         const uint32_t i = sl * bp.npix + pix;
-        const float4 d = st.direct[i], in = st.indirect[i], a = st.alpha[i], nn = st.nrm[i], al = st.alb[i];
+        float4 d = st.direct[i], in = st.indirect[i];
+        const float4 a = st.alpha[i], nn = st.nrm[i], al = st.alb[i];
+        apply_visible_contributions(st, i, d, in);
         // result += directLight + indirectLight; alpha += prd.alpha (:445-446)
         result = add3(result, add3(mk3(d.x, d.y, d.z), mk3(in.x, in.y, in.z)));
         alpha = add3(alpha, mk3(a.x, a.y, a.z));
@@ -499,6 +531,7 @@ __global__ void __launch_bounds__(256) k_generate_region(PathState st, FramePara
                 st.thr[i] = make_float4(1.f, 1.f, 1.f, 1.f);
                 st.rng[i] = make_uint2(r.seed1, r.seed2);
                 st.fd[i] = 0u;
+                if (st.vis) st.vis[i] = 0u;
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 st.direct[i] = z;
                 st.indirect[i] = z;
@@ -530,7 +563,9 @@ __global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParam
     v3 result = mk3(0.f), alpha = mk3(0.f);
     for (uint32_t sl = 0; sl < rg.spp; ++sl) {
         const uint32_t i = sl * nl + k;
-        const float4 d = st.direct[i], in = st.indirect[i], a = st.alpha[i];
+        float4 d = st.direct[i], in = st.indirect[i];
+        const float4 a = st.alpha[i];
+        apply_visible_contributions(st, i, d, in);
         result = add3(result, add3(mk3(d.x, d.y, d.z), mk3(in.x, in.y, in.z)));
         alpha = add3(alpha, mk3(a.x, a.y, a.z));
     }

@@ -511,7 +511,7 @@ def test_fullsize_1080p_terrain_properties(ptlib, orc_det):
         assert_bits_equal(g1["accum"][y], accum[y], f"row {y} of the 1080p frame")
     # the schedule never changes a bit at full size either: one stream / five streams / a third of the path slots
     # (samples split into passes) / separate shadow launches all reproduce the default frame
-    for opt in (dict(streams=1), dict(streams=5), dict(max_paths=3_000_000), dict(split_shadow=1)):
+    for opt in (dict(streams=1), dict(streams=5), dict(max_paths=3_000_000), dict(split_shadow=1), dict(split_shadow=2), dict(split_shadow=2, streams=1)):
         r2 = _renderer(m, probe, scenes.TERRAIN_CAMERA, w, h, **opt)
         g3 = _gpu_render(r2, 4)
         for k in ("accum", "color", "normal", "albedo"):
@@ -813,3 +813,36 @@ def test_cxx_facade_demo_matches_python(ptlib, small_probe, tmp_path):
     g = _gpu_render(_renderer(m, small_probe, cam, w, h), spp, subframes=nsub)
     assert_bits_equal(accum, g["accum"], "accum_buffer from the C++ process")
     assert np.array_equal(frame, g["frame"])
+
+
+def test_async_shadow_schedule_matches_oracle(ptlib, orc_det, small_probe):
+    """split_shadow = 2: per-bounce shadow records traced on side streams, visibility bits, contributions summed in bounce
+    order by the resolve.  Same bits as the checker for whole frames, progressive accumulation, sample/pixel chunking,
+    depth cutoffs, the Lambert mode, the foveated launches, and (falling back to the synchronous schedule) a shadow catcher."""
+    m = scenes.cornell_box()
+    w, h = 96, 64
+    o = _oracle_render(orc_det, m, small_probe, scenes.CORNELL_CAMERA, w, h, 5)
+    for max_paths in (0, 1000, 64):
+        r = _renderer(m, small_probe, scenes.CORNELL_CAMERA, w, h, max_paths=max_paths, split_shadow=2)
+        _compare(_gpu_render(r, 5), o)
+    o = _oracle_render(orc_det, m, small_probe, scenes.CORNELL_CAMERA, w, h, 2, subframes=3, max_depth=3, bsdf_mode=1)
+    r = _renderer(m, small_probe, scenes.CORNELL_CAMERA, w, h, max_depth=3, bsdf_mode=1, split_shadow=2)
+    _compare(_gpu_render(r, 2, subframes=3), o)
+    t = scenes.voxel_terrain(n=96, target_tris=70000)
+    probe = scenes.sky_probe(512, 256).BuildCDF()
+    r = _renderer(t, probe, scenes.TERRAIN_CAMERA, 160, 90, split_shadow=2)
+    g = _gpu_render(r, 4)
+    _compare(g, _oracle_render(orc_det, t, probe, scenes.TERRAIN_CAMERA, 160, 90, 4))
+    assert g["stats"]["shadow_launches"] == g["stats"]["shade_launches"]
+    # foveated launches (sv4 settings, depth 4)
+    r = _renderer(t, probe, scenes.TERRAIN_CAMERA, 160, 90, max_depth=4, split_shadow=2)
+    r2 = _renderer(t, probe, scenes.TERRAIN_CAMERA, 160, 90, max_depth=4)
+    for k, gaze in enumerate([(80, 45), (60, 50)]):
+        r.renderFoveated(gaze, inner_radius=12, outer_radius=36, spp=(1, 2, 4))
+        r2.renderFoveated(gaze, inner_radius=12, outer_radius=36, spp=(1, 2, 4))
+        assert_bits_equal(r.download(R_ACCUM), r2.download(R_ACCUM), f"foveated accum, frame {k}")
+        assert np.array_equal(r.download(R_FRAME), r2.download(R_FRAME))
+    # shadow catcher: the asynchronous schedule does not apply, the result must still be the reference's
+    c = scenes.two_box_scene(shadow_catcher=True)
+    r = _renderer(c, small_probe, scenes.TWO_BOX_CAMERA, 96, 64, split_shadow=2)
+    _compare(_gpu_render(r, 3), _oracle_render(orc_det, c, small_probe, scenes.TWO_BOX_CAMERA, 96, 64, 3))

@@ -251,6 +251,19 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cpu_share():
+    """CPUs this process may really use: the scheduler affinity, capped by the cgroup CPU quota (a 1-GPU box of the pool
+    shows 256 logical CPUs but a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(model, probe, cam, w, h, spp, depth):
     """The scalar C port of the same path (oracle/, 'port'), all host cores, on a bounded sample of the
     same workload: the same scene/camera/spp/depth at half resolution (a quarter of the frame's paths;
@@ -264,7 +277,7 @@ def cpu_baseline(model, probe, cam, w, h, spp, depth):
     sc = O.make_scene(model, True)
     pr = O.make_probe(probe)
     U, V, W = scenes.uvw_frame(**cam, aspect=w / h)
-    cores = os.cpu_count() or 1
+    cores = host_cpu_share()
     nthreads = min(cores, 64)
     sw, sh = max(16, w // 2), max(9, h // 2)
     U, V, W = scenes.uvw_frame(**cam, aspect=sw / sh)

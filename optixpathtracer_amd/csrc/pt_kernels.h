@@ -229,6 +229,162 @@ PT_DEV void queue_push(bool pred, uint32_t value, const QView& q) {
     if (pred) queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
 
+// One closest-hit / miss invocation for path slot p (the body of the reference's __closesthit__radiance / __miss__radiance
+// plus the raygen loop's bookkeeping).  push_next: the path continues with the ray now in rayO/rayD; push_shadow: a shadow
+// ray is pending (per-path slots, or the per-bounce record `shadow_bounce` with asynchronous shadow rays).
+template <int MODE, bool CATCHER>
+PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, uint32_t p, bool& push_next, bool& push_shadow, int& shadow_bounce) {
+    const float2 h = st.hit[p];
+    const int32_t prim = __float_as_int(h.y);
+    uint32_t fd = st.fd[p];
+    int depth = (int)(fd & 0xffu);
+    uint32_t flags = fd >> 8;
+    if (prim < 0) {
+        // __miss__radiance (:209-235): prd.normal = prd.albedo = 0 (adds nothing at depth 0), DONE
+        flags |= FLAG_DONE;
+        if (CATCHER) {
+            st.prdN[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            st.prdA[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+        const PrimTri tri = sp.prims[prim];
+        const v3 v0 = mk3(tri.t0.x, tri.t0.y, tri.t0.z), v1 = mk3(tri.t0.w, tri.t1.x, tri.t1.y),
+                 v2 = mk3(tri.t1.z, tri.t1.w, tri.t2.x);
+        const pt_material mat = sp.mats[__float_as_int(tri.t2.y)];
+        const float4 o4 = st.rayO[p], d4 = st.rayD[p];
+        const v3 ray_o = mk3(o4.x, o4.y, o4.z), ray_dir = mk3(d4.x, d4.y, d4.z);
+        const v3 N_0 = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
+        const v3 N = faceforward3(N_0, neg3(ray_dir), N_0);
+        const v3 P = add3(ray_o, scl3(ray_dir, h.x));
+        st.rayO[p] = make_float4(P.x, P.y, P.z, sp.tmin_radiance);
+        const bool is_catcher = (mat.flags & 1) != 0;
+        if (CATCHER && is_catcher && (flags & FLAG_SECONDARY)) {
+            // pass-through (:503-508): origin = P, direction unchanged, --depth; then raygen (:424-439)
+            --depth;
+            if (depth == 0) {
+                const float4 a = st.nrm[p], b = st.alb[p], pn = st.prdN[p], pa = st.prdA[p];
+                st.nrm[p] = make_float4(a.x + pn.x, a.y + pn.y, a.z + pn.z, 0.f);
+                st.alb[p] = make_float4(b.x + pa.x, b.y + pa.y, b.z + pa.z, 0.f);
+            }
+            ++depth;
+            push_next = true;
+        } else {
+            v3 albedo = mk3(mat.color[0], mat.color[1], mat.color[2]);
+            if (sp.mesh_tex) { // deviceProgram.cu:512-523: a textured mesh's albedo is REPLACED by tex2D at the hit's texcoord
+                const int tid = sp.mesh_tex[__float_as_int(tri.t2.y)];
+                if (tid >= 0) {
+                    // optixGetTriangleBarycentrics = (weight of vertex 1, weight of vertex 2): the hit test's own weights
+                    const v3 A = sub3(v0, ray_o), B = sub3(v1, ray_o), C = sub3(v2, ray_o);
+                    const v3 CxB = cross3(C, B), AxC = cross3(A, C), BxA = cross3(B, A);
+                    const float Uw = dot3(ray_dir, CxB), Vw = dot3(ray_dir, AxC), Ww = dot3(ray_dir, BxA);
+                    const float det = Uw + Vw + Ww;
+                    const float bu = Vw / det, bv = Ww / det;
+                    const PrimUV uv = sp.uvs[prim];
+                    const float w0 = 1.f - bu - bv;
+                    const float tcx = w0 * uv.c0.x + bu * uv.c1.x + bv * uv.c2.x;
+                    const float tcy = w0 * uv.c0.y + bu * uv.c1.y + bv * uv.c2.y;
+                    const float4 tx = tex2d_wrap_linear(sp.textures[tid], tcx, tcy);
+                    albedo = mk3(tx.x, tx.y, tx.z);
+                }
+            }
+            const float4 th = st.thr[p];
+            const v3 T_old = mk3(th.x, th.y, th.z);
+            float rayEta = th.w;
+            const float outEta = (rayEta == 1.0f) ? material_ior(mat) : 1.0f;
+            const v3 wo = neg3(ray_dir);
+            const uint2 rs = st.rng[p];
+            Rng rand;
+            rand.seed1 = rs.x;
+            rand.seed2 = rs.y;
+            // SampleLights / SampleShadow (:252-334) up to the visibility test
+            v3 wi, skyColor;
+            float skyPdf;
+            probe_sample(sp.probe, wi, skyColor, skyPdf, rand);
+            bool has_val = false;
+            v3 val = mk3(0.f);
+            {
+                const float bsdfPdf = bsdf_pdf<MODE>(mat, rayEta, outEta, N, wo, wi);
+                const v3 f = bsdf_eval<MODE>(mat, albedo, rayEta, outEta, N, wo, wi);
+                if (bsdfPdf > 0.0f) {
+                    const float weight = 0.5f * skyPdf / (0.5f * bsdfPdf + 0.5f * skyPdf);
+                    if (weight > 0.0f) {
+                        val = scl3(div3s(scl3(mul3(scl3(skyColor, weight), f), fabsf(dot3(wi, N))), skyPdf), 1.0f);
+                        has_val = true;
+                    }
+                }
+            }
+            if (!(CATCHER && is_catcher)) st.alpha[p] = make_float4(1.f, 1.f, 1.f, 0.f); // :547
+            const bool primary = (flags & FLAG_SECONDARY) == 0;
+            v3 u, v, bsdfDir = mk3(0.f);
+            float bsdfPdf;
+            basis_from_vector(N, u, v);
+            bsdf_sample<MODE>(mat, rayEta, outEta, u, v, N, wo, bsdfDir, bsdfPdf, rand);
+            v3 T_new = T_old;
+            if (bsdfPdf <= 0.0f) {
+                flags |= FLAG_DONE; // :570-573
+            } else {
+                const v3 f = bsdf_eval<MODE>(mat, albedo, rayEta, outEta, N, wo, bsdfDir);
+                if (dot3(bsdfDir, N) <= 0.0f) rayEta = outEta;
+                T_new = mul3(T_old, div3s(scl3(f, fabsf(dot3(N, bsdfDir))), bsdfPdf));
+                st.rayD[p] = make_float4(bsdfDir.x, bsdfDir.y, bsdfDir.z, 1e16f);
+                flags |= FLAG_SECONDARY;
+            }
+            st.thr[p] = make_float4(T_new.x, T_new.y, T_new.z, rayEta);
+            st.rng[p] = make_uint2(rand.seed1, rand.seed2);
+            if (CATCHER) {
+                st.prdN[p] = make_float4(N.x, N.y, N.z, 0.f);
+                st.prdA[p] = make_float4(albedo.x, albedo.y, albedo.z, 0.f);
+            }
+            // raygen loop body (:424-439)
+            if (depth == 0) {
+                const float4 a = st.nrm[p], b = st.alb[p];
+                st.nrm[p] = make_float4(a.x + N.x, a.y + N.y, a.z + N.z, 0.f);
+                st.alb[p] = make_float4(b.x + albedo.x, b.y + albedo.y, b.z + albedo.z, 0.f);
+            }
+            const bool term = (flags & FLAG_DONE) || depth >= sp.max_depth;
+            const v3 contrib = mul3(T_old, val);
+            if (CATCHER && is_catcher) {
+                // SampleShadow: alpha += T * shadowSample when OCCLUDED (:550-551), whatever happens next
+                if (has_val) {
+                    st.pend[p] = make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(PEND_ALPHA));
+                    st.srayD[p] = make_float4(wi.x, wi.y, wi.z, 0.f);
+                    push_shadow = true;
+                }
+                if (!term && primary) { // radiance = emission (:558-560)
+                    const float4 dd = st.direct[p];
+                    st.direct[p] = make_float4(dd.x + mat.emission[0], dd.y + mat.emission[1], dd.z + mat.emission[2], 0.f);
+                }
+            } else if (!term) {
+                // radiance = T*lightSample (+ emission on primary hits) is added to direct/indirect (:432-437)
+                // only when the path goes on; the visibility-dependent part is deferred to k_trace<1>.
+                if (primary) {
+                    const float4 dd = st.direct[p];
+                    st.direct[p] = make_float4(dd.x + mat.emission[0], dd.y + mat.emission[1], dd.z + mat.emission[2], 0.f);
+                }
+                if (has_val) {
+                    const float4 pe = make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(depth == 0 ? PEND_DIRECT : PEND_INDIRECT));
+                    if (st.vis) { // asynchronous shadow rays: a self-contained record of this bounce
+                        const size_t bi = (size_t)depth * st.bstride + p;
+                    shadow_bounce = depth;
+                        st.sO[bi] = make_float4(P.x, P.y, P.z, 0.f);
+                        st.sD[bi] = make_float4(wi.x, wi.y, wi.z, 0.f);
+                        st.pendB[bi] = pe;
+                    } else {
+                        st.pend[p] = pe;
+                        st.srayD[p] = make_float4(wi.x, wi.y, wi.z, 0.f);
+                    }
+                    push_shadow = true;
+                }
+            }
+            if (!term) {
+                ++depth;
+                push_next = true;
+            }
+        }
+    }
+    st.fd[p] = (uint32_t)depth | (flags << 8);
+}
+
 // k_shade is half latency-bound (dependent scattered loads: state, triangle, probe CDF search): 5 waves per SIMD at 96 VGPRs
 // (11 dwords of scratch) measured +1.5 % on C2 and C3 over the compiler's 4 waves at 109; 6 and more lose to spills
 #ifndef PT_SHADE_WAVES
@@ -242,157 +398,11 @@ __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, Shade
     const uint32_t nround = (n + 63u) & ~63u; // whole waves stay in the loop so ballots see every lane
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += gridDim.x * blockDim.x) {
         bool push_next = false, push_shadow = false;
+        int shadow_bounce = 0;
         uint32_t p = 0;
         if (i < n) {
             p = qreader_get(sp.queue, s_prefix, i);
-            const float2 h = st.hit[p];
-            const int32_t prim = __float_as_int(h.y);
-            uint32_t fd = st.fd[p];
-            int depth = (int)(fd & 0xffu);
-            uint32_t flags = fd >> 8;
-            if (prim < 0) {
-                // __miss__radiance (:209-235): prd.normal = prd.albedo = 0 (adds nothing at depth 0), DONE
-                flags |= FLAG_DONE;
-                if (CATCHER) {
-                    st.prdN[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    st.prdA[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            } else {
-                const PrimTri tri = sp.prims[prim];
-                const v3 v0 = mk3(tri.t0.x, tri.t0.y, tri.t0.z), v1 = mk3(tri.t0.w, tri.t1.x, tri.t1.y),
-                         v2 = mk3(tri.t1.z, tri.t1.w, tri.t2.x);
-                const pt_material mat = sp.mats[__float_as_int(tri.t2.y)];
-                const float4 o4 = st.rayO[p], d4 = st.rayD[p];
-                const v3 ray_o = mk3(o4.x, o4.y, o4.z), ray_dir = mk3(d4.x, d4.y, d4.z);
-                const v3 N_0 = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
-                const v3 N = faceforward3(N_0, neg3(ray_dir), N_0);
-                const v3 P = add3(ray_o, scl3(ray_dir, h.x));
-                st.rayO[p] = make_float4(P.x, P.y, P.z, sp.tmin_radiance);
-                const bool is_catcher = (mat.flags & 1) != 0;
-                if (CATCHER && is_catcher && (flags & FLAG_SECONDARY)) {
-                    // pass-through (:503-508): origin = P, direction unchanged, --depth; then raygen (:424-439)
-                    --depth;
-                    if (depth == 0) {
-                        const float4 a = st.nrm[p], b = st.alb[p], pn = st.prdN[p], pa = st.prdA[p];
-                        st.nrm[p] = make_float4(a.x + pn.x, a.y + pn.y, a.z + pn.z, 0.f);
-                        st.alb[p] = make_float4(b.x + pa.x, b.y + pa.y, b.z + pa.z, 0.f);
-                    }
-                    ++depth;
-                    push_next = true;
-                } else {
-                    v3 albedo = mk3(mat.color[0], mat.color[1], mat.color[2]);
-                    if (sp.mesh_tex) { // deviceProgram.cu:512-523: a textured mesh's albedo is REPLACED by tex2D at the hit's texcoord
-                        const int tid = sp.mesh_tex[__float_as_int(tri.t2.y)];
-                        if (tid >= 0) {
-                            // optixGetTriangleBarycentrics = (weight of vertex 1, weight of vertex 2): the hit test's own weights
-                            const v3 A = sub3(v0, ray_o), B = sub3(v1, ray_o), C = sub3(v2, ray_o);
-                            const v3 CxB = cross3(C, B), AxC = cross3(A, C), BxA = cross3(B, A);
-                            const float Uw = dot3(ray_dir, CxB), Vw = dot3(ray_dir, AxC), Ww = dot3(ray_dir, BxA);
-                            const float det = Uw + Vw + Ww;
-                            const float bu = Vw / det, bv = Ww / det;
-                            const PrimUV uv = sp.uvs[prim];
-                            const float w0 = 1.f - bu - bv;
-                            const float tcx = w0 * uv.c0.x + bu * uv.c1.x + bv * uv.c2.x;
-                            const float tcy = w0 * uv.c0.y + bu * uv.c1.y + bv * uv.c2.y;
-                            const float4 tx = tex2d_wrap_linear(sp.textures[tid], tcx, tcy);
-                            albedo = mk3(tx.x, tx.y, tx.z);
-                        }
-                    }
-                    const float4 th = st.thr[p];
-                    const v3 T_old = mk3(th.x, th.y, th.z);
-                    float rayEta = th.w;
-                    const float outEta = (rayEta == 1.0f) ? material_ior(mat) : 1.0f;
-                    const v3 wo = neg3(ray_dir);
-                    const uint2 rs = st.rng[p];
-                    Rng rand;
-                    rand.seed1 = rs.x;
-                    rand.seed2 = rs.y;
-                    // SampleLights / SampleShadow (:252-334) up to the visibility test
-                    v3 wi, skyColor;
-                    float skyPdf;
-                    probe_sample(sp.probe, wi, skyColor, skyPdf, rand);
-                    bool has_val = false;
-                    v3 val = mk3(0.f);
-                    {
-                        const float bsdfPdf = bsdf_pdf<MODE>(mat, rayEta, outEta, N, wo, wi);
-                        const v3 f = bsdf_eval<MODE>(mat, albedo, rayEta, outEta, N, wo, wi);
-                        if (bsdfPdf > 0.0f) {
-                            const float weight = 0.5f * skyPdf / (0.5f * bsdfPdf + 0.5f * skyPdf);
-                            if (weight > 0.0f) {
-                                val = scl3(div3s(scl3(mul3(scl3(skyColor, weight), f), fabsf(dot3(wi, N))), skyPdf), 1.0f);
-                                has_val = true;
-                            }
-                        }
-                    }
-                    if (!(CATCHER && is_catcher)) st.alpha[p] = make_float4(1.f, 1.f, 1.f, 0.f); // :547
-                    const bool primary = (flags & FLAG_SECONDARY) == 0;
-                    v3 u, v, bsdfDir = mk3(0.f);
-                    float bsdfPdf;
-                    basis_from_vector(N, u, v);
-                    bsdf_sample<MODE>(mat, rayEta, outEta, u, v, N, wo, bsdfDir, bsdfPdf, rand);
-                    v3 T_new = T_old;
-                    if (bsdfPdf <= 0.0f) {
-                        flags |= FLAG_DONE; // :570-573
-                    } else {
-                        const v3 f = bsdf_eval<MODE>(mat, albedo, rayEta, outEta, N, wo, bsdfDir);
-                        if (dot3(bsdfDir, N) <= 0.0f) rayEta = outEta;
-                        T_new = mul3(T_old, div3s(scl3(f, fabsf(dot3(N, bsdfDir))), bsdfPdf));
-                        st.rayD[p] = make_float4(bsdfDir.x, bsdfDir.y, bsdfDir.z, 1e16f);
-                        flags |= FLAG_SECONDARY;
-                    }
-                    st.thr[p] = make_float4(T_new.x, T_new.y, T_new.z, rayEta);
-                    st.rng[p] = make_uint2(rand.seed1, rand.seed2);
-                    if (CATCHER) {
-                        st.prdN[p] = make_float4(N.x, N.y, N.z, 0.f);
-                        st.prdA[p] = make_float4(albedo.x, albedo.y, albedo.z, 0.f);
-                    }
-                    // raygen loop body (:424-439)
-                    if (depth == 0) {
-                        const float4 a = st.nrm[p], b = st.alb[p];
-                        st.nrm[p] = make_float4(a.x + N.x, a.y + N.y, a.z + N.z, 0.f);
-                        st.alb[p] = make_float4(b.x + albedo.x, b.y + albedo.y, b.z + albedo.z, 0.f);
-                    }
-                    const bool term = (flags & FLAG_DONE) || depth >= sp.max_depth;
-                    const v3 contrib = mul3(T_old, val);
-                    if (CATCHER && is_catcher) {
-                        // SampleShadow: alpha += T * shadowSample when OCCLUDED (:550-551), whatever happens next
-                        if (has_val) {
-                            st.pend[p] = make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(PEND_ALPHA));
-                            st.srayD[p] = make_float4(wi.x, wi.y, wi.z, 0.f);
-                            push_shadow = true;
-                        }
-                        if (!term && primary) { // radiance = emission (:558-560)
-                            const float4 dd = st.direct[p];
-                            st.direct[p] = make_float4(dd.x + mat.emission[0], dd.y + mat.emission[1], dd.z + mat.emission[2], 0.f);
-                        }
-                    } else if (!term) {
-                        // radiance = T*lightSample (+ emission on primary hits) is added to direct/indirect (:432-437)
-                        // only when the path goes on; the visibility-dependent part is deferred to k_trace<1>.
-                        if (primary) {
-                            const float4 dd = st.direct[p];
-                            st.direct[p] = make_float4(dd.x + mat.emission[0], dd.y + mat.emission[1], dd.z + mat.emission[2], 0.f);
-                        }
-                        if (has_val) {
-                            const float4 pe = make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(depth == 0 ? PEND_DIRECT : PEND_INDIRECT));
-                            if (st.vis) { // asynchronous shadow rays: a self-contained record of this bounce
-                                const size_t bi = (size_t)depth * st.bstride + p;
-                                st.sO[bi] = make_float4(P.x, P.y, P.z, 0.f);
-                                st.sD[bi] = make_float4(wi.x, wi.y, wi.z, 0.f);
-                                st.pendB[bi] = pe;
-                            } else {
-                                st.pend[p] = pe;
-                                st.srayD[p] = make_float4(wi.x, wi.y, wi.z, 0.f);
-                            }
-                            push_shadow = true;
-                        }
-                    }
-                    if (!term) {
-                        ++depth;
-                        push_next = true;
-                    }
-                }
-            }
-            st.fd[p] = (uint32_t)depth | (flags << 8);
+            shade_path<MODE, CATCHER>(st, sp, p, push_next, push_shadow, shadow_bounce);
         }
         queue_push(push_next, p, sp.next_queue);
         queue_push(push_shadow, p, sp.shadow_queue);

@@ -4,15 +4,21 @@
 A "step" is one frame: one pt_render of the workload (the reference's one optixLaunch per frame,
 SimplePathtracer.cpp:73-97) with scene, BVH and probe already resident in HBM.  Default workload is
 BASELINE config C3: the procedural 1,000,000-triangle voxel terrain, 1920x1080, 4 spp, depth 8,
-Disney BSDF, 2048x1024 sky+sun probe.  N>1: the image is tile-partitioned (interleaved 64x16 tiles,
-no data-path collective).  Default for N>1 is WEAK scaling: per-GPU work is fixed, the image grows to N x the
-pixels (N=4: 3840x2160, config C4's size) so each rank renders one 1080p frame's worth of paths; `--scaling strong`
-splits the fixed 1080p frame N ways instead.  `value` = rays traced by all ranks / max-over-ranks time.  One RCCL all-gather of the packed frame
-runs after the timed region as the display hand-off (reported as gather_ms).
+Disney BSDF, 2048x1024 sky+sun probe — the frame the metric is quoted on.
+
+N>1 (one process per GPU, torch.distributed over RCCL): the FIXED frame is tile-partitioned (interleaved
+64x16 tiles, replicated scene, no data-path collective) — strong scaling, which is what "1/2/4/8 MI355X
+scaling" of a 1080p frame means.  `--scaling weak` (opt-in) grows the image to N x the pixels instead.
+`--workload c4_terrain1M_4k_16spp_d8` is BASELINE config C4 (3840x2160, 16 spp, tiled across the GPUs).
+`value` = rays traced by all ranks / max-over-ranks time of the K timed frames.  After the timed region a
+second, shorter loop renders AND hands the frame over for display every frame (pack -> one RCCL all-gather
+of the packed rgba8 strips -> unpack): `ms_per_displayed_frame`, with the exchange alone as `gather_ms`.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -34,9 +40,24 @@ WORKLOADS = {
     "sv4_foveated_terrain1M_4k_d4": ("terrain", "TERRAIN_CAMERA", 3840, 2160, 8, 4),
 }
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BYTES_PER_RADIANCE_RAY_TRACE = 32 + 4 + 8  # closest-hit ray: rayO+rayD (32) + queue entry (4) + hit write (8)
-BYTES_PER_SHADOW_RAY_TRACE = 32 + 4 + 16  # shadow ray: origin+direction (32) + queue entry (4) + pending contribution (16)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: FP32 vector peak
+# SURVEY.md §8(d), algorithmic bytes (SoA, no padding):
+BYTES_PER_RAY_FRAME = 160            # whole pipeline: 320 B per bounce (one radiance + one shadow ray) = 160 B per ray
+BYTES_PER_PIXEL_FRAME = 84           # 16 B accum read + (16*4 + 4) B written per pixel per frame
+BYTES_PER_RADIANCE_RAY_TRACE = 48    # traversal stage alone: read ray 32 B + write hit 16 B
+BYTES_PER_SHADOW_RAY_TRACE = 36      # read ray 32 B + write 4 B
+FLOPS_PER_HIT = 700                  # 2 x BSDFEval + 2 x BSDFPdf + BSDFSample + hit setup
+
+
+def source_hash():
+    """Hash of the kernel sources: PMC-derived numbers under profiles/ carry it and are only quoted for the code they were
+    measured on (a hash of the .so would change with every rebuild)."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "optixpathtracer_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -46,10 +67,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3_terrain1M_1080p_4spp_d8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-stream frames that give per-kernel (non-overlapped) durations")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --share-device rehearses the N>1 path on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use HIP device 0 (rehearsal only)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N>1: weak = per-GPU work fixed (image area grows with N, C4-style); strong = the fixed frame split N ways")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N>1: strong (default) = the metric's fixed frame split N ways; weak = per-GPU work fixed, image area grows with N")
     ap.add_argument("--simulate-world", type=int, default=0, help="single process: render only rank 0's tiles of an N-way partition (predicts per-GPU time at N GPUs)")
     ap.add_argument("--split-shadow", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="concurrent pixel chunks per frame (0 = library default)")
@@ -85,8 +107,7 @@ def main():
 
     scene_name, cam_name, w, h, spp, depth = WORKLOADS[args.workload]
     if world > 1 and args.scaling == "weak":
-        # per-GPU work fixed: the image grows to N x the pixels (same aspect, multiples of 8; N=4 is exactly 3840x2160,
-        # BASELINE config C4's size) and is tile-partitioned, so every rank still renders one 1080p frame's worth of paths
+        # per-GPU work fixed: the image grows to N x the pixels (same aspect, multiples of 8) and is tile-partitioned
         f = world ** 0.5
         w, h = int(round(w * f / 8)) * 8, int(round(h * f / 8)) * 8
     model = scenes.voxel_terrain() if scene_name == "terrain" else scenes.cornell_box()
@@ -95,7 +116,9 @@ def main():
 
     r = R.SampleRenderer(model, device=local_rank)
     r.setProbe(probe)
-    r.setOptions(max_depth=depth, max_paths=args.max_paths, trace_kernel=args.trace_kernel, bvh_kind=args.bvh_kind, streams=args.streams, split_shadow=args.split_shadow)
+    opts = dict(max_depth=depth, max_paths=args.max_paths, trace_kernel=args.trace_kernel, bvh_kind=args.bvh_kind, streams=args.streams, split_shadow=args.split_shadow)
+    r.setOptions(**opts)
+    part_world = world if world > 1 else max(1, args.simulate_world)
     if world > 1:
         r.setPartition(rank, world, 64, 16)
     elif args.simulate_world > 1:
@@ -129,7 +152,8 @@ def main():
         render_frame(k)
     barrier()
     rays = 0
-    agg = dict(trace_ms=0.0, shadow_ms=0.0, shade_ms=0.0, other_ms=0.0, render_ms=0.0, trace_launches=0, shadow_launches=0, radiance_rays=0, shadow_rays=0)
+    keys = ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms", "trace_launches", "shadow_launches", "shade_launches", "radiance_rays", "shadow_rays")
+    agg = dict.fromkeys(keys, 0.0)
     t0 = time.perf_counter()
     for k in range(args.steps):
         render_frame(args.warmup + k)
@@ -150,8 +174,8 @@ def main():
     else:
         dt_max, rays_all = dt, float(rays)
 
-    # display hand-off: one all-gather of the packed rgba8 frame (outside the timed region)
-    gather_ms = None
+    # displayed frames: render + the display hand-off (pack -> one all-gather of the packed rgba8 strips -> unpack) every frame
+    gather_ms = ms_displayed = None
     if dist is not None:
         from optixpathtracer_amd import multigpu
 
@@ -166,55 +190,91 @@ def main():
                 dst.copy_(d)
 
         multigpu.exchange_frame(packer, R.PT_BUF_FRAME, world, all_gather)  # warm RCCL
-        torch.cuda.synchronize()
-        g0 = time.perf_counter()
+        barrier()
+        nd = max(1, min(args.steps, 10))
+        g_acc = 0.0
+        d0 = time.perf_counter()
+        for k in range(nd):
+            render_frame(args.warmup + args.steps + k)
+            g0 = time.perf_counter()
+            multigpu.exchange_frame(packer, R.PT_BUF_FRAME, world, all_gather)
+            torch.cuda.synchronize()
+            g_acc += time.perf_counter() - g0
+        barrier()
+        dd = time.perf_counter() - d0
+        tt = torch.tensor([dd, g_acc], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms_displayed = float(tt[0]) / nd * 1e3
+        gather_ms = float(tt[1]) / nd * 1e3
+        # the assembled frame must be complete: every pixel of the float frame was written by exactly one rank (alpha = 1)
         multigpu.exchange_frame(packer, R.PT_BUF_ACCUM, world, all_gather)
         torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        # the assembled frame must be complete: every pixel of accum_buffer was written by exactly one rank (alpha = 1)
         full = r.download(R.PT_BUF_ACCUM)
         if not (full[..., 3] == 1.0).all():
             raise SystemExit(f"rank {rank}: assembled frame has unwritten pixels")
 
+    # isolated per-kernel durations: the default schedule overlaps three pixel chunks on separate streams, so its per-class
+    # HIP-event sums include time spent sharing the machine.  A few extra frames with ONE chunk stream give durations that
+    # add up to the frame (rank 0, N=1 only; not part of `value`).
+    iso = None
+    if world == 1 and not args.no_isolated and not sv4 and args.streams == 0:
+        r.setOptions(**dict(opts, streams=1))
+        n_iso = 3
+        render_frame(0)
+        ia = dict.fromkeys(keys, 0.0)
+        for k in range(n_iso):
+            render_frame(1 + k)
+            st1 = r.stats()
+            for key in ia:
+                ia[key] += st1[key]
+        iso = {k: ia[k] / n_iso for k in ia}
+        r.setOptions(**opts)
+
     if rank == 0:
         mrays = rays_all / dt_max / 1e6
-        # roofline of the dominant kernels, the BVH traversal launches (k_trace8<0> for the camera rays, then one
-        # k_trace8<3> per bounce tracing that bounce's closest-hit rays together with the previous bounce's shadow
-        # rays): algorithmic bytes per launch = (radiance rays x 44 B + shadow rays x 52 B) / launches,
-        # duration = mean HIP-event time of those launches on their own streams (pt_stats)
-        n_launch = max(1, agg["trace_launches"] + agg["shadow_launches"])
-        avg_ms = (agg["trace_ms"] + agg["shadow_ms"]) / n_launch
-        alg_bytes = (agg["radiance_rays"] * BYTES_PER_RADIANCE_RAY_TRACE + agg["shadow_rays"] * BYTES_PER_SHADOW_RAY_TRACE) / n_launch
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic per traversal launch from the committed rocprofv3 PMC passes of this same command
-        # (tools/profile.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the guide); PMC cannot be
-        # collected inside an unprofiled run, so the figure is read from profiles/ when the workload matches
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        if os.path.exists(tj) and args.workload == "c3_terrain1M_1080p_4spp_d8" and world == 1 and args.bvh_kind == 0 and args.trace_kernel == 0:
+        frame_s = dt_max / args.steps
+        owned_px = r.ownedPixels()[0]
+        # --- roofline.  (1) The frame against HBM with SURVEY.md §8(d)'s formula: (rays x 160 B + pixels x 84 B + scene bytes)
+        # per frame / frame time.  (2) The dominant kernel class, the BVH traversal launches (k_trace8<0> for the camera rays, one
+        # k_trace8<3> per bounce tracing that bounce's closest-hit rays with the previous bounce's shadow rays): §8(d)'s traversal-
+        # stage bytes (48 B per closest-hit ray, 36 B per shadow ray) per launch / mean ISOLATED launch time (single-stream frames,
+        # HIP events on the launch's own stream, pt_stats).
+        scene_bytes = st["bvh_bytes"] + 48 * model.num_triangles + probe.data.shape[0] * probe.data.shape[1] * (16 + 4 + 4)
+        rays_frame = rays_all / args.steps
+        px_frame = float(w * h) if world > 1 else float(owned_px)
+        alg_frame = rays_frame * BYTES_PER_RAY_FRAME + px_frame * BYTES_PER_PIXEL_FRAME + scene_bytes * (world if world > 1 else 1)
+        achieved = alg_frame / frame_s / 1e9 / max(1, world)  # per GPU, against one GPU's peak
+        src = iso if iso is not None else {k: agg[k] / args.steps for k in agg}
+        n_launch = max(1.0, src["trace_launches"] + src["shadow_launches"])
+        trav_ms = (src["trace_ms"] + src["shadow_ms"]) / n_launch
+        trav_bytes = (src["radiance_rays"] * BYTES_PER_RADIANCE_RAY_TRACE + src["shadow_rays"] * BYTES_PER_SHADOW_RAY_TRACE) / n_launch
+        trav_gbs = trav_bytes / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
+        # shade kernel against the FP32 vector peak: closest hits x 700 flop (§8(d)) / isolated k_shade time
+        hits = src["shadow_rays"] if src["shadow_rays"] else src["radiance_rays"]  # one shadow ray per shaded hit with a usable light sample
+        shade = None
+        if src["shade_ms"] > 0:
+            tf = hits * FLOPS_PER_HIT / (src["shade_ms"] * 1e-3) / 1e12
+            shade = {"kernel": "k_shade", "bound": "fp32_valu", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / FP32_PEAK_TFLOPS, 5), "flops_per_hit": FLOPS_PER_HIT, "hits_per_frame": int(hits),
+                     "isolated_ms_per_frame": round(src["shade_ms"], 3), "launches_per_frame": int(src["shade_launches"])}
+        # PMC-derived figures (HBM traffic, VALU issue / lane utilisation) cannot be collected inside an unprofiled run: they are
+        # read from the committed rocprofv3 passes of this same command and quoted only for the sources they were measured on
+        traffic = valu = None
+        shash = source_hash()
+        default_cfg = args.workload == "c3_terrain1M_1080p_4spp_d8" and world == 1 and args.bvh_kind == 0 and args.trace_kernel == 0 and args.simulate_world == 0
+        tj = os.path.join(ROOT, "profiles", "r2_pmc.json")
+        if default_cfg and os.path.exists(tj):
             try:
                 T = json.load(open(tj))
-                num = den = 0.0
-                for k, v in T.items():
-                    if k.startswith("k_trace8"):
-                        num += (v["fetch_bytes_per_dispatch_x2"] + v["write_bytes_per_dispatch"]) * v["dispatches"]
-                        den += v["dispatches"]
-                traffic = int(num / den) if den else None
+                if T.get("src_hash") == shash:
+                    traffic = T.get("traffic_bytes_per_traversal_launch")
+                    valu = T.get("valu")
+                    if shade is not None and "shade" in T:
+                        shade["pmc"] = T["shade"]
             except Exception:
-                traffic = None
-        # what actually bounds the path (committed PMC pass, profiles/r1_04_pmc_valu.md): VALU issue slots used by the
-        # frame = VALU wave-instructions x 4 SIMD cycles / (SIMDs x clock x frame time), and the lane utilisation
-        valu = None
-        vj = os.path.join(ROOT, "profiles", "r1_pmc_valu.json")
-        if traffic is not None and os.path.exists(vj):
-            try:
-                P = json.load(open(vj))
-                frame_s = dt_max / args.steps
-                valu = {"issue_frac": round(P["valu_insts_per_frame"] * P["simd_cycles_per_valu_inst"] / (P["simds"] * P["clock_ghz"] * 1e9 * frame_s), 3),
-                        "lane_util_traversal": P["valu_lane_util"]["k_trace8<3>"], "source": P["source"]}
-            except Exception:
-                valu = None
+                traffic = valu = None
         kname = {(1, 0): "k_trace2", (1, 1): "k_trace", (0, 1): "k_trace"}.get((args.bvh_kind, args.trace_kernel), "k_trace8<3>/<0>")
+        strong = world > 1 and args.scaling == "strong"
         out = {
             "metric": "Mrays/s (and ms/frame) at 1080p 4spp depth8; 1/2/4/8 MI355X scaling",
             "value": round(mrays, 2),
@@ -222,25 +282,34 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt_max / args.steps * 1e3, 3),
+            "ms_per_step": round(frame_s * 1e3, 3),
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": "strong" if (world == 1 or strong) else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": args.workload + (f"_weak_x{world}_area" if (world > 1 and args.scaling == "weak") else ""), "triangles": model.num_triangles, "width": w, "height": h, "spp": spp,
-                "max_depth": depth, "bsdf": "disney", "probe": "sky2048x1024+sun", "partition": f"tiles64x16/{world}",
+                "workload": args.workload + (f"_weak_x{world}_area" if (world > 1 and not strong) else ""), "triangles": model.num_triangles, "width": w, "height": h, "spp": spp,
+                "max_depth": depth, "bsdf": "disney", "probe": "sky2048x1024+sun", "partition": f"tiles64x16/{part_world}",
             },
-            "rays_per_frame": int(rays_all / args.steps),
+            "rays_per_frame": int(rays_frame),
             "fps": round(args.steps / dt_max, 2),
             "kernel_ms_per_frame": {k: round(agg[k] / args.steps, 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
-            "bvh": {"nodes": st["bvh_nodes"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2)},
+            "kernel_ms_per_frame_isolated": None if iso is None else {k: round(iso[k], 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
+            "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2)},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "ms_per_displayed_frame": None if ms_displayed is None else round(ms_displayed, 3),
             "roofline": {
-                "kernel": kname + " (BVH traversal: closest-hit + shadow rays)", "bound": "hbm", "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes), "valu": valu,
+                "kernel": "whole frame, all wavefront stages (SURVEY.md 8d: rays x 160 B + pixels x 84 B + scene bytes)", "bound": "hbm",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "alg_bytes_per_frame": int(alg_frame), "scene_bytes": int(scene_bytes),
+                "measured_limiter": "VALU issue + dependent-load latency of the traversal kernel, not HBM (see valu / profiles/)",
+                "dominant_kernel": {
+                    "kernel": kname + " (BVH traversal: closest-hit + shadow rays per launch)", "bytes_per_ray": [BYTES_PER_RADIANCE_RAY_TRACE, BYTES_PER_SHADOW_RAY_TRACE],
+                    "alg_bytes_per_launch": int(trav_bytes), "avg_launch_ms": round(trav_ms, 4), "isolated": iso is not None,
+                    "achieved": round(trav_gbs, 2), "unit": "GB/s", "frac": round(trav_gbs / HBM_PEAK_GBS, 5),
+                },
+                "shade": shade, "valu": valu, "src_hash": shash,
             },
         }
         if not args.no_cpu_baseline and world == 1:
@@ -265,29 +334,36 @@ def host_cpu_share():
 
 
 def cpu_baseline(model, probe, cam, w, h, spp, depth):
-    """The scalar C port of the same path (oracle/, 'port'), all host cores, on a bounded sample of the
-    same workload: the same scene/camera/spp/depth at half resolution (a quarter of the frame's paths;
-    rays are counted, not extrapolated).  Timed region = the render only (BVH build excluded, as on the GPU)."""
-    import ctypes as C
-
+    """The scalar C port of the same path (oracle/, 'port') on the GPU box's host cores, on bounded samples of the same
+    workload (same scene/camera/spp/depth at reduced resolution; rays are counted, not extrapolated): all cores on a half-
+    resolution frame, and ONE thread on a quarter-resolution frame.  The port traverses ITS OWN median-split binary BVH
+    (oracle/pt_oracle.c), not the product's 8-wide tree.  Timed region = the render only (BVH build excluded, as on the GPU)."""
     from oracle import orc
     from optixpathtracer_amd import scenes
 
     O = orc.Oracle("det")
     sc = O.make_scene(model, True)
     pr = O.make_probe(probe)
-    U, V, W = scenes.uvw_frame(**cam, aspect=w / h)
     cores = host_cpu_share()
     nthreads = min(cores, 64)
+
+    def run(sw, sh, threads):
+        U, V, W = scenes.uvw_frame(**cam, aspect=sw / sh)
+        t0 = time.perf_counter()
+        out = O.render(sc, pr, (U, V, W), cam["eye"], sw, sh, spp, depth, 0, 0, None, threads)
+        dt = time.perf_counter() - t0
+        rays = out["radiance_rays"] + out["shadow_rays"]
+        return rays, dt
+
     sw, sh = max(16, w // 2), max(9, h // 2)
-    U, V, W = scenes.uvw_frame(**cam, aspect=sw / sh)
-    t0 = time.perf_counter()
-    out = O.render(sc, pr, (U, V, W), cam["eye"], sw, sh, spp, depth, 0, 0, None, nthreads)
-    dt = time.perf_counter() - t0
-    rays = out["radiance_rays"] + out["shadow_rays"]
+    rays, dt = run(sw, sh, nthreads)
+    qw, qh = max(16, w // 4), max(9, h // 4)
+    rays1, dt1 = run(qw, qh, 1)
     return {
         "value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": nthreads, "kind": "port",
-        "sample": f"{sw}x{sh} frame of the same scene/camera/{spp}spp/depth{depth}, {rays} rays in {dt:.2f}s (reference-order ray count)",
+        "sample": f"{sw}x{sh} frame of the same scene/camera/{spp}spp/depth{depth}, {rays} rays in {dt:.2f}s (reference-order ray count); tree = the port's own median-split BVH2",
+        "single_thread": {"value": round(rays1 / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                          "sample": f"{qw}x{qh} frame, {rays1} rays in {dt1:.2f}s"},
     }
 
 

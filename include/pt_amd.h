@@ -78,9 +78,9 @@ typedef struct pt_options {
     int32_t max_depth;      /* the literal 8 in deviceProgram.cu:429 */
     int32_t bsdf_mode;      /* pt_bsdf_mode */
     uint32_t max_paths;     /* paths in flight per wavefront batch (0 = default 8Mi) */
-    int32_t sort_rays;      /* reserved: per-bounce ray sort (0 = off) */
-    int32_t bvh_kind;       /* 0 = default: 8-wide compressed BVH (k_trace8); 1 = binary BVH (k_trace2) */
-    int32_t trace_kernel;   /* 0 = default (persistent-wave k_trace2), 1 = first grid-stride kernel (A/B) */
+    int32_t reserved0;      /* must be 0 (was sort_rays: per-bounce ray sorting was measured and rejected) */
+    int32_t bvh_kind;       /* 0 = default: 8-wide compressed BVH (k_trace8); 1 = binary BVH (k_trace2), A/B only: built on first request */
+    int32_t trace_kernel;   /* 0 = default: persistent-wave traversal (k_trace8, or k_trace2 with bvh_kind 1); 1 = first grid-stride kernel over the binary BVH (A/B) */
     int32_t streams;        /* pixel chunks of a frame run concurrently on this many stream pairs (0 = default 3, the measured optimum: tails of one chunk overlap the bulk of the others) */
     int32_t split_shadow;   /* 0 = default: shadow rays of bounce b share a launch with the closest-hit rays of b+1; 1 = separate kernels;
                              * 2 = asynchronous: per-bounce shadow records traced on side streams, nothing waits for them before the
@@ -109,6 +109,7 @@ typedef struct pt_stats {
     uint32_t bvh_nodes;     /* internal nodes of the traversal structure */
     uint64_t bvh_bytes;     /* nodes + leaf triangles resident in HBM */
     double bvh_build_ms;    /* one-time on-GPU build (excluded from render_ms) */
+    uint32_t bvh_levels;    /* levels of the traversal structure (must not exceed the traversal stack: pt_create checks) */
 } pt_stats;
 
 /* SampleRenderer::SampleRenderer(const Model*) (SimplePathtracer.cpp:39-71): uploads the meshes
@@ -132,8 +133,9 @@ int pt_set_probe(pt_ctx* ctx, const float* data_rgba, const float* pdfX, const f
                  const float* cdfY, int width, int height);
 
 /* main.cpp:146-156 loadProbe + ProbeData::BuildCDF (Probe.h:29-77) + setProbe in one call, with the CDF built ON THE
- * GPU: one thread per row performs the reference's sequential float running sum (so the
- * arrays are bit-identical to the host BuildCDF), one thread accumulates the row totals.  data = w*h float4. */
+ * GPU: one wave per row loads 64 texels at a time and every lane runs the reference's sequential
+ * left-to-right float running sum over them (so the arrays are bit-identical to the host BuildCDF; a parallel scan would
+ * reassociate the sums); one wave does the same over the row totals.  data = w*h float4. */
 int pt_set_probe_image(pt_ctx* ctx, const float* data_rgba, int width, int height);
 /* read back the device CDF arrays (pdfX,cdfX: w*h floats; pdfY,cdfY: h floats); any pointer may be NULL */
 int pt_get_probe_cdf(pt_ctx* ctx, float* pdfX, float* cdfX, float* pdfY, float* cdfY);

@@ -51,7 +51,7 @@ class SceneDesc(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [
-        ("max_depth", C.c_int32), ("bsdf_mode", C.c_int32), ("max_paths", C.c_uint32), ("sort_rays", C.c_int32),
+        ("max_depth", C.c_int32), ("bsdf_mode", C.c_int32), ("max_paths", C.c_uint32), ("reserved0", C.c_int32),
         ("bvh_kind", C.c_int32), ("trace_kernel", C.c_int32), ("streams", C.c_int32), ("split_shadow", C.c_int32),
     ]
 
@@ -74,7 +74,7 @@ class Stats(C.Structure):
         ("render_ms", C.c_double), ("trace_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
         ("other_ms", C.c_double),
         ("trace_launches", C.c_uint32), ("shadow_launches", C.c_uint32), ("shade_launches", C.c_uint32),
-        ("bvh_nodes", C.c_uint32), ("bvh_bytes", C.c_uint64), ("bvh_build_ms", C.c_double),
+        ("bvh_nodes", C.c_uint32), ("bvh_bytes", C.c_uint64), ("bvh_build_ms", C.c_double), ("bvh_levels", C.c_uint32),
     ]
 
     def as_dict(self):

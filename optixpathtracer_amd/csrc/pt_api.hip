@@ -43,6 +43,7 @@ struct pt_ctx {
     DevProbe probe{};
     float4* d_probe_data = nullptr;
     float *d_pdfX = nullptr, *d_cdfX = nullptr, *d_pdfY = nullptr, *d_cdfY = nullptr, *d_c64X = nullptr, *d_c8X = nullptr, *d_c64Y = nullptr, *d_c8Y = nullptr;
+    float4* d_data_pdf = nullptr; // (rgb, pdfX) per texel
     // frame
     int width = 0, height = 0;
     float4 *accum = nullptr, *color = nullptr, *normal = nullptr, *albedo = nullptr;
@@ -70,11 +71,13 @@ struct pt_ctx {
     uint32_t set_cap = 0, set_pix_cap = 0, sub_cap = 0;
     bool cap_catcher = false, cap_async = false;
     int nq = 0;
-    unsigned long long* d_totals = nullptr;
+    unsigned long long* d_totals = nullptr; // [0] radiance rays, [1] shadow rays, [2] low word = traversal fault bits (pt_bvh8.h push)
     uint32_t* ovf = nullptr; // spill stacks for pt_trace queries
     unsigned long long* dbg = nullptr; // PT_DEBUG_COUNTS: traversal step counters of the last frame
     int trace_grid = 0;
     int lds_skip = 0; // PT_STACK_LDS_SKIP (test hook, pt_bvh8.h)
+    int ovf_depth = 0; // spill levels of the traversal stack (PT8_OVF_DEPTH; test hook PT_STACK_CAP lowers the total capacity)
+    int stack_check = 1; // PT_STACK_NOCHECK=1 (test hook): skip the build-time depth check so that the in-kernel fault flag is reached
     // stats + timing
     pt_stats stats{};
     std::vector<hipEvent_t> ev_pool;
@@ -141,6 +144,23 @@ static void default_options(pt_options* o) {
 }
 
 static size_t ovf_words(const pt_ctx* ctx);
+static uint32_t* fault_word(pt_ctx* ctx) { return reinterpret_cast<uint32_t*>(ctx->d_totals + 2); }
+static int stack_capacity8(const pt_ctx* ctx) { return (PT8_LDS_DEPTH - ctx->lds_skip) + ctx->ovf_depth; }
+
+// The traversal stacks are finite (k_trace8: one pushed group per level of the wide tree; k_trace/k_trace2: one node per level of
+// the binary tree).  A tree deeper than the stack is refused here, loudly, instead of being traversed with dropped entries.
+static int check_tree_depth(pt_ctx* ctx, char* msg, size_t msg_len) {
+    if (!ctx->stack_check) return PT_OK;
+    if (ctx->bvh.levels8 > stack_capacity8(ctx)) {
+        snprintf(msg, msg_len, "acceleration structure has %d levels, the traversal stack holds %d", ctx->bvh.levels8, stack_capacity8(ctx));
+        return PT_ERR_UNSUPPORTED;
+    }
+    if (ctx->bvh.nodes && ctx->bvh.depth2 > PT_STACK_DEPTH) {
+        snprintf(msg, msg_len, "binary acceleration structure is %d levels deep, the traversal stack holds %d", ctx->bvh.depth2, PT_STACK_DEPTH);
+        return PT_ERR_UNSUPPORTED;
+    }
+    return PT_OK;
+}
 
 extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ctx) {
     if (!scene || !out_ctx || scene->num_meshes == 0 || !scene->meshes) return fail(nullptr, PT_ERR_INVALID, "pt_create: null or empty scene");
@@ -249,13 +269,14 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
     CKC(tmp.event(&e0));
     CKC(tmp.event(&e1));
     CKC(hipEventRecord(e0, ctx->stream));
-    CKC(pt_bvh_build(ctx->d_verts, ctx->d_idx, (uint32_t)nt, ctx->stream, &ctx->bvh));
+    CKC(pt_bvh_build(ctx->d_verts, ctx->d_idx, (uint32_t)nt, 0, ctx->stream, &ctx->bvh));
     CKC(hipEventRecord(e1, ctx->stream));
     CKC(hipStreamSynchronize(ctx->stream));
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     ctx->bvh_build_ms = ms;
-    CKC(dalloc(&ctx->d_totals, 2));
+    CKC(dalloc(&ctx->d_totals, 3));
+    CKC(hipMemset(ctx->d_totals, 0, sizeof(unsigned long long) * 3));
     {
         hipDeviceProp_t prop;
         CKC(hipGetDeviceProperties(&prop, device));
@@ -264,6 +285,14 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
         if (const char* e = getenv("PT_STACK_LDS_SKIP")) ctx->lds_skip = std::max(0, std::min(PT8_LDS_DEPTH, atoi(e)));
         ctx->trace_grid = prop.multiProcessorCount * 4 * wpe;
         CKC(dalloc(&ctx->ovf, ovf_words(ctx)));
+        ctx->ovf_depth = PT8_OVF_DEPTH;
+        if (const char* e = getenv("PT_STACK_CAP")) ctx->ovf_depth = std::max(0, std::min(PT8_OVF_DEPTH, atoi(e) - (PT8_LDS_DEPTH - ctx->lds_skip)));
+        if (const char* e = getenv("PT_STACK_NOCHECK")) ctx->stack_check = atoi(e) == 0;
+        char msg[160];
+        if (check_tree_depth(ctx, msg, sizeof(msg)) != PT_OK) {
+            ctx->err = std::string("pt_create: ") + msg;
+            return bail(PT_ERR_UNSUPPORTED);
+        }
     }
     *out_ctx = ctx;
     return PT_OK;
@@ -304,7 +333,7 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     for (uint32_t*& px : ctx->d_tex_pixels) dfree(px);
     pt_bvh_free(&ctx->bvh);
     dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
-    dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y);
+    dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y); dfree(ctx->d_data_pdf);
     dfree(ctx->d_totals);
     dfree(ctx->ovf);
     dfree(ctx->dbg);
@@ -318,6 +347,20 @@ extern "C" int pt_set_options(pt_ctx* ctx, const pt_options* opt) {
     if (!ctx || !opt) return PT_ERR_INVALID;
     if (opt->max_depth < 0 || opt->max_depth > 250) return fail(ctx, PT_ERR_INVALID, "pt_set_options: max_depth out of range [0,250]");
     if (opt->bsdf_mode != PT_BSDF_DISNEY && opt->bsdf_mode != PT_BSDF_LAMBERT) return fail(ctx, PT_ERR_INVALID, "pt_set_options: bad bsdf_mode");
+    if (opt->reserved0 != 0) return fail(ctx, PT_ERR_INVALID, "pt_set_options: reserved0 must be 0");
+    if ((opt->bvh_kind == 1 || opt->trace_kernel == 1) && !ctx->bvh.nodes) {
+        // the binary tree is an A/B path: built (with the wide tree, from the same hierarchy) the first time it is asked for
+        CK(hipSetDevice(ctx->device));
+        CK(hipStreamSynchronize(ctx->stream));
+        pt_bvh_free(&ctx->bvh);
+        CK(pt_bvh_build(ctx->d_verts, ctx->d_idx, ctx->ntri, 1, ctx->stream, &ctx->bvh));
+        CK(hipStreamSynchronize(ctx->stream));
+        char msg[160];
+        if (check_tree_depth(ctx, msg, sizeof(msg)) != PT_OK) {
+            ctx->err = std::string("pt_set_options: ") + msg;
+            return PT_ERR_UNSUPPORTED;
+        }
+    }
     ctx->opt = *opt;
     if (ctx->opt.max_paths == 0) ctx->opt.max_paths = 8u << 20;
     return PT_OK;
@@ -390,7 +433,12 @@ extern "C" int pt_uvw_frame(const float eye[3], const float lookat[3], const flo
 
 // finish a probe upload: build the block-search accelerators and publish the device view
 static int finish_probe(pt_ctx* ctx, int w, int h) {
-    dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y);
+    dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y); dfree(ctx->d_data_pdf);
+    {
+        const size_t n = (size_t)w * h;
+        CK(dalloc(&ctx->d_data_pdf, n));
+        hipLaunchKernelGGL(k_probe_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_probe_data, ctx->d_pdfX, n, ctx->d_data_pdf);
+    }
     const int ncx = w / PT_CDF_BLOCK, ncy = h / PT_CDF_BLOCK;
     const int ncx_pad = (ncx + 7) & ~7, ncy_pad = (ncy + 7) & ~7;
     const bool okx = (w % PT_CDF_BLOCK) == 0 && w >= PT_CDF_BLOCK, oky = (h % PT_CDF_BLOCK) == 0 && h >= PT_CDF_BLOCK;
@@ -410,7 +458,7 @@ static int finish_probe(pt_ctx* ctx, int w, int h) {
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipGetLastError());
     ctx->probe = DevProbe{w, h, ctx->d_probe_data, ctx->d_pdfX, ctx->d_cdfX, ctx->d_pdfY, ctx->d_cdfY,
-                          ctx->d_c64X, ctx->d_c8X, ctx->d_c64Y, ctx->d_c8Y, ncx, ncx_pad, ncy};
+                          ctx->d_c64X, ctx->d_c8X, ctx->d_c64Y, ctx->d_c8Y, ncx, ncx_pad, ncy, ctx->d_data_pdf};
     return PT_OK;
 }
 
@@ -553,7 +601,9 @@ static bool async_shadows(const pt_ctx* ctx) {
 }
 
 static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_cap) {
-    const int nq = ctx->opt.max_depth + 2;
+    // one queue-counter slot per bounce plus the "would continue" slot; shadow-catcher scenes get two more for the extra
+    // iterations of paths that passed through catcher surfaces (enqueue_chunk)
+    const int nq = ctx->opt.max_depth + 2 + (ctx->has_catcher ? 2 : 0);
     const bool async = async_shadows(ctx);
     if ((int)ctx->sets.size() == nsets && cap <= ctx->set_cap && pix_cap <= ctx->set_pix_cap && nq <= ctx->nq &&
         (!ctx->has_catcher || ctx->cap_catcher) && async == ctx->cap_async)
@@ -568,8 +618,8 @@ static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_
         PathState& s = b.st;
         CK(dalloc(&s.rayO, cap)); CK(dalloc(&s.rayD, cap)); CK(dalloc(&s.srayD, cap)); CK(dalloc(&s.pend, cap));
         CK(dalloc(&s.hit, cap)); CK(dalloc(&s.thr, cap)); CK(dalloc(&s.rng, cap)); CK(dalloc(&s.fd, cap));
-        CK(dalloc(&s.direct, cap)); CK(dalloc(&s.indirect, cap)); CK(dalloc(&s.alpha, cap)); CK(dalloc(&s.nrm, cap)); CK(dalloc(&s.alb, cap));
-        if (ctx->has_catcher) { CK(dalloc(&s.prdN, cap)); CK(dalloc(&s.prdA, cap)); }
+        CK(dalloc(&s.direct, cap)); CK(dalloc(&s.indirect, cap)); CK(dalloc(&s.nrm, cap)); CK(dalloc(&s.alb, cap));
+        if (ctx->has_catcher) { CK(dalloc(&s.alpha, cap)); CK(dalloc(&s.prdN, cap)); CK(dalloc(&s.prdA, cap)); }
         CK(dalloc(&b.queueA, qsize)); CK(dalloc(&b.queueB, qsize)); CK(dalloc(&b.squeue, qsize));
         CK(dalloc(&b.counters, (size_t)2 * nq * PT_NSUB * PT_CSTRIDE + 2 * nq));
         CK(dalloc(&b.ovf, ovf_words(ctx))); CK(dalloc(&b.ovf2, ovf_words(ctx)));
@@ -678,14 +728,14 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             std::vector<hipEvent_t> shadow_done;
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip};
+                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeueB + (size_t)b * qsize, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow};
+                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? 0 : 1};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
@@ -699,7 +749,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     hipStreamWaitEvent(ss, ev_shaded, 0);
                     {
                         SpanGuard g(ctx, CLS_SHADOW, ss);
-                        Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, (b & 1) ? bs.ovf3 : bs.ovf2, cull, nullptr, b, ctx->lds_skip};
+                        Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, (b & 1) ? bs.ovf3 : bs.ovf2, cull, nullptr, b, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
                         hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, ss, ta);
                         ++lc.shadow;
                     }
@@ -709,7 +759,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qnext, QView{}, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip};
+                    Trace8Args ta{bs.st, bvh8, qnext, QView{}, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 }
@@ -723,14 +773,14 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             // and a frame has max_depth+1 traversal launches instead of 2*max_depth.
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip};
+                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeue, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow};
+                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? 0 : 1};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
@@ -739,12 +789,12 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip};
+                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
                     hipLaunchKernelGGL((k_trace8<TR_UNIFIED>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 } else {
                     SpanGuard g(ctx, CLS_SHADOW, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip};
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.shadow;
                 }
@@ -763,12 +813,12 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     Trace2Args ta{bs.st, bvh, qcur, work + b, bs.ovf, nullptr};
                     hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 } else {
-                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip};
+                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 }
                 ++lc.trace;
             }
-            ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow};
+            ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? 0 : 1};
             if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0); // shade overwrites what shadow(b-1) reads
             {
                 SpanGuard g(ctx, CLS_SHADE, bs.stream);
@@ -789,7 +839,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     Trace2Args ta{bs.st, bvh, qshadow, work + nq + b, bs.ovf2, nullptr};
                     hipLaunchKernelGGL((k_trace2<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
                 } else {
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr, 0, ctx->lds_skip};
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
                 }
                 ++lc.shadow;
@@ -800,6 +850,52 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             qnext_base = (qnext_base == bs.queueA) ? bs.queueB : bs.queueA;
         }
         if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0);
+        if (ctx->has_catcher) {
+            // A secondary hit on a shadow-catcher surface passes through WITHOUT consuming depth (--prd->depth, deviceProgram.cu:503-508),
+            // so a path with k pass-throughs is traced max_depth+1+k times by the reference's raygen loop (:411-443).  The chain
+            // above ran max_depth+1 iterations; the paths still queued are exactly those, and they are iterated until none is left
+            // (a host read of one queue size per extra iteration — shadow-catcher scenes only).
+            const int e0 = last_bounce + 1;
+            int cur = e0;
+            for (int guard = 0; guard < 4096; ++guard) {
+                uint32_t hc[PT_NSUB * PT_CSTRIDE];
+                if (hipMemcpyAsync(hc, cntA + (size_t)cur * CS, sizeof(hc), hipMemcpyDeviceToHost, bs.stream) != hipSuccess) break;
+                if (hipStreamSynchronize(bs.stream) != hipSuccess) break;
+                unsigned long long left = 0;
+                for (int q = 0; q < PT_NSUB; ++q) left += hc[q * PT_CSTRIDE];
+                if (left == 0) break;
+                const int nxt = (cur == e0 + 1) ? e0 + 2 : e0 + 1;
+                hipMemsetAsync(cntA + (size_t)nxt * CS, 0, sizeof(uint32_t) * CS, bs.stream);
+                hipMemsetAsync(cntS + (size_t)cur * CS, 0, sizeof(uint32_t) * CS, bs.stream);
+                hipMemsetAsync(work + cur, 0, sizeof(uint32_t), bs.stream);
+                hipMemsetAsync(work + nq + cur, 0, sizeof(uint32_t), bs.stream);
+                QView qnext{qnext_base, cntA + (size_t)nxt * CS, ctx->sub_cap};
+                QView qshadow{bs.squeue, cntS + (size_t)cur * CS, ctx->sub_cap};
+                {
+                    SpanGuard g(ctx, CLS_TRACE, bs.stream);
+                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
+                    hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                    ++lc.trace;
+                }
+                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, 1};
+                {
+                    SpanGuard g(ctx, CLS_SHADE, bs.stream);
+                    if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
+                    else launch_shade<PT_BSDF_DISNEY>(ctx, bs, sp);
+                    ++lc.shade;
+                }
+                {
+                    SpanGuard g(ctx, CLS_SHADOW, bs.stream);
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
+                    hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                    ++lc.shadow;
+                }
+                hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters + (size_t)cur * CS, nq, 1, ctx->d_totals);
+                qcur = qnext;
+                qnext_base = (qnext_base == bs.queueA) ? bs.queueB : bs.queueA;
+                cur = nxt;
+            }
+        }
         if (before_resolve) // foveated launches: this launch's pixels are written after the previous launch's (they overlap)
             for (hipEvent_t e : *before_resolve) hipStreamWaitEvent(bs.stream, e, 0);
         {
@@ -836,12 +932,12 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
         if (rc) return rc;
     }
     if (getenv("PT_DEBUG_COUNTS")) {
-        if (!ctx->dbg) CK(dalloc(&ctx->dbg, 16));
-        CK(hipMemset(ctx->dbg, 0, 128));
+        if (!ctx->dbg) CK(dalloc(&ctx->dbg, 64));
+        CK(hipMemset(ctx->dbg, 0, 512));
     }
     ctx->ev_used = 0;
     ctx->spans.clear();
-    CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 2, ctx->stream));
+    CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 3, ctx->stream));
     hipEvent_t ev_begin = next_event(ctx);
     CK(hipEventRecord(ev_begin, ctx->stream));
     FrameParams fp{ctx->accum, ctx->frame, ctx->color, ctx->normal, ctx->albedo, ctx->width, ctx->height, subframe_index,
@@ -862,11 +958,17 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     CK(hipEventRecord(ev_end, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream)); // SimplePathtracer.cpp:96 CUDA_SYNC_CHECK
     CK(hipGetLastError());
-    unsigned long long totals[2] = {0, 0};
+    unsigned long long totals[3] = {0, 0, 0};
     CK(hipMemcpy(totals, ctx->d_totals, sizeof(totals), hipMemcpyDeviceToHost));
+    if (totals[2] & 1ull) return fail(ctx, PT_ERR_UNSUPPORTED, "traversal stack overflow: the acceleration structure is deeper than the traversal stack; the frame is invalid");
     if (ctx->dbg) {
-        unsigned long long h[16];
-        CK(hipMemcpy(h, ctx->dbg, 128, hipMemcpyDeviceToHost));
+        unsigned long long h[64];
+        CK(hipMemcpy(h, ctx->dbg, 512, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pt_render] rays by traversal steps (2^k..): closest");
+        for (int k = 0; k < 14; ++k) fprintf(stderr, " %llu", h[16 + k]);
+        fprintf(stderr, " | shadow");
+        for (int k = 0; k < 14; ++k) fprintf(stderr, " %llu", h[32 + k]);
+        fprintf(stderr, "\n");
         fprintf(stderr, "[pt_render] traversal: node steps %llu, tri tests %llu, max steps of one ray %llu, max wave loop iterations %llu, mean %.1f\n", h[0], h[1], h[4], h[5], h[7] ? (double)h[6] / h[7] : 0.0);
         fprintf(stderr, "[pt_render] per loop iteration: lanes holding a ray %.1f / 64, lanes executing the chosen step %.1f / 64, node-step iterations %.1f %%\n",
                 h[6] ? (double)h[8] / h[6] : 0.0, h[6] ? (double)h[9] / h[6] : 0.0, h[6] ? 100.0 * h[10] / h[6] : 0.0);
@@ -946,7 +1048,7 @@ extern "C" int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t
     }
     ctx->ev_used = 0;
     ctx->spans.clear();
-    CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 2, ctx->stream));
+    CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 3, ctx->stream));
     hipEvent_t ev_begin = next_event(ctx);
     CK(hipEventRecord(ev_begin, ctx->stream));
     for (auto& b : ctx->sets) hipStreamWaitEvent(b.stream, ev_begin, 0);
@@ -990,8 +1092,9 @@ extern "C" int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t
     CK(hipEventRecord(ev_end, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipGetLastError());
-    unsigned long long totals[2] = {0, 0};
+    unsigned long long totals[3] = {0, 0, 0};
     CK(hipMemcpy(totals, ctx->d_totals, sizeof(totals), hipMemcpyDeviceToHost));
+    if (totals[2] & 1ull) return fail(ctx, PT_ERR_UNSUPPORTED, "traversal stack overflow: the acceleration structure is deeper than the traversal stack; the frame is invalid");
     pt_stats& st = ctx->stats;
     st.radiance_rays = totals[0];
     st.shadow_rays = totals[1];
@@ -1160,6 +1263,7 @@ extern "C" int pt_get_stats(const pt_ctx* ctx, pt_stats* out) {
     out->bvh_bytes = wide ? (uint64_t)ctx->bvh.num_nodes8 * sizeof(Node8) + (uint64_t)ctx->bvh.num_tris8 * sizeof(LeafTri)
                           : (uint64_t)ctx->bvh.num_nodes * sizeof(Node2) + (uint64_t)ctx->bvh.num_tris * sizeof(LeafTri);
     out->bvh_build_ms = ctx->bvh_build_ms;
+    out->bvh_levels = (uint32_t)(wide ? ctx->bvh.levels8 : ctx->bvh.depth2);
     return PT_OK;
 }
 
@@ -1208,10 +1312,11 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     st.rayD = dD;
     st.hit = dHit;
     if (getenv("PT_DEBUG_COUNTS")) {
-        CK(tmp.alloc(&dDbg, 16));
-        CK(hipMemset(dDbg, 0, 128));
+        CK(tmp.alloc(&dDbg, 64));
+        CK(hipMemset(dDbg, 0, 512));
     }
     CK(hipMemsetAsync(dWork, 0, sizeof(uint32_t) * iters, ctx->stream));
+    CK(hipMemsetAsync(ctx->d_totals + 2, 0, sizeof(unsigned long long), ctx->stream));
     CK(hipEventRecord(e0, ctx->stream));
     for (int it = 0; it < iters; ++it) {
         if (ctx->opt.trace_kernel == 1) {
@@ -1224,7 +1329,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
             if (any_hit) hipLaunchKernelGGL((k_trace2<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         } else {
-            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8}, QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, 0, dDbg, 0, ctx->lds_skip};
+            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8}, QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, 0, dDbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
             if (any_hit) hipLaunchKernelGGL((k_trace8<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         }
@@ -1235,6 +1340,11 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     if (kernel_ms) *kernel_ms = ms / iters;
+    {
+        unsigned long long fault = 0;
+        CK(hipMemcpy(&fault, ctx->d_totals + 2, sizeof(fault), hipMemcpyDeviceToHost));
+        if (fault & 1ull) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_trace: traversal stack overflow: the acceleration structure is deeper than the traversal stack");
+    }
     if (dDbg) {
         unsigned long long h[8];
         CK(hipMemcpy(h, dDbg, 64, hipMemcpyDeviceToHost));

@@ -55,6 +55,24 @@ struct Bvh8Dev {
 #ifndef PT8_WAVES_PER_EU
 #define PT8_WAVES_PER_EU 4
 #endif
+// In-wave work stealing (tail of a launch).  Once a wave has taken its last chunk of the queue, a lane that runs dry no
+// longer idles until the wave's longest ray is done: it takes over the BOTTOM entry of a busy lane's traversal stack (the
+// far end of that ray: the not yet visited children of the node closest to the root) together with a copy of the ray, and
+// traverses it as a co-worker.  Co-workers of a ray share one record in LDS — the best (t, primitive) found so far as a
+// 64-bit key merged with an atomic minimum (closest hit = lexicographic minimum, exactly the kernel's tie-break rule; a
+// shadow ray's key drops to 0 when any co-worker finds an occluder) and a count of workers; whoever brings the count to 0
+// writes the ray's result.  The answer is the minimum over the same set of accepted triangles whatever the split, so
+// images do not change by a bit; what changes is that a 500-step ray that used to hold its wave (and the launch: 9 launches
+// per frame, each as long as its longest ray) for 500 iterations is traversed by up to 64 lanes.
+#ifndef PT8_STEAL
+#define PT8_STEAL 1
+#endif
+#ifndef PT8_STEAL_MIN_STEPS
+#define PT8_STEAL_MIN_STEPS 24 // a lane becomes a victim once its ray has taken this many steps (short rays are left alone)
+#endif
+#ifndef PT8_STEAL_PERIOD
+#define PT8_STEAL_PERIOD 3 // traversal iterations between two steal rounds while lanes are idle
+#endif
 
 #ifdef PT_DEBUG_STATS
 #define PT_STAT(x) x
@@ -70,9 +88,12 @@ struct Trace8Args {
     uint32_t* work;
     uint32_t* ovf; // spill stack: [PT8_OVF_DEPTH][2][gridDim.x * 64]
     int cull_back; // shadow rays ignore back-facing triangles (sv3/sv4 occlusion ray flag)
-    unsigned long long* dbg; // optional: [0] node steps, [1] triangle tests, [2] max stack depth, [3] pushes (pt_trace + PT_DEBUG_COUNTS)
+    unsigned long long* dbg; // optional, 64 words: [0] node steps, [1] triangle tests, [2] max stack depth, [3] pushes, ...; [16+k] closest-hit rays and
+                             // [32+k] shadow rays that took 2^k..2^(k+1)-1 steps (PT_DEBUG_STATS builds + PT_DEBUG_COUNTS)
     int bounce;   // shadow modes with asynchronous shadow records (st.vis != null): the bounce whose records this launch traces
     int lds_skip; // test hook (PT_STACK_LDS_SKIP): keep this many fewer stack levels in LDS, so shallow trees exercise the global spill path
+    int ovf_depth;  // spill levels available (PT8_OVF_DEPTH; the test hook PT_STACK_CAP lowers it)
+    uint32_t* fault; // device word: bit 0 set when a push found the stack full — the host turns it into PT_ERR_UNSUPPORTED
 };
 
 PT_DEV float u8f(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
@@ -83,6 +104,11 @@ k_trace8(Trace8Args a) {
     __shared__ uint32_t s_stack[PT8_LDS_DEPTH * 2 * 64];
     __shared__ uint32_t s_prefix[PT_NSUB + 1];
     __shared__ uint32_t s_prefix2[PT_NSUB + 1];
+#if PT8_STEAL
+    __shared__ unsigned long long s_key[64]; // per owner lane: merged result of the ray that lane loaded
+    __shared__ uint32_t s_cnt[64];           // per owner lane: co-workers still traversing that ray
+    __shared__ uint32_t s_vlane[64];         // steal round: victim lane by rank
+#endif
     const uint32_t lane = threadIdx.x;
     const uint32_t gtid = blockIdx.x * 64u + lane;
     const uint32_t gstride = gridDim.x * 64u;
@@ -108,6 +134,10 @@ k_trace8(Trace8Args a) {
     uint32_t g_base = 0, g_imask = 0, g_hits = 0; // current node group: children still to visit (slot positions)
     uint32_t t_base = 0, t_mask = 0, t_bits = 0; // current triangle group: pending bits of the node's leafbits
     int sp = 0;
+    int sb = 0;              // stack bottom: levels [sb, sp) are live (entries below sb were taken by co-workers)
+    bool stealing = false;   // wave-uniform: the queue is exhausted and the shared records are in use
+    uint32_t owner = lane;   // the lane whose record this lane's ray belongs to
+    uint32_t nsteps = 0;     // steps taken for the current ray (inherited by co-workers)
     uint32_t slot = 0, hint1 = 0, hint2 = 0;
     PT_STAT(uint32_t c_nodes = 0; uint32_t c_tris = 0; uint32_t c_maxsp = 0; uint32_t c_push = 0; uint32_t c_ray = 0; uint32_t c_raymax = 0; uint32_t c_iters = 0;
             uint32_t c_act = 0; uint32_t c_exec = 0; uint32_t c_nodeit = 0;)
@@ -117,13 +147,19 @@ k_trace8(Trace8Args a) {
         if (sp < lds_depth) {
             s_stack[(sp * 2) * 64 + lane] = v0;
             s_stack[(sp * 2 + 1) * 64 + lane] = v1;
-        } else if (sp < lds_depth + PT8_OVF_DEPTH) {
+        } else if (sp < lds_depth + a.ovf_depth) {
             a.ovf[(size_t)((sp - lds_depth) * 2) * gstride + gtid] = v0;
             a.ovf[(size_t)((sp - lds_depth) * 2 + 1) * gstride + gtid] = v1;
+        } else {
+            // Stack full: pt_create refuses trees deeper than the stack, so this is unreachable unless that check is
+            // bypassed; the entry is dropped WITHOUT advancing sp (pops stay matched, no stray read) and the launch is
+            // reported as failed instead of returning a silently wrong image.
+            atomicOr(a.fault, 1u);
+            return;
         }
         ++sp;
     };
-    auto pop = [&](uint32_t& v0, uint32_t& v1) {
+    auto pop = [&](uint32_t& v0, uint32_t& v1) { // caller checked sp > sb
         --sp;
         if (sp < lds_depth) {
             v0 = s_stack[(sp * 2) * 64 + lane];
@@ -133,13 +169,12 @@ k_trace8(Trace8Args a) {
             v1 = a.ovf[(size_t)((sp - lds_depth) * 2 + 1) * gstride + gtid];
         }
     };
-    auto finish = [&]() {
+    // write the ray's result: (best, bprim) = closest hit / occlusion flag
+    auto write_result = [&](float rbest, int32_t rprim) {
         if (MODE == TR_SHADOW_APPLY || (MODE == TR_UNIFIED && shadow_lane)) {
-            const bool occluded = bprim != 0;
+            const bool occluded = rprim != 0;
             if (a.st.vis) { // asynchronous shadow records: only publish the visibility, k_resolve sums in bounce order
                 if (!occluded) atomicOr(&a.st.vis[slot], 1u << a.bounce);
-                active = false;
-                PT_STAT(if (c_ray > c_raymax) c_raymax = c_ray; c_ray = 0;)
                 return;
             }
             const float4 pe = a.st.pend[slot];
@@ -155,10 +190,37 @@ k_trace8(Trace8Args a) {
                 acc[slot] = make_float4(x.x + pe.x, x.y + pe.y, x.z + pe.z, 0.f);
             }
         } else {
-            a.st.hit[slot] = make_float2(best, __int_as_float(bprim));
+            a.st.hit[slot] = make_float2(rbest, __int_as_float(rprim));
         }
+    };
+    const auto is_shadow = [&]() { return MODE == TR_SHADOW_APPLY || MODE == TR_ANY_QUERY || (MODE == TR_UNIFIED && shadow_lane); };
+#if PT8_STEAL
+    // 64-bit result key: closest hit = (bits of t) << 32 | primitive (t > 0, so the bits order like the floats; "no hit" is
+    // (tmax, -1) = the largest key of the ray); shadow ray = 0 occluded / ~0 not occluded
+    auto local_key = [&]() -> unsigned long long {
+        if (is_shadow()) return bprim != 0 ? 0ull : ~0ull;
+        return ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(uint32_t)bprim;
+    };
+#endif
+    // this lane is done with its (share of the) ray
+    auto finish = [&]() {
+#if PT8_STEAL
+        if (stealing) {
+            atomicMin(&s_key[owner], local_key());
+            if (atomicSub(&s_cnt[owner], 1u) == 1u) { // the last co-worker publishes the merged result
+                const unsigned long long k = s_key[owner];
+                if (is_shadow()) write_result(0.f, k == 0ull ? 1 : 0);
+                else write_result(__uint_as_float((uint32_t)(k >> 32)), (int32_t)(uint32_t)k);
+            }
+            active = false;
+            return;
+        }
+#endif
+        write_result(best, bprim);
         active = false;
-        PT_STAT(if (c_ray > c_raymax) c_raymax = c_ray; c_ray = 0;)
+        PT_STAT(if (c_ray > c_raymax) c_raymax = c_ray;
+                if (a.dbg) atomicAdd(&a.dbg[(is_shadow() ? 32 : 16) + (31 - __clz((int)(c_ray | 1u)))], 1ull);
+                c_ray = 0;)
     };
 
     for (;;) {
@@ -231,6 +293,8 @@ k_trace8(Trace8Args a) {
                 best = tmax;
                 bprim = (MODE == TR_CLOSEST || (MODE == TR_UNIFIED && !shadow_lane)) ? -1 : 0;
                 sp = 0;
+                sb = 0;
+                nsteps = 0;
                 // the root is node 0: a group whose only internal child is slot 0 of a virtual parent
                 g_base = 0;
                 g_imask = 1u;
@@ -239,18 +303,99 @@ k_trace8(Trace8Args a) {
                 active = true;
             }
         }
+#if PT8_STEAL
+        if (exhausted) {
+            if (!stealing) { // the wave took its last chunk: from here on its rays are shared work
+                stealing = true;
+                owner = lane;
+                if (active) {
+                    s_cnt[lane] = 1u;
+                    s_key[lane] = local_key();
+                }
+                __syncthreads(); // one wave per workgroup: orders the LDS writes above before other lanes' reads
+            }
+            // ---------------- steal round: idle lane k takes the bottom stack entry of victim k
+            const unsigned long long idle2 = __ballot(!active);
+            const bool victim = active && sp > sb && sb < lds_depth && nsteps >= (uint32_t)PT8_STEAL_MIN_STEPS;
+            const unsigned long long vmask = __ballot(victim);
+            if (idle2 != 0ull && vmask != 0ull) {
+                const uint32_t ni = (uint32_t)__popcll(idle2), nv = (uint32_t)__popcll(vmask);
+                const uint32_t m = ni < nv ? ni : nv;
+                const uint32_t vrank = (uint32_t)__popcll(vmask & lt_mask), irank = (uint32_t)__popcll(idle2 & lt_mask);
+                const bool give = victim && vrank < m, take = !active && irank < m;
+                if (give) s_vlane[vrank] = lane;
+                __syncthreads();
+                const uint32_t v = take ? s_vlane[irank] : lane; // every lane runs the shuffles; only takers keep what they read
+                const float ox = __shfl(r.o.x, (int)v), oy = __shfl(r.o.y, (int)v), oz = __shfl(r.o.z, (int)v);
+                const float dx = __shfl(r.d.x, (int)v), dy = __shfl(r.d.y, (int)v), dz = __shfl(r.d.z, (int)v);
+                const float ix = __shfl(r.idir.x, (int)v), iy = __shfl(r.idir.y, (int)v), iz = __shfl(r.idir.z, (int)v);
+                const float nx_ = __shfl(r.dn.x, (int)v), ny_ = __shfl(r.dn.y, (int)v), nz_ = __shfl(r.dn.z, (int)v);
+                const float vtmin = __shfl(tmin, (int)v), vtmax = __shfl(tmax, (int)v);
+                const uint32_t vpm = __shfl(pm, (int)v), vslot = __shfl(slot, (int)v), vowner = __shfl(owner, (int)v), vsteps = __shfl(nsteps, (int)v);
+                const int vsb = __shfl(sb, (int)v);
+                const int vshadow = __shfl((int)shadow_lane, (int)v);
+                if (take) {
+                    r.o = mk3(ox, oy, oz);
+                    r.d = mk3(dx, dy, dz);
+                    r.idir = mk3(ix, iy, iz);
+                    r.dn = mk3(nx_, ny_, nz_);
+                    tmin = vtmin;
+                    tmax = vtmax;
+                    pm = vpm;
+                    slot = vslot;
+                    owner = vowner;
+                    nsteps = vsteps;
+                    shadow_lane = vshadow != 0;
+                    const uint32_t e0 = s_stack[(vsb * 2) * 64 + v], e1 = s_stack[(vsb * 2 + 1) * 64 + v];
+                    g_base = e0;
+                    g_imask = e1 & 0xffu;
+                    g_hits = e1 >> 8;
+                    t_mask = 0;
+                    sp = sb = 0;
+                    // start from the ray's merged state (so that the tie-break "equal t, lower primitive" sees the current holder)
+                    const unsigned long long k = s_key[owner];
+                    if (is_shadow()) {
+                        best = tmax;
+                        bprim = 0; // k == 0 (already occluded) is caught by the refresh below
+                    } else {
+                        best = __uint_as_float((uint32_t)(k >> 32));
+                        bprim = (int32_t)(uint32_t)k;
+                    }
+                    atomicAdd(&s_cnt[owner], 1u);
+                    active = true;
+                }
+                __syncthreads(); // takers have read the entries before their victims may overwrite those levels
+                if (give) {
+                    ++sb;
+                    if (sb == sp) sb = sp = 0;
+                }
+            }
+        }
+#endif
         unsigned long long act = __ballot(active);
         if (act == 0ull) break;
         const uint32_t thresh = exhausted ? 1u : (uint32_t)PT8_REFILL;
+        uint32_t it = 0;
         // ---------------- traverse
         do {
+#if PT8_STEAL
+            if (stealing && active) { // pick up what the ray's other workers found
+                const unsigned long long k = s_key[owner];
+                if (is_shadow()) {
+                    if (k == 0ull) finish(); // occluded elsewhere: nothing left to do for this ray
+                } else if (k < local_key()) {
+                    best = __uint_as_float((uint32_t)(k >> 32));
+                    bprim = (int32_t)(uint32_t)k;
+                }
+            }
+#endif
             const bool want_tri = active && t_mask != 0u;
             const bool want_node = active && t_mask == 0u; // node step also covers "group empty → pop"
             const unsigned long long m_tri = __ballot(want_tri), m_node = __ballot(want_node);
             if (__popcll(m_node) >= PT8_TRI_BIAS * __popcll(m_tri)) {
                 if (want_node) {
                     if (g_hits == 0u) {
-                        if (sp == 0) {
+                        if (sp == sb) {
                             finish();
                         } else {
                             uint32_t v0, v1;
@@ -272,6 +417,7 @@ k_trace8(Trace8Args a) {
                         const uint32_t idx = g_base + (uint32_t)__popc(g_imask & (h - 1u));
                         if (g_hits != 0u) push(g_base, g_imask | (g_hits << 8));
                         PT_STAT(++c_nodes; ++c_ray;)
+                        ++nsteps;
                         const Node8* nd = &a.bvh.nodes[idx];
                         const float4 n0 = nd->n0, n1 = nd->n1, n2 = nd->n2, n3 = nd->n3, n4 = nd->n4;
                         const uint32_t e01 = __float_as_uint(n0.w), e2m = __float_as_uint(n1.w);
@@ -336,6 +482,9 @@ k_trace8(Trace8Args a) {
                         } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim))) {
                             best = t;
                             bprim = prim;
+#if PT8_STEAL
+                            if (stealing) atomicMin(&s_key[owner], local_key());
+#endif
                         }
                     }
                 }
@@ -347,6 +496,11 @@ k_trace8(Trace8Args a) {
                 c_nodeit += node_step ? 1u : 0u;
             })
             act = __ballot(active);
+            ++it;
+#if PT8_STEAL
+            // with idle lanes around, return to the steal round every PT8_STEAL_PERIOD iterations
+            if (stealing && act != ~0ull && it >= (uint32_t)PT8_STEAL_PERIOD) break;
+#endif
         } while ((uint32_t)__popcll(act) >= thresh);
     }
     PT_STAT(if (a.dbg) {

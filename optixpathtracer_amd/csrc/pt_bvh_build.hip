@@ -674,11 +674,12 @@ static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt,
 }
 
 // Builds the traversal structure for (verts, idx) already resident on the device.
-hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t ntri, hipStream_t stream, PtBvh* out) {
+hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t ntri, int want_bvh2, hipStream_t stream, PtBvh* out) {
     out->nodes = nullptr;
     out->tris = nullptr;
     out->num_nodes = 0;
     out->num_tris = ntri;
+    out->depth2 = 0;
     const int n = (int)ntri;
     const int B = 256;
     // leaf triangles + keys
@@ -730,6 +731,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t nt
         out->nodes8 = nodes8; out->tris8 = tris8; out->num_nodes8 = 1; out->num_tris8 = (uint32_t)n; out->levels8 = 1;
         HIPCHK(hipStreamSynchronize(stream));
         hipFree(dbounds);
+        if (!want_bvh2) { hipFree(tris); out->tris = nullptr; out->num_tris = 0; }
         hipFree(keys); hipFree(keys_sorted); hipFree(bounds); hipFree(tmp);
         return hipSuccess;
     }
@@ -760,14 +762,37 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t nt
     HIPCHK(hipMemcpyAsync(&last_remap, remap + (n - 2), 4, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     const uint32_t nnodes = last_keep + last_remap;
-    Node2* nodes = nullptr;
-    HIPCHK(hipMalloc(&nodes, sizeof(Node2) * (size_t)(nnodes ? nnodes : 1)));
-    hipLaunchKernelGGL(k_emit_nodes, dim3((n + B - 1) / B), dim3(B), 0, stream, n, left, right, rfirst, rlast, keep, remap, box, pad, nodes);
-    HIPCHK(hipStreamSynchronize(stream));
-    HIPCHK(hipGetLastError());
-    out->nodes = nodes;
-    out->num_nodes = nnodes;
-    out->root = 0; // node 0 (range = everything) always stays internal when n > PT_LEAF_MAX, and remap[0] = 0
+    if (want_bvh2) { // the binary form is an A/B path (pt_options.bvh_kind = 1 / trace_kernel = 1): only built on request
+        Node2* nodes = nullptr;
+        HIPCHK(hipMalloc(&nodes, sizeof(Node2) * (size_t)(nnodes ? nnodes : 1)));
+        hipLaunchKernelGGL(k_emit_nodes, dim3((n + B - 1) / B), dim3(B), 0, stream, n, left, right, rfirst, rlast, keep, remap, box, pad, nodes);
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipGetLastError());
+        out->nodes = nodes;
+        out->num_nodes = nnodes;
+        out->root = 0; // node 0 (range = everything) always stays internal when n > PT_LEAF_MAX, and remap[0] = 0
+        // depth of the binary tree (bounds the traversal stack of bvh2_traverse / k_trace2): host walk over the emitted nodes
+        std::vector<Node2> h(nnodes);
+        HIPCHK(hipMemcpy(h.data(), nodes, sizeof(Node2) * h.size(), hipMemcpyDeviceToHost));
+        std::vector<int> depth(nnodes, 0);
+        std::vector<int32_t> todo{0};
+        depth[0] = 1;
+        int dmax = 1;
+        while (!todo.empty()) {
+            const int32_t k = todo.back();
+            todo.pop_back();
+            int32_t c[2];
+            memcpy(&c[0], &h[k].d.x, 4);
+            memcpy(&c[1], &h[k].d.y, 4);
+            for (int j = 0; j < 2; ++j)
+                if (c[j] >= 0 && c[j] != PT_REF_EMPTY && (uint32_t)c[j] < nnodes) {
+                    depth[c[j]] = depth[k] + 1;
+                    dmax = depth[c[j]] > dmax ? depth[c[j]] : dmax;
+                    todo.push_back(c[j]);
+                }
+        }
+        out->depth2 = dmax;
+    }
     {
         // hierarchy for the wide tree: the LBVH itself (default) or PLOC (PT_BVH_BUILDER=ploc).  Measured on the C3 voxel
         // terrain: PLOC gives MORE node visits per ray (13.3 vs 12.5 primary, 15.9 vs 13.6 diffuse bounce) and 5 % lower
@@ -785,6 +810,11 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t nt
     hipFree(keys); hipFree(keys_sorted); hipFree(bounds); hipFree(tmp); hipFree(tmp2);
     hipFree(left); hipFree(right); hipFree(parent); hipFree(rfirst); hipFree(rlast); hipFree(visits);
     hipFree(box); hipFree(keep); hipFree(remap);
+    if (!want_bvh2) { // the sorted leaf triangles only fed the wide tree's leaf arrays
+        hipFree(tris);
+        out->tris = nullptr;
+        out->num_tris = 0;
+    }
     return hipSuccess;
 }
 

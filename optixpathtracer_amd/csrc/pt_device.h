@@ -335,7 +335,14 @@ struct DevProbe {
     // search accelerators built at setProbe: the last CDF value of every PT_CDF_BLOCK-entry block, per row / of cdfY
     const float *c64X, *c8X, *c64Y, *c8Y; // [height][ncx_pad], [height][width/8], [ncy_pad], [height/8]; null = binary search
     int ncx, ncx_pad, ncy;
+    const float4* data_pdf; // (data.rgb, pdfX) per texel: ProbeSample's colour and conditional pdf in one 16-byte load
 };
+// The marginal (row) arrays ProbeSample reads: the global ones, or k_shade's per-workgroup LDS copy (≈4.6 KB for a 1024-row
+// probe) so that the row search and pdfY never leave the CU
+struct ProbeMarg {
+    const float *cdfY, *pdfY, *c64Y, *c8Y;
+};
+PT_DEV ProbeMarg probe_marg_global(const DevProbe& p) { return ProbeMarg{p.cdfY, p.pdfY, p.c64Y, p.c8Y}; }
 
 // :38-46
 PT_DEV void probe_dir_to_uv(v3 dir, float& u, float& v) {
@@ -399,23 +406,23 @@ PT_DEV int lower_bound_blocked(const float* __restrict__ row, int n, const float
 }
 
 // :138-169 (row/col clamped: unreachable for a valid CDF, guards a degenerate probe)
-PT_DEV void probe_sample(const DevProbe& p, v3& dir, v3& color, float& pdf, Rng& rand) {
+PT_DEV void probe_sample(const DevProbe& p, const ProbeMarg& pm, v3& dir, v3& color, float& pdf, Rng& rand) {
     float r1, r2;
     sample2d(rand, r1, r2);
 #ifdef PT_EXP_NO_SEARCH
     int row = (int)(r1 * p.height);
     int col = (int)(r2 * p.width);
 #else
-    int row = p.c64Y ? lower_bound_blocked(p.cdfY, p.height, p.c64Y, p.ncy, p.c8Y, r1) : lower_bound(p.cdfY, 0, p.height, r1);
+    int row = pm.c64Y ? lower_bound_blocked(pm.cdfY, p.height, pm.c64Y, p.ncy, pm.c8Y, r1) : lower_bound(pm.cdfY, 0, p.height, r1);
     if (row > p.height - 1) row = p.height - 1;
     int col = p.c64X ? lower_bound_blocked(p.cdfX + (size_t)row * p.width, p.width, p.c64X + (size_t)row * p.ncx_pad, p.ncx,
                                            p.c8X + (size_t)row * (p.width / 8), r2)
                      : lower_bound(p.cdfX, row * p.width, (row + 1) * p.width, r2) - row * p.width;
 #endif
     if (col > p.width - 1) col = p.width - 1;
-    float4 px = p.data[(size_t)row * p.width + col];
+    float4 px = p.data_pdf[(size_t)row * p.width + col];
     color = mk3(px.x, px.y, px.z);
-    pdf = p.pdfX[(size_t)row * p.width + col] * p.pdfY[row];
+    pdf = px.w * pm.pdfY[row];
     float u = col / (float)p.width;
     float v = row / (float)p.height;
     float sinTheta = pt_sinf(v * kPi);

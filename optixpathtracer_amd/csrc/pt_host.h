@@ -22,8 +22,10 @@ struct PtBvh {
     const Node8* nodes8 = nullptr;
     const LeafTri* tris8 = nullptr;
     uint32_t num_nodes8 = 0, num_tris8 = 0;
-    int levels8 = 0;
+    int levels8 = 0; // levels of the wide tree = upper bound of its traversal stack depth (one pushed group per level)
+    int depth2 = 0;  // depth of the binary tree (0: not built)
 };
 
-hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t ntri, hipStream_t stream, PtBvh* out);
+// want_bvh2: also keep the binary form (A/B paths only; the default traversal uses the 8-wide tree alone)
+hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t ntri, int want_bvh2, hipStream_t stream, PtBvh* out);
 void pt_bvh_free(PtBvh* b);

@@ -15,7 +15,8 @@
 #pragma once
 #include "pt_bvh.h"
 
-enum { FLAG_DONE = 1, FLAG_SECONDARY = 2, FLAG_CULLED = 4 /* outside the foveation annulus */ }; // RAY_STATE_FLAGS_* deviceProgram.cu:46-48
+enum { FLAG_DONE = 1, FLAG_SECONDARY = 2, FLAG_CULLED = 4 /* outside the foveation annulus */,
+       FLAG_HIT0 = 8 /* scenes without shadow catchers: prd.alpha = 1 (deviceProgram.cu:547) as one bit, materialised by the resolve kernels */ }; // RAY_STATE_FLAGS_* deviceProgram.cu:46-48
 enum { PEND_DIRECT = 1, PEND_INDIRECT = 2, PEND_ALPHA = 3 };
 enum { TR_CLOSEST = 0, TR_SHADOW_APPLY = 1, TR_ANY_QUERY = 2, TR_UNIFIED = 3 /* closest-hit queue + shadow queue in one launch */ }; // modes of the persistent traversal kernels
 
@@ -33,7 +34,11 @@ struct PathState {
     float4* thr;   // pathThroughput xyz, rayEta
     uint2* rng;    // Random seed1, seed2
     uint32_t* fd;  // depth | flags << 8
-    float4 *direct, *indirect, *alpha, *nrm, *alb;
+    float4 *direct, *indirect, *nrm, *alb;
+    // Scenes without shadow-catcher materials (prdN == null): prd.alpha is the FLAG_HIT0 bit of fd, and nrm/alb are written once,
+    // by the depth-0 closest-hit/miss, never read back by k_shade.  Shadow-catcher scenes keep alpha as a float sum (SampleShadow
+    // accumulates into it, a later ordinary hit overwrites it) and nrm/alb as running sums (pass-throughs re-add prd.normal).
+    float4* alpha;
     float4 *prdN, *prdA; // prd.normal / prd.albedo, shadow-catcher scenes only (else null)
     // asynchronous shadow rays (pt_options.split_shadow = 2; null otherwise): every bounce b has its own shadow records
     // [b * bstride + slot] — origin, direction, pending contribution — so that the shadow rays of bounce b no longer have to
@@ -146,10 +151,10 @@ __global__ void __launch_bounds__(256) k_generate(PathState st, FrameParams fp, 
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         st.direct[i] = z;
         st.indirect[i] = z;
-        st.alpha[i] = z;
-        st.nrm[i] = (bp.carry && bp.s0 > 0) ? bp.pixNormal[pix] : z; // carry-in of the running per-pixel sum
-        st.alb[i] = (bp.carry && bp.s0 > 0) ? bp.pixAlbedo[pix] : z;
-        if (st.prdN) {
+        if (st.prdN) { // shadow-catcher scenes
+            st.alpha[i] = z;
+            st.nrm[i] = (bp.carry && bp.s0 > 0) ? bp.pixNormal[pix] : z; // carry-in of the running per-pixel sum
+            st.alb[i] = (bp.carry && bp.s0 > 0) ? bp.pixAlbedo[pix] : z;
             st.prdN[i] = z;
             st.prdA[i] = z;
         }
@@ -213,6 +218,7 @@ struct ShadeParams {
     QView queue;        // paths to shade (identity at bounce 0)
     QView next_queue;   // paths that continue
     QView shadow_queue; // paths with a live shadow ray
+    int aov;            // write the first-hit normal/albedo (the foveated variants only keep accum/frame)
 };
 
 // wave-aggregated queue append: one atomic per wave
@@ -233,7 +239,7 @@ PT_DEV void queue_push(bool pred, uint32_t value, const QView& q) {
 // plus the raygen loop's bookkeeping).  push_next: the path continues with the ray now in rayO/rayD; push_shadow: a shadow
 // ray is pending (per-path slots, or the per-bounce record `shadow_bounce` with asynchronous shadow rays).
 template <int MODE, bool CATCHER>
-PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, uint32_t p, bool& push_next, bool& push_shadow, int& shadow_bounce) {
+PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMarg& pm, uint32_t p, bool& push_next, bool& push_shadow, int& shadow_bounce) {
     const float2 h = st.hit[p];
     const int32_t prim = __float_as_int(h.y);
     uint32_t fd = st.fd[p];
@@ -245,6 +251,9 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, uint32_t p, b
         if (CATCHER) {
             st.prdN[p] = make_float4(0.f, 0.f, 0.f, 0.f);
             st.prdA[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (depth == 0 && sp.aov) { // primary miss: normal += 0, albedo += 0 (:424-427)
+            st.nrm[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            st.alb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
         const PrimTri tri = sp.prims[prim];
@@ -299,7 +308,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, uint32_t p, b
             // SampleLights / SampleShadow (:252-334) up to the visibility test
             v3 wi, skyColor;
             float skyPdf;
-            probe_sample(sp.probe, wi, skyColor, skyPdf, rand);
+            probe_sample(sp.probe, pm, wi, skyColor, skyPdf, rand);
             bool has_val = false;
             v3 val = mk3(0.f);
             {
@@ -313,7 +322,11 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, uint32_t p, b
                     }
                 }
             }
-            if (!(CATCHER && is_catcher)) st.alpha[p] = make_float4(1.f, 1.f, 1.f, 0.f); // :547
+            if (CATCHER) {
+                if (!is_catcher) st.alpha[p] = make_float4(1.f, 1.f, 1.f, 0.f); // :547
+            } else {
+                flags |= FLAG_HIT0; // :547 — every hit assigns the same value, one bit is enough
+            }
             const bool primary = (flags & FLAG_SECONDARY) == 0;
             v3 u, v, bsdfDir = mk3(0.f);
             float bsdfPdf;
@@ -337,9 +350,14 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, uint32_t p, b
             }
             // raygen loop body (:424-439)
             if (depth == 0) {
-                const float4 a = st.nrm[p], b = st.alb[p];
-                st.nrm[p] = make_float4(a.x + N.x, a.y + N.y, a.z + N.z, 0.f);
-                st.alb[p] = make_float4(b.x + albedo.x, b.y + albedo.y, b.z + albedo.z, 0.f);
+                if (CATCHER) {
+                    const float4 a = st.nrm[p], b = st.alb[p];
+                    st.nrm[p] = make_float4(a.x + N.x, a.y + N.y, a.z + N.z, 0.f);
+                    st.alb[p] = make_float4(b.x + albedo.x, b.y + albedo.y, b.z + albedo.z, 0.f);
+                } else if (sp.aov) { // the only depth-0 closest hit of this path: 0 + x, written once (0 + -0 = +0 as in the sum)
+                    st.nrm[p] = make_float4(0.f + N.x, 0.f + N.y, 0.f + N.z, 0.f);
+                    st.alb[p] = make_float4(0.f + albedo.x, 0.f + albedo.y, 0.f + albedo.z, 0.f);
+                }
             }
             const bool term = (flags & FLAG_DONE) || depth >= sp.max_depth;
             const v3 contrib = mul3(T_old, val);
@@ -391,10 +409,31 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, uint32_t p, b
 #define PT_SHADE_WAVES 5
 #endif
 #define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, PT_SHADE_WAVES)))
+// rows of the probe whose marginal arrays fit k_shade's LDS copy: cdfY + pdfY (rows each), c8Y (rows/8), c64Y (rows/64 padded to 8)
+#define PT_LDS_PROBE_ROWS 2048
 template <int MODE, bool CATCHER>
 __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, ShadeParams sp) {
     __shared__ uint32_t s_prefix[PT_NSUB + 1];
-    const uint32_t n = qreader_init(sp.queue, s_prefix);
+    __shared__ __attribute__((aligned(16))) float s_marg[2 * PT_LDS_PROBE_ROWS + PT_LDS_PROBE_ROWS / 8 + PT_LDS_PROBE_ROWS / 64 + 8];
+    ProbeMarg pm = probe_marg_global(sp.probe);
+    if (sp.probe.c64Y && sp.probe.height <= PT_LDS_PROBE_ROWS) {
+        // ProbeSample's row search (cdfY through its 64- and 8-entry count tables) and pdfY from LDS: 3 of the 6 dependent
+        // loads of the lookup stay on the CU (hard part 3)
+        const int h = sp.probe.height, h8 = h / 8, n64 = (sp.probe.ncy + 7) & ~7;
+        float* s_cdfY = s_marg;
+        float* s_pdfY = s_cdfY + h;
+        float* s_c8Y = s_pdfY + h;
+        float* s_c64Y = s_c8Y + h8;
+        for (int k = threadIdx.x; k < h; k += blockDim.x) {
+            s_cdfY[k] = sp.probe.cdfY[k];
+            s_pdfY[k] = sp.probe.pdfY[k];
+        }
+        for (int k = threadIdx.x; k < h8; k += blockDim.x) s_c8Y[k] = sp.probe.c8Y[k];
+        for (int k = threadIdx.x; k < n64; k += blockDim.x) s_c64Y[k] = sp.probe.c64Y[k];
+        pm = ProbeMarg{s_cdfY, s_pdfY, s_c64Y, s_c8Y};
+    }
+    const uint32_t n = qreader_init(sp.queue, s_prefix); // ends in a workgroup barrier (identity queue: see below)
+    if (sp.queue.base == nullptr) __syncthreads();
     const uint32_t nround = (n + 63u) & ~63u; // whole waves stay in the loop so ballots see every lane
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += gridDim.x * blockDim.x) {
         bool push_next = false, push_shadow = false;
@@ -402,7 +441,7 @@ __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, Shade
         uint32_t p = 0;
         if (i < n) {
             p = qreader_get(sp.queue, s_prefix, i);
-            shade_path<MODE, CATCHER>(st, sp, p, push_next, push_shadow, shadow_bounce);
+            shade_path<MODE, CATCHER>(st, sp, pm, p, push_next, push_shadow, shadow_bounce);
         }
         queue_push(push_next, p, sp.next_queue);
         queue_push(push_shadow, p, sp.shadow_queue);
@@ -438,7 +477,14 @@ __global__ void __launch_bounds__(256) k_resolve(PathState st, FrameParams fp, B
     for (uint32_t sl = 0; sl < bp.S; ++sl) {
         const uint32_t i = sl * bp.npix + pix;
         float4 d = st.direct[i], in = st.indirect[i];
-        const float4 a = st.alpha[i], nn = st.nrm[i], al = st.alb[i];
+        const float4 nn = st.nrm[i], al = st.alb[i];
+        float4 a;
+        if (st.prdN) {
+            a = st.alpha[i];
+        } else {
+            const float hit0 = ((st.fd[i] >> 8) & FLAG_HIT0) ? 1.0f : 0.0f;
+            a = make_float4(hit0, hit0, hit0, 0.f);
+        }
         apply_visible_contributions(st, i, d, in);
         // result += directLight + indirectLight; alpha += prd.alpha (:445-446)
         result = add3(result, add3(mk3(d.x, d.y, d.z), mk3(in.x, in.y, in.z)));
@@ -545,10 +591,10 @@ __global__ void __launch_bounds__(256) k_generate_region(PathState st, FramePara
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 st.direct[i] = z;
                 st.indirect[i] = z;
-                st.alpha[i] = z;
-                st.nrm[i] = z;
-                st.alb[i] = z;
                 if (st.prdN) {
+                    st.alpha[i] = z;
+                    st.nrm[i] = z;
+                    st.alb[i] = z;
                     st.prdN[i] = z;
                     st.prdA[i] = z;
                 }
@@ -574,10 +620,10 @@ __global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParam
     for (uint32_t sl = 0; sl < rg.spp; ++sl) {
         const uint32_t i = sl * nl + k;
         float4 d = st.direct[i], in = st.indirect[i];
-        const float4 a = st.alpha[i];
+        const float hit0 = ((st.fd[i] >> 8) & FLAG_HIT0) ? 1.0f : 0.0f; // foveated launches never run with shadow catchers
         apply_visible_contributions(st, i, d, in);
         result = add3(result, add3(mk3(d.x, d.y, d.z), mk3(in.x, in.y, in.z)));
-        alpha = add3(alpha, mk3(a.x, a.y, a.z));
+        alpha = add3(alpha, mk3(hit0, hit0, hit0));
     }
     const float spp = (float)rg.spp;
     alpha = div3s(alpha, spp);
@@ -788,6 +834,12 @@ __global__ void __launch_bounds__(64) k_cdf_marginal(const float* __restrict__ r
     }
 }
 
+__global__ void k_probe_pack(const float4* __restrict__ data, const float* __restrict__ pdfX, size_t n, float4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = data[i];
+    out[i] = make_float4(c.x, c.y, c.z, pdfX[i]);
+}
 __global__ void k_probe_coarse(const float* __restrict__ cdf, int rows, int n, int stride, int row_pitch, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * row_pitch) return;
@@ -833,7 +885,7 @@ __global__ void k_table_probe_sample(DevProbe probe, const float* __restrict__ i
     r.init(__float_as_uint(in[i]));
     v3 dir, color;
     float pdf;
-    probe_sample(probe, dir, color, pdf, r);
+    probe_sample(probe, probe_marg_global(probe), dir, color, pdf, r);
     float* o = &out[9 * (size_t)i];
     o[0] = dir.x; o[1] = dir.y; o[2] = dir.z;
     o[3] = color.x; o[4] = color.y; o[5] = color.z;

@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT2_WAV
         if ((uint32_t)sp + 1 > c_maxsp) c_maxsp = sp + 1;
         if (sp < PT2_LDS_DEPTH) s_stack[sp * 64 + lane] = v;
         else if (sp < PT2_LDS_DEPTH + PT2_OVF_DEPTH) a.ovf[(size_t)(sp - PT2_LDS_DEPTH) * gstride + gtid] = v;
+        else return; // unreachable: binary trees deeper than PT_STACK_DEPTH are refused when they are built (pt_api.hip)
         ++sp;
     };
     auto pop = [&]() -> uint32_t {

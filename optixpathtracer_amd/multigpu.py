@@ -37,16 +37,29 @@ class DevicePacker:
 
         self.torch = torch
         self.r = renderer
+        self._bufs = {}
 
     def owned_padded(self):
         return self.r.ownedPixels()
 
-    def alloc(self, n, which):
+    def alloc(self, n, which, role=0):
         from .renderer import PT_BUF_FRAME
 
-        if which == PT_BUF_FRAME:
-            return self.torch.zeros(n, dtype=self.torch.int32, device="cuda")
-        return self.torch.zeros((n, 4), dtype=self.torch.float32, device="cuda")
+        key = (n, which == PT_BUF_FRAME, role)
+        # one send and one receive buffer per (size, element type), reused every frame (sizes differ: padded vs padded * world)
+        buf = self._bufs.get(key)
+        if buf is None:
+            if which == PT_BUF_FRAME:
+                buf = self.torch.zeros(n, dtype=self.torch.int32, device="cuda")
+            else:
+                buf = self.torch.zeros((n, 4), dtype=self.torch.float32, device="cuda")
+            self._bufs[key] = buf
+        return buf
+
+    def sync(self):
+        """The all-gather runs on RCCL's stream and torch's current stream waits for it; pt_unpack runs on the library's
+        own stream, so the hand-over between the two is made explicit instead of relying on null-stream semantics."""
+        self.torch.cuda.current_stream().synchronize()
 
     def pack(self, which, dst):
         self.r.pack(which, dst.data_ptr())
@@ -60,8 +73,10 @@ def exchange_frame(packer, which, world: int, all_gather_into_tensor):
     torch.distributed's (backend nccl == RCCL on ROCm; gloo in the CPU tests)."""
     owned, padded = packer.owned_padded()
     src = packer.alloc(padded, which)
-    dst = packer.alloc(padded * world, which)
-    packer.pack(which, src)
+    dst = packer.alloc(padded * world, which, 1) if isinstance(packer, DevicePacker) else packer.alloc(padded * world, which)
+    packer.pack(which, src)  # returns after the pack kernel finished (pt_pack synchronises its stream)
     all_gather_into_tensor(dst, src)
+    if hasattr(packer, "sync"):
+        packer.sync()
     packer.unpack(which, dst)
     return dst

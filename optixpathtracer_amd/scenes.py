@@ -222,6 +222,22 @@ def two_box_scene(shadow_catcher: bool = True) -> Model:
     return m
 
 
+def catcher_stack_scene() -> Model:
+    """Shadow-catcher stress scene (no reference counterpart): the two-box scene plus a second catcher slab standing behind the
+    box and an ordinary diffuse slab BELOW the catcher ground.  Secondary rays cross the catcher slabs (two faces each, two
+    pass-throughs that do not consume depth, deviceProgram.cu:503-508) and still find ordinary geometry afterwards, so a path
+    is traced up to max_depth + 1 + (number of pass-throughs) times."""
+    m = Model()
+    add_box(m, Material(color=(0.85, 0.8, 0.7), metallic=0.6, roughness=0.35), (0.0, 0.5, 0.0), (0.5, 0.5, 0.5))
+    catcher = Material()
+    catcher["flags"] |= MATERIAL_FLAG_SHADOW_CATCHER
+    add_box(m, catcher, (0.0, -0.1, 0.0), (4.0, 0.1, 4.0))   # ground slab
+    add_box(m, catcher, (0.0, 1.5, 2.0), (3.0, 1.5, 0.1))    # wall slab behind the box
+    add_box(m, Material(color=(0.3, 0.5, 0.8)), (0.0, -1.2, 0.0), (5.0, 0.4, 5.0))  # ordinary slab under the ground
+    add_box(m, Material(color=(0.8, 0.3, 0.2), roughness=0.6), (0.0, 1.2, 3.2), (2.0, 1.0, 0.3))  # ordinary slab behind the wall
+    return m
+
+
 TWO_BOX_CAMERA = dict(eye=(3.0, 2.5, -4.0), lookat=(0.0, 0.4, 0.0), up=(0.0, 1.0, 0.0), fovY=40.0)
 
 

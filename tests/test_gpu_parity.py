@@ -412,6 +412,27 @@ def test_render_shadow_catcher_two_box(ptlib, orc_det):
         _compare(g, o)
 
 
+def test_render_shadow_catcher_pass_through_chains(ptlib, orc_det):
+    """Paths that cross several shadow-catcher faces and then keep bouncing: a pass-through does not consume depth
+    (deviceProgram.cu:503-508), so the reference's raygen loop (:411-443) traces such a path more than max_depth+1 times.
+    The wavefront schedule must keep iterating until no path is left (it used to stop after max_depth+1 launches)."""
+    m = scenes.catcher_stack_scene()
+    probe = scenes.disc_probe().BuildCDF()
+    w, h = 96, 64
+    for depth in (8, 3, 1):
+        r = _renderer(m, probe, scenes.TWO_BOX_CAMERA, w, h, max_depth=depth)
+        g = _gpu_render(r, 3, subframes=2)
+        o = _oracle_render(orc_det, m, probe, scenes.TWO_BOX_CAMERA, w, h, 3, subframes=2, max_depth=depth, use_bvh=False)
+        _compare(g, o)
+        if depth < 8:  # 3 sample passes of depth+1 closest-hit launches each, plus the extra iterations
+            assert g["stats"]["trace_launches"] > 3 * (depth + 1), g["stats"]
+    # several chunks / streams and sample passes: the extra iterations of one chunk must not disturb the others
+    r = _renderer(m, probe, scenes.TWO_BOX_CAMERA, w, h, max_depth=3, max_paths=2048, streams=2)
+    g = _gpu_render(r, 3, subframes=2)
+    o = _oracle_render(orc_det, m, probe, scenes.TWO_BOX_CAMERA, w, h, 3, subframes=2, max_depth=3, use_bvh=False)
+    _compare(g, o)
+
+
 def test_render_constant_probe_and_edge_sizes(ptlib, orc_det):
     """Constant-white probe (loadColor, sv4 main.cpp:167-180); odd sizes that do not fill 8x8 blocks; 1x1."""
     m = scenes.cornell_box()
@@ -768,6 +789,37 @@ def test_traversal_stack_spill_path(ptlib, orc_det, small_probe, monkeypatch):
     monkeypatch.delenv("PT_STACK_LDS_SKIP")
     o = _oracle_render(orc_det, m, small_probe, scenes.TERRAIN_CAMERA, w, h, 2, use_bvh=True)
     _compare(ref, o)
+
+
+def test_traversal_stack_overflow_fails_loudly(ptlib, small_probe, monkeypatch):
+    """A tree deeper than the traversal stack must never give a silently wrong image.  (a) pt_create compares the wide tree's
+    level count with the stack capacity and refuses the scene with PT_ERR_UNSUPPORTED (-4); (b) with that check bypassed
+    (test hook PT_STACK_NOCHECK) the traversal kernel's push reports the overflow and pt_render / pt_trace return
+    PT_ERR_UNSUPPORTED.  The LBVH's 58-bit keys bound real trees at far fewer levels than the 64 the stack holds, so the
+    capacity is lowered by the test hooks PT_STACK_LDS_SKIP / PT_STACK_CAP to reach both paths."""
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    m = scenes.voxel_terrain(n=96, target_tris=70000)
+    w, h = 96, 64
+    monkeypatch.setenv("PT_STACK_LDS_SKIP", "11")
+    monkeypatch.setenv("PT_STACK_CAP", "2")  # 1 level in LDS + 1 spill level; the tree has 5 or more
+    with pytest.raises(RuntimeError, match=r"pt_create failed \(-4\).*levels.*traversal stack holds 2"):
+        SampleRenderer(m)
+    monkeypatch.setenv("PT_STACK_NOCHECK", "1")
+    r = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h)
+    r.launchParams.samples_per_launch = 1
+    with pytest.raises(RuntimeError, match=r"\(-4\).*traversal stack overflow"):
+        r.render()
+    rays = _random_rays(np.random.default_rng(5), 20000, -110, 110)
+    with pytest.raises(RuntimeError, match=r"\(-4\).*traversal stack overflow"):
+        r.trace(rays)
+    # the full-size stack on the same scene: no fault, and the context stays usable after a reported fault
+    monkeypatch.delenv("PT_STACK_CAP")
+    monkeypatch.delenv("PT_STACK_NOCHECK")
+    monkeypatch.delenv("PT_STACK_LDS_SKIP")
+    r2 = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h)
+    _gpu_render(r2, 1)
+    assert r2.stats()["bvh_levels"] >= 3
 
 
 def test_cxx_facade_demo_matches_python(ptlib, small_probe, tmp_path):

@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--simulate-world", type=int, default=0, help="single process: render only rank 0's tiles of an N-way partition (predicts per-GPU time at N GPUs)")
     ap.add_argument("--split-shadow", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="concurrent pixel chunks per frame (0 = library default)")
+    ap.add_argument("--kernel-timing", type=int, default=0, help="1: per-launch HIP-event timing inside the timed loop (slower; the isolated phase always has it)")
     ap.add_argument("--bvh-kind", type=int, default=0, help="0 = 8-wide compressed BVH (default), 1 = binary BVH")
     ap.add_argument("--trace-kernel", type=int, default=0, help="0 = persistent-wave traversal (default), 1 = first grid-stride kernel")
     args = ap.parse_args()
@@ -116,7 +117,7 @@ def main():
 
     r = R.SampleRenderer(model, device=local_rank)
     r.setProbe(probe)
-    opts = dict(max_depth=depth, max_paths=args.max_paths, trace_kernel=args.trace_kernel, bvh_kind=args.bvh_kind, streams=args.streams, split_shadow=args.split_shadow)
+    opts = dict(max_depth=depth, max_paths=args.max_paths, trace_kernel=args.trace_kernel, bvh_kind=args.bvh_kind, streams=args.streams, split_shadow=args.split_shadow, kernel_timing=args.kernel_timing)
     r.setOptions(**opts)
     part_world = world if world > 1 else max(1, args.simulate_world)
     if world > 1:
@@ -218,7 +219,7 @@ def main():
     # add up to the frame (rank 0, N=1 only; not part of `value`).
     iso = None
     if world == 1 and not args.no_isolated and not sv4 and args.streams == 0:
-        r.setOptions(**dict(opts, streams=1))
+        r.setOptions(**dict(opts, streams=1, kernel_timing=1))
         n_iso = 3
         render_frame(0)
         ia = dict.fromkeys(keys, 0.0)
@@ -294,7 +295,7 @@ def main():
             },
             "rays_per_frame": int(rays_frame),
             "fps": round(args.steps / dt_max, 2),
-            "kernel_ms_per_frame": {k: round(agg[k] / args.steps, 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
+            "render_ms_per_frame": round(agg["render_ms"] / args.steps, 3),
             "kernel_ms_per_frame_isolated": None if iso is None else {k: round(iso[k], 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
             "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2)},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),

@@ -51,7 +51,7 @@ class SceneDesc(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [
-        ("max_depth", C.c_int32), ("bsdf_mode", C.c_int32), ("max_paths", C.c_uint32), ("reserved0", C.c_int32),
+        ("max_depth", C.c_int32), ("bsdf_mode", C.c_int32), ("max_paths", C.c_uint32), ("kernel_timing", C.c_int32),
         ("bvh_kind", C.c_int32), ("trace_kernel", C.c_int32), ("streams", C.c_int32), ("split_shadow", C.c_int32),
     ]
 

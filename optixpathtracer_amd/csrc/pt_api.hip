@@ -84,7 +84,8 @@ struct pt_ctx {
     size_t ev_used = 0;
     struct Span { size_t a, b; int cls; };
     std::vector<Span> spans;
-    bool span_timing = true; // per-kernel-class HIP-event timing (PT_TIMING=0 turns it off: ~2 events per launch less)
+    int env_timing = -1; // PT_TIMING=0/1 overrides pt_options.kernel_timing
+    bool span_timing() const { return env_timing >= 0 ? env_timing != 0 : opt.kernel_timing != 0; }
 };
 
 #define CK(call)                                                                                   \
@@ -184,7 +185,7 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
     pt_ctx* ctx = new pt_ctx();
     default_options(&ctx->opt);
     ctx->device = device;
-    if (const char* e = getenv("PT_TIMING")) ctx->span_timing = atoi(e) != 0;
+    if (const char* e = getenv("PT_TIMING")) ctx->env_timing = atoi(e) != 0;
     auto bail = [&](int code) { g_create_error = ctx->err; pt_destroy(ctx); return code; };
 #define CKC(call)                                                           \
     do {                                                                    \
@@ -347,7 +348,6 @@ extern "C" int pt_set_options(pt_ctx* ctx, const pt_options* opt) {
     if (!ctx || !opt) return PT_ERR_INVALID;
     if (opt->max_depth < 0 || opt->max_depth > 250) return fail(ctx, PT_ERR_INVALID, "pt_set_options: max_depth out of range [0,250]");
     if (opt->bsdf_mode != PT_BSDF_DISNEY && opt->bsdf_mode != PT_BSDF_LAMBERT) return fail(ctx, PT_ERR_INVALID, "pt_set_options: bad bsdf_mode");
-    if (opt->reserved0 != 0) return fail(ctx, PT_ERR_INVALID, "pt_set_options: reserved0 must be 0");
     if ((opt->bvh_kind == 1 || opt->trace_kernel == 1) && !ctx->bvh.nodes) {
         // the binary tree is an A/B path: built (with the wide tree, from the same hierarchy) the first time it is asked for
         CK(hipSetDevice(ctx->device));
@@ -657,12 +657,12 @@ struct SpanGuard {
     int cls;
     hipStream_t s;
     SpanGuard(pt_ctx* c, int cl, hipStream_t st = nullptr) : ctx(c), cls(cl), s(st ? st : c->stream) {
-        if (!ctx->span_timing) return;
+        if (!ctx->span_timing()) return;
         a = ctx->ev_used;
         hipEventRecord(next_event(ctx), s);
     }
     ~SpanGuard() {
-        if (!ctx->span_timing) return;
+        if (!ctx->span_timing()) return;
         size_t b = ctx->ev_used;
         hipEventRecord(next_event(ctx), s);
         ctx->spans.push_back({a, b, cls});
@@ -921,7 +921,7 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     // chunks that run concurrently on separate stream pairs; a chunk holds at most max_paths/streams paths, so
     // samples are split when spp*pixels exceed that; shadow-catcher scenes run one sample per pass so that the
     // per-pixel normal/albedo sums keep the reference order.  None of this changes a bit of the result.
-    const int nsets = std::max(1, std::min(16, ctx->opt.streams > 0 ? ctx->opt.streams : 3));
+    const int nsets = std::max(1, std::min(16, ctx->opt.streams > 0 ? ctx->opt.streams : 2));
     const uint32_t max_paths = std::max<uint32_t>(ctx->opt.max_paths, 64u);
     const uint32_t cap = std::max<uint32_t>(64u, max_paths / nsets);
     uint32_t Np = (owned + nsets - 1) / nsets;        // pixels per chunk ...
@@ -1030,7 +1030,7 @@ extern "C" int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t
     // The launches of one frame are independent until they write pixels: their passes are dealt round-robin to the batch
     // sets (separate streams, so one launch's long-ray tails overlap the others' work) and only the resolves are ordered —
     // a launch's pixels are written after all pixels of the previous launch, as later launches overwrite earlier ones.
-    const int nsets = std::max(1, std::min(16, ctx->opt.streams > 0 ? ctx->opt.streams : 3));
+    const int nsets = std::max(1, std::min(16, ctx->opt.streams > 0 ? ctx->opt.streams : 2));
     const uint32_t cap = std::max<uint32_t>(64u, max_paths / nsets);
     uint32_t need = 64;
     for (uint32_t r = 0; r < n; ++r) {

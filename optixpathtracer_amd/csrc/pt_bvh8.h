@@ -68,7 +68,7 @@ struct Bvh8Dev {
 #define PT8_STEAL 1
 #endif
 #ifndef PT8_STEAL_MIN_STEPS
-#define PT8_STEAL_MIN_STEPS 24 // a lane becomes a victim once its ray has taken this many steps (short rays are left alone)
+#define PT8_STEAL_MIN_STEPS 0 // a lane may be robbed once its ray has taken this many steps (measured: 0 is best — 24: +13 % frame time at a 1/8 share, 64: +26 %)
 #endif
 #ifndef PT8_STEAL_PERIOD
 #define PT8_STEAL_PERIOD 3 // traversal iterations between two steal rounds while lanes are idle

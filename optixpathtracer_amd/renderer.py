@@ -197,8 +197,8 @@ class SampleRenderer:
         self.launchParams.frame.subframe_index += 1
 
     # -- beyond the reference (runtime versions of its compile-time constants, multi-GPU, stats)
-    def setOptions(self, max_depth=8, bsdf_mode=PT_BSDF_DISNEY, max_paths=0, bvh_kind=0, trace_kernel=0, streams=0, split_shadow=0):
-        o = Options(max_depth, bsdf_mode, max_paths, 0, bvh_kind, trace_kernel, streams, split_shadow)
+    def setOptions(self, max_depth=8, bsdf_mode=PT_BSDF_DISNEY, max_paths=0, bvh_kind=0, trace_kernel=0, streams=0, split_shadow=0, kernel_timing=0):
+        o = Options(max_depth, bsdf_mode, max_paths, kernel_timing, bvh_kind, trace_kernel, streams, split_shadow)
         self._ck(self._L.pt_set_options(self._ctx, C.byref(o)), "pt_set_options")
 
     def setPartition(self, rank, world, tile_w=64, tile_h=16):

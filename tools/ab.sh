@@ -8,8 +8,8 @@ for v in $VARS; do
     timeout -k 10 150 python bench.py --steps 20 --warmup 5 --simulate-world $sw --no-cpu-baseline --no-isolated "$@" > /tmp/ab.json 2>/tmp/ab.err || { echo "$v w$sw FAILED"; tail -3 /tmp/ab.err; continue; }
     python - "$v" "$sw" <<'PY'
 import json,sys
-d=json.load(open("/tmp/ab.json")); k=d["kernel_ms_per_frame"]
-print(f"{sys.argv[1]:>12s} world {sys.argv[2]}: {d['ms_per_step']:.3f} ms  {d['value']:.0f} Mrays/s  trace {k['trace_ms']:.2f} shade {k['shade_ms']:.2f}", flush=True)
+d=json.load(open("/tmp/ab.json"))
+print(f"{sys.argv[1]:>12s} world {sys.argv[2]}: {d['ms_per_step']:.3f} ms  {d['value']:.0f} Mrays/s  (device {d['render_ms_per_frame']:.3f} ms)", flush=True)
 PY
   done
 done

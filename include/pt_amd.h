@@ -168,7 +168,8 @@ int pt_set_partition(pt_ctx* ctx, int rank, int world, int tile_w, int tile_h);
  * buffer is copied into it (render(CUDAOutputBuffer&) + downloadPixels, :99-107,149-153). */
 int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8);
 
-/* Foveated variants (the HelloPathtracing_sv, _sv2, _sv3, _sv4_vmv23 directories).  One pt_region = one optixLaunch of the sv4 raygen
+/* Foveated variants (the HelloPathtracing_sv, _sv2, _sv3, _sv4_vmv23 directories; sv and sv2 share one device
+ * program and differ from sv3/sv4 by pt_variant.initial_depth / write_aov and their host schedules).  One pt_region = one optixLaunch of the sv4 raygen
  * (HelloPathtracing_sv4_vmv23/deviceProgram.cu:388-590): LaunchParams.frame.{factor,fillSize,c,r_inner,r_outer,offset,
  * redraw} (sv4 LaunchParams.h:62-70) + the launch dimensions, samples_per_launch and subframe_index of that launch. */
 typedef struct pt_region {
@@ -191,11 +192,15 @@ typedef struct pt_variant {
                                    * 2: make_color(accum * exposure) (sv3 :580-604, where the later plain write wins) */
     float exposure;               /* sv4: pow(2,2) = 4; sv3: pow(2,3) = 8 */
     float white;                  /* sv4: 1 */
+    int32_t initial_depth;        /* prd.depth at the camera ray: 0 canonical/sv3/sv4; 1 in sv and sv2 (HelloPathtracing_sv/deviceProgram.cu:428,
+                                   * with the cutoff `prd.depth >= 3` at :483 = pt_options.max_depth 3): every contribution then goes to
+                                   * indirectLight and no first-hit normal/albedo is ever accumulated */
+    int32_t write_aov;            /* 1: the launch also writes normal_buffer, color_buffer and albedo_buffer like sv/sv2 (:553-555); 0: accum/frame only (sv3/sv4) */
 } pt_variant;
 
 /* SampleRenderer::render() of the foveated variants (HelloPathtracing_sv4_vmv23/SimplePathtracer.cpp:77-216): the
  * given launches in order (later ones overwrite earlier pixels).  Depth cutoff = pt_options.max_depth (sv4: 4).
- * Writes accum_buffer and frame_buffer only, like sv4.  variant may be NULL (canonical settings). */
+ * Writes accum_buffer and frame_buffer (plus the three AOV buffers with pt_variant.write_aov).  variant may be NULL (canonical settings). */
 int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t n, const pt_variant* variant, uint32_t* host_rgba8);
 
 /* SampleRenderer::downloadPixels (SimplePathtracer.cpp:149-153), generalised to all five buffers.

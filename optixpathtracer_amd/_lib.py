@@ -65,7 +65,8 @@ class Region(C.Structure):  # pt_region
 
 
 class Variant(C.Structure):  # pt_variant
-    _fields_ = [("radiance_tmin", C.c_float), ("cull_back_occlusion", C.c_int32), ("tonemap", C.c_int32), ("exposure", C.c_float), ("white", C.c_float)]
+    _fields_ = [("radiance_tmin", C.c_float), ("cull_back_occlusion", C.c_int32), ("tonemap", C.c_int32), ("exposure", C.c_float), ("white", C.c_float),
+                ("initial_depth", C.c_int32), ("write_aov", C.c_int32)]
 
 
 class Stats(C.Structure):

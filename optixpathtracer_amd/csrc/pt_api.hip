@@ -710,14 +710,16 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
         {
             SpanGuard g(ctx, CLS_OTHER, bs.stream);
             if (job)
-                hipLaunchKernelGGL(k_generate_region, dim3(GRID), dim3(256), 0, bs.stream, bs.st, fp, job->rg, tmin_rad, job->l0, job->nl, qcur);
+                hipLaunchKernelGGL(k_generate_region, dim3(GRID), dim3(256), 0, bs.stream, bs.st, fp, job->rg, tmin_rad, (uint32_t)job->var.initial_depth, job->l0, job->nl, qcur);
             else
                 hipLaunchKernelGGL(k_generate, dim3(GRID), dim3(256), 0, bs.stream, bs.st, fp, bp, bs.counters + 0);
         }
         uint32_t* qnext_base = bs.queueA;
         // depth d = 0..max_depth traces in the reference (the trace at depth == max_depth can only matter
         // through a shadow-catcher pass-through or alpha; without catcher materials it is provably dead and skipped)
-        const int last_bounce = ctx->has_catcher ? ctx->opt.max_depth : ctx->opt.max_depth - 1;
+        // (a foveated launch of the sv / sv2 variants starts its paths at depth 1: that many fewer bounces are live)
+        const int depth0 = job ? job->var.initial_depth : 0;
+        const int last_bounce = (ctx->has_catcher ? ctx->opt.max_depth : ctx->opt.max_depth - 1) - depth0;
         hipEvent_t ev_shadow_done = nullptr;
         const bool unified = ctx->opt.trace_kernel == 0 && ctx->opt.bvh_kind == 0 && ctx->opt.split_shadow == 0;
         const bool async = ctx->cap_async;
@@ -735,7 +737,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeueB + (size_t)b * qsize, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? 0 : 1};
+                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
@@ -780,7 +782,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeue, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? 0 : 1};
+                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
@@ -818,7 +820,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 ++lc.trace;
             }
-            ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? 0 : 1};
+            ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
             if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0); // shade overwrites what shadow(b-1) reads
             {
                 SpanGuard g(ctx, CLS_SHADE, bs.stream);
@@ -1024,8 +1026,9 @@ extern "C" int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t
     if (ctx->has_catcher) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_regions: shadow-catcher materials are not supported in foveated launches");
     if (ctx->world != 1) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_regions: single-GPU only");
     CK(hipSetDevice(ctx->device));
-    VariantParams var{0.001f, 0, 0, 1.0f, 1.0f};
-    if (variant) var = VariantParams{variant->radiance_tmin, variant->cull_back_occlusion, variant->tonemap, variant->exposure, variant->white};
+    VariantParams var{0.001f, 0, 0, 1.0f, 1.0f, 0, 0};
+    if (variant) var = VariantParams{variant->radiance_tmin, variant->cull_back_occlusion, variant->tonemap, variant->exposure, variant->white, variant->initial_depth, variant->write_aov};
+    if (var.initial_depth < 0 || (var.initial_depth > 0 && var.initial_depth >= ctx->opt.max_depth)) return fail(ctx, PT_ERR_INVALID, "pt_render_regions: initial_depth must be 0 or below max_depth");
     const uint32_t max_paths = std::max<uint32_t>(ctx->opt.max_paths, 64u);
     // The launches of one frame are independent until they write pixels: their passes are dealt round-robin to the batch
     // sets (separate streams, so one launch's long-ray tails overlap the others' work) and only the resolves are ordered —

@@ -557,10 +557,11 @@ struct VariantParams {
     int cull_back_occlusion;
     int tonemap;
     float exposure, white;
+    int initial_depth, write_aov;
 };
 
 // paths: i = sample * nl + (launch index - l0); culled launch indices are flagged and never queued
-__global__ void __launch_bounds__(256) k_generate_region(PathState st, FrameParams fp, RegionParams rg, float tmin, uint32_t l0, uint32_t nl, QView qgen) {
+__global__ void __launch_bounds__(256) k_generate_region(PathState st, FrameParams fp, RegionParams rg, float tmin, uint32_t depth0, uint32_t l0, uint32_t nl, QView qgen) {
     const uint32_t total = nl * rg.spp;
     const uint32_t nround = (total + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += gridDim.x * blockDim.x) {
@@ -586,7 +587,7 @@ __global__ void __launch_bounds__(256) k_generate_region(PathState st, FramePara
                 st.rayD[i] = make_float4(dir.x, dir.y, dir.z, 1e16f);
                 st.thr[i] = make_float4(1.f, 1.f, 1.f, 1.f);
                 st.rng[i] = make_uint2(r.seed1, r.seed2);
-                st.fd[i] = 0u;
+                st.fd[i] = depth0; // prd.depth = 0 (1 in the sv / sv2 variants)
                 if (st.vis) st.vis[i] = 0u;
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 st.direct[i] = z;
@@ -616,7 +617,8 @@ __global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParam
     if ((st.fd[k] >> 8) & FLAG_CULLED) return;
     const uint32_t li = l0 + k;
     const uint32_t lx = li % rg.launch_w, ly = li / rg.launch_w;
-    v3 result = mk3(0.f), alpha = mk3(0.f);
+    v3 result = mk3(0.f), alpha = mk3(0.f), normal = mk3(0.f), albedo = mk3(0.f);
+    const bool aov_sums = var.write_aov && var.initial_depth == 0; // with prd.depth starting at 1 nothing is ever added (:474-477)
     for (uint32_t sl = 0; sl < rg.spp; ++sl) {
         const uint32_t i = sl * nl + k;
         float4 d = st.direct[i], in = st.indirect[i];
@@ -624,9 +626,16 @@ __global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParam
         apply_visible_contributions(st, i, d, in);
         result = add3(result, add3(mk3(d.x, d.y, d.z), mk3(in.x, in.y, in.z)));
         alpha = add3(alpha, mk3(hit0, hit0, hit0));
+        if (aov_sums) {
+            const float4 nn = st.nrm[i], al = st.alb[i];
+            normal = add3(normal, mk3(nn.x, nn.y, nn.z));
+            albedo = add3(albedo, mk3(al.x, al.y, al.z));
+        }
     }
     const float spp = (float)rg.spp;
     alpha = div3s(alpha, spp);
+    normal = div3s(normal, spp);
+    albedo = div3s(albedo, spp);
     // backplate of the last sample's camera ray
     uint32_t seed = tea4(ly * (uint32_t)fp.width + lx, rg.subframe_index);
     for (uint32_t q = 0; q < 2u * (rg.spp - 1u); ++q) lcg(seed);
@@ -658,6 +667,11 @@ __global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParam
             if (var.tonemap == 1) shown = reinhard_tonemap(scl3(accum_color, var.exposure), var.white);
             else if (var.tonemap == 2) shown = scl3(accum_color, var.exposure); // sv3: its Reinhard write is overwritten (sv3 :591-604)
             fp.frame[image_index] = make_color(shown);
+            if (var.write_aov) { // sv / sv2 (HelloPathtracing_sv/deviceProgram.cu:553-555)
+                fp.normal[image_index] = make_float4(normal.x, normal.y, normal.z, 1.0f);
+                fp.color[image_index] = make_float4(accum_color.x, accum_color.y, accum_color.z, 1.0f);
+                fp.albedo[image_index] = make_float4(albedo.x, albedo.y, albedo.z, 1.0f);
+            }
         }
     }
 }

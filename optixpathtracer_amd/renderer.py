@@ -159,6 +159,11 @@ class SampleRenderer:
     # HelloPathtracing_sv3: same device code except exposure 2^3 and no Reinhard in the final write; host radii 100/200, spp 2/8/64
     SV3_VARIANT = dict(radiance_tmin=0.01, cull_back_occlusion=1, tonemap=2, exposure=8.0, white=1.0)
     SV3_SCHEDULE = dict(inner_radius=100, outer_radius=200, spp=(2, 8, 64))
+    # HelloPathtracing_sv and _sv2 (one device program): canonical tmin / occlusion flags / make_color, but prd.depth starts at 1 with
+    # the cutoff `depth >= 3` (deviceProgram.cu:428,483 -> setOptions(max_depth=3)) and the launch also writes the AOV buffers (:553-555);
+    # host schedule = sv3's radii and sample counts (HelloPathtracing_sv/SimplePathtracer.cpp:131-198)
+    SV_VARIANT = dict(radiance_tmin=0.001, cull_back_occlusion=0, tonemap=0, exposure=1.0, white=1.0, initial_depth=1, write_aov=1)
+    SV_MAX_DEPTH = 3
 
     def renderRegions(self, regions, variant=None, out: np.ndarray | None = None):
         """regions: list of dicts with pt_region's fields; variant: dict with pt_variant's fields (None = canonical)."""

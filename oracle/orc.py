@@ -47,7 +47,8 @@ class Region(C.Structure):
 
 
 class Variant(C.Structure):
-    _fields_ = [("radiance_tmin", C.c_float), ("cull_back_occlusion", C.c_int), ("tonemap", C.c_int), ("exposure", C.c_float), ("white", C.c_float)]
+    _fields_ = [("radiance_tmin", C.c_float), ("cull_back_occlusion", C.c_int), ("tonemap", C.c_int), ("exposure", C.c_float), ("white", C.c_float),
+                ("initial_depth", C.c_int), ("write_aov", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -102,6 +103,7 @@ class Oracle:
         L.orc_math_table.argtypes = [C.c_int, f32p, f32p, C.c_int, f32p]
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(Probe), C.POINTER(Params), f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_render_region.argtypes = [C.c_void_p, C.POINTER(Probe), C.POINTER(Params), C.POINTER(Region), C.POINTER(Variant), f32p, u32p, C.POINTER(Stats)]
+        L.orc_render_region_aov.argtypes = [C.c_void_p, C.POINTER(Probe), C.POINTER(Params), C.POINTER(Region), C.POINTER(Variant), f32p, u32p, f32p, f32p, f32p, C.POINTER(Stats)]
         L.orc_denoise.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, f32p, f32p, f32p, f32p]
         L.orc_tex2d.argtypes = [u32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p]
         L.orc_scene_set_textures.argtypes = [C.c_void_p, C.c_void_p, i32p, u8p, C.c_uint32, C.c_void_p, i32p, i32p]
@@ -161,8 +163,9 @@ class Oracle:
         self.lib.orc_render(scene.h, C.byref(probe), C.byref(prm), accum.reshape(-1), frame.ctypes.data, normal.ctypes.data, color.ctypes.data, albedo.ctypes.data, nthreads, C.byref(st))
         return dict(accum=accum, frame=frame, normal=normal, color=color, albedo=albedo, radiance_rays=int(st.radiance_rays), shadow_rays=int(st.shadow_rays), n=n)
 
-    def render_regions(self, scene, probe, cam_uvw, eye, width, height, regions, variant, max_depth, accum, frame, bsdf_mode=BSDF_DISNEY):
-        """The foveated variants' launches, in order, in place on (accum, frame). Returns total rays."""
+    def render_regions(self, scene, probe, cam_uvw, eye, width, height, regions, variant, max_depth, accum, frame, bsdf_mode=BSDF_DISNEY, aov=None):
+        """The foveated variants' launches, in order, in place on (accum, frame) and, for variants with write_aov, on
+        aov = (normal, color, albedo). Returns total rays."""
         prm = Params()
         prm.width, prm.height, prm.max_depth, prm.bsdf_mode = width, height, max_depth, bsdf_mode
         U, V, W = cam_uvw
@@ -174,7 +177,11 @@ class Oracle:
         for g in regions:
             rg = Region(**g)
             st = Stats()
-            self.lib.orc_render_region(scene.h, C.byref(probe), C.byref(prm), C.byref(rg), C.byref(var), accum.reshape(-1), frame.reshape(-1), C.byref(st))
+            if aov is not None:
+                self.lib.orc_render_region_aov(scene.h, C.byref(probe), C.byref(prm), C.byref(rg), C.byref(var), accum.reshape(-1), frame.reshape(-1),
+                                               aov[0].reshape(-1), aov[1].reshape(-1), aov[2].reshape(-1), C.byref(st))
+            else:
+                self.lib.orc_render_region(scene.h, C.byref(probe), C.byref(prm), C.byref(rg), C.byref(var), accum.reshape(-1), frame.reshape(-1), C.byref(st))
             rays += int(st.radiance_rays) + int(st.shadow_rays)
         return rays
 

@@ -954,8 +954,10 @@ typedef struct {
     int cull_back_occlusion;  /* 0 original (TERMINATE_ON_FIRST_HIT); 1 sv3/sv4 (CULL_BACK_FACING_TRIANGLES, :240) */
     int tonemap;              /* 0 = make_color(accum) ; 1 = make_color(reinhard(accum * exposure, white)) (sv4 :555-569); 2 = make_color(accum * exposure) (sv3) */
     float exposure, white;
+    int initial_depth;        /* prd.depth at the camera ray: 1 in HelloPathtracing_sv / _sv2 (deviceProgram.cu:428), else 0 */
+    int write_aov;            /* sv / sv2 also write normal/color/albedo buffers (sv deviceProgram.cu:553-555) */
 } orc_variant;
-static __thread orc_variant g_var = {0.001f, 0, 0, 1.0f, 1.0f};
+static __thread orc_variant g_var = {0.001f, 0, 0, 1.0f, 1.0f, 0, 0};
 
 /* deviceProgram.cu:252-334 SampleLights / SampleShadow (want_occluded selects) */
 static f3 sample_lights(const orc_scene* s, const orc_probe* probe, int mode, const orc_material* mat, f3 albedo, float etaI,
@@ -1235,7 +1237,7 @@ static inline f3 reinhard(f3 color, float white) { /* sv4 deviceProgram.cu:124-1
 }
 
 static void raygen_region_thread(const orc_scene* s, const orc_probe* probe, const orc_params* prm, const orc_region* rg, uint32_t lx,
-                                 uint32_t ly, float* accum, uint32_t* frame, orc_stats* st) {
+                                 uint32_t ly, float* accum, uint32_t* frame, float* normal_buf, float* color_buf, float* albedo_buf, orc_stats* st) {
     const int w = prm->width, h = prm->height;
     const f3 eye = mk3(prm->eye[0], prm->eye[1], prm->eye[2]);
     const f3 U = mk3(prm->U[0], prm->U[1], prm->U[2]), V = mk3(prm->V[0], prm->V[1], prm->V[2]), W = mk3(prm->W[0], prm->W[1], prm->W[2]);
@@ -1249,7 +1251,7 @@ static void raygen_region_thread(const orc_scene* s, const orc_probe* probe, con
         const float range = sqrtf(dot3(dv, dv));
         if (range < rg->r_inner || range > rg->r_outer) return; /* :421-426 */
     }
-    f3 alpha = mk3s(0.f), backplate = mk3s(0.f);
+    f3 alpha = mk3s(0.f), backplate = mk3s(0.f), normal = mk3s(0.f), albedo = mk3s(0.f);
     do {
         f3 directLight = mk3s(0.0f), indirectLight = mk3s(0.0f);
         prd_t prd;
@@ -1262,7 +1264,7 @@ static void raygen_region_thread(const orc_scene* s, const orc_probe* probe, con
         prd.normal = mk3s(0.0f);
         prd.albedo = mk3s(0.0f);
         prd.flags = 0;
-        prd.depth = 0;
+        prd.depth = g_var.initial_depth; /* 0; sv / sv2: 1 (HelloPathtracing_sv/deviceProgram.cu:428) */
         prd.origin = eye;
         prd.direction = mk3s(0.f);
         float jx = orc_rnd(&seed), jy = orc_rnd(&seed);
@@ -1288,6 +1290,10 @@ static void raygen_region_thread(const orc_scene* s, const orc_probe* probe, con
                 prd.normal = mk3s(0.f);
                 prd.flags |= FLAG_DONE;
             }
+            if (prd.depth == 0) { /* sv :474-477 (never true when prd.depth starts at 1) */
+                normal = add3(normal, prd.normal);
+                albedo = add3(albedo, prd.albedo);
+            }
             if ((prd.flags & FLAG_DONE) || prd.depth >= prm->max_depth) break;
             if (prd.depth == 0)
                 directLight = add3(directLight, prd.radiance);
@@ -1301,6 +1307,8 @@ static void raygen_region_thread(const orc_scene* s, const orc_probe* probe, con
         alpha = add3(alpha, prd.alpha);
     } while (--i);
     alpha = div3s(alpha, (float)spp);
+    normal = div3s(normal, (float)spp);
+    albedo = div3s(albedo, (float)spp);
     for (int fi = 0; fi < rg->fill_size; ++fi) {
         for (int fj = 0; fj < rg->fill_size; ++fj) {
             uint32_t px = lx * rg->factor_x + (uint32_t)fi + rg->offset_x, py = ly * rg->factor_y + (uint32_t)fj + rg->offset_y;
@@ -1322,20 +1330,33 @@ static void raygen_region_thread(const orc_scene* s, const orc_probe* probe, con
             else if (g_var.tonemap == 2) shown = scl3(accum_color, g_var.exposure); /* sv3 :580-604: the Reinhard write is overwritten by make_color(exposure-corrected) */
             float c[3] = {shown.x, shown.y, shown.z};
             frame[image_index] = orc_make_color(c);
+            if (g_var.write_aov && normal_buf && color_buf && albedo_buf) { /* sv :553-555 */
+                float* nb = &normal_buf[4 * image_index];
+                float* cb = &color_buf[4 * image_index];
+                float* ab = &albedo_buf[4 * image_index];
+                nb[0] = normal.x; nb[1] = normal.y; nb[2] = normal.z; nb[3] = 1.0f;
+                cb[0] = accum_color.x; cb[1] = accum_color.y; cb[2] = accum_color.z; cb[3] = 1.0f;
+                ab[0] = albedo.x; ab[1] = albedo.y; ab[2] = albedo.z; ab[3] = 1.0f;
+            }
         }
     }
 }
 
-/* sequential over the launch grid (launches with overlapping splats are order-dependent in the reference too) */
-void orc_render_region(const orc_scene* s, const orc_probe* probe, const orc_params* prm, const orc_region* rg, const orc_variant* var,
-                       float* accum, uint32_t* frame, orc_stats* stats) {
+/* sequential over the launch grid (launches with overlapping splats are order-dependent in the reference too);
+ * normal/color/albedo may be NULL (only written with var->write_aov) */
+void orc_render_region_aov(const orc_scene* s, const orc_probe* probe, const orc_params* prm, const orc_region* rg, const orc_variant* var,
+                           float* accum, uint32_t* frame, float* normal, float* color, float* albedo, orc_stats* stats) {
     g_var = *var;
     orc_stats st = {0, 0};
     for (uint32_t ly = 0; ly < rg->launch_h; ++ly)
-        for (uint32_t lx = 0; lx < rg->launch_w; ++lx) raygen_region_thread(s, probe, prm, rg, lx, ly, accum, frame, &st);
+        for (uint32_t lx = 0; lx < rg->launch_w; ++lx) raygen_region_thread(s, probe, prm, rg, lx, ly, accum, frame, normal, color, albedo, &st);
     if (stats) *stats = st;
-    orc_variant def = {0.001f, 0, 0, 1.0f, 1.0f};
+    orc_variant def = {0.001f, 0, 0, 1.0f, 1.0f, 0, 0};
     g_var = def;
+}
+void orc_render_region(const orc_scene* s, const orc_probe* probe, const orc_params* prm, const orc_region* rg, const orc_variant* var,
+                       float* accum, uint32_t* frame, orc_stats* stats) {
+    orc_render_region_aov(s, probe, prm, rg, var, accum, frame, NULL, NULL, NULL, stats);
 }
 
 /* ---------------------------------------------------------------- AOV-guided a-trous filter (include/pt_amd.h pt_denoise)

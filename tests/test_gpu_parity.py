@@ -542,6 +542,88 @@ def test_fullsize_1080p_terrain_properties(ptlib, orc_det):
         del r2
 
 
+def test_c4_4k_16spp_8way_partition_rank_by_rank(ptlib, orc_det):
+    """BASELINE config C4 at its literal size: the 1 M-triangle scene, 3840x2160, 16 spp, depth 8, image tile-partitioned
+    8 ways (interleaved 64x16 tiles).  The eight shares are rendered one after the other on this GPU; their union must cover
+    every pixel exactly once and equal the checker's rows of the unpartitioned 4K frame bit for bit."""
+    from oracle import orc as orc_mod
+    import ctypes as C
+
+    m = scenes.voxel_terrain()
+    probe = scenes.sky_probe(2048, 1024).BuildCDF()
+    w, h, spp, world = 3840, 2160, 16, 8
+    r = _renderer(m, probe, scenes.TERRAIN_CAMERA, w, h)
+    r.launchParams.samples_per_launch = spp
+    r.launchParams.frame.subframe_index = 0
+    from optixpathtracer_amd import renderer as R
+
+    union = np.zeros((h, w, 4), np.float32)
+    cover = np.zeros((h, w), np.int32)
+    rays = 0
+    owned_total = 0
+    for rank in range(world):
+        r.setPartition(rank, world, 64, 16)  # re-applies to the 4K frame: buffers are cleared, only this rank's tiles get written
+        r.render()
+        a = r.download(R.PT_BUF_ACCUM)
+        mine = a[..., 3] == 1.0
+        cover += mine
+        union[mine] = a[mine]
+        st = r.stats()
+        rays += st["radiance_rays"] + st["shadow_rays"]
+        owned_total += r.ownedPixels()[0]
+        assert st["paths"] == r.ownedPixels()[0] * spp
+        assert abs(int(mine.sum()) - w * h // world) <= 64 * 16 * 8  # shares are balanced to within a few tiles
+    assert owned_total == w * h and (cover == 1).all(), "every pixel is rendered by exactly one rank"
+    assert np.isfinite(union).all() and rays > 4 * w * h * spp
+    sc = orc_det.make_scene(m, True)
+    pr = orc_det.make_probe(probe)
+    U, V, W = scenes.uvw_frame(**scenes.TERRAIN_CAMERA, aspect=w / h)
+    prm = orc_mod.Params()
+    prm.width, prm.height, prm.subframe_index, prm.samples_per_launch, prm.max_depth, prm.bsdf_mode = w, h, 0, spp, 8, 0
+    for dst, src in ((prm.eye, scenes.TERRAIN_CAMERA["eye"]), (prm.U, U), (prm.V, V), (prm.W, W)):
+        for k in range(3):
+            dst[k] = float(src[k])
+    rows = [3, 1040, 1519, 2159]  # rows owned by different ranks (tile rows 0, 65, 94, 134)
+    accum = np.zeros((h, w, 4), np.float32)
+    orc_det.lib.orc_render_rows.argtypes = [C.c_void_p, C.POINTER(orc_mod.Probe), C.POINTER(orc_mod.Params), orc_mod.f32p, orc_mod.i32p, C.c_int, C.c_int]
+    orc_det.lib.orc_render_rows(sc.h, C.byref(pr), C.byref(prm), accum.reshape(-1), np.array(rows, np.int32), len(rows), 16)
+    for y in rows:
+        assert_bits_equal(union[y], accum[y], f"row {y} of the 4K / 16 spp frame assembled from 8 shares")
+
+
+def test_converged_image_vs_reference_pinned_checker(ptlib, orc_libm, capsys):
+    """north_star's tolerance, measured against the REFERENCE-PINNED side: the checker's "libm" build is the one whose RNG,
+    samplers, probe functions and make_color are bit-equal to the reference's own headers compiled here
+    (tests/test_oracle_golden.py); the HIP kernels use the deterministic-math twin.  Accumulate 1024 spp (64 subframes of
+    16 spp through the progressive blend, deviceProgram.cu:456-466) and require relative L2 <= 1e-3 between the GPU's
+    accum_buffer and the libm checker's."""
+    from optixpathtracer_amd import renderer as R
+
+    probe = scenes.sky_probe(256, 128).BuildCDF()
+    w, h, spp, sub = 48, 32, 16, 64
+    report = []
+    for name, model, cam, bvh in (("cornell", scenes.cornell_box(), scenes.CORNELL_CAMERA, False),
+                                  ("terrain70k", scenes.voxel_terrain(n=96, target_tris=70000), scenes.TERRAIN_CAMERA, True)):
+        r = _renderer(model, probe, cam, w, h)
+        r.launchParams.samples_per_launch = spp
+        for sf in range(sub):
+            r.launchParams.frame.subframe_index = sf
+            r.render()
+        g = r.download(R.PT_BUF_ACCUM)[..., :3].astype(np.float64)
+        sc = orc_libm.make_scene(model, bvh)
+        pr = orc_libm.make_probe(probe)
+        U, V, W = scenes.uvw_frame(**cam, aspect=w / h)
+        accum = None
+        for sf in range(sub):
+            accum = orc_libm.render(sc, pr, (U, V, W), cam["eye"], w, h, spp, 8, sf, 0, accum)["accum"]
+        o = accum[..., :3].astype(np.float64)
+        l2 = float(np.sqrt(((g - o) ** 2).sum() / (o ** 2).sum()))
+        report.append((name, l2))
+        assert l2 <= 1e-3, f"{name}: relative L2 {l2:.3e} after {spp * sub} spp exceeds 1e-3"
+    with capsys.disabled():
+        print("\n[converged image, GPU vs reference-pinned libm checker, %d spp] " % (spp * sub) + ", ".join(f"{n}: rel L2 {v:.2e}" for n, v in report))
+
+
 def test_partition_matches_host_mirror(ptlib, small_probe):
     """The library's pixel partition equals optixpathtracer_amd.multigpu.pixel_lists (the layout contract of
     the all-gather), checked through pack(): packed accum == accum gathered with the host list."""
@@ -650,6 +732,60 @@ def test_foveated_sv4_three_launches(ptlib, orc_det, variant_name):
 
 
 R_ACCUM, R_FRAME = 0, 1
+
+
+def test_foveated_sv_sv2_initial_depth_and_aov_writes(ptlib, orc_det):
+    """The sv / sv2 directories (one device program): prd.depth starts at 1 with the cutoff `depth >= 3`
+    (HelloPathtracing_sv/deviceProgram.cu:428,483) — all radiance goes to indirectLight (a different float association than
+    direct + indirect), nothing is added to normal/albedo — canonical tmin/occlusion/make_color, and every launch also writes
+    normal_buffer (zeros, w = 1), color_buffer and albedo_buffer (:553-555).  Three frames of the sv host schedule's three
+    launches with a moving gaze: all five buffers bit-exact against the checker."""
+    from optixpathtracer_amd import renderer as R
+    from optixpathtracer_amd.renderer import SampleRenderer, make_camera
+
+    m = scenes.voxel_terrain(n=64, target_tris=30000)
+    probe = scenes.sky_probe(256, 128).BuildCDF()
+    w, h = 192, 128
+    r = SampleRenderer(m)
+    r.setProbe(probe)
+    r.setOptions(max_depth=SampleRenderer.SV_MAX_DEPTH)
+    r.resize((w, h))
+    r.setCamera(make_camera(scenes.TERRAIN_CAMERA, w / h))
+    sc = orc_det.make_scene(m, True)
+    pr = orc_det.make_probe(probe)
+    U, V, W = scenes.uvw_frame(**scenes.TERRAIN_CAMERA, aspect=w / h)
+    accum = np.zeros((h, w, 4), np.float32)
+    frame = np.zeros((h, w), np.uint32)
+    aov = [np.zeros((h, w, 4), np.float32) for _ in range(3)]
+    variant = SampleRenderer.SV_VARIANT
+    for k, gaze in enumerate([(96, 64), (100, 60), (70, 80)]):
+        regs = r.foveatedRegions((w, h), gaze, k, inner_radius=14, outer_radius=44, spp=(1, 2, 4))
+        r.renderFoveated(gaze, inner_radius=14, outer_radius=44, spp=(1, 2, 4), variant=variant)
+        orc_det.render_regions(sc, pr, (U, V, W), scenes.TERRAIN_CAMERA["eye"], w, h, regs, variant, SampleRenderer.SV_MAX_DEPTH, accum, frame, aov=aov)
+        assert_bits_equal(r.download(R.PT_BUF_ACCUM), accum, f"sv accum_buffer, frame {k}")
+        assert np.array_equal(r.download(R.PT_BUF_FRAME), frame), f"sv frame_buffer, frame {k}"
+        assert_bits_equal(r.download(R.PT_BUF_NORMAL), aov[0], f"sv normal_buffer, frame {k}")
+        assert_bits_equal(r.download(R.PT_BUF_COLOR), aov[1], f"sv color_buffer, frame {k}")
+        assert_bits_equal(r.download(R.PT_BUF_ALBEDO), aov[2], f"sv albedo_buffer, frame {k}")
+    n = r.download(R.PT_BUF_NORMAL)
+    assert (n[..., :3] == 0).all() and (n[..., 3] == 1).all()  # depth never 0: the AOVs stay empty, as in the reference
+    # initial depth 0 with AOV writes (the canonical raygen in launch form): first-hit sums are written
+    v2 = dict(variant, initial_depth=0)
+    accum[:] = 0; frame[:] = 0
+    for a in aov:
+        a[:] = 0
+    r2 = SampleRenderer(m)
+    r2.setProbe(probe)
+    r2.setOptions(max_depth=4)
+    r2.resize((w, h))
+    r2.setCamera(make_camera(scenes.TERRAIN_CAMERA, w / h))
+    regs = r2.foveatedRegions((w, h), (96, 64), 0, inner_radius=14, outer_radius=44, spp=(1, 2, 4))
+    r2.renderFoveated((96, 64), inner_radius=14, outer_radius=44, spp=(1, 2, 4), variant=v2)
+    orc_det.render_regions(sc, pr, (U, V, W), scenes.TERRAIN_CAMERA["eye"], w, h, regs, v2, 4, accum, frame, aov=aov)
+    assert_bits_equal(r2.download(R.PT_BUF_ACCUM), accum, "accum_buffer, initial depth 0 + AOVs")
+    assert_bits_equal(r2.download(R.PT_BUF_NORMAL), aov[0], "normal_buffer, initial depth 0 + AOVs")
+    assert_bits_equal(r2.download(R.PT_BUF_ALBEDO), aov[2], "albedo_buffer, initial depth 0 + AOVs")
+    assert (aov[0][..., :3] != 0).any()
 
 
 def test_textured_meshes(ptlib, orc_det):

@@ -1,0 +1,21 @@
+#!/bin/bash
+# tools/profile_r2.sh <tag>   (GPU box, from the repo root)
+# rocprofv3 evidence for the bench line: kernel-trace stats of the default schedule and of a single chunk stream (isolated
+# per-kernel durations), then separate PMC passes (FETCH_SIZE, WRITE_SIZE cannot share a pass on gfx950; VALU counters 4 at a time).
+# Writes gpurun_out/prof_<tag>/ and the judged summaries: profiles/<tag>_*.  Every pass profiles the same command.
+set -e
+TAG=${1:-r2}
+OUT=$PWD/gpurun_out/prof_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT" profiles
+export TMPDIR=/tmp
+ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ARGS > "$OUT/bench_stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -- python3 $ARGS --streams 1 > "$OUT/bench_stats1.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $ARGS > "$OUT/bench_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $ARGS > "$OUT/bench_write.log" 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_valu" -- python3 $ARGS > "$OUT/bench_valu.log" 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_busy" -- python3 $ARGS > "$OUT/bench_busy.log" 2>&1
+python3 tools/summarize_r2.py "$OUT" "$TAG"
+find "$OUT" -name "*_kernel_trace.csv" -size +2M -delete || true
+find "$OUT" -name "*counter_collection.csv" -size +2M -delete || true
+ls profiles | grep "$TAG"

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_r2.sh directory into profiles/<tag>_summary.md, profiles/<tag>_kernel_stats{,_streams1}.csv and
+profiles/r2_pmc.json (the PMC-derived numbers bench.py quotes, tagged with the hash of the kernel sources they were measured on).
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide reads by 2x (MI355X_MICROARCH.md, HBM section): the
+raw and the doubled figure are both given, the doubled one is what `roofline.traffic` uses."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def find(d, pat):
+    r = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+def short(name):
+    return name.replace("void ", "").split("(")[0][:60]
+
+
+def bench_line(path):
+    if not os.path.exists(path):
+        return None
+    lines = [l for l in open(path) if l.startswith("{")]
+    return json.loads(lines[-1]) if lines else None
+
+
+def counters(d):
+    cc = find(d, "*counter_collection.csv")
+    agg = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(int))
+    if cc:
+        for r in csv.DictReader(open(cc)):
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[k][r["Counter_Name"]] += 1
+    return agg, cnt
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    from bench import source_hash
+
+    md = [f"# rocprofv3 summary — {tag} (kernel sources {source_hash()})\n",
+          "Command of every pass: `rocprofv3 <mode> -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated` (C3: 1 M triangles,",
+          "1920x1080, 4 spp, depth 8; 7 frames).  Profiled runs clock lower than unprofiled ones; PMC passes serialise kernels.\n"]
+    frames = 7
+    for name, sub, log in (("default schedule (2 chunk streams)", "stats", "bench_stats.log"), ("one chunk stream (isolated kernel durations)", "stats1", "bench_stats1.log")):
+        st = find(os.path.join(out, sub), "*kernel_stats.csv")
+        b = bench_line(os.path.join(out, log))
+        md.append(f"## kernel time, {name} (--kernel-trace --stats)\n")
+        if b:
+            md.append(f"bench line under the profiler: {b['ms_per_step']} ms/frame, {b['value']} Mrays/s\n")
+        if st:
+            dst = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats{'_streams1' if sub == 'stats1' else ''}.csv")
+            shutil.copy(st, dst)
+            md += ["| kernel | calls | total ms | avg us | ms / frame | % |", "|---|---|---|---|---|---|"]
+            tot = 0.0
+            for r in list(csv.DictReader(open(st)))[:12]:
+                ms = float(r["TotalDurationNs"]) / 1e6
+                tot += ms
+                md.append(f"| {short(r['Name'])} | {r['Calls']} | {ms:.3f} | {float(r['AverageNs']) / 1e3:.1f} | {ms / frames:.3f} | {float(r['Percentage']):.1f} |")
+            md.append(f"\nsum of kernel durations per frame: {tot / frames:.3f} ms" + (f" (frame under the profiler: {b['ms_per_step']} ms)" if b else "") + "\n")
+    fetch, fcnt = counters(os.path.join(out, "pmc_fetch"))
+    write, _ = counters(os.path.join(out, "pmc_write"))
+    md += ["## HBM traffic per kernel (FETCH_SIZE and WRITE_SIZE, separate passes; KiB -> MiB)\n",
+           "| kernel | dispatches | FETCH MiB / dispatch (raw) | x2 (gfx950 correction) | WRITE MiB / dispatch | FETCH x2 + WRITE, MB |", "|---|---|---|---|---|---|"]
+    traffic = {}
+    for k in sorted(fetch, key=lambda k: -fetch[k]["FETCH_SIZE"])[:10]:
+        n = max(1, fcnt[k]["FETCH_SIZE"])
+        f = fetch[k]["FETCH_SIZE"] / n / 1024
+        w = write.get(k, {}).get("WRITE_SIZE", 0.0) / n / 1024
+        traffic[k] = {"dispatches": n, "fetch_raw_bytes": f * 2**20, "write_bytes": w * 2**20, "total_bytes_x2": (2 * f + w) * 2**20}
+        md.append(f"| {k} | {n} | {f:.2f} | {2 * f:.2f} | {w:.2f} | {(2 * f + w) * 2**20 / 1e6:.1f} |")
+    md.append("")
+    valu, vcnt = counters(os.path.join(out, "pmc_valu"))
+    busy, _ = counters(os.path.join(out, "pmc_busy"))
+    md += ["## VALU counters (sums over all dispatches of the pass)\n", "| kernel | dispatches | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU | SQ_THREAD_CYCLES_VALU | lane utilisation | SQ_WAVE_CYCLES | SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES |", "|---|---|---|---|---|---|---|---|"]
+    lane = {}
+    insts_frame = 0.0
+    for k in sorted(valu, key=lambda k: -valu[k]["SQ_INSTS_VALU"])[:8]:
+        v = valu[k]
+        lu = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64) if v["SQ_ACTIVE_INST_VALU"] else 0.0
+        lane[k] = round(lu, 4)
+        insts_frame += v["SQ_INSTS_VALU"] / frames
+        wait = busy.get(k, {}).get("SQ_WAIT_INST_ANY", 0.0) / v["SQ_WAVE_CYCLES"] if v["SQ_WAVE_CYCLES"] else 0.0
+        md.append(f"| {k} | {vcnt[k]['SQ_INSTS_VALU']} | {v['SQ_INSTS_VALU']:.4g} | {v['SQ_ACTIVE_INST_VALU']:.4g} | {v['SQ_THREAD_CYCLES_VALU']:.4g} | {lu * 100:.1f} % | {v['SQ_WAVE_CYCLES']:.4g} | {wait * 100:.0f} % |")
+    md.append(f"\nVALU wave-instructions per frame: {insts_frame:.4g} (x 4 SIMD cycles each, 1024 SIMDs x 2.4 GHz available)\n")
+    b0 = bench_line(os.path.join(out, "bench_stats.log"))
+    trav = [k for k in traffic if k.startswith("k_trace8")]
+    tnum = sum(traffic[k]["total_bytes_x2"] * traffic[k]["dispatches"] for k in trav)
+    tden = sum(traffic[k]["dispatches"] for k in trav)
+    shade_k = [k for k in traffic if k.startswith("k_shade")]
+    pmc = {
+        "source": f"profiles/{tag}_summary.md", "src_hash": source_hash(), "frames": frames,
+        "traffic_bytes_per_traversal_launch": int(tnum / tden) if tden else None,
+        "per_kernel_traffic": {k: {kk: (int(vv) if kk != "dispatches" else vv) for kk, vv in v.items()} for k, v in traffic.items()},
+        "valu": {"lane_util": lane, "valu_insts_per_frame": insts_frame, "simd_cycles_per_valu_inst": 4, "simds": 1024, "clock_ghz": 2.4,
+                 "issue_frac_at_profiled_frame_ms": (round(insts_frame * 4 / (1024 * 2.4e9 * b0["ms_per_step"] * 1e-3), 3) if b0 else None),
+                 "source": f"profiles/{tag}_summary.md"},
+        "shade": ({"fetch_x2_plus_write_bytes_per_dispatch": int(traffic[shade_k[0]]["total_bytes_x2"]), "lane_util": lane.get(shade_k[0]),
+                   "source": f"profiles/{tag}_summary.md"} if shade_k else None),
+    }
+    json.dump(pmc, open(os.path.join(ROOT, "profiles", "r2_pmc.json"), "w"), indent=1)
+    open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w").write("\n".join(md) + "\n")
+    print("\n".join(md[-14:]))
+
+
+if __name__ == "__main__":
+    main()

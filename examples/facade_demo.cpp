@@ -1,7 +1,7 @@
 // facade_demo.cpp — the reference application's call sequence (main.cpp:211-218,262,273,286) through the C++ facade
 // (optixpathtracer_amd/csrc/SampleRenderer.h) over the C ABI: no Python, no torch, no hipcc on the application side.
 //   g++ -std=c++17 -I<repo> -I<repo>/include facade_demo.cpp -L<repo>/optixpathtracer_amd -lptamd -o facade_demo
-//   ./facade_demo scene.bin out.bin
+//   ./facade_demo scene.bin out.bin [ncontexts]      ncontexts > 0: MultiSampleRenderer with that many contexts on device 0
 // scene.bin (little endian): u32 nmesh; per mesh { u32 nv, u32 nt, Material (104 B), nv*3 f32, nt*3 u32 };
 //   u32 probe_w, probe_h, probe_w*probe_h*4 f32; f32 eye[3], lookat[3], up[3], fovY; u32 width, height, spp, subframes
 // out.bin: width*height u32 rgba8 frame, then width*height*4 f32 accum_buffer.
@@ -52,10 +52,37 @@ int main(int argc, char** argv) {
         rd(f, &w, 1); rd(f, &h, 1); rd(f, &spp, 1); rd(f, &subframes, 1);
         fclose(f);
 
-        SampleRenderer sample(&model);                  // main.cpp:211
         ProbeData probe;                                // main.cpp:146-156 (loadProbe) + BuildCDF
         probe.width = (int)pw; probe.height = (int)ph; probe.data = pdata.data();
         probe.BuildCDF();
+        const int ncontexts = argc > 3 ? atoi(argv[3]) : 0;
+        if (ncontexts > 0) {                            // the same application code on several contexts of one process
+            MultiSampleRenderer multi(&model, std::vector<int>((size_t)ncontexts, 0));
+            multi.setProbe(probe);
+            multi.resize(int2{(int)w, (int)h});
+            cam.aspectRatio = (float)w / (float)h;
+            multi.setCamera(cam);
+            multi.launchParams.samples_per_launch = spp;
+            std::vector<uint32_t> pixels((size_t)w * h);
+            for (uint32_t s = 0; s < subframes; ++s) {
+                multi.launchParams.frame.subframe_index = s;
+                multi.render(pixels.data());
+            }
+            multi.gather(PT_BUF_ACCUM);
+            std::vector<float> accum((size_t)w * h * 4);
+            if (pt_download(pt_multi_ctx(multi.multi, ncontexts - 1), PT_BUF_ACCUM, accum.data(), accum.size() * sizeof(float)) != PT_OK) throw std::runtime_error("download");
+            FILE* o = fopen(argv[2], "wb");
+            if (!o) { perror(argv[2]); return 2; }
+            fwrite(pixels.data(), sizeof(uint32_t), pixels.size(), o);
+            fwrite(accum.data(), sizeof(float), accum.size(), o);
+            fclose(o);
+            pt_multi_stats ms;
+            pt_multi_get_stats(multi.multi, &ms);
+            printf("%d contexts: %ux%u, %u spp x %u subframes: last frame %.3f ms (max over ranks), gather %.3f ms (exchange kind %d), %llu rays\n", ncontexts, w, h, spp,
+                   subframes, ms.sum.render_ms, ms.gather_ms, ms.exchange, (unsigned long long)(ms.sum.radiance_rays + ms.sum.shadow_rays));
+            return 0;
+        }
+        SampleRenderer sample(&model);                  // main.cpp:211
         sample.setProbe(probe);                         // main.cpp:216
         sample.resize(int2{(int)w, (int)h});            // main.cpp:218
         cam.aspectRatio = (float)w / (float)h;

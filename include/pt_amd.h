@@ -251,6 +251,43 @@ int pt_unpack(pt_ctx* ctx, int which, const void* dev_src_all);
 
 int pt_get_stats(const pt_ctx* ctx, pt_stats* out);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Several GPUs from ONE process (SURVEY.md 8b "pt_create_multi"; the reference renders on whatever single device is
+ * current, SimplePathtracer.cpp:203-212).  A pt_multi is ndev contexts — rank r on HIP device devices[r] — that share
+ * one flattened scene (uploaded to every device, acceleration structure built on each), the same probe / camera /
+ * options, and one frame cut into interleaved tile_w x tile_h tiles (pt_set_partition with world = ndev, the pattern of
+ * sutil/WorkDistribution.h:34-91).  pt_multi_render enqueues the frame on every device before it waits for any, so
+ * the devices work concurrently from one host thread; no collective is on the data path.  The display hand-off,
+ * pt_multi_gather, makes a buffer complete on EVERY rank: pack of the owned pixels -> one all-gather of the packed
+ * strips -> unpack.  The all-gather is RCCL's ncclAllGather, one communicator per rank inside one ncclGroup
+ * (librccl is opened on first use); when two ranks share a device (rehearsal on a one-GPU box: RCCL refuses duplicate
+ * devices) or librccl is absent, the strips travel as direct device-to-device copies (hipMemcpyPeerAsync over xGMI).
+ * devices may repeat.  Every call returns a pt_status; pt_multi_last_error gives the message. */
+typedef struct pt_multi pt_multi;
+enum pt_exchange { PT_EXCHANGE_NONE = 0, PT_EXCHANGE_RCCL = 1, PT_EXCHANGE_PEER_COPY = 2 };
+typedef struct pt_multi_stats {
+    pt_stats sum;            /* rays / paths summed over the ranks; the *_ms fields are the MAXIMUM over the ranks */
+    double gather_ms;        /* wall time of the last pt_multi_gather (pack + exchange + unpack, all ranks) */
+    int32_t exchange;        /* pt_exchange used by the last gather */
+    int32_t ndev;
+} pt_multi_stats;
+int pt_create_multi(const pt_scene_desc* scene, const int* devices, int ndev, pt_multi** out);
+int pt_multi_destroy(pt_multi* m);
+const char* pt_multi_last_error(const pt_multi* m); /* m may be NULL: last error of a failed pt_create_multi */
+int pt_multi_size(const pt_multi* m);
+pt_ctx* pt_multi_ctx(pt_multi* m, int rank); /* the rank's context, for per-rank calls (pt_download, pt_get_stats, pt_device_buffer) */
+int pt_multi_set_options(pt_multi* m, const pt_options* opt);
+int pt_multi_set_probe(pt_multi* m, const float* data_rgba, const float* pdfX, const float* cdfX, const float* pdfY, const float* cdfY, int width, int height);
+int pt_multi_set_probe_image(pt_multi* m, const float* data_rgba, int width, int height);
+int pt_multi_resize(pt_multi* m, int width, int height, int tile_w, int tile_h); /* tile sizes: multiples of 8; 0 = 64 x 16 */
+int pt_multi_set_camera(pt_multi* m, const float eye[3], const float U[3], const float V[3], const float W[3]);
+/* gather_mask: bit (1 << pt_buffer) for every buffer to assemble on all ranks after the frame (0 = none: pure throughput);
+ * host_rgba8 (may be NULL) receives rank 0's frame buffer and implies gathering PT_BUF_FRAME */
+int pt_multi_render(pt_multi* m, uint32_t spp, uint32_t subframe_index, uint32_t gather_mask, uint32_t* host_rgba8);
+int pt_multi_render_regions(pt_multi* m, const pt_region* regions, uint32_t n, const pt_variant* variant, uint32_t gather_mask, uint32_t* host_rgba8);
+int pt_multi_gather(pt_multi* m, int which /* pt_buffer */);
+int pt_multi_get_stats(const pt_multi* m, pt_multi_stats* out);
+
 /* Ray-search entry (what optixTrace did: deviceProgram.cu:165,190).  rays = n * 8 floats
  * (o.xyz, tmin, d.xyz, tmax) in HOST memory.  any_hit=0: t_out[n], prim_out[n] (global triangle
  * index in mesh order, -1 = miss; t_out = tmax on miss).  any_hit=1: prim_out[n] = 1 occluded / 0.

@@ -16,6 +16,9 @@ EXPORTS = [
     "pt_resize", "pt_set_camera", "pt_uvw_frame", "pt_set_partition", "pt_render", "pt_download", "pt_upload_accum",
     "pt_device_buffer", "pt_tonemap_sqrt", "pt_owned_pixels", "pt_pack", "pt_unpack", "pt_get_stats", "pt_trace",
     "pt_eval_table", "pt_version", "pt_set_probe_image", "pt_get_probe_cdf", "pt_render_regions", "pt_denoise",
+    "pt_create_multi", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_size", "pt_multi_ctx", "pt_multi_set_options", "pt_multi_set_probe",
+    "pt_multi_set_probe_image", "pt_multi_resize", "pt_multi_set_camera", "pt_multi_render", "pt_multi_render_regions", "pt_multi_gather",
+    "pt_multi_get_stats",
 ]
 
 
@@ -82,6 +85,10 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class MultiStats(C.Structure):  # pt_multi_stats
+    _fields_ = [("sum", Stats), ("gather_ms", C.c_double), ("exchange", C.c_int32), ("ndev", C.c_int32)]
+
+
 assert C.sizeof(Material) == 104
 
 _lib = None
@@ -146,6 +153,23 @@ def load_library() -> C.CDLL:
     L.pt_trace.argtypes = [vp, vp, u32, i, vp, vp, i, C.POINTER(C.c_double)]
     L.pt_eval_table.argtypes = [vp, i, vp, i, vp, u32, vp]
     L.pt_version.restype = C.c_char_p
+    f3p = C.POINTER(f * 3)
+    L.pt_create_multi.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), i, C.POINTER(vp)]
+    L.pt_multi_destroy.argtypes = [vp]
+    L.pt_multi_last_error.restype = C.c_char_p
+    L.pt_multi_last_error.argtypes = [vp]
+    L.pt_multi_size.argtypes = [vp]
+    L.pt_multi_ctx.restype = vp
+    L.pt_multi_ctx.argtypes = [vp, i]
+    L.pt_multi_set_options.argtypes = [vp, C.POINTER(Options)]
+    L.pt_multi_set_probe.argtypes = [vp, vp, vp, vp, vp, vp, i, i]
+    L.pt_multi_set_probe_image.argtypes = [vp, vp, i, i]
+    L.pt_multi_resize.argtypes = [vp, i, i, i, i]
+    L.pt_multi_set_camera.argtypes = [vp, f3p, f3p, f3p, f3p]
+    L.pt_multi_render.argtypes = [vp, u32, u32, u32, vp]
+    L.pt_multi_render_regions.argtypes = [vp, C.POINTER(Region), u32, C.POINTER(Variant), u32, vp]
+    L.pt_multi_gather.argtypes = [vp, i]
+    L.pt_multi_get_stats.argtypes = [vp, C.POINTER(MultiStats)]
     _lib = L
     return L
 

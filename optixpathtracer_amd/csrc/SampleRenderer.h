@@ -149,4 +149,54 @@ class SampleRenderer {
     void ck(int rc) { if (rc != PT_OK) throw std::runtime_error(pt_last_error(ctx)); }
 };
 
+// The same surface over several GPUs of one process (pt_create_multi, include/pt_amd.h): the frame is tile-partitioned over
+// `devices`, rendered concurrently, and the rgba8 frame is assembled on every rank by one RCCL all-gather per displayed frame.
+class MultiSampleRenderer {
+  public:
+    MultiSampleRenderer(const Model* model, const std::vector<int>& devices) {
+        std::vector<pt_mesh_desc> md(model->meshes.size());
+        for (size_t i = 0; i < md.size(); ++i) {
+            const TriangleMesh* m = model->meshes[i];
+            md[i].vertex = &m->vertex[0].x; md[i].num_vertices = (uint32_t)m->vertex.size();
+            md[i].index = &m->index[0].x; md[i].num_triangles = (uint32_t)m->index.size();
+            md[i].material = *reinterpret_cast<const pt_material*>(&m->material);
+            md[i].diffuse_texture_id = m->diffuseTextureID;
+            md[i].texcoord = m->texcoord.size() == m->vertex.size() && !m->texcoord.empty() ? &m->texcoord[0].x : nullptr;
+        }
+        std::vector<pt_texture_desc> td(model->textures.size());
+        for (size_t i = 0; i < td.size(); ++i) td[i] = pt_texture_desc{model->textures[i]->pixel, model->textures[i]->resolution.x, model->textures[i]->resolution.y};
+        pt_scene_desc sd{md.data(), (uint32_t)md.size(), td.data(), (uint32_t)td.size()};
+        if (pt_create_multi(&sd, devices.data(), (int)devices.size(), &multi) != PT_OK) throw std::runtime_error(std::string("MultiSampleRenderer: ") + pt_multi_last_error(nullptr));
+    }
+    ~MultiSampleRenderer() { pt_multi_destroy(multi); }
+    MultiSampleRenderer(const MultiSampleRenderer&) = delete;
+    MultiSampleRenderer& operator=(const MultiSampleRenderer&) = delete;
+
+    void render() { ck(pt_multi_render(multi, launchParams.samples_per_launch, launchParams.frame.subframe_index, 1u << PT_BUF_FRAME, nullptr)); }
+    void render(uint32_t* h_pixels) { ck(pt_multi_render(multi, launchParams.samples_per_launch, launchParams.frame.subframe_index, 1u << PT_BUF_FRAME, h_pixels)); }
+    void resize(const int2& newSize) {
+        ck(pt_multi_resize(multi, newSize.x, newSize.y, 0, 0));
+        if (newSize.x && newSize.y) launchParams.frame.size = newSize;
+    }
+    void downloadPixels(uint32_t h_pixels[]) { // rank 0 holds the assembled frame after render()
+        if (pt_download(pt_multi_ctx(multi, 0), PT_BUF_FRAME, h_pixels, sizeof(uint32_t) * (size_t)launchParams.frame.size.x * launchParams.frame.size.y) != PT_OK)
+            throw std::runtime_error(pt_last_error(pt_multi_ctx(multi, 0)));
+    }
+    void setCamera(const Camera& camera) {
+        float3 U, V, W;
+        camera.UVWFrame(U, V, W);
+        ck(pt_multi_set_camera(multi, &camera.eye.x, &U.x, &V.x, &W.x));
+    }
+    void setProbe(const ProbeData& probe) {
+        if (!probe.valid) throw std::runtime_error("Probe Data is not valid");
+        ck(pt_multi_set_probe(multi, &probe.data[0].x, probe.pdfValuesX.data(), probe.cdfValuesX.data(), probe.pdfValuesY.data(), probe.cdfValuesY.data(), probe.width, probe.height));
+    }
+    void gather(int which) { ck(pt_multi_gather(multi, which)); } // assemble another buffer (e.g. PT_BUF_ACCUM) on every rank
+    LaunchParams launchParams;
+    pt_multi* multi = nullptr;
+
+  private:
+    void ck(int rc) { if (rc != PT_OK) throw std::runtime_error(pt_multi_last_error(multi)); }
+};
+
 } // namespace ptamd

@@ -18,6 +18,10 @@
 
 static thread_local std::string g_create_error;
 
+struct LaunchCounts {
+    uint32_t trace = 0, shadow = 0, shade = 0;
+};
+
 struct pt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -84,6 +88,11 @@ struct pt_ctx {
     size_t ev_used = 0;
     struct Span { size_t a, b; int cls; };
     std::vector<Span> spans;
+    // a frame that is enqueued but not yet waited for (render_enqueue / render_finish)
+    int pending = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    uint64_t pending_paths = 0;
+    LaunchCounts pending_lc;
     int env_timing = -1; // PT_TIMING=0/1 overrides pt_options.kernel_timing
     bool span_timing() const { return env_timing >= 0 ? env_timing != 0 : opt.kernel_timing != 0; }
 };
@@ -163,11 +172,20 @@ static int check_tree_depth(pt_ctx* ctx, char* msg, size_t msg_len) {
     return PT_OK;
 }
 
-extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ctx) {
-    if (!scene || !out_ctx || scene->num_meshes == 0 || !scene->meshes) return fail(nullptr, PT_ERR_INVALID, "pt_create: null or empty scene");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, PT_ERR_NO_DEVICE, "pt_create: no HIP device");
-    if (device < 0 || device >= ndev) return fail(nullptr, PT_ERR_INVALID, "pt_create: bad device ordinal");
+// The scene in one global vertex / index space, flattened once on the host like buildAccel (SimplePathtracer.cpp:481-489);
+// pt_create_multi uploads the same flat scene to every device.
+struct FlatScene {
+    std::vector<float> verts, tc;
+    std::vector<uint32_t> idx, tri_mesh;
+    std::vector<pt_material> mats;
+    std::vector<int32_t> mesh_tex;
+    bool any_tex = false, has_catcher = false;
+    size_t nv = 0, nt = 0;
+    const pt_scene_desc* scene = nullptr; // textures are read from the caller's arrays
+};
+
+static int flatten_scene(const pt_scene_desc* scene, FlatScene& fs) {
+    if (!scene || scene->num_meshes == 0 || !scene->meshes) return fail(nullptr, PT_ERR_INVALID, "pt_create: null or empty scene");
     size_t nv = 0, nt = 0;
     for (uint32_t m = 0; m < scene->num_meshes; ++m) {
         const pt_mesh_desc& md = scene->meshes[m];
@@ -182,9 +200,51 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
     for (uint32_t t = 0; t < scene->num_textures; ++t)
         if (!scene->textures || !scene->textures[t].pixel || scene->textures[t].width <= 0 || scene->textures[t].height <= 0)
             return fail(nullptr, PT_ERR_INVALID, "pt_create: bad texture");
+    fs.scene = scene;
+    fs.nv = nv;
+    fs.nt = nt;
+    fs.verts.resize(3 * nv);
+    fs.idx.resize(3 * nt);
+    fs.tri_mesh.resize(nt);
+    fs.mats.resize(scene->num_meshes);
+    fs.mesh_tex.assign(scene->num_meshes, -1);
+    size_t vb = 0, tb = 0;
+    for (uint32_t m = 0; m < scene->num_meshes; ++m) {
+        const pt_mesh_desc& md = scene->meshes[m];
+        memcpy(&fs.verts[3 * vb], md.vertex, sizeof(float) * 3 * md.num_vertices);
+        for (size_t k = 0; k < 3 * (size_t)md.num_triangles; ++k) fs.idx[3 * tb + k] = md.index[k] + (uint32_t)vb;
+        for (size_t k = 0; k < md.num_triangles; ++k) fs.tri_mesh[tb + k] = m;
+        fs.mats[m] = md.material;
+        if (md.material.flags & 1) fs.has_catcher = true;
+        if (md.diffuse_texture_id >= 0 && md.texcoord) { // hasTexture && sbtData.texcoord (deviceProgram.cu:512)
+            fs.mesh_tex[m] = md.diffuse_texture_id;
+            fs.any_tex = true;
+        }
+        vb += md.num_vertices;
+        tb += md.num_triangles;
+    }
+    if (fs.any_tex) { // per-vertex texcoords in the global vertex space (buildSBT, SimplePathtracer.cpp:430-447)
+        fs.tc.assign(2 * nv, 0.f);
+        size_t vb2 = 0;
+        for (uint32_t m = 0; m < scene->num_meshes; ++m) {
+            const pt_mesh_desc& md = scene->meshes[m];
+            if (md.texcoord) memcpy(&fs.tc[2 * vb2], md.texcoord, sizeof(float) * 2 * md.num_vertices);
+            vb2 += md.num_vertices;
+        }
+    }
+    return PT_OK;
+}
+
+static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, PT_ERR_NO_DEVICE, "pt_create: no HIP device");
+    if (device < 0 || device >= ndev) return fail(nullptr, PT_ERR_INVALID, "pt_create: bad device ordinal");
+    const pt_scene_desc* scene = fs.scene;
+    const size_t nv = fs.nv, nt = fs.nt;
     pt_ctx* ctx = new pt_ctx();
     default_options(&ctx->opt);
     ctx->device = device;
+    ctx->has_catcher = fs.has_catcher;
     if (const char* e = getenv("PT_TIMING")) ctx->env_timing = atoi(e) != 0;
     auto bail = [&](int code) { g_create_error = ctx->err; pt_destroy(ctx); return code; };
 #define CKC(call)                                                           \
@@ -198,58 +258,29 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
     DevScope tmp;
     CKC(hipSetDevice(device));
     CKC(hipStreamCreate(&ctx->stream));
-    // flatten like buildAccel (SimplePathtracer.cpp:481-489) — one global vertex/index space
-    std::vector<float> verts(3 * nv);
-    std::vector<uint32_t> idx(3 * nt), tri_mesh(nt);
-    std::vector<pt_material> mats(scene->num_meshes);
-    size_t vb = 0, tb = 0;
-    for (uint32_t m = 0; m < scene->num_meshes; ++m) {
-        const pt_mesh_desc& md = scene->meshes[m];
-        memcpy(&verts[3 * vb], md.vertex, sizeof(float) * 3 * md.num_vertices);
-        for (size_t k = 0; k < 3 * (size_t)md.num_triangles; ++k) idx[3 * tb + k] = md.index[k] + (uint32_t)vb;
-        for (size_t k = 0; k < md.num_triangles; ++k) tri_mesh[tb + k] = m;
-        mats[m] = md.material;
-        if (md.material.flags & 1) ctx->has_catcher = true;
-        vb += md.num_vertices;
-        tb += md.num_triangles;
-    }
     ctx->ntri = (uint32_t)nt;
     ctx->nmesh = scene->num_meshes;
     CKC(dalloc(&ctx->d_verts, 3 * nv));
     CKC(dalloc(&ctx->d_idx, 3 * nt));
     CKC(dalloc(&ctx->d_tri_mesh, nt));
-    CKC(dalloc(&ctx->d_mats, mats.size()));
+    CKC(dalloc(&ctx->d_mats, fs.mats.size()));
     CKC(dalloc(&ctx->d_prims, nt));
-    CKC(hipMemcpy(ctx->d_verts, verts.data(), sizeof(float) * 3 * nv, hipMemcpyHostToDevice));
-    CKC(hipMemcpy(ctx->d_idx, idx.data(), sizeof(uint32_t) * 3 * nt, hipMemcpyHostToDevice));
-    CKC(hipMemcpy(ctx->d_tri_mesh, tri_mesh.data(), sizeof(uint32_t) * nt, hipMemcpyHostToDevice));
-    CKC(hipMemcpy(ctx->d_mats, mats.data(), sizeof(pt_material) * mats.size(), hipMemcpyHostToDevice));
+    CKC(hipMemcpy(ctx->d_verts, fs.verts.data(), sizeof(float) * 3 * nv, hipMemcpyHostToDevice));
+    CKC(hipMemcpy(ctx->d_idx, fs.idx.data(), sizeof(uint32_t) * 3 * nt, hipMemcpyHostToDevice));
+    CKC(hipMemcpy(ctx->d_tri_mesh, fs.tri_mesh.data(), sizeof(uint32_t) * nt, hipMemcpyHostToDevice));
+    CKC(hipMemcpy(ctx->d_mats, fs.mats.data(), sizeof(pt_material) * fs.mats.size(), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_emit_prims, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_verts, ctx->d_idx,
                        ctx->d_tri_mesh, (uint32_t)nt, ctx->d_prims);
     {   // textures (createTextures, SimplePathtracer.cpp:603-654) and per-primitive texcoords (buildSBT :430-447)
-        std::vector<int32_t> mesh_tex(scene->num_meshes, -1);
-        bool any = false;
-        for (uint32_t m = 0; m < scene->num_meshes; ++m)
-            if (scene->meshes[m].diffuse_texture_id >= 0 && scene->meshes[m].texcoord) { // hasTexture && sbtData.texcoord (:512)
-                mesh_tex[m] = scene->meshes[m].diffuse_texture_id;
-                any = true;
-            }
-        if (any) {
-            std::vector<float> tc(2 * nv, 0.f);
-            size_t vb2 = 0;
-            for (uint32_t m = 0; m < scene->num_meshes; ++m) {
-                const pt_mesh_desc& md = scene->meshes[m];
-                if (md.texcoord) memcpy(&tc[2 * vb2], md.texcoord, sizeof(float) * 2 * md.num_vertices);
-                vb2 += md.num_vertices;
-            }
+        if (fs.any_tex) {
             float* d_tc = nullptr;
             CKC(tmp.alloc(&d_tc, 2 * nv));
-            CKC(hipMemcpy(d_tc, tc.data(), sizeof(float) * 2 * nv, hipMemcpyHostToDevice));
+            CKC(hipMemcpy(d_tc, fs.tc.data(), sizeof(float) * 2 * nv, hipMemcpyHostToDevice));
             CKC(dalloc(&ctx->d_uvs, nt));
             hipLaunchKernelGGL(k_emit_uvs, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, d_tc, ctx->d_idx, (uint32_t)nt, ctx->d_uvs);
             CKC(hipStreamSynchronize(ctx->stream));
-            CKC(dalloc(&ctx->d_mesh_tex, mesh_tex.size()));
-            CKC(hipMemcpy(ctx->d_mesh_tex, mesh_tex.data(), sizeof(int32_t) * mesh_tex.size(), hipMemcpyHostToDevice));
+            CKC(dalloc(&ctx->d_mesh_tex, fs.mesh_tex.size()));
+            CKC(hipMemcpy(ctx->d_mesh_tex, fs.mesh_tex.data(), sizeof(int32_t) * fs.mesh_tex.size(), hipMemcpyHostToDevice));
         }
         std::vector<DevTex> tex(scene->num_textures);
         for (uint32_t t = 0; t < scene->num_textures; ++t) {
@@ -298,6 +329,14 @@ extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ct
     *out_ctx = ctx;
     return PT_OK;
 #undef CKC
+}
+
+extern "C" int pt_create(const pt_scene_desc* scene, int device, pt_ctx** out_ctx) {
+    if (!out_ctx) return fail(nullptr, PT_ERR_INVALID, "pt_create: null output pointer");
+    FlatScene fs;
+    int rc = flatten_scene(scene, fs);
+    if (rc != PT_OK) return rc;
+    return create_from_flat(fs, device, out_ctx);
 }
 
 static void free_path_state(pt_ctx* ctx) {
@@ -679,10 +718,6 @@ static void launch_shade(pt_ctx* ctx, pt_ctx::BatchSet& bs, const ShadeParams& s
         hipLaunchKernelGGL((k_shade<MODE, false>), dim3(GRID), dim3(256), 0, bs.stream, bs.st, sp);
 }
 
-struct LaunchCounts {
-    uint32_t trace = 0, shadow = 0, shade = 0;
-};
-
 // enqueue every kernel of one pixel chunk (all its samples) on the streams of one batch set
 struct RegionJob { // non-null: one launch-index range of a foveated launch instead of a pixel chunk
     RegionParams rg;
@@ -710,7 +745,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
         {
             SpanGuard g(ctx, CLS_OTHER, bs.stream);
             if (job)
-                hipLaunchKernelGGL(k_generate_region, dim3(GRID), dim3(256), 0, bs.stream, bs.st, fp, job->rg, tmin_rad, (uint32_t)job->var.initial_depth, job->l0, job->nl, qcur);
+                hipLaunchKernelGGL(k_generate_region, dim3(GRID), dim3(256), 0, bs.stream, bs.st, fp, job->rg, PartParams{ctx->rank, ctx->world, ctx->tile_w, ctx->tile_h}, tmin_rad, (uint32_t)job->var.initial_depth, job->l0, job->nl, qcur);
             else
                 hipLaunchKernelGGL(k_generate, dim3(GRID), dim3(256), 0, bs.stream, bs.st, fp, bp, bs.counters + 0);
         }
@@ -730,7 +765,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             std::vector<hipEvent_t> shadow_done;
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
+                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
@@ -751,7 +786,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     hipStreamWaitEvent(ss, ev_shaded, 0);
                     {
                         SpanGuard g(ctx, CLS_SHADOW, ss);
-                        Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, (b & 1) ? bs.ovf3 : bs.ovf2, cull, nullptr, b, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
+                        Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, (b & 1) ? bs.ovf3 : bs.ovf2, cull, nullptr, b, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
                         hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, ss, ta);
                         ++lc.shadow;
                     }
@@ -761,7 +796,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qnext, QView{}, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
+                    Trace8Args ta{bs.st, bvh8, qnext, QView{}, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 }
@@ -775,7 +810,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             // and a frame has max_depth+1 traversal launches instead of 2*max_depth.
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
+                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
@@ -791,12 +826,12 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
+                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_UNIFIED>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 } else {
                     SpanGuard g(ctx, CLS_SHADOW, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.shadow;
                 }
@@ -815,7 +850,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     Trace2Args ta{bs.st, bvh, qcur, work + b, bs.ovf, nullptr};
                     hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 } else {
-                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
+                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 }
                 ++lc.trace;
@@ -841,7 +876,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     Trace2Args ta{bs.st, bvh, qshadow, work + nq + b, bs.ovf2, nullptr};
                     hipLaunchKernelGGL((k_trace2<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
                 } else {
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
                 }
                 ++lc.shadow;
@@ -875,7 +910,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 QView qshadow{bs.squeue, cntS + (size_t)cur * CS, ctx->sub_cap};
                 {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
+                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 }
@@ -888,7 +923,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 {
                     SpanGuard g(ctx, CLS_SHADOW, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.shadow;
                 }
@@ -905,15 +940,17 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             // counters[last_bounce+1] holds paths that would have continued: not traced, not counted
             hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters, nq, last_bounce + 1, ctx->d_totals);
             if (job)
-                hipLaunchKernelGGL(k_resolve_region, dim3((job->nl + 255) / 256), dim3(256), 0, bs.stream, bs.st, fp, job->rg, job->var, job->l0, job->nl);
+                hipLaunchKernelGGL(k_resolve_region, dim3((job->nl + 255) / 256), dim3(256), 0, bs.stream, bs.st, fp, job->rg, PartParams{ctx->rank, ctx->world, ctx->tile_w, ctx->tile_h}, job->var, job->l0, job->nl);
             else
                 hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, bs.stream, bs.st, fp, bp, (int)(s0 == 0), (int)(s0 + Sc >= spp));
         }
     }
 }
 
-extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8) {
-    if (!ctx) return PT_ERR_INVALID;
+// pt_render in two halves, so that pt_multi_render can have every device working before it waits for any of them:
+// render_enqueue launches the whole frame asynchronously, render_finish waits for it and collects the statistics.
+static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index) {
+    ctx->pending = 0;
     if (ctx->width == 0) return PT_OK; // not resized yet (SimplePathtracer.cpp:77)
     if (spp == 0 || spp > 4096) return fail(ctx, PT_ERR_INVALID, "pt_render: samples_per_launch must be in [1,4096]");
     if (!ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_render: no probe set (setProbe)");
@@ -942,6 +979,7 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 3, ctx->stream));
     hipEvent_t ev_begin = next_event(ctx);
     CK(hipEventRecord(ev_begin, ctx->stream));
+    ctx->ev_begin = ev_begin;
     FrameParams fp{ctx->accum, ctx->frame, ctx->color, ctx->normal, ctx->albedo, ctx->width, ctx->height, subframe_index,
                    ctx->eye, ctx->U, ctx->V, ctx->W, spp, ctx->probe};
     LaunchCounts lc;
@@ -958,6 +996,20 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     }
     hipEvent_t ev_end = next_event(ctx);
     CK(hipEventRecord(ev_end, ctx->stream));
+    ctx->ev_end = ev_end;
+    ctx->pending = 1;
+    ctx->pending_paths = (uint64_t)owned * spp;
+    ctx->pending_lc = lc;
+    return PT_OK;
+}
+
+static int render_finish(pt_ctx* ctx) {
+    if (!ctx->pending) return PT_OK;
+    ctx->pending = 0;
+    CK(hipSetDevice(ctx->device));
+    const uint32_t owned = ctx->owned;
+    const LaunchCounts lc = ctx->pending_lc;
+    hipEvent_t ev_begin = ctx->ev_begin, ev_end = ctx->ev_end;
     CK(hipStreamSynchronize(ctx->stream)); // SimplePathtracer.cpp:96 CUDA_SYNC_CHECK
     CK(hipGetLastError());
     unsigned long long totals[3] = {0, 0, 0};
@@ -993,7 +1045,7 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     pt_stats& st = ctx->stats;
     st.radiance_rays = totals[0];
     st.shadow_rays = totals[1];
-    st.paths = (uint64_t)owned * spp;
+    st.paths = ctx->pending_paths;
     float ms = 0;
     hipEventElapsedTime(&ms, ev_begin, ev_end);
     st.render_ms = ms;
@@ -1010,21 +1062,29 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
     st.trace_launches = lc.trace;
     st.shadow_launches = lc.shadow;
     st.shade_launches = lc.shade;
-    if (host_rgba8) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)ctx->width * ctx->height);
     return PT_OK;
 }
+
+extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8) {
+    if (!ctx) return PT_ERR_INVALID;
+    int rc = render_enqueue(ctx, spp, subframe_index);
+    if (rc == PT_OK) rc = render_finish(ctx);
+    if (rc != PT_OK) return rc;
+    if (host_rgba8 && ctx->width) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)ctx->width * ctx->height);
+    return PT_OK;
+}
+
 
 // The foveated variants' render() (HelloPathtracing_sv4_vmv23/SimplePathtracer.cpp:132-216) issues up to three
 // optixLaunch calls per frame with different LaunchParams.frame.{factor,fillSize,c,r_inner,r_outer,offset,redraw},
 // samples_per_launch and subframe_index; later launches overwrite the pixels of earlier ones, so the launches run
 // in order on one stream.
-extern "C" int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t n, const pt_variant* variant, uint32_t* host_rgba8) {
-    if (!ctx || (!regions && n)) return PT_ERR_INVALID;
+static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, const pt_variant* variant) {
+    ctx->pending = 0;
     if (ctx->width == 0) return PT_OK;
     if (!ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_render_regions: no probe set (setProbe)");
     if (ctx->opt.bvh_kind != 0 || ctx->opt.trace_kernel != 0) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_regions: needs the default traversal (bvh_kind 0, trace_kernel 0)");
     if (ctx->has_catcher) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_regions: shadow-catcher materials are not supported in foveated launches");
-    if (ctx->world != 1) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_regions: single-GPU only");
     CK(hipSetDevice(ctx->device));
     VariantParams var{0.001f, 0, 0, 1.0f, 1.0f, 0, 0};
     if (variant) var = VariantParams{variant->radiance_tmin, variant->cull_back_occlusion, variant->tonemap, variant->exposure, variant->white, variant->initial_depth, variant->write_aov};
@@ -1054,6 +1114,7 @@ extern "C" int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t
     CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 3, ctx->stream));
     hipEvent_t ev_begin = next_event(ctx);
     CK(hipEventRecord(ev_begin, ctx->stream));
+    ctx->ev_begin = ev_begin;
     for (auto& b : ctx->sets) hipStreamWaitEvent(b.stream, ev_begin, 0);
     LaunchCounts lc;
     uint64_t paths = 0;
@@ -1093,32 +1154,19 @@ extern "C" int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t
     }
     hipEvent_t ev_end = next_event(ctx);
     CK(hipEventRecord(ev_end, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
-    CK(hipGetLastError());
-    unsigned long long totals[3] = {0, 0, 0};
-    CK(hipMemcpy(totals, ctx->d_totals, sizeof(totals), hipMemcpyDeviceToHost));
-    if (totals[2] & 1ull) return fail(ctx, PT_ERR_UNSUPPORTED, "traversal stack overflow: the acceleration structure is deeper than the traversal stack; the frame is invalid");
-    pt_stats& st = ctx->stats;
-    st.radiance_rays = totals[0];
-    st.shadow_rays = totals[1];
-    st.paths = paths;
-    float ms = 0;
-    hipEventElapsedTime(&ms, ev_begin, ev_end);
-    st.render_ms = ms;
-    double cls_ms[4] = {0, 0, 0, 0};
-    for (auto& sp : ctx->spans) {
-        float m = 0;
-        hipEventElapsedTime(&m, ctx->ev_pool[sp.a], ctx->ev_pool[sp.b]);
-        cls_ms[sp.cls] += m;
-    }
-    st.trace_ms = cls_ms[CLS_TRACE];
-    st.shadow_ms = cls_ms[CLS_SHADOW];
-    st.shade_ms = cls_ms[CLS_SHADE];
-    st.other_ms = cls_ms[CLS_OTHER];
-    st.trace_launches = lc.trace;
-    st.shadow_launches = lc.shadow;
-    st.shade_launches = lc.shade;
-    if (host_rgba8) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)ctx->width * ctx->height);
+    ctx->ev_end = ev_end;
+    ctx->pending = 1;
+    ctx->pending_paths = paths;
+    ctx->pending_lc = lc;
+    return PT_OK;
+}
+
+extern "C" int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t n, const pt_variant* variant, uint32_t* host_rgba8) {
+    if (!ctx || (!regions && n)) return PT_ERR_INVALID;
+    int rc = regions_enqueue(ctx, regions, n, variant);
+    if (rc == PT_OK) rc = render_finish(ctx);
+    if (rc != PT_OK) return rc;
+    if (host_rgba8 && ctx->width) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)ctx->width * ctx->height);
     return PT_OK;
 }
 
@@ -1224,8 +1272,24 @@ extern "C" int pt_owned_pixels(const pt_ctx* ctx, uint32_t* owned, uint32_t* pad
     return PT_OK;
 }
 
+static int pack_launch(pt_ctx* ctx, int which, void* dev_dst);
+static int unpack_launch(pt_ctx* ctx, int which, const void* dev_src_all);
 extern "C" int pt_pack(pt_ctx* ctx, int which, void* dev_dst) {
     if (!ctx || !dev_dst) return PT_ERR_INVALID;
+    int rc = pack_launch(ctx, which, dev_dst);
+    if (rc != PT_OK) return rc;
+    CK(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+extern "C" int pt_unpack(pt_ctx* ctx, int which, const void* dev_src_all) {
+    if (!ctx || !dev_src_all) return PT_ERR_INVALID;
+    int rc = unpack_launch(ctx, which, dev_src_all);
+    if (rc != PT_OK) return rc;
+    CK(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+// the kernels alone, on the context's stream (pt_multi_gather chains pack -> exchange -> unpack without host waits)
+static int pack_launch(pt_ctx* ctx, int which, void* dev_dst) {
     size_t elem;
     void* p = buffer_ptr(ctx, which, &elem);
     if (!p) return fail(ctx, PT_ERR_INVALID, "pt_pack: unknown buffer or not resized");
@@ -1237,12 +1301,10 @@ extern "C" int pt_pack(pt_ctx* ctx, int which, void* dev_dst) {
         else
             hipLaunchKernelGGL((k_pack<uint32_t>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)p, ctx->d_pixels, n, ctx->width, (uint32_t*)dev_dst);
     }
-    CK(hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
 
-extern "C" int pt_unpack(pt_ctx* ctx, int which, const void* dev_src_all) {
-    if (!ctx || !dev_src_all) return PT_ERR_INVALID;
+static int unpack_launch(pt_ctx* ctx, int which, const void* dev_src_all) {
     size_t elem;
     void* p = buffer_ptr(ctx, which, &elem);
     if (!p) return fail(ctx, PT_ERR_INVALID, "pt_unpack: unknown buffer or not resized");
@@ -1254,7 +1316,6 @@ extern "C" int pt_unpack(pt_ctx* ctx, int which, const void* dev_src_all) {
         else
             hipLaunchKernelGGL((k_unpack<uint32_t>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t*)p, ctx->d_all_pixels, n, ctx->width, (const uint32_t*)dev_src_all);
     }
-    CK(hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
 
@@ -1332,7 +1393,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
             if (any_hit) hipLaunchKernelGGL((k_trace2<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         } else {
-            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8}, QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, 0, dDbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx)};
+            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8}, QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, 0, dDbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
             if (any_hit) hipLaunchKernelGGL((k_trace8<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         }
@@ -1408,5 +1469,353 @@ extern "C" int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipGetLastError());
     CK(hipMemcpy(out, dOut, sizeof(float) * (size_t)n * out_w[which], hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+// ===================================================================================================================
+// pt_multi: N contexts in one process (include/pt_amd.h).  No reference counterpart: the reference is single-GPU.
+#include <dlfcn.h>
+
+#include <chrono>
+
+namespace {
+// the six RCCL entry points the exchange needs, resolved at run time: libptamd must load (and the single-GPU path must
+// work) on a box without librccl, and a process that already holds torch's bundled librccl must not get a second copy
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok() const { return lib && CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather && GetErrorString; }
+};
+const int kNcclUint8 = 1; // ncclDataType_t (rccl.h:460)
+
+Rccl& rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (r.lib) {
+            r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
+            r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+            r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+            r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+            r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+            r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+        }
+    }
+    return r;
+}
+thread_local std::string g_multi_error;
+} // namespace
+
+struct pt_multi {
+    std::vector<pt_ctx*> ctx;
+    std::vector<int> devices;
+    std::string err;
+    bool distinct = true;           // no device appears twice (RCCL's requirement)
+    std::vector<void*> comms;       // ncclComm_t per rank (empty until the first RCCL gather)
+    int exchange_pref = 0;          // PT_MULTI_EXCHANGE: 0 auto, 1 rccl, 2 peer copies
+    std::vector<void*> send, recv;  // per rank: padded * 16 bytes, world * padded * 16 bytes
+    uint32_t padded = 0;
+    double gather_ms = 0;
+    int last_exchange = PT_EXCHANGE_NONE;
+};
+
+static int mfail(pt_multi* m, int code, const std::string& msg) {
+    if (m) m->err = msg; else g_multi_error = msg;
+    return code;
+}
+// forward a per-context failure
+static int mctx(pt_multi* m, int r, int rc, const char* what) {
+    if (rc == PT_OK) return PT_OK;
+    return mfail(m, rc, std::string(what) + " (rank " + std::to_string(r) + ", device " + std::to_string(m->devices[r]) + "): " + m->ctx[r]->err);
+}
+#define MCK(m, call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return mfail(m, PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char* pt_multi_last_error(const pt_multi* m) { return m ? m->err.c_str() : g_multi_error.c_str(); }
+extern "C" int pt_multi_size(const pt_multi* m) { return m ? (int)m->ctx.size() : 0; }
+extern "C" pt_ctx* pt_multi_ctx(pt_multi* m, int rank) { return (m && rank >= 0 && rank < (int)m->ctx.size()) ? m->ctx[rank] : nullptr; }
+
+static void multi_free_exchange(pt_multi* m) {
+    for (size_t r = 0; r < m->send.size(); ++r) {
+        hipSetDevice(m->devices[r]);
+        if (m->send[r]) hipFree(m->send[r]);
+        if (m->recv[r]) hipFree(m->recv[r]);
+    }
+    m->send.clear();
+    m->recv.clear();
+    m->padded = 0;
+}
+
+extern "C" int pt_multi_destroy(pt_multi* m) {
+    if (!m) return PT_OK;
+    multi_free_exchange(m);
+    if (!m->comms.empty() && rccl().ok())
+        for (void* c : m->comms)
+            if (c) rccl().CommDestroy(c);
+    for (pt_ctx* c : m->ctx) pt_destroy(c);
+    delete m;
+    return PT_OK;
+}
+
+extern "C" int pt_create_multi(const pt_scene_desc* scene, const int* devices, int ndev, pt_multi** out) {
+    if (!out || !devices || ndev < 1 || ndev > 64) return mfail(nullptr, PT_ERR_INVALID, "pt_create_multi: need 1..64 devices and an output pointer");
+    FlatScene fs; // ONE host-side flatten + validation, shared by all ranks
+    int rc = flatten_scene(scene, fs);
+    if (rc != PT_OK) return mfail(nullptr, rc, g_create_error);
+    pt_multi* m = new pt_multi();
+    m->devices.assign(devices, devices + ndev);
+    for (int a = 0; a < ndev; ++a)
+        for (int b = a + 1; b < ndev; ++b)
+            if (devices[a] == devices[b]) m->distinct = false;
+    if (const char* e = getenv("PT_MULTI_EXCHANGE")) m->exchange_pref = !strcmp(e, "rccl") ? 1 : (!strcmp(e, "peer") ? 2 : 0);
+    for (int r = 0; r < ndev; ++r) {
+        pt_ctx* c = nullptr;
+        rc = create_from_flat(fs, devices[r], &c);
+        if (rc != PT_OK) {
+            const std::string msg = "pt_create_multi: rank " + std::to_string(r) + ": " + g_create_error;
+            pt_multi_destroy(m);
+            return mfail(nullptr, rc, msg);
+        }
+        m->ctx.push_back(c);
+    }
+    // direct device-to-device copies between distinct devices need peer access (xGMI); failure is not fatal — hipMemcpyPeerAsync
+    // then stages through the host
+    if (m->distinct && ndev > 1)
+        for (int a = 0; a < ndev; ++a) {
+            hipSetDevice(devices[a]);
+            for (int b = 0; b < ndev; ++b) {
+                int can = 0;
+                if (a != b && hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+                    hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                }
+            }
+        }
+    *out = m;
+    return PT_OK;
+}
+
+extern "C" int pt_multi_set_options(pt_multi* m, const pt_options* opt) {
+    if (!m || !opt) return PT_ERR_INVALID;
+    for (size_t r = 0; r < m->ctx.size(); ++r) {
+        int rc = mctx(m, (int)r, pt_set_options(m->ctx[r], opt), "pt_multi_set_options");
+        if (rc) return rc;
+    }
+    return PT_OK;
+}
+extern "C" int pt_multi_set_probe(pt_multi* m, const float* data, const float* pdfX, const float* cdfX, const float* pdfY, const float* cdfY, int w, int h) {
+    if (!m) return PT_ERR_INVALID;
+    for (size_t r = 0; r < m->ctx.size(); ++r) {
+        int rc = mctx(m, (int)r, pt_set_probe(m->ctx[r], data, pdfX, cdfX, pdfY, cdfY, w, h), "pt_multi_set_probe");
+        if (rc) return rc;
+    }
+    return PT_OK;
+}
+extern "C" int pt_multi_set_probe_image(pt_multi* m, const float* data, int w, int h) {
+    if (!m) return PT_ERR_INVALID;
+    for (size_t r = 0; r < m->ctx.size(); ++r) {
+        int rc = mctx(m, (int)r, pt_set_probe_image(m->ctx[r], data, w, h), "pt_multi_set_probe_image");
+        if (rc) return rc;
+    }
+    return PT_OK;
+}
+extern "C" int pt_multi_set_camera(pt_multi* m, const float eye[3], const float U[3], const float V[3], const float W[3]) {
+    if (!m) return PT_ERR_INVALID;
+    for (size_t r = 0; r < m->ctx.size(); ++r) {
+        int rc = mctx(m, (int)r, pt_set_camera(m->ctx[r], eye, U, V, W), "pt_multi_set_camera");
+        if (rc) return rc;
+    }
+    return PT_OK;
+}
+
+extern "C" int pt_multi_resize(pt_multi* m, int width, int height, int tile_w, int tile_h) {
+    if (!m) return PT_ERR_INVALID;
+    if (width == 0 || height == 0) return PT_OK;
+    if (tile_w == 0) tile_w = 64;
+    if (tile_h == 0) tile_h = 16;
+    const int world = (int)m->ctx.size();
+    multi_free_exchange(m);
+    for (int r = 0; r < world; ++r) {
+        pt_ctx* c = m->ctx[r];
+        c->width = c->height = 0; // pt_set_partition then only records the partition; pt_resize applies it
+        int rc = mctx(m, r, pt_set_partition(c, r, world, tile_w, tile_h), "pt_multi_resize");
+        if (rc == PT_OK) rc = mctx(m, r, pt_resize(c, width, height), "pt_multi_resize");
+        if (rc) return rc;
+    }
+    m->padded = m->ctx[0]->padded;
+    m->send.assign(world, nullptr);
+    m->recv.assign(world, nullptr);
+    for (int r = 0; r < world; ++r) {
+        MCK(m, hipSetDevice(m->devices[r]));
+        MCK(m, hipMalloc(&m->send[r], std::max<size_t>(16, (size_t)m->padded * 16)));
+        MCK(m, hipMalloc(&m->recv[r], std::max<size_t>(16, (size_t)world * m->padded * 16)));
+    }
+    return PT_OK;
+}
+
+extern "C" int pt_multi_gather(pt_multi* m, int which) {
+    if (!m) return PT_ERR_INVALID;
+    const int world = (int)m->ctx.size();
+    if (m->send.empty()) return mfail(m, PT_ERR_INVALID, "pt_multi_gather: not resized");
+    size_t elem = 0;
+    if (!buffer_ptr(m->ctx[0], which, &elem)) return mfail(m, PT_ERR_INVALID, "pt_multi_gather: unknown buffer");
+    const size_t bytes = (size_t)m->padded * elem; // one rank's packed strip (padded to the largest share: same on every rank)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < world; ++r) {
+        int rc = mctx(m, r, pack_launch(m->ctx[r], which, m->send[r]), "pt_multi_gather(pack)");
+        if (rc) return rc;
+    }
+    bool use_rccl = m->exchange_pref == 1 || (m->exchange_pref == 0 && m->distinct && world > 1);
+    if (use_rccl && (!rccl().ok() || !m->distinct)) {
+        if (m->exchange_pref == 1) return mfail(m, PT_ERR_UNSUPPORTED, !m->distinct ? "pt_multi_gather: RCCL needs distinct devices" : "pt_multi_gather: librccl not found");
+        use_rccl = false;
+    }
+    if (use_rccl) {
+        Rccl& R = rccl();
+        if (m->comms.empty()) {
+            m->comms.assign(world, nullptr);
+            const int e = R.CommInitAll(m->comms.data(), world, m->devices.data());
+            if (e != 0) {
+                m->comms.clear();
+                return mfail(m, PT_ERR_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(e));
+            }
+        }
+        // one all-gather of `bytes` per rank: with 8 GPUs each of the 7 xGMI links of a GPU carries one strip
+        int e = R.GroupStart();
+        for (int r = 0; r < world && e == 0; ++r) {
+            MCK(m, hipSetDevice(m->devices[r]));
+            e = R.AllGather(m->send[r], m->recv[r], bytes, kNcclUint8, m->comms[r], m->ctx[r]->stream);
+        }
+        const int e2 = R.GroupEnd();
+        if (e != 0 || e2 != 0) return mfail(m, PT_ERR_HIP, std::string("ncclAllGather: ") + R.GetErrorString(e ? e : e2));
+        m->last_exchange = PT_EXCHANGE_RCCL;
+    } else {
+        // every rank writes its strip into slot r of every rank's receive buffer (direct peer writes over xGMI; a plain
+        // device-to-device copy when both ranks live on one device), then every rank waits for all writers
+        std::vector<hipEvent_t> done(world);
+        for (int r = 0; r < world; ++r) {
+            MCK(m, hipSetDevice(m->devices[r]));
+            for (int p = 0; p < world; ++p) {
+                char* dst = (char*)m->recv[p] + (size_t)r * bytes;
+                if (m->devices[p] == m->devices[r]) MCK(m, hipMemcpyAsync(dst, m->send[r], bytes, hipMemcpyDeviceToDevice, m->ctx[r]->stream));
+                else MCK(m, hipMemcpyPeerAsync(dst, m->devices[p], m->send[r], m->devices[r], bytes, m->ctx[r]->stream));
+            }
+            MCK(m, hipEventCreateWithFlags(&done[r], hipEventDisableTiming));
+            MCK(m, hipEventRecord(done[r], m->ctx[r]->stream));
+        }
+        for (int p = 0; p < world; ++p) {
+            MCK(m, hipSetDevice(m->devices[p]));
+            for (int r = 0; r < world; ++r)
+                if (r != p) MCK(m, hipStreamWaitEvent(m->ctx[p]->stream, done[r], 0));
+        }
+        // the events must outlive the waits: destroyed after the streams are synchronised below
+        for (int r = 0; r < world; ++r) {
+            int rc = mctx(m, r, unpack_launch(m->ctx[r], which, m->recv[r]), "pt_multi_gather(unpack)");
+            if (rc) return rc;
+        }
+        for (int r = 0; r < world; ++r) {
+            MCK(m, hipSetDevice(m->devices[r]));
+            MCK(m, hipStreamSynchronize(m->ctx[r]->stream));
+        }
+        for (int r = 0; r < world; ++r) hipEventDestroy(done[r]);
+        m->last_exchange = PT_EXCHANGE_PEER_COPY;
+        m->gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return PT_OK;
+    }
+    for (int r = 0; r < world; ++r) {
+        int rc = mctx(m, r, unpack_launch(m->ctx[r], which, m->recv[r]), "pt_multi_gather(unpack)");
+        if (rc) return rc;
+    }
+    for (int r = 0; r < world; ++r) {
+        MCK(m, hipSetDevice(m->devices[r]));
+        MCK(m, hipStreamSynchronize(m->ctx[r]->stream));
+    }
+    m->gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PT_OK;
+}
+
+static int multi_after_render(pt_multi* m, uint32_t gather_mask, uint32_t* host_rgba8) {
+    if (host_rgba8) gather_mask |= 1u << PT_BUF_FRAME;
+    if (m->ctx[0]->width == 0) return PT_OK;
+    for (int which = 0; which <= PT_BUF_DENOISED; ++which)
+        if (gather_mask & (1u << which)) {
+            int rc = pt_multi_gather(m, which);
+            if (rc) return rc;
+        }
+    if (host_rgba8) return mctx(m, 0, pt_download(m->ctx[0], PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)m->ctx[0]->width * m->ctx[0]->height), "pt_multi_render(download)");
+    return PT_OK;
+}
+
+extern "C" int pt_multi_render(pt_multi* m, uint32_t spp, uint32_t subframe_index, uint32_t gather_mask, uint32_t* host_rgba8) {
+    if (!m) return PT_ERR_INVALID;
+    const int world = (int)m->ctx.size();
+    // enqueue on every device, then wait: the devices render their tiles concurrently
+    for (int r = 0; r < world; ++r) {
+        int rc = mctx(m, r, render_enqueue(m->ctx[r], spp, subframe_index), "pt_multi_render");
+        if (rc) return rc;
+    }
+    int first = PT_OK;
+    for (int r = 0; r < world; ++r) {
+        int rc = mctx(m, r, render_finish(m->ctx[r]), "pt_multi_render");
+        if (rc && !first) first = rc;
+    }
+    if (first) return first;
+    return multi_after_render(m, gather_mask, host_rgba8);
+}
+
+extern "C" int pt_multi_render_regions(pt_multi* m, const pt_region* regions, uint32_t n, const pt_variant* variant, uint32_t gather_mask, uint32_t* host_rgba8) {
+    if (!m || (!regions && n)) return PT_ERR_INVALID;
+    const int world = (int)m->ctx.size();
+    for (int r = 0; r < world; ++r) {
+        int rc = mctx(m, r, regions_enqueue(m->ctx[r], regions, n, variant), "pt_multi_render_regions");
+        if (rc) return rc;
+    }
+    int first = PT_OK;
+    for (int r = 0; r < world; ++r) {
+        int rc = mctx(m, r, render_finish(m->ctx[r]), "pt_multi_render_regions");
+        if (rc && !first) first = rc;
+    }
+    if (first) return first;
+    return multi_after_render(m, gather_mask, host_rgba8);
+}
+
+extern "C" int pt_multi_get_stats(const pt_multi* m, pt_multi_stats* out) {
+    if (!m || !out) return PT_ERR_INVALID;
+    memset(out, 0, sizeof(*out));
+    for (size_t r = 0; r < m->ctx.size(); ++r) {
+        pt_stats s;
+        pt_get_stats(m->ctx[r], &s);
+        out->sum.radiance_rays += s.radiance_rays;
+        out->sum.shadow_rays += s.shadow_rays;
+        out->sum.paths += s.paths;
+        out->sum.render_ms = std::max(out->sum.render_ms, s.render_ms);
+        out->sum.trace_ms = std::max(out->sum.trace_ms, s.trace_ms);
+        out->sum.shadow_ms = std::max(out->sum.shadow_ms, s.shadow_ms);
+        out->sum.shade_ms = std::max(out->sum.shade_ms, s.shade_ms);
+        out->sum.other_ms = std::max(out->sum.other_ms, s.other_ms);
+        out->sum.trace_launches += s.trace_launches;
+        out->sum.shadow_launches += s.shadow_launches;
+        out->sum.shade_launches += s.shade_launches;
+        out->sum.bvh_nodes = s.bvh_nodes;
+        out->sum.bvh_bytes = s.bvh_bytes;
+        out->sum.bvh_levels = s.bvh_levels;
+        out->sum.bvh_build_ms = std::max(out->sum.bvh_build_ms, s.bvh_build_ms);
+    }
+    out->gather_ms = m->gather_ms;
+    out->exchange = m->last_exchange;
+    out->ndev = (int)m->ctx.size();
     return PT_OK;
 }

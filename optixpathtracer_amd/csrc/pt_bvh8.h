@@ -94,6 +94,7 @@ struct Trace8Args {
     int lds_skip; // test hook (PT_STACK_LDS_SKIP): keep this many fewer stack levels in LDS, so shallow trees exercise the global spill path
     int ovf_depth;  // spill levels available (PT8_OVF_DEPTH; the test hook PT_STACK_CAP lowers it)
     uint32_t* fault; // device word: bit 0 set when a push found the stack full — the host turns it into PT_ERR_UNSUPPORTED
+    uint32_t num_nodes;
 };
 
 PT_DEV float u8f(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
@@ -104,6 +105,14 @@ k_trace8(Trace8Args a) {
     __shared__ uint32_t s_stack[PT8_LDS_DEPTH * 2 * 64];
     __shared__ uint32_t s_prefix[PT_NSUB + 1];
     __shared__ uint32_t s_prefix2[PT_NSUB + 1];
+#ifdef PT8_TOP_NODES
+    // experiment (north_star: "BVH nodes staged in LDS"): the first PT8_TOP_NODES nodes of the breadth-first node array — the root and
+    // its children (9), or two levels (73) — are copied to LDS by every workgroup and read from there
+    __shared__ Node8 s_top[PT8_TOP_NODES];
+    for (uint32_t k = threadIdx.x; k < (uint32_t)PT8_TOP_NODES * 5u; k += 64u)
+        if (k / 5u < a.num_nodes) reinterpret_cast<float4*>(s_top)[k] = reinterpret_cast<const float4*>(a.bvh.nodes)[k];
+    __syncthreads();
+#endif
 #if PT8_STEAL
     __shared__ unsigned long long s_key[64]; // per owner lane: merged result of the ray that lane loaded
     __shared__ uint32_t s_cnt[64];           // per owner lane: co-workers still traversing that ray
@@ -418,7 +427,11 @@ k_trace8(Trace8Args a) {
                         if (g_hits != 0u) push(g_base, g_imask | (g_hits << 8));
                         PT_STAT(++c_nodes; ++c_ray;)
                         ++nsteps;
+#ifdef PT8_TOP_NODES
+                        const Node8* nd = idx < (uint32_t)PT8_TOP_NODES ? &s_top[idx] : &a.bvh.nodes[idx];
+#else
                         const Node8* nd = &a.bvh.nodes[idx];
+#endif
                         const float4 n0 = nd->n0, n1 = nd->n1, n2 = nd->n2, n3 = nd->n3, n4 = nd->n4;
                         const uint32_t e01 = __float_as_uint(n0.w), e2m = __float_as_uint(n1.w);
                         const float sx = __uint_as_float(e01 << 16), sy = __uint_as_float(e01 & 0xffff0000u), sz = __uint_as_float(e2m << 16);

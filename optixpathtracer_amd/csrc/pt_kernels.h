@@ -552,6 +552,12 @@ struct RegionParams { // LaunchParams.frame.{factor,fillSize,c,r_inner,r_outer,o
     uint32_t spp;
     uint32_t subframe_index;
 };
+struct PartParams { // image partition of the context (pt_set_partition): pixel (x,y) belongs to rank (x / tile_w + y / tile_h) % world
+    int rank, world, tile_w, tile_h;
+};
+PT_DEV bool part_owns(const PartParams& pp, uint32_t px, uint32_t py) {
+    return pp.world <= 1 || (int)((px / (uint32_t)pp.tile_w + py / (uint32_t)pp.tile_h) % (uint32_t)pp.world) == pp.rank;
+}
 struct VariantParams {
     float radiance_tmin;
     int cull_back_occlusion;
@@ -561,7 +567,7 @@ struct VariantParams {
 };
 
 // paths: i = sample * nl + (launch index - l0); culled launch indices are flagged and never queued
-__global__ void __launch_bounds__(256) k_generate_region(PathState st, FrameParams fp, RegionParams rg, float tmin, uint32_t depth0, uint32_t l0, uint32_t nl, QView qgen) {
+__global__ void __launch_bounds__(256) k_generate_region(PathState st, FrameParams fp, RegionParams rg, PartParams pp, float tmin, uint32_t depth0, uint32_t l0, uint32_t nl, QView qgen) {
     const uint32_t total = nl * rg.spp;
     const uint32_t nround = (total + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += gridDim.x * blockDim.x) {
@@ -573,7 +579,18 @@ __global__ void __launch_bounds__(256) k_generate_region(PathState st, FramePara
             const uint32_t ix = lx * rg.factor_x + rg.offset_x, iy = ly * rg.factor_y + rg.offset_y;
             const v3 dv = sub3(mk3((float)ix, (float)iy, 0.0f), mk3((float)rg.cx, (float)rg.cy, 0.0f));
             const float range = sqrtf(dot3(dv, dv));
-            if (range < rg.r_inner || range > rg.r_outer) {
+            // On a partitioned image (multi-GPU) a launch index is traced by every rank that owns at least one pixel of its
+            // fillSize^2 splat (the pixel coordinates are the resolve kernel's: u32 arithmetic, clamped to the image); a splat
+            // that straddles a tile border is traced by both neighbours — same seeds, same bits — and each writes only its pixels.
+            bool mine = pp.world <= 1;
+            for (int fi = 0; fi < rg.fill_size && !mine; ++fi)
+                for (int fj = 0; fj < rg.fill_size && !mine; ++fj) {
+                    uint32_t px = lx * rg.factor_x + (uint32_t)fi + rg.offset_x, py = ly * rg.factor_y + (uint32_t)fj + rg.offset_y;
+                    px = px > (uint32_t)(fp.width - 1) ? (uint32_t)(fp.width - 1) : px;
+                    py = py > (uint32_t)(fp.height - 1) ? (uint32_t)(fp.height - 1) : py;
+                    mine = part_owns(pp, px, py);
+                }
+            if (range < rg.r_inner || range > rg.r_outer || !mine) {
                 st.fd[i] = (uint32_t)FLAG_CULLED << 8;
             } else {
                 for (uint32_t k = 0; k < 2u * sl; ++k) lcg(seed);
@@ -611,7 +628,7 @@ PT_DEV v3 reinhard_tonemap(v3 color, float white) { // sv4 deviceProgram.cu:124-
     return div3s(scl3(color, 1.0f), 1.0f + luminance / white);
 }
 
-__global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParams fp, RegionParams rg, VariantParams var, uint32_t l0, uint32_t nl) {
+__global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParams fp, RegionParams rg, PartParams pp, VariantParams var, uint32_t l0, uint32_t nl) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nl) return;
     if ((st.fd[k] >> 8) & FLAG_CULLED) return;
@@ -653,6 +670,7 @@ __global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParam
             uint32_t px = lx * rg.factor_x + (uint32_t)fi + rg.offset_x, py = ly * rg.factor_y + (uint32_t)fj + rg.offset_y;
             px = px > (uint32_t)(fp.width - 1) ? (uint32_t)(fp.width - 1) : px;
             py = py > (uint32_t)(fp.height - 1) ? (uint32_t)(fp.height - 1) : py;
+            if (!part_owns(pp, px, py)) continue;
             const size_t image_index = (size_t)py * fp.width + px;
             const v3 color = add3(mul3(scl3(backplate, spp), sub3(mk3(1.0f), alpha)), result);
             v3 accum_color = div3s(color, spp);

@@ -55,36 +55,42 @@ class LaunchParams:
     samples_per_launch: int = 1
 
 
+def _scene_desc(model: Model):
+    """pt_scene_desc for a Model plus the arrays it points into (keep them alive until pt_create returns)."""
+    meshes = (MeshDesc * len(model.meshes))()
+    keep = []
+    for k, m in enumerate(model.meshes):
+        v = np.ascontiguousarray(m.vertex, np.float32)
+        ix = np.ascontiguousarray(m.index, np.uint32)
+        keep += [v, ix]
+        meshes[k].vertex = v.ctypes.data
+        meshes[k].num_vertices = len(v)
+        meshes[k].index = ix.ctypes.data
+        meshes[k].num_triangles = len(ix)
+        C.memmove(C.byref(meshes[k].material), np.asarray(m.material).tobytes(), 104)
+        meshes[k].diffuse_texture_id = m.diffuseTextureID
+        if m.texcoord is not None and len(m.texcoord):
+            tc = np.ascontiguousarray(m.texcoord, np.float32)
+            assert tc.shape == (len(v), 2)
+            keep.append(tc)
+            meshes[k].texcoord = tc.ctypes.data
+    textures = getattr(model, "textures", []) or []
+    tdesc = (TextureDesc * max(1, len(textures)))()
+    for k, t in enumerate(textures):
+        px = np.ascontiguousarray(t.pixel, np.uint32)
+        keep.append(px)
+        tdesc[k].pixel = px.ctypes.data
+        tdesc[k].height, tdesc[k].width = px.shape
+    keep += [meshes, tdesc]
+    return SceneDesc(meshes, len(model.meshes), tdesc, len(textures)), keep
+
+
 class SampleRenderer:
     def __init__(self, model: Model, device: int = 0):
         self._L = L = _lib.load_library()
         self._ctx = C.c_void_p()
         self.launchParams = LaunchParams()
-        meshes = (MeshDesc * len(model.meshes))()
-        self._keep = []
-        for k, m in enumerate(model.meshes):
-            v = np.ascontiguousarray(m.vertex, np.float32)
-            ix = np.ascontiguousarray(m.index, np.uint32)
-            self._keep += [v, ix]
-            meshes[k].vertex = v.ctypes.data
-            meshes[k].num_vertices = len(v)
-            meshes[k].index = ix.ctypes.data
-            meshes[k].num_triangles = len(ix)
-            C.memmove(C.byref(meshes[k].material), np.asarray(m.material).tobytes(), 104)
-            meshes[k].diffuse_texture_id = m.diffuseTextureID
-            if m.texcoord is not None and len(m.texcoord):
-                tc = np.ascontiguousarray(m.texcoord, np.float32)
-                assert tc.shape == (len(v), 2)
-                self._keep.append(tc)
-                meshes[k].texcoord = tc.ctypes.data
-        textures = getattr(model, "textures", []) or []
-        tdesc = (TextureDesc * max(1, len(textures)))()
-        for k, t in enumerate(textures):
-            px = np.ascontiguousarray(t.pixel, np.uint32)
-            self._keep.append(px)
-            tdesc[k].pixel = px.ctypes.data
-            tdesc[k].height, tdesc[k].width = px.shape
-        sd = SceneDesc(meshes, len(model.meshes), tdesc, len(textures))
+        sd, self._keep = _scene_desc(model)
         rc = L.pt_create(C.byref(sd), device, C.byref(self._ctx))
         if rc:
             self._ctx = C.c_void_p()
@@ -279,6 +285,127 @@ class SampleRenderer:
             mp = C.cast(C.byref(mbuf), C.c_void_p)
         self._ck(self._L.pt_eval_table(self._ctx, which, mp, bsdf_mode, inp.ctypes.data, n, out.ctypes.data), "pt_eval_table")
         return out
+
+
+class _RankView(SampleRenderer):
+    """A rank's context of a MultiRenderer seen through the single-context facade (download, stats, deviceBuffer ...).
+    It does not own the context."""
+
+    def __init__(self, L, ctx, launchParams):
+        self._L, self._ctx, self.launchParams = L, ctx, launchParams
+
+    def close(self):
+        self._ctx = C.c_void_p()
+
+
+class MultiRenderer:
+    """SampleRenderer over several GPUs of ONE process (pt_create_multi, include/pt_amd.h): the same call sequence as
+    the reference's renderer; the frame is tile-partitioned over `devices`, rendered concurrently, and gathered on every
+    rank by one RCCL all-gather (direct device-to-device copies when ranks share a device)."""
+
+    EXCHANGE = {0: "none", 1: "rccl", 2: "peer_copy"}
+
+    def __init__(self, model: Model, devices=(0,)):
+        from ._lib import MultiStats  # noqa: F401
+
+        self._L = L = _lib.load_library()
+        self._m = C.c_void_p()
+        self.launchParams = LaunchParams()
+        self.devices = [int(d) for d in devices]
+        sd, keep = _scene_desc(model)
+        dv = (C.c_int * len(self.devices))(*self.devices)
+        rc = L.pt_create_multi(C.byref(sd), dv, len(self.devices), C.byref(self._m))
+        del keep
+        if rc:
+            self._m = C.c_void_p()
+            raise RuntimeError(f"pt_create_multi failed ({rc}): {L.pt_multi_last_error(None).decode()}")
+        self.gather_mask = 1 << PT_BUF_FRAME  # what render() assembles on every rank (the reference displays frame_buffer)
+
+    def _ck(self, rc, what):
+        if rc:
+            raise RuntimeError(f"{what} failed ({rc}): {self._L.pt_multi_last_error(self._m).decode()}")
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._L.pt_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def world(self):
+        return self._L.pt_multi_size(self._m)
+
+    def rank(self, r) -> SampleRenderer:
+        ctx = self._L.pt_multi_ctx(self._m, int(r))
+        if not ctx:
+            raise IndexError(r)
+        return _RankView(self._L, C.c_void_p(ctx), self.launchParams)
+
+    def setOptions(self, max_depth=8, bsdf_mode=PT_BSDF_DISNEY, max_paths=0, bvh_kind=0, trace_kernel=0, streams=0, split_shadow=0, kernel_timing=0):
+        o = Options(max_depth, bsdf_mode, max_paths, kernel_timing, bvh_kind, trace_kernel, streams, split_shadow)
+        self._ck(self._L.pt_multi_set_options(self._m, C.byref(o)), "pt_multi_set_options")
+
+    def setProbe(self, probe):
+        if not getattr(probe, "valid", False):
+            raise RuntimeError("Probe Data is not valid")  # Probe.h:104-105
+        d = np.ascontiguousarray(probe.data, np.float32)
+        a = [np.ascontiguousarray(x, np.float32) for x in (probe.pdfValuesX, probe.cdfValuesX, probe.pdfValuesY, probe.cdfValuesY)]
+        self._ck(self._L.pt_multi_set_probe(self._m, d.ctypes.data, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, probe.width, probe.height), "pt_multi_set_probe")
+
+    def resize(self, newSize, tile=(64, 16)):
+        w, h = int(newSize[0]), int(newSize[1])
+        self._ck(self._L.pt_multi_resize(self._m, w, h, int(tile[0]), int(tile[1])), "pt_multi_resize")
+        if w and h:
+            self.launchParams.frame.size = (w, h)
+
+    def setCamera(self, camera: Camera):
+        U, V, W = camera.UVWFrame()
+        f3 = C.c_float * 3
+        self._ck(self._L.pt_multi_set_camera(self._m, C.byref(f3(*[float(x) for x in camera.eye])), C.byref(f3(*[float(x) for x in U])), C.byref(f3(*[float(x) for x in V])), C.byref(f3(*[float(x) for x in W]))), "pt_multi_set_camera")
+
+    def render(self, out: np.ndarray | None = None):
+        ptr = out.ctypes.data if out is not None else None
+        self._ck(self._L.pt_multi_render(self._m, int(self.launchParams.samples_per_launch), int(self.launchParams.frame.subframe_index), int(self.gather_mask), ptr), "pt_multi_render")
+
+    def renderRegions(self, regions, variant=None, out: np.ndarray | None = None):
+        arr = (Region * len(regions))()
+        for k, g in enumerate(regions):
+            for name, _ in Region._fields_:
+                setattr(arr[k], name, g[name])
+        vp = None
+        if variant is not None:
+            v = Variant(**variant)
+            vp = C.byref(v)
+        ptr = out.ctypes.data if out is not None else None
+        self._ck(self._L.pt_multi_render_regions(self._m, arr, len(regions), vp, int(self.gather_mask), ptr), "pt_multi_render_regions")
+
+    def renderFoveated(self, c, inner_radius=157, outer_radius=515, spp=(1, 2, 8), out=None, variant=None):
+        regs = SampleRenderer.foveatedRegions(self.launchParams.frame.size, c, int(self.launchParams.frame.subframe_index), inner_radius, outer_radius, spp)
+        self.renderRegions(regs, variant or SampleRenderer.SV4_VARIANT, out)
+        self.launchParams.frame.subframe_index += 1
+
+    def gather(self, which):
+        self._ck(self._L.pt_multi_gather(self._m, int(which)), "pt_multi_gather")
+
+    def download(self, which, rank=0) -> np.ndarray:
+        return self.rank(rank).download(which)
+
+    def downloadPixels(self) -> np.ndarray:
+        return self.download(PT_BUF_FRAME)
+
+    def stats(self) -> dict:
+        from ._lib import MultiStats
+
+        s = MultiStats()
+        self._ck(self._L.pt_multi_get_stats(self._m, C.byref(s)), "pt_multi_get_stats")
+        d = s.sum.as_dict()
+        d.update(gather_ms=s.gather_ms, exchange=self.EXCHANGE.get(s.exchange, "?"), ndev=s.ndev)
+        return d
 
 
 def make_camera(cam: dict, aspect: float) -> Camera:

@@ -1001,6 +1001,101 @@ def test_cxx_facade_demo_matches_python(ptlib, small_probe, tmp_path):
     g = _gpu_render(_renderer(m, small_probe, cam, w, h), spp, subframes=nsub)
     assert_bits_equal(accum, g["accum"], "accum_buffer from the C++ process")
     assert np.array_equal(frame, g["frame"])
+    # the same application on MultiSampleRenderer: 3 contexts in one process (all on device 0 here), frame assembled by the
+    # library's own exchange; rank 2's accum_buffer after an explicit gather
+    out3 = tmp_path / "out3.bin"
+    res = subprocess.run([str(exe), str(scene), str(out3), "3"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    raw = np.fromfile(out3, np.uint8)
+    assert np.array_equal(raw[: w * h * 4].view(np.uint32).reshape(h, w), g["frame"])
+    assert_bits_equal(raw[w * h * 4 :].view(np.float32).reshape(h, w, 4), g["accum"], "accum_buffer from the 3-context C++ process")
+
+
+def test_multi_context_one_process(ptlib, small_probe, monkeypatch):
+    """pt_create_multi: N contexts of ONE process render interleaved tiles of one frame concurrently and assemble it with the
+    library's own exchange.  On this one-GPU box all contexts live on device 0 (direct device-to-device copies; RCCL refuses
+    duplicate devices) — the partition, the enqueue-all-then-wait schedule, pack / exchange / unpack and the per-rank buffers
+    are the multi-GPU code path.  Every rank's assembled buffers must equal the single-context render bit for bit; the
+    forced-RCCL run (one rank, its own communicator) exercises the ncclAllGather branch."""
+    from optixpathtracer_amd import renderer as R
+
+    for model, cam, (w, h), spp in ((scenes.cornell_box(), scenes.CORNELL_CAMERA, (100, 60), 2),
+                                    (scenes.voxel_terrain(n=96, target_tris=70000), scenes.TERRAIN_CAMERA, (200, 120), 3)):
+        ref = _gpu_render(_renderer(model, small_probe, cam, w, h), spp, subframes=2)
+        for ndev in (3, 8):
+            mr = R.MultiRenderer(model, devices=[0] * ndev)
+            assert mr.world == ndev
+            mr.setProbe(small_probe)
+            mr.resize((w, h), tile=(16, 8))
+            mr.setCamera(R.make_camera(cam, w / h))
+            mr.launchParams.samples_per_launch = spp
+            mr.gather_mask = sum(1 << b for b in (R.PT_BUF_ACCUM, R.PT_BUF_FRAME, R.PT_BUF_COLOR, R.PT_BUF_NORMAL, R.PT_BUF_ALBEDO))
+            for sf in range(2):
+                mr.launchParams.frame.subframe_index = sf
+                mr.render()
+            st = mr.stats()
+            assert st["exchange"] == "peer_copy" and st["ndev"] == ndev
+            assert st["radiance_rays"] == ref["stats"]["radiance_rays"] and st["shadow_rays"] == ref["stats"]["shadow_rays"]
+            assert st["paths"] == w * h * spp
+            for rank in (0, ndev - 1):
+                assert_bits_equal(mr.download(R.PT_BUF_ACCUM, rank), ref["accum"], f"accum_buffer assembled on rank {rank} of {ndev}")
+                assert_bits_equal(mr.download(R.PT_BUF_NORMAL, rank), ref["normal"], f"normal_buffer on rank {rank}")
+                assert_bits_equal(mr.download(R.PT_BUF_ALBEDO, rank), ref["albedo"], f"albedo_buffer on rank {rank}")
+                assert np.array_equal(mr.download(R.PT_BUF_FRAME, rank), ref["frame"])
+            mr.close()
+    # RCCL branch: a single-rank communicator (the only RCCL configuration a one-GPU box can run)
+    monkeypatch.setenv("PT_MULTI_EXCHANGE", "rccl")
+    model, cam, (w, h), spp = scenes.cornell_box(), scenes.CORNELL_CAMERA, (100, 60), 2
+    ref = _gpu_render(_renderer(model, small_probe, cam, w, h), spp)
+    mr = R.MultiRenderer(model, devices=[0])
+    mr.setProbe(small_probe)
+    mr.resize((w, h))
+    mr.setCamera(R.make_camera(cam, w / h))
+    mr.launchParams.samples_per_launch = spp
+    out = np.zeros((h, w), np.uint32)
+    mr.render(out)
+    assert mr.stats()["exchange"] == "rccl"
+    assert np.array_equal(out, ref["frame"])
+    mr.gather(R.PT_BUF_ACCUM)
+    assert_bits_equal(mr.download(R.PT_BUF_ACCUM), ref["accum"], "accum_buffer through ncclAllGather")
+    mr.close()
+    monkeypatch.setenv("PT_MULTI_EXCHANGE", "rccl")
+    with pytest.raises(RuntimeError, match="distinct devices"):
+        m2 = R.MultiRenderer(model, devices=[0, 0])
+        m2.setProbe(small_probe)
+        m2.resize((w, h))
+        m2.setCamera(R.make_camera(cam, w / h))
+        m2.render()
+
+
+def test_multi_context_foveated_launches(ptlib):
+    """The foveated launches on a partitioned image (pt_render_regions no longer refuses world != 1): a launch index is traced
+    by every rank that owns a pixel of its splat, each rank writes only its own pixels, and the assembled accum_buffer /
+    frame_buffer equal the single-context frames bit for bit over several frames with a moving gaze (periphery accumulating,
+    annulus and fovea redrawn, odd offsets so that 2x2 splats straddle tile borders)."""
+    from optixpathtracer_amd import renderer as R
+
+    m = scenes.voxel_terrain(n=64, target_tris=30000)
+    probe = scenes.sky_probe(256, 128).BuildCDF()
+    w, h = 192, 128
+    single = R.SampleRenderer(m)
+    single.setProbe(probe)
+    single.setOptions(max_depth=4)
+    single.resize((w, h))
+    single.setCamera(R.make_camera(scenes.TERRAIN_CAMERA, w / h))
+    mr = R.MultiRenderer(m, devices=[0, 0, 0])
+    mr.setProbe(probe)
+    mr.setOptions(max_depth=4)
+    mr.resize((w, h), tile=(16, 8))
+    mr.setCamera(R.make_camera(scenes.TERRAIN_CAMERA, w / h))
+    mr.gather_mask = (1 << R.PT_BUF_ACCUM) | (1 << R.PT_BUF_FRAME)
+    for k, gaze in enumerate([(96, 64), (101, 59), (71, 80)]):
+        single.renderFoveated(gaze, inner_radius=14, outer_radius=44, spp=(1, 2, 4))
+        mr.renderFoveated(gaze, inner_radius=14, outer_radius=44, spp=(1, 2, 4))
+        for rank in (0, 2):
+            assert_bits_equal(mr.download(R.PT_BUF_ACCUM, rank), single.download(R.PT_BUF_ACCUM), f"foveated accum_buffer, frame {k}, rank {rank}")
+            assert np.array_equal(mr.download(R.PT_BUF_FRAME, rank), single.download(R.PT_BUF_FRAME)), f"foveated frame_buffer, frame {k}"
+    assert mr.stats()["radiance_rays"] >= single.stats()["radiance_rays"]  # straddling splats are traced by both neighbours
 
 
 def test_async_shadow_schedule_matches_oracle(ptlib, orc_det, small_probe):

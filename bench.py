@@ -314,7 +314,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model, probe, cam, w, h, spp, depth)
+            out["cpu_baseline"] = cpu_baseline(model, probe, cam, w, h, spp, depth, r.exportBVH())
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -334,16 +334,17 @@ def host_cpu_share():
     return max(1, n)
 
 
-def cpu_baseline(model, probe, cam, w, h, spp, depth):
+def cpu_baseline(model, probe, cam, w, h, spp, depth, bvh8):
     """The scalar C port of the same path (oracle/, 'port') on the GPU box's host cores, on bounded samples of the same
     workload (same scene/camera/spp/depth at reduced resolution; rays are counted, not extrapolated): all cores on a half-
-    resolution frame, and ONE thread on a quarter-resolution frame.  The port traverses ITS OWN median-split binary BVH
-    (oracle/pt_oracle.c), not the product's 8-wide tree.  Timed region = the render only (BVH build excluded, as on the GPU)."""
+    resolution frame, and ONE thread on a quarter-resolution frame.  The port traverses THE SAME 8-wide tree as the GPU kernels,
+    exported through pt_export_bvh (scalar stack traversal, oracle/pt_oracle.c bvh8_traverse).  Timed region = the render only."""
     from oracle import orc
     from optixpathtracer_amd import scenes
 
     O = orc.Oracle("det")
-    sc = O.make_scene(model, True)
+    sc = O.make_scene(model, False)
+    O.set_bvh8(sc, *bvh8)
     pr = O.make_probe(probe)
     cores = host_cpu_share()
     nthreads = min(cores, 64)
@@ -362,7 +363,7 @@ def cpu_baseline(model, probe, cam, w, h, spp, depth):
     rays1, dt1 = run(qw, qh, 1)
     return {
         "value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": nthreads, "kind": "port",
-        "sample": f"{sw}x{sh} frame of the same scene/camera/{spp}spp/depth{depth}, {rays} rays in {dt:.2f}s (reference-order ray count); tree = the port's own median-split BVH2",
+        "sample": f"{sw}x{sh} frame of the same scene/camera/{spp}spp/depth{depth}, {rays} rays in {dt:.2f}s (reference-order ray count); tree = the product's 8-wide BVH exported through pt_export_bvh",
         "single_thread": {"value": round(rays1 / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
                           "sample": f"{qw}x{qh} frame, {rays1} rays in {dt1:.2f}s"},
     }

@@ -295,6 +295,18 @@ int pt_multi_get_stats(const pt_multi* m, pt_multi_stats* out);
 int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit, float* t_out, int32_t* prim_out, int iters,
              double* kernel_ms);
 
+/* The acceleration structure as the traversal kernels see it, copied to host memory — for inspection, for a host-side
+ * traversal of the SAME tree (bench.py's CPU baseline, tests) or for serialisation.  Call with nodes == tris == NULL to get the
+ * counts.  nodes: num_nodes x 80 bytes, node 0 = root, breadth-first by level (20 little-endian 32-bit words each):
+ *   [0..2] origin.xyz (f32) | [3] upper 16 bits of the f32 grid steps sx (low half) and sy (high half) | [4] child_base |
+ *   [5] tri_base | [6] leafbits | [7] upper 16 bits of sz (low half), imask (high half) |
+ *   [8,9] qlo.x[8] | [10,11] qlo.y[8] | [12,13] qlo.z[8] | [14,15] qhi.x[8] | [16,17] qhi.y[8] | [18,19] qhi.z[8]  (one byte per child slot)
+ * child box s = origin + q * step per axis (rounded outward at build; an unused slot has qlo 255 > qhi 0);
+ * internal child s = node child_base + popcount(imask & ((1 << s) - 1)); leafbits bit 3s+k: slot s holds more than k
+ * triangles, triangle (s,k) = tris[tri_base + popcount(leafbits & ((1 << (3s+k)) - 1))].
+ * tris: num_tris x 48 bytes = 12 f32: v0.xyz, v1.xyz, v2.xyz, the global primitive index (i32 bits), 2 unused. */
+int pt_export_bvh(pt_ctx* ctx, void* nodes, size_t nodes_bytes, void* tris, size_t tris_bytes, uint32_t* num_nodes, uint32_t* num_tris);
+
 /* Device-function tables for function-level parity tests (the reference's commented-out BSDFTest /
  * ProbeCreateTest, Disney.cuh:430-503, Probe.cuh:207-269, turned into entry points).
  *  which = 0: BSDFEval+BSDFPdf  in: n x {N[3],V[3],L[3],etaI,etaO} (11 floats)  out: n x {f[3],pdf}

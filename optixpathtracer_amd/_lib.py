@@ -18,7 +18,7 @@ EXPORTS = [
     "pt_eval_table", "pt_version", "pt_set_probe_image", "pt_get_probe_cdf", "pt_render_regions", "pt_denoise",
     "pt_create_multi", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_size", "pt_multi_ctx", "pt_multi_set_options", "pt_multi_set_probe",
     "pt_multi_set_probe_image", "pt_multi_resize", "pt_multi_set_camera", "pt_multi_render", "pt_multi_render_regions", "pt_multi_gather",
-    "pt_multi_get_stats",
+    "pt_multi_get_stats", "pt_export_bvh",
 ]
 
 
@@ -152,6 +152,7 @@ def load_library() -> C.CDLL:
     L.pt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.pt_trace.argtypes = [vp, vp, u32, i, vp, vp, i, C.POINTER(C.c_double)]
     L.pt_eval_table.argtypes = [vp, i, vp, i, vp, u32, vp]
+    L.pt_export_bvh.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(u32), C.POINTER(u32)]
     L.pt_version.restype = C.c_char_p
     f3p = C.POINTER(f * 3)
     L.pt_create_multi.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), i, C.POINTER(vp)]

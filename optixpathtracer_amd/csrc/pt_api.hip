@@ -1433,6 +1433,20 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     return PT_OK;
 }
 
+extern "C" int pt_export_bvh(pt_ctx* ctx, void* nodes, size_t nodes_bytes, void* tris, size_t tris_bytes, uint32_t* num_nodes, uint32_t* num_tris) {
+    if (!ctx) return PT_ERR_INVALID;
+    static_assert(sizeof(Node8) == 80 && sizeof(LeafTri) == 48, "exported layout");
+    if (num_nodes) *num_nodes = ctx->bvh.num_nodes8;
+    if (num_tris) *num_tris = ctx->bvh.num_tris8;
+    if (!nodes && !tris) return PT_OK;
+    if (!nodes || !tris || nodes_bytes != sizeof(Node8) * (size_t)ctx->bvh.num_nodes8 || tris_bytes != sizeof(LeafTri) * (size_t)ctx->bvh.num_tris8)
+        return fail(ctx, PT_ERR_INVALID, "pt_export_bvh: buffer sizes must be num_nodes * 80 and num_tris * 48 bytes");
+    CK(hipSetDevice(ctx->device));
+    CK(hipMemcpy(nodes, ctx->bvh.nodes8, nodes_bytes, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(tris, ctx->bvh.tris8, tris_bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 extern "C" int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material, int bsdf_mode, const float* in, uint32_t n, float* out) {
     if (!ctx || !in || !out) return PT_ERR_INVALID;
     if (n == 0) return PT_OK;

@@ -264,6 +264,15 @@ class SampleRenderer:
     def unpack(self, which, dev_ptr: int):
         self._ck(self._L.pt_unpack(self._ctx, which, dev_ptr), "pt_unpack")
 
+    def exportBVH(self):
+        """The traversal structure as the kernels see it (pt_export_bvh): (nodes uint32[num_nodes, 20], tris float32[num_tris, 12])."""
+        nn, nt = C.c_uint32(), C.c_uint32()
+        self._ck(self._L.pt_export_bvh(self._ctx, None, 0, None, 0, C.byref(nn), C.byref(nt)), "pt_export_bvh")
+        nodes = np.empty((nn.value, 20), np.uint32)
+        tris = np.empty((nt.value, 12), np.float32)
+        self._ck(self._L.pt_export_bvh(self._ctx, nodes.ctypes.data, nodes.nbytes, tris.ctypes.data, tris.nbytes, None, None), "pt_export_bvh")
+        return nodes, tris
+
     def trace(self, rays: np.ndarray, any_hit=False, iters=1):
         """optixTrace as a batch query: rays (n,8) = o.xyz,tmin,d.xyz,tmax → (t, prim) or occluded flags; + kernel ms."""
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

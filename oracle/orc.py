@@ -91,6 +91,7 @@ class Oracle:
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [f32p, C.c_uint32, u32p, C.c_uint32, u32p, C.c_void_p, C.c_uint32, C.c_int]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_set_bvh8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.orc_trace_closest.argtypes = [C.c_void_p, f32p, C.c_int, f32p, i32p]
         L.orc_trace_any.argtypes = [C.c_void_p, f32p, C.c_int, u8p]
         L.orc_bsdf_eval.argtypes = [C.c_int, C.c_void_p, f32p, C.c_float, C.c_float, f32p, f32p, f32p, f32p]
@@ -184,6 +185,17 @@ class Oracle:
                 self.lib.orc_render_region(scene.h, C.byref(probe), C.byref(prm), C.byref(rg), C.byref(var), accum.reshape(-1), frame.reshape(-1), C.byref(st))
             rays += int(st.radiance_rays) + int(st.shadow_rays)
         return rays
+
+    def set_bvh8(self, scene, nodes, tris):
+        """Make the checker traverse the PRODUCT's 8-wide tree (arrays from SampleRenderer.exportBVH(); None = its own search)."""
+        if nodes is None:
+            scene._bvh8 = None
+            self.lib.orc_scene_set_bvh8(scene.h, None, 0, None, 0)
+            return
+        nodes = np.ascontiguousarray(nodes, np.uint32)
+        tris = np.ascontiguousarray(tris, np.float32)
+        scene._bvh8 = (nodes, tris)  # keep alive: the scene borrows them
+        self.lib.orc_scene_set_bvh8(scene.h, nodes.ctypes.data, len(nodes), tris.ctypes.data, len(tris))
 
     def trace_closest(self, scene, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

@@ -569,6 +569,13 @@ typedef struct {
     uint32_t nnodes;
     uint32_t* order; /* leaf-order primitive ids */
     float pad;
+    /* optional: the PRODUCT's 8-wide compressed tree, exported through pt_export_bvh (include/pt_amd.h documents the 80-byte
+     * node and the 48-byte leaf triangle).  When set, closest_hit / any_hit_c traverse it with a scalar stack traversal: the
+     * "scalar C++ CPU traversal of the same BVH" north_star asks for beside the GPU number, and an independent check that the
+     * tree the GPU kernels walk holds every triangle. */
+    const uint32_t* n8;    /* nnodes8 * 20 words */
+    const float* t8;       /* ntris8 * 12 floats: v0.xyz v1.xyz v2.xyz, prim bits, 2 unused */
+    uint32_t nnodes8, ntris8;
 } orc_scene;
 
 typedef struct {
@@ -634,9 +641,77 @@ static inline int slab(const onode* n, const float o[3], const float inv[3], flo
 }
 
 /* closest hit: smallest t in (tmin,tmax); ties -> lowest prim id. returns prim or -1 */
+/* ---- scalar traversal of the product's 8-wide tree (layout: optixpathtracer_amd/csrc/pt_bvh8.h, include/pt_amd.h pt_export_bvh)
+ * node words: [0..2] origin.xyz (f32) | [3] hi16(sx) | hi16(sy) << 16 | [4] child_base | [5] tri_base | [6] leafbits | [7] hi16(sz) | imask << 16
+ *             [8,9] qlo.x[8] | [10,11] qlo.y[8] | [12,13] qlo.z[8] | [14,15] qhi.x[8] | [16,17] qhi.y[8] | [18,19] qhi.z[8]
+ * child box s = origin + q * step per axis; internal child s = node child_base + popcount(imask & ((1 << s) - 1));
+ * leafbits bit 3s+k: slot s holds more than k triangles; triangle (s,k) = tri_base + popcount(leafbits & ((1 << (3s+k)) - 1)).
+ * The box test is done in double on the dequantised box (conservative: the GPU's float test may only ever admit more). */
+static inline float n8_f(uint32_t bits) { float f; memcpy(&f, &bits, 4); return f; }
+static inline uint32_t n8_q(const uint32_t* w, int first, int s) { return (w[first + (s >> 2)] >> (8 * (s & 3))) & 0xffu; }
+/* any == 0: closest hit (returns prim or -1, *t_hit); any == 1: returns 1 at the first accepted hit */
+static int64_t bvh8_traverse(const orc_scene* s, const wray* r, f3 o, f3 d, float tmin, float tmax, int any, int cull_back, float* t_hit) {
+    float best = tmax;
+    int64_t bp = -1;
+    uint32_t stack[256];
+    int sp = 0;
+    stack[sp++] = 0;
+    const double od[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    while (sp) {
+        const uint32_t* w = &s->n8[(size_t)stack[--sp] * 20];
+        const double org[3] = {n8_f(w[0]), n8_f(w[1]), n8_f(w[2])};
+        const double stp[3] = {n8_f(w[3] << 16), n8_f(w[3] & 0xffff0000u), n8_f(w[7] << 16)};
+        const uint32_t imask = w[7] >> 16, leafbits = w[6];
+        for (int c = 0; c < 8; ++c) {
+            double t0 = tmin, t1 = best;
+            int empty = 0;
+            for (int a = 0; a < 3 && !empty; ++a) {
+                const uint32_t qlo = n8_q(w, 8 + 2 * a, c), qhi = n8_q(w, 14 + 2 * a, c);
+                if (qlo > qhi) { empty = 1; break; } /* inverted = unused slot */
+                const double lo = org[a] + qlo * stp[a], hi = org[a] + qhi * stp[a];
+                if (dd[a] == 0.0) {
+                    if (od[a] < lo - 1e-9 * (1.0 + fabs(lo)) || od[a] > hi + 1e-9 * (1.0 + fabs(hi))) empty = 1;
+                    continue;
+                }
+                double ta = (lo - od[a]) / dd[a], tb = (hi - od[a]) / dd[a];
+                if (ta > tb) { const double x = ta; ta = tb; tb = x; }
+                ta -= 1e-9 * (1.0 + fabs(ta));
+                tb += 1e-9 * (1.0 + fabs(tb));
+                if (ta > t0) t0 = ta;
+                if (tb < t1) t1 = tb;
+            }
+            if (empty || t0 > t1) continue;
+            if (imask & (1u << c)) {
+                if (sp < 255) stack[sp++] = w[4] + (uint32_t)__builtin_popcount(imask & ((1u << c) - 1u));
+                continue;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const int bit = 3 * c + k;
+                if (!(leafbits & (1u << bit))) break;
+                const float* tv = &s->t8[(size_t)(w[5] + (uint32_t)__builtin_popcount(leafbits & ((1u << bit) - 1u))) * 12];
+                uint32_t pbits;
+                memcpy(&pbits, &tv[9], 4);
+                const int64_t p = (int64_t)(int32_t)pbits;
+                float t, det;
+                if (!wtri2(r, &tv[0], &tv[3], &tv[6], &t, &det)) continue;
+                if (any) {
+                    if (t > tmin && t < tmax && (!cull_back || det > 0.0f)) return 1;
+                } else if (t > tmin && (t < best || (t == best && bp >= 0 && p < bp))) {
+                    best = t;
+                    bp = p;
+                }
+            }
+        }
+    }
+    if (any) return 0;
+    *t_hit = best;
+    return bp;
+}
+
 static int64_t closest_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tmax, float* t_hit) {
     wray r;
     wray_init(&r, o, d);
+    if (s->n8) return bvh8_traverse(s, &r, o, d, tmin, tmax, 0, 0, t_hit);
     float best = tmax;
     int64_t bp = -1;
     if (!s->use_bvh) {
@@ -685,6 +760,7 @@ static int64_t closest_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tma
 static int any_hit_c(const orc_scene* s, f3 o, f3 d, float tmin, float tmax, int cull_back) {
     wray r;
     wray_init(&r, o, d);
+    if (s->n8) return (int)bvh8_traverse(s, &r, o, d, tmin, tmax, 1, cull_back, NULL);
     if (!s->use_bvh) {
         for (uint32_t p = 0; p < s->ntri; ++p) {
             const float *v0, *v1, *v2;
@@ -806,6 +882,14 @@ orc_scene* orc_scene_create(const float* verts, uint32_t nv, const uint32_t* idx
     }
     return s;
 }
+/* borrow the product's tree (arrays stay owned by the caller and must outlive the scene); NULL nodes = back to the checker's own search */
+void orc_scene_set_bvh8(orc_scene* s, const uint32_t* nodes, uint32_t nnodes, const float* tris, uint32_t ntris) {
+    s->n8 = nodes;
+    s->nnodes8 = nnodes;
+    s->t8 = tris;
+    s->ntris8 = ntris;
+}
+
 void orc_scene_destroy(orc_scene* s) {
     if (!s) return;
     free(s->verts); free(s->idx); free(s->tri_mesh); free(s->mats); free(s->nodes); free(s->order);

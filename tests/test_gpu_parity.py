@@ -357,6 +357,34 @@ def test_render_cornell_disney_4spp_depth8(ptlib, orc_det, small_probe):
     assert g["stats"]["radiance_rays"] > 0.8 * o["radiance_rays"]
 
 
+def test_c2_cornell_1080p_4spp_depth8_rows(ptlib, orc_det):
+    """BASELINE config C2 at its literal size (Cornell box, 1920x1080, 4 spp, depth 8, Disney BSDF, the 2048x1024 sky+sun probe):
+    rows of the frame re-rendered by the checker (brute-force ray search over the 32 triangles) match bit for bit."""
+    import ctypes as C
+
+    from oracle import orc as orc_mod
+
+    m = scenes.cornell_box()
+    probe = scenes.sky_probe(2048, 1024).BuildCDF()
+    w, h = 1920, 1080
+    g = _gpu_render(_renderer(m, probe, scenes.CORNELL_CAMERA, w, h), 4)
+    assert g["stats"]["paths"] == w * h * 4
+    sc = orc_det.make_scene(m, False)
+    pr = orc_det.make_probe(probe)
+    U, V, W = scenes.uvw_frame(**scenes.CORNELL_CAMERA, aspect=w / h)
+    prm = orc_mod.Params()
+    prm.width, prm.height, prm.subframe_index, prm.samples_per_launch, prm.max_depth, prm.bsdf_mode = w, h, 0, 4, 8, 0
+    for dst, src in ((prm.eye, scenes.CORNELL_CAMERA["eye"]), (prm.U, U), (prm.V, V), (prm.W, W)):
+        for k in range(3):
+            dst[k] = float(src[k])
+    rows = np.array([0, 300, 540, 811, 1079], np.int32)
+    accum = np.zeros((h, w, 4), np.float32)
+    orc_det.lib.orc_render_rows.argtypes = [C.c_void_p, C.POINTER(orc_mod.Probe), C.POINTER(orc_mod.Params), orc_mod.f32p, orc_mod.i32p, C.c_int, C.c_int]
+    orc_det.lib.orc_render_rows(sc.h, C.byref(pr), C.byref(prm), accum.reshape(-1), rows, len(rows), 16)
+    for y in rows:
+        assert_bits_equal(g["accum"][y], accum[y], f"row {y} of the C2 frame")
+
+
 def test_both_traversal_kernels_agree(ptlib, orc_det, small_probe):
     """The persistent-wave kernel (default) and the first grid-stride kernel give the same bits."""
     m = scenes.voxel_terrain(n=96, target_tris=70000)
@@ -823,18 +851,20 @@ def test_textured_meshes(ptlib, orc_det):
     assert len(np.unique(alb.round(4), axis=0)) > 100
 
 
-def test_fullsize_c5_progressive_rows(ptlib, orc_det):
-    """C5 at full size: 1 M triangles, 1920x1080, 12 subframes x 4 spp of progressive accumulation; five rows of the
-    final accum_buffer are re-rendered by the checker through all 12 subframes and must match bit for bit."""
+@pytest.mark.parametrize("spp,nsub", [(4, 12), (1, 64)])
+def test_fullsize_c5_progressive_rows(ptlib, orc_det, spp, nsub):
+    """C5 at full size: 1 M triangles, 1920x1080, progressive accumulation — the literal configuration (64 subframes x 1 spp,
+    then the HIP tone-map epilogue) and 12 subframes x 4 spp; rows of the final accum_buffer are re-rendered by the checker
+    through all subframes and must match bit for bit (per-pixel L2 vs the checker: exactly 0), the epilogue likewise."""
     import ctypes as C
 
     from oracle import orc as orc_mod
 
     m = scenes.voxel_terrain()
     probe = scenes.sky_probe(2048, 1024).BuildCDF()
-    w, h, nsub = 1920, 1080, 12
+    w, h = 1920, 1080
     r = _renderer(m, probe, scenes.TERRAIN_CAMERA, w, h)
-    g = _gpu_render(r, 4, subframes=nsub)
+    g = _gpu_render(r, spp, subframes=nsub)
     sc = orc_det.make_scene(m, True)
     pr = orc_det.make_probe(probe)
     U, V, W = scenes.uvw_frame(**scenes.TERRAIN_CAMERA, aspect=w / h)
@@ -843,13 +873,18 @@ def test_fullsize_c5_progressive_rows(ptlib, orc_det):
     orc_det.lib.orc_render_rows.argtypes = [C.c_void_p, C.POINTER(orc_mod.Probe), C.POINTER(orc_mod.Params), orc_mod.f32p, orc_mod.i32p, C.c_int, C.c_int]
     for sf in range(nsub):
         prm = orc_mod.Params()
-        prm.width, prm.height, prm.subframe_index, prm.samples_per_launch, prm.max_depth, prm.bsdf_mode = w, h, sf, 4, 8, 0
+        prm.width, prm.height, prm.subframe_index, prm.samples_per_launch, prm.max_depth, prm.bsdf_mode = w, h, sf, spp, 8, 0
         for dst, src in ((prm.eye, scenes.TERRAIN_CAMERA["eye"]), (prm.U, U), (prm.V, V), (prm.W, W)):
             for k in range(3):
                 dst[k] = float(src[k])
-        orc_det.lib.orc_render_rows(sc.h, C.byref(pr), C.byref(prm), accum.reshape(-1), rows, len(rows), 8)
+        orc_det.lib.orc_render_rows(sc.h, C.byref(pr), C.byref(prm), accum.reshape(-1), rows, len(rows), 16)
     for y in rows:
         assert_bits_equal(g["accum"][y], accum[y], f"row {y} after {nsub} subframes")
+    tm = r.tonemapSqrt()  # toneMap.cu epilogue on the accumulated frame
+    ref = np.zeros(w, np.uint32)
+    for y in rows:
+        orc_det.lib.orc_tonemap_sqrt(np.ascontiguousarray(accum[y]).reshape(-1), ref, w)
+        assert np.array_equal(tm[y], ref), f"tone-mapped row {y}"
     assert (g["accum"][..., :3] <= 50.0 + 1e-3).all()  # subframe 0 is unclamped (sun radiance 50), later ones clamp to 10
 
 
@@ -925,6 +960,41 @@ def test_traversal_stack_spill_path(ptlib, orc_det, small_probe, monkeypatch):
     monkeypatch.delenv("PT_STACK_LDS_SKIP")
     o = _oracle_render(orc_det, m, small_probe, scenes.TERRAIN_CAMERA, w, h, 2, use_bvh=True)
     _compare(ref, o)
+
+
+def test_cpu_traversal_of_the_exported_product_tree(ptlib, orc_det, small_probe):
+    """pt_export_bvh hands the 8-wide tree to the host; the checker's scalar traversal of THAT tree (oracle/pt_oracle.c
+    bvh8_traverse — what bench.py times as the CPU baseline "on the same BVH") must (a) find every triangle of the scene exactly
+    once in the leaf array, (b) agree with brute force over all triangles on closest hits (t and primitive bit-exact) and on
+    occlusion, and (c) render the same image as the GPU."""
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    m = scenes.voxel_terrain(n=96, target_tris=70000)
+    r = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, 96, 64)
+    nodes, tris = r.exportBVH()
+    st = r.stats()
+    assert len(nodes) == st["bvh_nodes"] and len(tris) == m.num_triangles
+    prim = tris[:, 9].view(np.int32)
+    assert np.array_equal(np.sort(prim), np.arange(m.num_triangles))
+    rng = np.random.default_rng(77)
+    rays = _random_rays(rng, 3000, -110, 110)
+    brute = orc_det.make_scene(m, False)
+    t0, p0 = orc_det.trace_closest(brute, rays)
+    o0 = orc_det.trace_any(brute, rays)
+    sc = orc_det.make_scene(m, False)
+    orc_det.set_bvh8(sc, nodes, tris)
+    t1, p1 = orc_det.trace_closest(sc, rays)
+    o1 = orc_det.trace_any(sc, rays)
+    assert np.array_equal(p0, p1) and np.array_equal(o0, o1)
+    assert_bits_equal(t0, t1, "closest-hit t: CPU traversal of the exported tree vs brute force")
+    (tg, pg), _ = r.trace(rays)
+    assert np.array_equal(pg, p1)
+    g = _gpu_render(r, 2)
+    U, V, W = scenes.uvw_frame(**scenes.TERRAIN_CAMERA, aspect=96 / 64)
+    o = orc_det.render(sc, orc_det.make_probe(small_probe), (U, V, W), scenes.TERRAIN_CAMERA["eye"], 96, 64, 2)
+    _compare(g, o)
+    with pytest.raises(RuntimeError, match="buffer sizes"):
+        r._ck(r._L.pt_export_bvh(r._ctx, nodes.ctypes.data, 16, tris.ctypes.data, tris.nbytes, None, None), "pt_export_bvh")
 
 
 def test_traversal_stack_overflow_fails_loudly(ptlib, small_probe, monkeypatch):

@@ -410,7 +410,9 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
 #endif
 #define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, PT_SHADE_WAVES)))
 // rows of the probe whose marginal arrays fit k_shade's LDS copy: cdfY + pdfY (rows each), c8Y (rows/8), c64Y (rows/64 padded to 8)
+#ifndef PT_LDS_PROBE_ROWS
 #define PT_LDS_PROBE_ROWS 2048
+#endif
 template <int MODE, bool CATCHER>
 __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, ShadeParams sp) {
     __shared__ uint32_t s_prefix[PT_NSUB + 1];

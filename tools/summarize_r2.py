@@ -87,7 +87,8 @@ def main():
     for k in sorted(valu, key=lambda k: -valu[k]["SQ_INSTS_VALU"])[:8]:
         v = valu[k]
         lu = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64) if v["SQ_ACTIVE_INST_VALU"] else 0.0
-        lane[k] = round(lu, 4)
+        if k.startswith("k_"):
+            lane[k] = round(lu, 4)
         insts_frame += v["SQ_INSTS_VALU"] / frames
         wait = busy.get(k, {}).get("SQ_WAIT_INST_ANY", 0.0) / v["SQ_WAVE_CYCLES"] if v["SQ_WAVE_CYCLES"] else 0.0
         md.append(f"| {k} | {vcnt[k]['SQ_INSTS_VALU']} | {v['SQ_INSTS_VALU']:.4g} | {v['SQ_ACTIVE_INST_VALU']:.4g} | {v['SQ_THREAD_CYCLES_VALU']:.4g} | {lu * 100:.1f} % | {v['SQ_WAVE_CYCLES']:.4g} | {wait * 100:.0f} % |")

@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="all ranks use HIP device 0 (rehearsal only)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N>1: strong (default) = the metric's fixed frame split N ways; weak = per-GPU work fixed, image area grows with N")
     ap.add_argument("--simulate-world", type=int, default=0, help="single process: render only rank 0's tiles of an N-way partition (predicts per-GPU time at N GPUs)")
+    ap.add_argument("--simulate-rank", type=int, default=0, help="with --simulate-world N: which rank's share to render (load balance of the interleaved tiles)")
     ap.add_argument("--split-shadow", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="concurrent pixel chunks per frame (0 = library default)")
     ap.add_argument("--kernel-timing", type=int, default=0, help="1: per-launch HIP-event timing inside the timed loop (slower; the isolated phase always has it)")
@@ -123,7 +124,7 @@ def main():
     if world > 1:
         r.setPartition(rank, world, 64, 16)
     elif args.simulate_world > 1:
-        r.setPartition(0, args.simulate_world, 64, 16)
+        r.setPartition(args.simulate_rank % args.simulate_world, args.simulate_world, 64, 16)
     r.resize((w, h))
     r.setCamera(R.make_camera(cam, w / h))
     r.launchParams.samples_per_launch = spp

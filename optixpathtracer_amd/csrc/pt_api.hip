@@ -710,12 +710,18 @@ struct SpanGuard {
 
 static const int GRID = 256 * 8;
 
+// dynamic LDS of k_shade: its copy of the probe's marginal arrays (cdfY, pdfY, c8Y, c64Y), or nothing when they stay in global memory
+static size_t shade_lds_bytes(const DevProbe& p) {
+    if (!p.c64Y || p.height > PT_LDS_PROBE_ROWS) return 0;
+    return sizeof(float) * ((size_t)2 * p.height + p.height / 8 + ((p.ncy + 7) & ~7));
+}
 template <int MODE>
 static void launch_shade(pt_ctx* ctx, pt_ctx::BatchSet& bs, const ShadeParams& sp) {
+    const unsigned lds = (unsigned)shade_lds_bytes(sp.probe);
     if (ctx->has_catcher)
-        hipLaunchKernelGGL((k_shade<MODE, true>), dim3(GRID), dim3(256), 0, bs.stream, bs.st, sp);
+        hipLaunchKernelGGL((k_shade<MODE, true>), dim3(GRID), dim3(256), lds, bs.stream, bs.st, sp);
     else
-        hipLaunchKernelGGL((k_shade<MODE, false>), dim3(GRID), dim3(256), 0, bs.stream, bs.st, sp);
+        hipLaunchKernelGGL((k_shade<MODE, false>), dim3(GRID), dim3(256), lds, bs.stream, bs.st, sp);
 }
 
 // enqueue every kernel of one pixel chunk (all its samples) on the streams of one batch set
@@ -960,7 +966,7 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index) {
     // chunks that run concurrently on separate stream pairs; a chunk holds at most max_paths/streams paths, so
     // samples are split when spp*pixels exceed that; shadow-catcher scenes run one sample per pass so that the
     // per-pixel normal/albedo sums keep the reference order.  None of this changes a bit of the result.
-    const int nsets = std::max(1, std::min(16, ctx->opt.streams > 0 ? ctx->opt.streams : 2));
+    const int nsets = std::max(1, std::min(16, ctx->opt.streams > 0 ? ctx->opt.streams : 3));
     const uint32_t max_paths = std::max<uint32_t>(ctx->opt.max_paths, 64u);
     const uint32_t cap = std::max<uint32_t>(64u, max_paths / nsets);
     uint32_t Np = (owned + nsets - 1) / nsets;        // pixels per chunk ...
@@ -1093,7 +1099,7 @@ static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, co
     // The launches of one frame are independent until they write pixels: their passes are dealt round-robin to the batch
     // sets (separate streams, so one launch's long-ray tails overlap the others' work) and only the resolves are ordered —
     // a launch's pixels are written after all pixels of the previous launch, as later launches overwrite earlier ones.
-    const int nsets = std::max(1, std::min(16, ctx->opt.streams > 0 ? ctx->opt.streams : 2));
+    const int nsets = std::max(1, std::min(16, ctx->opt.streams > 0 ? ctx->opt.streams : 3));
     const uint32_t cap = std::max<uint32_t>(64u, max_paths / nsets);
     uint32_t need = 64;
     for (uint32_t r = 0; r < n; ++r) {

@@ -40,7 +40,9 @@ struct Bvh8Dev {
 };
 
 #ifndef PT_BVH8_NODE_ONLY
-#define PT8_LDS_DEPTH 12
+#ifndef PT8_LDS_DEPTH
+#define PT8_LDS_DEPTH 10 // levels of the traversal stack kept in LDS (5 KB per wave at 5 waves per SIMD = 100 KB per CU: room is left for k_shade workgroups of the other chunk streams; 12: +2 % frame time, 8: +1 %)
+#endif
 #define PT8_OVF_DEPTH 52
 #ifndef PT8_REFILL
 #define PT8_REFILL 24
@@ -53,7 +55,7 @@ struct Bvh8Dev {
 #endif
 #define PT8_CHUNK 512
 #ifndef PT8_WAVES_PER_EU
-#define PT8_WAVES_PER_EU 4
+#define PT8_WAVES_PER_EU 5
 #endif
 // In-wave work stealing (tail of a launch).  Once a wave has taken its last chunk of the queue, a lane that runs dry no
 // longer idles until the wave's longest ray is done: it takes over the BOTTOM entry of a busy lane's traversal stack (the

@@ -416,7 +416,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
 template <int MODE, bool CATCHER>
 __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, ShadeParams sp) {
     __shared__ uint32_t s_prefix[PT_NSUB + 1];
-    __shared__ __attribute__((aligned(16))) float s_marg[2 * PT_LDS_PROBE_ROWS + PT_LDS_PROBE_ROWS / 8 + PT_LDS_PROBE_ROWS / 64 + 8];
+    extern __shared__ __attribute__((aligned(16))) float s_marg[]; // sized at launch for the probe in use (shade_lds_bytes): 8.8 KB for 1024 rows
     ProbeMarg pm = probe_marg_global(sp.probe);
     if (sp.probe.c64Y && sp.probe.height <= PT_LDS_PROBE_ROWS) {
         // ProbeSample's row search (cdfY through its 64- and 8-entry count tables) and pdfY from LDS: 3 of the 6 dependent

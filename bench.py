@@ -261,7 +261,7 @@ def main():
                      "isolated_ms_per_frame": round(src["shade_ms"], 3), "launches_per_frame": int(src["shade_launches"])}
         # PMC-derived figures (HBM traffic, VALU issue / lane utilisation) cannot be collected inside an unprofiled run: they are
         # read from the committed rocprofv3 passes of this same command and quoted only for the sources they were measured on
-        traffic = valu = None
+        traffic = valu = trav_traffic_frame = None
         shash = source_hash()
         default_cfg = args.workload == "c3_terrain1M_1080p_4spp_d8" and world == 1 and args.bvh_kind == 0 and args.trace_kernel == 0 and args.simulate_world == 0
         tj = os.path.join(ROOT, "profiles", "r2_pmc.json")
@@ -269,7 +269,8 @@ def main():
             try:
                 T = json.load(open(tj))
                 if T.get("src_hash") == shash:
-                    traffic = T.get("traffic_bytes_per_traversal_launch")
+                    traffic = T.get("traffic_bytes_per_frame")  # per frame, like `achieved` / alg_bytes_per_frame
+                    trav_traffic_frame = T.get("traversal_traffic_bytes_per_frame")
                     valu = T.get("valu")
                     if shade is not None and "shade" in T:
                         shade["pmc"] = T["shade"]
@@ -310,6 +311,8 @@ def main():
                     "kernel": kname + " (BVH traversal: closest-hit + shadow rays per launch)", "bytes_per_ray": [BYTES_PER_RADIANCE_RAY_TRACE, BYTES_PER_SHADOW_RAY_TRACE],
                     "alg_bytes_per_launch": int(trav_bytes), "avg_launch_ms": round(trav_ms, 4), "isolated": iso is not None,
                     "achieved": round(trav_gbs, 2), "unit": "GB/s", "frac": round(trav_gbs / HBM_PEAK_GBS, 5),
+                    # measured fabric traffic of the traversal kernels per frame / launches per frame of THIS (single-stream) schedule
+                    "traffic": None if trav_traffic_frame is None else int(trav_traffic_frame / n_launch),
                 },
                 "shade": shade, "valu": valu, "src_hash": shash,
             },

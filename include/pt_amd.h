@@ -82,7 +82,7 @@ typedef struct pt_options {
                              *    (costs ≈0.3 ms of a 2 ms frame at a 1/8 share); 0 (default): only render_ms is measured */
     int32_t bvh_kind;       /* 0 = default: 8-wide compressed BVH (k_trace8); 1 = binary BVH (k_trace2), A/B only: built on first request */
     int32_t trace_kernel;   /* 0 = default: persistent-wave traversal (k_trace8, or k_trace2 with bvh_kind 1); 1 = first grid-stride kernel over the binary BVH (A/B) */
-    int32_t streams;        /* pixel chunks of a frame run concurrently on this many stream pairs (0 = default 2, the measured optimum: tails of one chunk overlap the bulk of the other) */
+    int32_t streams;        /* pixel chunks of a frame run concurrently on this many stream pairs (0 = default 3, the measured optimum: tails of one chunk overlap the bulk of the others) */
     int32_t split_shadow;   /* 0 = default: shadow rays of bounce b share a launch with the closest-hit rays of b+1; 1 = separate kernels;
                              * 2 = asynchronous: per-bounce shadow records traced on side streams, nothing waits for them before the
                              *     resolve, which sums the visible contributions in bounce order (not with shadow-catcher materials) */
@@ -100,7 +100,7 @@ enum pt_buffer {          /* LaunchParams.frame.* (LaunchParams.h:53-63) */
 typedef struct pt_stats {
     uint64_t radiance_rays; /* closest-hit rays traced by the last pt_render */
     uint64_t shadow_rays;   /* any-hit rays traced by the last pt_render */
-    uint64_t paths;         /* camera paths started */
+    uint64_t paths;         /* camera paths started (pt_render_regions: launch indices x samples, before annulus / partition culling) */
     double render_ms;       /* device time of the last pt_render (hipEvent, stream-local) */
     double trace_ms;        /* with pt_options.kernel_timing (else 0) — of which: closest-hit traversal kernels */
     double shadow_ms;       /*           any-hit traversal kernels */

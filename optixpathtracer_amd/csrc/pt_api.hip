@@ -142,7 +142,7 @@ struct DevScope {
     }
 };
 
-extern "C" const char* pt_version(void) { return "ptamd 0.1 (gfx950 wavefront path tracer)"; }
+extern "C" const char* pt_version(void) { return "ptamd 0.2 (gfx950 wavefront path tracer)"; }
 
 extern "C" const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 

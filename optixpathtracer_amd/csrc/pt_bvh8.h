@@ -69,9 +69,7 @@ struct Bvh8Dev {
 #ifndef PT8_STEAL
 #define PT8_STEAL 1
 #endif
-#ifndef PT8_STEAL_MIN_STEPS
-#define PT8_STEAL_MIN_STEPS 0 // a lane may be robbed once its ray has taken this many steps (measured: 0 is best — 24: +13 % frame time at a 1/8 share, 64: +26 %)
-#endif
+// (a lane may be robbed from its first step: requiring 24 / 64 prior steps of the victim cost +13 % / +26 % frame time at a 1/8 share)
 #ifndef PT8_STEAL_PERIOD
 #define PT8_STEAL_PERIOD 3 // traversal iterations between two steal rounds while lanes are idle
 #endif
@@ -148,7 +146,6 @@ k_trace8(Trace8Args a) {
     int sb = 0;              // stack bottom: levels [sb, sp) are live (entries below sb were taken by co-workers)
     bool stealing = false;   // wave-uniform: the queue is exhausted and the shared records are in use
     uint32_t owner = lane;   // the lane whose record this lane's ray belongs to
-    uint32_t nsteps = 0;     // steps taken for the current ray (inherited by co-workers)
     uint32_t slot = 0, hint1 = 0, hint2 = 0;
     PT_STAT(uint32_t c_nodes = 0; uint32_t c_tris = 0; uint32_t c_maxsp = 0; uint32_t c_push = 0; uint32_t c_ray = 0; uint32_t c_raymax = 0; uint32_t c_iters = 0;
             uint32_t c_act = 0; uint32_t c_exec = 0; uint32_t c_nodeit = 0;)
@@ -305,8 +302,7 @@ k_trace8(Trace8Args a) {
                 bprim = (MODE == TR_CLOSEST || (MODE == TR_UNIFIED && !shadow_lane)) ? -1 : 0;
                 sp = 0;
                 sb = 0;
-                nsteps = 0;
-                // the root is node 0: a group whose only internal child is slot 0 of a virtual parent
+                        // the root is node 0: a group whose only internal child is slot 0 of a virtual parent
                 g_base = 0;
                 g_imask = 1u;
                 g_hits = 1u;
@@ -327,7 +323,7 @@ k_trace8(Trace8Args a) {
             }
             // ---------------- steal round: idle lane k takes the bottom stack entry of victim k
             const unsigned long long idle2 = __ballot(!active);
-            const bool victim = active && sp > sb && sb < lds_depth && nsteps >= (uint32_t)PT8_STEAL_MIN_STEPS;
+            const bool victim = active && sp > sb && sb < lds_depth;
             const unsigned long long vmask = __ballot(victim);
             if (idle2 != 0ull && vmask != 0ull) {
                 const uint32_t ni = (uint32_t)__popcll(idle2), nv = (uint32_t)__popcll(vmask);
@@ -342,7 +338,7 @@ k_trace8(Trace8Args a) {
                 const float ix = __shfl(r.idir.x, (int)v), iy = __shfl(r.idir.y, (int)v), iz = __shfl(r.idir.z, (int)v);
                 const float nx_ = __shfl(r.dn.x, (int)v), ny_ = __shfl(r.dn.y, (int)v), nz_ = __shfl(r.dn.z, (int)v);
                 const float vtmin = __shfl(tmin, (int)v), vtmax = __shfl(tmax, (int)v);
-                const uint32_t vpm = __shfl(pm, (int)v), vslot = __shfl(slot, (int)v), vowner = __shfl(owner, (int)v), vsteps = __shfl(nsteps, (int)v);
+                const uint32_t vpm = __shfl(pm, (int)v), vslot = __shfl(slot, (int)v), vowner = __shfl(owner, (int)v);
                 const int vsb = __shfl(sb, (int)v);
                 const int vshadow = __shfl((int)shadow_lane, (int)v);
                 if (take) {
@@ -355,7 +351,6 @@ k_trace8(Trace8Args a) {
                     pm = vpm;
                     slot = vslot;
                     owner = vowner;
-                    nsteps = vsteps;
                     shadow_lane = vshadow != 0;
                     const uint32_t e0 = s_stack[(vsb * 2) * 64 + v], e1 = s_stack[(vsb * 2 + 1) * 64 + v];
                     g_base = e0;
@@ -428,7 +423,6 @@ k_trace8(Trace8Args a) {
                         const uint32_t idx = g_base + (uint32_t)__popc(g_imask & (h - 1u));
                         if (g_hits != 0u) push(g_base, g_imask | (g_hits << 8));
                         PT_STAT(++c_nodes; ++c_ray;)
-                        ++nsteps;
 #ifdef PT8_TOP_NODES
                         const Node8* nd = idx < (uint32_t)PT8_TOP_NODES ? &s_top[idx] : &a.bvh.nodes[idx];
 #else

@@ -51,7 +51,7 @@ def main():
           "Command of every pass: `rocprofv3 <mode> -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated` (C3: 1 M triangles,",
           "1920x1080, 4 spp, depth 8; 7 frames).  Profiled runs clock lower than unprofiled ones; PMC passes serialise kernels.\n"]
     frames = 7
-    for name, sub, log in (("default schedule (2 chunk streams)", "stats", "bench_stats.log"), ("one chunk stream (isolated kernel durations)", "stats1", "bench_stats1.log")):
+    for name, sub, log in (("default schedule (3 chunk streams)", "stats", "bench_stats.log"), ("one chunk stream (isolated kernel durations)", "stats1", "bench_stats1.log")):
         st = find(os.path.join(out, sub), "*kernel_stats.csv")
         b = bench_line(os.path.join(out, log))
         md.append(f"## kernel time, {name} (--kernel-trace --stats)\n")
@@ -101,6 +101,9 @@ def main():
     pmc = {
         "source": f"profiles/{tag}_summary.md", "src_hash": source_hash(), "frames": frames,
         "traffic_bytes_per_traversal_launch": int(tnum / tden) if tden else None,
+        # whole-frame figures (FETCH x2 + WRITE of every per-frame kernel) — what bench.py sets against its per-frame algorithmic bytes
+        "traffic_bytes_per_frame": int(sum(v["total_bytes_x2"] * v["dispatches"] for k, v in traffic.items() if k.startswith(("k_trace8", "k_shade", "k_generate", "k_resolve", "k_accum"))) / frames),
+        "traversal_traffic_bytes_per_frame": int(sum(v["total_bytes_x2"] * v["dispatches"] for k, v in traffic.items() if k.startswith("k_trace8")) / frames),
         "per_kernel_traffic": {k: {kk: (int(vv) if kk != "dispatches" else vv) for kk, vv in v.items()} for k, v in traffic.items()},
         "valu": {"lane_util": lane, "valu_insts_per_frame": insts_frame, "simd_cycles_per_valu_inst": 4, "simds": 1024, "clock_ghz": 2.4,
                  "issue_frac_at_profiled_frame_ms": (round(insts_frame * 4 / (1024 * 2.4e9 * b0["ms_per_step"] * 1e-3), 3) if b0 else None),

@@ -997,6 +997,29 @@ def test_cpu_traversal_of_the_exported_product_tree(ptlib, orc_det, small_probe)
         r._ck(r._L.pt_export_bvh(r._ctx, nodes.ctypes.data, 16, tris.ctypes.data, tris.nbytes, None, None), "pt_export_bvh")
 
 
+def test_work_stealing_results_do_not_depend_on_timing(ptlib, small_probe):
+    """Which lane steals which subtree, and when, depends on run-time timing; the image must not.  The same frame is rendered
+    several hundred times (small frames, where most launches are all tail and stealing is busiest, and full-size frames of the
+    1 M-triangle scene) and every repetition must reproduce the first bit for bit, ray counts included."""
+    import zlib
+
+    from optixpathtracer_amd import renderer as R
+
+    for model, (w, h), spp, reps in ((scenes.voxel_terrain(n=96, target_tris=70000), (160, 96), 2, 300),
+                                     (scenes.voxel_terrain(), (1920, 1080), 4, 40)):
+        r = _renderer(model, small_probe, scenes.TERRAIN_CAMERA, w, h)
+        r.launchParams.samples_per_launch = spp
+        r.launchParams.frame.subframe_index = 0
+        first = None
+        for k in range(reps):
+            r.render()
+            st = r.stats()
+            sig = (zlib.crc32(r.download(R.PT_BUF_ACCUM).tobytes()), st["radiance_rays"], st["shadow_rays"])
+            if first is None:
+                first = sig
+            assert sig == first, f"repetition {k} of the {w}x{h} frame differs: {sig} vs {first}"
+
+
 def test_traversal_stack_overflow_fails_loudly(ptlib, small_probe, monkeypatch):
     """A tree deeper than the traversal stack must never give a silently wrong image.  (a) pt_create compares the wide tree's
     level count with the stack capacity and refuses the scene with PT_ERR_UNSUPPORTED (-4); (b) with that check bypassed
@@ -1129,6 +1152,16 @@ def test_multi_context_one_process(ptlib, small_probe, monkeypatch):
     mr.gather(R.PT_BUF_ACCUM)
     assert_bits_equal(mr.download(R.PT_BUF_ACCUM), ref["accum"], "accum_buffer through ncclAllGather")
     mr.close()
+    # error behaviour of the multi-context layer: status + message naming the rank, never a crash
+    with pytest.raises(RuntimeError, match=r"pt_create_multi failed \(-1\).*rank 1.*bad device ordinal"):
+        R.MultiRenderer(model, devices=[0, 99])
+    m3 = R.MultiRenderer(model, devices=[0, 0])
+    with pytest.raises(RuntimeError, match="not resized"):
+        m3.gather(R.PT_BUF_FRAME)
+    with pytest.raises(RuntimeError, match=r"rank 0.*no probe set"):
+        m3.resize((32, 16))
+        m3.render()
+    m3.close()
     monkeypatch.setenv("PT_MULTI_EXCHANGE", "rccl")
     with pytest.raises(RuntimeError, match="distinct devices"):
         m2 = R.MultiRenderer(model, devices=[0, 0])

@@ -173,8 +173,13 @@ def main():
         tsum = tot.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt_max, rays_all = float(tmax[0]), float(tsum[1])
+        per_rank = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        per_rank[rank] = dt / args.steps * 1e3
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(x), 3) for x in per_rank.tolist()]
     else:
         dt_max, rays_all = dt, float(rays)
+        per_rank_ms = None
 
     # displayed frames: render + the display hand-off (pack -> one all-gather of the packed rgba8 strips -> unpack) every frame
     gather_ms = ms_displayed = None
@@ -298,6 +303,7 @@ def main():
             "rays_per_frame": int(rays_frame),
             "fps": round(args.steps / dt_max, 2),
             "render_ms_per_frame": round(agg["render_ms"] / args.steps, 3),
+            "ms_per_step_per_rank": per_rank_ms,
             "kernel_ms_per_frame_isolated": None if iso is None else {k: round(iso[k], 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
             "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2)},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),

@@ -70,6 +70,9 @@ struct Bvh8Dev {
 #define PT8_STEAL 1
 #endif
 // (a lane may be robbed from its first step: requiring 24 / 64 prior steps of the victim cost +13 % / +26 % frame time at a 1/8 share)
+#ifndef PT8_DEFER_WRITE
+#define PT8_DEFER_WRITE 1
+#endif
 #ifndef PT8_STEAL_PERIOD
 #define PT8_STEAL_PERIOD 3 // traversal iterations between two steal rounds while lanes are idle
 #endif
@@ -147,6 +150,9 @@ k_trace8(Trace8Args a) {
     bool stealing = false;   // wave-uniform: the queue is exhausted and the shared records are in use
     uint32_t owner = lane;   // the lane whose record this lane's ray belongs to
     uint32_t slot = 0, hint1 = 0, hint2 = 0;
+#if PT8_DEFER_WRITE
+    bool unwritten = false; // this lane holds a finished ray whose result is not written yet
+#endif
     PT_STAT(uint32_t c_nodes = 0; uint32_t c_tris = 0; uint32_t c_maxsp = 0; uint32_t c_push = 0; uint32_t c_ray = 0; uint32_t c_raymax = 0; uint32_t c_iters = 0;
             uint32_t c_act = 0; uint32_t c_exec = 0; uint32_t c_nodeit = 0;)
 
@@ -224,7 +230,14 @@ k_trace8(Trace8Args a) {
             return;
         }
 #endif
+#if PT8_DEFER_WRITE
+        // Before the stealing phase the result is not written here: a finish reached by one or two lanes at a time would stall the whole
+        // wave on the write-back's dependent loads (pending contribution -> accumulator).  The lane keeps (slot, best, bprim) — it is
+        // idle until the next refill — and all finished lanes write together at the top of the loop.
+        unwritten = true;
+#else
         write_result(best, bprim);
+#endif
         active = false;
         PT_STAT(if (c_ray > c_raymax) c_raymax = c_ray;
                 if (a.dbg) atomicAdd(&a.dbg[(is_shadow() ? 32 : 16) + (31 - __clz((int)(c_ray | 1u)))], 1ull);
@@ -232,6 +245,12 @@ k_trace8(Trace8Args a) {
     };
 
     for (;;) {
+#if PT8_DEFER_WRITE
+        if (unwritten) { // results of the rays that finished since the last pass: all finished lanes at once
+            write_result(best, bprim);
+            unwritten = false;
+        }
+#endif
         // ---------------- refill idle lanes
         const unsigned long long idle = __ballot(!active);
         if (idle != 0ull && !exhausted) {
@@ -253,8 +272,7 @@ k_trace8(Trace8Args a) {
                 const uint32_t gi = first + rank;
                 if (MODE == TR_UNIFIED) {
                     // shadow rays first: the longest rays of a launch are probe shadow rays that graze the terrain and hit nothing;
-                    // started early, their tails overlap the closest-hit bulk instead of trailing it (and within each queue the
-                    // rays flagged long by k_shade come first, pt_kernels.h queue_push)
+                    // started early, their tails overlap the closest-hit bulk instead of trailing it
                     shadow_lane = gi < n2;
                     slot = shadow_lane ? qreader_get_hint(a.queue2, s_prefix2, gi, hint2) : qreader_get_hint(a.queue, s_prefix, gi - n2, hint1);
                 } else {

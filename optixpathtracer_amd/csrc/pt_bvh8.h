@@ -416,103 +416,117 @@ k_trace8(Trace8Args a) {
             const bool want_tri = active && t_mask != 0u;
             const bool want_node = active && t_mask == 0u; // node step also covers "group empty → pop"
             const unsigned long long m_tri = __ballot(want_tri), m_node = __ballot(want_node);
-            if (__popcll(m_node) >= PT8_TRI_BIAS * __popcll(m_tri)) {
-                if (want_node) {
-                    if (g_hits == 0u) {
-                        if (sp == sb) {
-                            finish();
-                        } else {
-                            uint32_t v0, v1;
-                            pop(v0, v1);
-                            g_base = v0;
-                            g_imask = v1 & 0xffu;
-                            g_hits = v1 >> 8;
-                        }
-                    }
-                    if (active) {
-                        // next child of the group in (slot ^ octant) order
-                        uint32_t h = g_hits, t = h & pm;
-                        h = t ? t : h;
-                        t = h & (pm >> 8);
-                        h = t ? t : h;
-                        t = h & (pm >> 16);
-                        h = t ? t : h; // a single bit now
-                        g_hits ^= h;
-                        const uint32_t idx = g_base + (uint32_t)__popc(g_imask & (h - 1u));
-                        if (g_hits != 0u) push(g_base, g_imask | (g_hits << 8));
-                        PT_STAT(++c_nodes; ++c_ray;)
-#ifdef PT8_TOP_NODES
-                        const Node8* nd = idx < (uint32_t)PT8_TOP_NODES ? &s_top[idx] : &a.bvh.nodes[idx];
-#else
-                        const Node8* nd = &a.bvh.nodes[idx];
-#endif
-                        const float4 n0 = nd->n0, n1 = nd->n1, n2 = nd->n2, n3 = nd->n3, n4 = nd->n4;
-                        const uint32_t e01 = __float_as_uint(n0.w), e2m = __float_as_uint(n1.w);
-                        const float sx = __uint_as_float(e01 << 16), sy = __uint_as_float(e01 & 0xffff0000u), sz = __uint_as_float(e2m << 16);
-                        const uint32_t imask = e2m >> 16;
-                        const float ax = sx * r.idir.x, ay = sy * r.idir.y, az = sz * r.idir.z;
-                        const float bx = (n0.x - r.o.x) * r.idir.x, by = (n0.y - r.o.y) * r.idir.y, bz = (n0.z - r.o.z) * r.idir.z;
-                        // near/far planes per axis follow the direction sign
-                        const bool nx = r.idir.x < 0.0f, ny = r.idir.y < 0.0f, nz = r.idir.z < 0.0f;
-                        const uint32_t lox0 = __float_as_uint(n2.x), lox1 = __float_as_uint(n2.y), loy0 = __float_as_uint(n2.z), loy1 = __float_as_uint(n2.w);
-                        const uint32_t loz0 = __float_as_uint(n3.x), loz1 = __float_as_uint(n3.y), hix0 = __float_as_uint(n3.z), hix1 = __float_as_uint(n3.w);
-                        const uint32_t hiy0 = __float_as_uint(n4.x), hiy1 = __float_as_uint(n4.y), hiz0 = __float_as_uint(n4.z), hiz1 = __float_as_uint(n4.w);
-                        const uint32_t nearx[2] = {nx ? hix0 : lox0, nx ? hix1 : lox1}, farx[2] = {nx ? lox0 : hix0, nx ? lox1 : hix1};
-                        const uint32_t neary[2] = {ny ? hiy0 : loy0, ny ? hiy1 : loy1}, fary[2] = {ny ? loy0 : hiy0, ny ? loy1 : hiy1};
-                        const uint32_t nearz[2] = {nz ? hiz0 : loz0, nz ? hiz1 : loz1}, farz[2] = {nz ? loz0 : hiz0, nz ? loz1 : hiz1};
-                        // No extra widening of the far plane here: the 8-bit grid (rounded outward from boxes already padded
-                        // by 2^-16 of the scene size) is orders of magnitude coarser than the rounding of these products.
-                        // (Measured and rejected: 2-wide vectors → v_pk_fma_f32; the packing moves and VGPR pairs cost more.)
-                        uint32_t miss = 0u; // sign bits of tfar - tnear, slot 7 first (one subtract + one funnel shift per child)
-#pragma unroll
-                        for (int s = 7; s >= 0; --s) {
-                            const int w = s >> 2, k = s & 3;
-                            const float tnx = __builtin_fmaf(u8f(nearx[w], k), ax, bx), tfx = __builtin_fmaf(u8f(farx[w], k), ax, bx);
-                            const float tny = __builtin_fmaf(u8f(neary[w], k), ay, by), tfy = __builtin_fmaf(u8f(fary[w], k), ay, by);
-                            const float tnz = __builtin_fmaf(u8f(nearz[w], k), az, bz), tfz = __builtin_fmaf(u8f(farz[w], k), az, bz);
-                            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-                            const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best));
-                            miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31u);
-                        }
-                        const uint32_t hm = miss ^ 0xffu; // hit mask in slot positions
-                        const uint32_t hits = hm & imask;
-                        // triangles of the leaf children that were hit: every hit bit s → bits 3s..3s+2, masked by the node's leafbits
-                        const uint32_t leafbits = __float_as_uint(n1.z);
-                        uint32_t sp3 = (hm | (hm << 8)) & 0x00F00Fu;
-                        sp3 = (sp3 | (sp3 << 4)) & 0x0C30C3u;
-                        sp3 = (sp3 | (sp3 << 2)) & 0x249249u;
-                        const uint32_t tm = (sp3 * 7u) & leafbits;
-                        g_base = __float_as_uint(n1.x);
-                        g_imask = imask;
-                        g_hits = hits;
-                        t_base = __float_as_uint(n1.y);
-                        t_bits = leafbits;
-                        t_mask = tm;
+            // One step type per iteration, the one more lanes wait for (biased 2:1 towards triangle steps), so that the two code paths never
+            // run with complementary half-empty masks.  (Running BOTH types per iteration in the tail phase, their loads in flight together,
+            // was measured: no gain — a lone wave of 64 rays takes 40 us either way.)
+            const bool node_turn = __popcll(m_node) >= PT8_TRI_BIAS * __popcll(m_tri);
+            const bool tri_turn = !node_turn;
+            // ---- phase 1: addresses and loads (r0..r4 hold a node for node lanes, r0..r2 a triangle for triangle lanes)
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0;
+            bool do_node = false;
+            if (want_node && node_turn) {
+                if (g_hits == 0u) {
+                    if (sp == sb) {
+                        finish();
+                    } else {
+                        uint32_t v0, v1;
+                        pop(v0, v1);
+                        g_base = v0;
+                        g_imask = v1 & 0xffu;
+                        g_hits = v1 >> 8;
                     }
                 }
-            } else {
-                if (want_tri) {
-                    const uint32_t bit = (uint32_t)__ffs((int)t_mask) - 1u;
-                    t_mask &= t_mask - 1u;
-                    PT_STAT(++c_tris; ++c_ray;)
-                    const LeafTri* tp = &a.bvh.tris[t_base + (uint32_t)__popc(t_bits & ((1u << bit) - 1u))];
-                    const float4 ta = tp->t0, tb = tp->t1, tc = tp->t2;
-                    float t, det;
-                    if (tri_test_det(r, mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), t, det)) {
-                        const int32_t prim = __float_as_int(tc.y);
-                        if (MODE == TR_SHADOW_APPLY || MODE == TR_ANY_QUERY || (MODE == TR_UNIFIED && shadow_lane)) {
-                            if (t > tmin && t < tmax && (!a.cull_back || det > 0.0f)) {
-                                bprim = 1;
-                                best = t;
-                                finish();
-                            }
-                        } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim))) {
-                            best = t;
-                            bprim = prim;
-#if PT8_STEAL
-                            if (stealing) atomicMin(&s_key[owner], local_key());
+                if (active) {
+                    // next child of the group in (slot ^ octant) order
+                    uint32_t h = g_hits, t = h & pm;
+                    h = t ? t : h;
+                    t = h & (pm >> 8);
+                    h = t ? t : h;
+                    t = h & (pm >> 16);
+                    h = t ? t : h; // a single bit now
+                    g_hits ^= h;
+                    const uint32_t idx = g_base + (uint32_t)__popc(g_imask & (h - 1u));
+                    if (g_hits != 0u) push(g_base, g_imask | (g_hits << 8));
+                    PT_STAT(++c_nodes; ++c_ray;)
+#ifdef PT8_TOP_NODES
+                    const Node8* nd = idx < (uint32_t)PT8_TOP_NODES ? &s_top[idx] : &a.bvh.nodes[idx];
+#else
+                    const Node8* nd = &a.bvh.nodes[idx];
 #endif
+                    r0 = nd->n0; r1 = nd->n1; r2 = nd->n2; r3 = nd->n3; r4 = nd->n4;
+                    do_node = true;
+                }
+            }
+            const bool do_tri = want_tri && tri_turn;
+            if (do_tri) {
+                const uint32_t bit = (uint32_t)__ffs((int)t_mask) - 1u;
+                t_mask &= t_mask - 1u;
+                PT_STAT(++c_tris; ++c_ray;)
+                const LeafTri* tp = &a.bvh.tris[t_base + (uint32_t)__popc(t_bits & ((1u << bit) - 1u))];
+                r0 = tp->t0; r1 = tp->t1; r2 = tp->t2;
+            }
+            // ---- phase 2: the arithmetic
+            if (do_node) {
+                const float4 n0 = r0, n1 = r1, n2 = r2, n3 = r3, n4 = r4;
+                const uint32_t e01 = __float_as_uint(n0.w), e2m = __float_as_uint(n1.w);
+                const float sx = __uint_as_float(e01 << 16), sy = __uint_as_float(e01 & 0xffff0000u), sz = __uint_as_float(e2m << 16);
+                const uint32_t imask = e2m >> 16;
+                const float ax = sx * r.idir.x, ay = sy * r.idir.y, az = sz * r.idir.z;
+                const float bx = (n0.x - r.o.x) * r.idir.x, by = (n0.y - r.o.y) * r.idir.y, bz = (n0.z - r.o.z) * r.idir.z;
+                // near/far planes per axis follow the direction sign
+                const bool nx = r.idir.x < 0.0f, ny = r.idir.y < 0.0f, nz = r.idir.z < 0.0f;
+                const uint32_t lox0 = __float_as_uint(n2.x), lox1 = __float_as_uint(n2.y), loy0 = __float_as_uint(n2.z), loy1 = __float_as_uint(n2.w);
+                const uint32_t loz0 = __float_as_uint(n3.x), loz1 = __float_as_uint(n3.y), hix0 = __float_as_uint(n3.z), hix1 = __float_as_uint(n3.w);
+                const uint32_t hiy0 = __float_as_uint(n4.x), hiy1 = __float_as_uint(n4.y), hiz0 = __float_as_uint(n4.z), hiz1 = __float_as_uint(n4.w);
+                const uint32_t nearx[2] = {nx ? hix0 : lox0, nx ? hix1 : lox1}, farx[2] = {nx ? lox0 : hix0, nx ? lox1 : hix1};
+                const uint32_t neary[2] = {ny ? hiy0 : loy0, ny ? hiy1 : loy1}, fary[2] = {ny ? loy0 : hiy0, ny ? loy1 : hiy1};
+                const uint32_t nearz[2] = {nz ? hiz0 : loz0, nz ? hiz1 : loz1}, farz[2] = {nz ? loz0 : hiz0, nz ? loz1 : hiz1};
+                // No extra widening of the far plane here: the 8-bit grid (rounded outward from boxes already padded
+                // by 2^-16 of the scene size) is orders of magnitude coarser than the rounding of these products.
+                // (Measured and rejected: 2-wide vectors → v_pk_fma_f32; the packing moves and VGPR pairs cost more.)
+                uint32_t miss = 0u; // sign bits of tfar - tnear, slot 7 first (one subtract + one funnel shift per child)
+#pragma unroll
+                for (int s = 7; s >= 0; --s) {
+                    const int w = s >> 2, k = s & 3;
+                    const float tnx = __builtin_fmaf(u8f(nearx[w], k), ax, bx), tfx = __builtin_fmaf(u8f(farx[w], k), ax, bx);
+                    const float tny = __builtin_fmaf(u8f(neary[w], k), ay, by), tfy = __builtin_fmaf(u8f(fary[w], k), ay, by);
+                    const float tnz = __builtin_fmaf(u8f(nearz[w], k), az, bz), tfz = __builtin_fmaf(u8f(farz[w], k), az, bz);
+                    const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+                    const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best));
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31u);
+                }
+                const uint32_t hm = miss ^ 0xffu; // hit mask in slot positions
+                const uint32_t hits = hm & imask;
+                // triangles of the leaf children that were hit: every hit bit s → bits 3s..3s+2, masked by the node's leafbits
+                const uint32_t leafbits = __float_as_uint(n1.z);
+                uint32_t sp3 = (hm | (hm << 8)) & 0x00F00Fu;
+                sp3 = (sp3 | (sp3 << 4)) & 0x0C30C3u;
+                sp3 = (sp3 | (sp3 << 2)) & 0x249249u;
+                const uint32_t tm = (sp3 * 7u) & leafbits;
+                g_base = __float_as_uint(n1.x);
+                g_imask = imask;
+                g_hits = hits;
+                t_base = __float_as_uint(n1.y);
+                t_bits = leafbits;
+                t_mask = tm;
+            }
+            if (do_tri) {
+                const float4 ta = r0, tb = r1, tc = r2;
+                float t, det;
+                if (tri_test_det(r, mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), t, det)) {
+                    const int32_t prim = __float_as_int(tc.y);
+                    if (MODE == TR_SHADOW_APPLY || MODE == TR_ANY_QUERY || (MODE == TR_UNIFIED && shadow_lane)) {
+                        if (t > tmin && t < tmax && (!a.cull_back || det > 0.0f)) {
+                            bprim = 1;
+                            best = t;
+                            finish();
                         }
+                    } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim))) {
+                        best = t;
+                        bprim = prim;
+#if PT8_STEAL
+                        if (stealing) atomicMin(&s_key[owner], local_key());
+#endif
                     }
                 }
             }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Timeline of the last frame in a rocprofv3 kernel trace (tools/timeline.sh): a frame starts at a k_generate dispatch that
-follows a k_resolve; prints every dispatch with its start offset and duration, per queue, and the frame's critical numbers."""
+"""Timeline of the last stretch of GPU activity that contains a k_resolve in a rocprofv3 kernel trace (tools/timeline.sh; back-to-back
+frames form one stretch): every dispatch with its start offset, duration and queue, then per-kernel sums."""
 import csv, glob, sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]

@@ -154,7 +154,7 @@ def main():
         render_frame(k)
     barrier()
     rays = 0
-    keys = ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms", "trace_launches", "shadow_launches", "shade_launches", "radiance_rays", "shadow_rays")
+    keys = ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms", "trace_launches", "shadow_launches", "shade_launches", "radiance_rays", "shadow_rays", "shaded_hits")
     agg = dict.fromkeys(keys, 0.0)
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -257,7 +257,7 @@ def main():
         trav_bytes = (src["radiance_rays"] * BYTES_PER_RADIANCE_RAY_TRACE + src["shadow_rays"] * BYTES_PER_SHADOW_RAY_TRACE) / n_launch
         trav_gbs = trav_bytes / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
         # shade kernel against the FP32 vector peak: closest hits x 700 flop (§8(d)) / isolated k_shade time
-        hits = src["shadow_rays"] if src["shadow_rays"] else src["radiance_rays"]  # one shadow ray per shaded hit with a usable light sample
+        hits = src["shaded_hits"]  # closest hits shaded with an accepted BSDF sample, counted on the device (pt_stats)
         shade = None
         if src["shade_ms"] > 0:
             tf = hits * FLOPS_PER_HIT / (src["shade_ms"] * 1e-3) / 1e12

@@ -111,6 +111,8 @@ typedef struct pt_stats {
     uint64_t bvh_bytes;     /* nodes + leaf triangles resident in HBM */
     double bvh_build_ms;    /* one-time on-GPU build (excluded from render_ms) */
     uint32_t bvh_levels;    /* levels of the traversal structure (must not exceed the traversal stack: pt_create checks) */
+    uint64_t shaded_hits;   /* closest hits shaded by the last render whose BSDF sample was accepted (every one cost a BSDFSample, two
+                             * BSDFEval and two BSDFPdf: the unit of the shade kernel's FLOP roofline) */
 } pt_stats;
 
 /* SampleRenderer::SampleRenderer(const Model*) (SimplePathtracer.cpp:39-71): uploads the meshes

@@ -78,7 +78,7 @@ class Stats(C.Structure):
         ("render_ms", C.c_double), ("trace_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
         ("other_ms", C.c_double),
         ("trace_launches", C.c_uint32), ("shadow_launches", C.c_uint32), ("shade_launches", C.c_uint32),
-        ("bvh_nodes", C.c_uint32), ("bvh_bytes", C.c_uint64), ("bvh_build_ms", C.c_double), ("bvh_levels", C.c_uint32),
+        ("bvh_nodes", C.c_uint32), ("bvh_bytes", C.c_uint64), ("bvh_build_ms", C.c_double), ("bvh_levels", C.c_uint32), ("shaded_hits", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -75,7 +75,7 @@ struct pt_ctx {
     uint32_t set_cap = 0, set_pix_cap = 0, sub_cap = 0;
     bool cap_catcher = false, cap_async = false;
     int nq = 0;
-    unsigned long long* d_totals = nullptr; // [0] radiance rays, [1] shadow rays, [2] low word = traversal fault bits (pt_bvh8.h push)
+    unsigned long long* d_totals = nullptr; // [0] radiance rays, [1] shadow rays, [2] low word = traversal fault bits (pt_bvh8.h push), [3] shaded hits
     uint32_t* ovf = nullptr; // spill stacks for pt_trace queries
     unsigned long long* dbg = nullptr; // PT_DEBUG_COUNTS: traversal step counters of the last frame
     int trace_grid = 0;
@@ -307,8 +307,8 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     ctx->bvh_build_ms = ms;
-    CKC(dalloc(&ctx->d_totals, 3));
-    CKC(hipMemset(ctx->d_totals, 0, sizeof(unsigned long long) * 3));
+    CKC(dalloc(&ctx->d_totals, 4));
+    CKC(hipMemset(ctx->d_totals, 0, sizeof(unsigned long long) * 4));
     {
         hipDeviceProp_t prop;
         CKC(hipGetDeviceProperties(&prop, device));
@@ -933,7 +933,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.shadow;
                 }
-                hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters + (size_t)cur * CS, nq, 1, ctx->d_totals);
+                hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters + (size_t)cur * CS, nq, 1, 0, ctx->d_totals);
                 qcur = qnext;
                 qnext_base = (qnext_base == bs.queueA) ? bs.queueB : bs.queueA;
                 cur = nxt;
@@ -944,7 +944,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
         {
             SpanGuard g(ctx, CLS_OTHER, bs.stream);
             // counters[last_bounce+1] holds paths that would have continued: not traced, not counted
-            hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters, nq, last_bounce + 1, ctx->d_totals);
+            hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters, nq, last_bounce + 1, 1, ctx->d_totals);
             if (job)
                 hipLaunchKernelGGL(k_resolve_region, dim3((job->nl + 255) / 256), dim3(256), 0, bs.stream, bs.st, fp, job->rg, PartParams{ctx->rank, ctx->world, ctx->tile_w, ctx->tile_h}, job->var, job->l0, job->nl);
             else
@@ -982,7 +982,7 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index) {
     }
     ctx->ev_used = 0;
     ctx->spans.clear();
-    CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 3, ctx->stream));
+    CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 4, ctx->stream));
     hipEvent_t ev_begin = next_event(ctx);
     CK(hipEventRecord(ev_begin, ctx->stream));
     ctx->ev_begin = ev_begin;
@@ -1018,7 +1018,7 @@ static int render_finish(pt_ctx* ctx) {
     hipEvent_t ev_begin = ctx->ev_begin, ev_end = ctx->ev_end;
     CK(hipStreamSynchronize(ctx->stream)); // SimplePathtracer.cpp:96 CUDA_SYNC_CHECK
     CK(hipGetLastError());
-    unsigned long long totals[3] = {0, 0, 0};
+    unsigned long long totals[4] = {0, 0, 0, 0};
     CK(hipMemcpy(totals, ctx->d_totals, sizeof(totals), hipMemcpyDeviceToHost));
     if (totals[2] & 1ull) return fail(ctx, PT_ERR_UNSUPPORTED, "traversal stack overflow: the acceleration structure is deeper than the traversal stack; the frame is invalid");
     if (ctx->dbg) {
@@ -1051,6 +1051,7 @@ static int render_finish(pt_ctx* ctx) {
     pt_stats& st = ctx->stats;
     st.radiance_rays = totals[0];
     st.shadow_rays = totals[1];
+    st.shaded_hits = totals[3];
     st.paths = ctx->pending_paths;
     float ms = 0;
     hipEventElapsedTime(&ms, ev_begin, ev_end);
@@ -1117,7 +1118,7 @@ static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, co
     }
     ctx->ev_used = 0;
     ctx->spans.clear();
-    CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 3, ctx->stream));
+    CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 4, ctx->stream));
     hipEvent_t ev_begin = next_event(ctx);
     CK(hipEventRecord(ev_begin, ctx->stream));
     ctx->ev_begin = ev_begin;
@@ -1820,6 +1821,7 @@ extern "C" int pt_multi_get_stats(const pt_multi* m, pt_multi_stats* out) {
         pt_get_stats(m->ctx[r], &s);
         out->sum.radiance_rays += s.radiance_rays;
         out->sum.shadow_rays += s.shadow_rays;
+        out->sum.shaded_hits += s.shaded_hits;
         out->sum.paths += s.paths;
         out->sum.render_ms = std::max(out->sum.render_ms, s.render_ms);
         out->sum.trace_ms = std::max(out->sum.trace_ms, s.trace_ms);

@@ -770,20 +770,25 @@ __global__ void k_unpack(T* __restrict__ buf, const uint32_t* __restrict__ all_p
 }
 
 // counters: [nq][PT_NSUB*PT_CSTRIDE] radiance sub-queue counts, then the same for shadow queues
-__global__ void k_accum_stats(const uint32_t* __restrict__ counters, int nq, int nb, unsigned long long* __restrict__ totals) {
-    unsigned long long r = 0, s = 0; // one wave: lane q sums sub-queue q over the traced bounces
+__global__ void k_accum_stats(const uint32_t* __restrict__ counters, int nq, int nb, int count_hits, unsigned long long* __restrict__ totals) {
+    unsigned long long r = 0, s = 0, h = 0; // one wave: lane q sums sub-queue q over the traced bounces
     const uint32_t q = threadIdx.x;
     for (int b = 0; b < nb; ++b) {
         r += counters[(size_t)b * PT_NSUB * PT_CSTRIDE + q * PT_CSTRIDE];
         s += counters[(size_t)(nq + b) * PT_NSUB * PT_CSTRIDE + q * PT_CSTRIDE];
+        // closest hits whose BSDF sample was accepted = the paths k_shade(b) queued for bounce b+1 (the last slot holds those that
+        // "would continue" past the depth cutoff: shaded, not traced)
+        if (count_hits) h += counters[(size_t)(b + 1) * PT_NSUB * PT_CSTRIDE + q * PT_CSTRIDE];
     }
     for (int off = 32; off > 0; off >>= 1) {
         r += __shfl_xor(r, off);
         s += __shfl_xor(s, off);
+        h += __shfl_xor(h, off);
     }
     if (q == 0) { // several batch sets finish concurrently
         atomicAdd(&totals[0], r);
         atomicAdd(&totals[1], s);
+        atomicAdd(&totals[3], h);
     }
 }
 

@@ -355,6 +355,8 @@ def test_render_cornell_disney_4spp_depth8(ptlib, orc_det, small_probe):
     # rays: the GPU skips provably dead rays (see DESIGN.md "ray accounting"), never traces more than the reference
     assert g["stats"]["radiance_rays"] <= o["radiance_rays"] and g["stats"]["shadow_rays"] <= o["shadow_rays"]
     assert g["stats"]["radiance_rays"] > 0.8 * o["radiance_rays"]
+    # shaded hits (pt_stats): every live shadow ray comes from one, and every one was reached by a traced closest-hit ray
+    assert g["stats"]["shadow_rays"] <= g["stats"]["shaded_hits"] <= g["stats"]["radiance_rays"]
 
 
 def test_c2_cornell_1080p_4spp_depth8_rows(ptlib, orc_det):

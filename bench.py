@@ -312,7 +312,7 @@ def main():
                 "kernel": "whole frame, all wavefront stages (SURVEY.md 8d: rays x 160 B + pixels x 84 B + scene bytes)", "bound": "hbm",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "alg_bytes_per_frame": int(alg_frame), "scene_bytes": int(scene_bytes),
-                "measured_limiter": "VALU issue + dependent-load latency of the traversal kernel, not HBM (see valu / profiles/)",
+                "measured_limiter": "dependent-load latency at 5 waves/SIMD (waves wait on memory 42 % of their time, VALU pipe 59 % used) — not HBM (see valu.wave_state / profiles/r2_08_wave_state.md)",
                 "dominant_kernel": None if trav_ms <= 0 else {
                     "kernel": kname + " (BVH traversal: closest-hit + shadow rays per launch)", "bytes_per_ray": [BYTES_PER_RADIANCE_RAY_TRACE, BYTES_PER_SHADOW_RAY_TRACE],
                     "alg_bytes_per_launch": int(trav_bytes), "avg_launch_ms": round(trav_ms, 4), "isolated": iso is not None,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/profile_r2.sh <tag>   (GPU box, from the repo root)
 # rocprofv3 evidence for the bench line: kernel-trace stats of the default schedule and of a single chunk stream (isolated
-# per-kernel durations), then separate PMC passes (FETCH_SIZE, WRITE_SIZE cannot share a pass on gfx950; VALU counters 4 at a time).
+# per-kernel durations), then separate PMC passes (FETCH_SIZE, WRITE_SIZE cannot share a pass on gfx950; VALU counters 4 at a time; wave-state, TA/L1 and L1->L2 latency counters one pass each).
 # Writes gpurun_out/prof_<tag>/ and the judged summaries: profiles/<tag>_*.  Every pass profiles the same command.
 set -e
 TAG=${1:-r2}
@@ -15,6 +15,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $A
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $ARGS > "$OUT/bench_write.log" 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_valu" -- python3 $ARGS > "$OUT/bench_valu.log" 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_busy" -- python3 $ARGS > "$OUT/bench_busy.log" 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/pmc_state" -- python3 $ARGS > "$OUT/bench_state.log" 2>&1
+rocprofv3 --pmc TA_TA_BUSY_sum TCP_GATE_EN1_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum --output-format csv -d "$OUT/pmc_ta" -- python3 $ARGS > "$OUT/bench_ta.log" 2>&1
+rocprofv3 --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum --output-format csv -d "$OUT/pmc_lat" -- python3 $ARGS > "$OUT/bench_lat.log" 2>&1
 python3 tools/summarize_r2.py "$OUT" "$TAG"
 find "$OUT" -name "*_kernel_trace.csv" -size +2M -delete || true
 find "$OUT" -name "*counter_collection.csv" -size +2M -delete || true

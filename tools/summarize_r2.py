@@ -92,7 +92,34 @@ def main():
         insts_frame += v["SQ_INSTS_VALU"] / frames
         wait = busy.get(k, {}).get("SQ_WAIT_INST_ANY", 0.0) / v["SQ_WAVE_CYCLES"] if v["SQ_WAVE_CYCLES"] else 0.0
         md.append(f"| {k} | {vcnt[k]['SQ_INSTS_VALU']} | {v['SQ_INSTS_VALU']:.4g} | {v['SQ_ACTIVE_INST_VALU']:.4g} | {v['SQ_THREAD_CYCLES_VALU']:.4g} | {lu * 100:.1f} % | {v['SQ_WAVE_CYCLES']:.4g} | {wait * 100:.0f} % |")
-    md.append(f"\nVALU wave-instructions per frame: {insts_frame:.4g} (x 4 SIMD cycles each, 1024 SIMDs x 2.4 GHz available)\n")
+    md.append(f"\nVALU wave-instructions per frame: {insts_frame:.4g} (x 2 SIMD cycles each on the 32-lane SIMDs — one wave alone issues every 4 —, 1024 SIMDs x 2.4 GHz available)\n")
+    # where a wave's time goes (SQ wave-state counters, one pass) and how loaded the vector-memory path is (TA / L1, two passes)
+    state, _ = counters(os.path.join(out, "pmc_state"))
+    ta, _ = counters(os.path.join(out, "pmc_ta"))
+    lat, _ = counters(os.path.join(out, "pmc_lat"))
+    wave_state = {}
+    if state:
+        md += ["## Wave-state split (SQ_WAIT_ANY + SQ_WAIT_INST_ANY + SQ_ACTIVE_INST_ANY = SQ_WAVE_CYCLES) and vector-memory path\n",
+               "| kernel | waiting on memory | ready, not issued | issuing | of which VALU | VALU pipe use (5 waves/SIMD, 2 cycles per wave64 instruction) | TA busy / L1 clocked | L1 stalled on pending misses | mean L1->L2 read round trip, cycles |",
+               "|---|---|---|---|---|---|---|---|---|"]
+        for k in sorted(state, key=lambda k: -state[k]["SQ_WAVE_CYCLES"]):
+            r = state[k]
+            w = r["SQ_WAVE_CYCLES"]
+            if not k.startswith("k_") or not w:
+                continue
+            e = {"wait_mem": r["SQ_WAIT_ANY"] / w, "wait_issue": r["SQ_WAIT_INST_ANY"] / w, "active": r["SQ_ACTIVE_INST_ANY"] / w, "valu": r["SQ_ACTIVE_INST_VALU"] / w}
+            e["valu_pipe"] = 5 * e["valu"] * 2 / 4
+            t, l = ta.get(k), lat.get(k)
+            if t and t["TCP_GATE_EN1_sum"]:
+                e["ta_busy"] = t["TA_TA_BUSY_sum"] / t["TCP_GATE_EN1_sum"]
+                e["pending_stall"] = t["TCP_PENDING_STALL_CYCLES_sum"] / t["TCP_GATE_EN1_sum"]
+                e["acc_per_cycle"] = t["TCP_TOTAL_CACHE_ACCESSES_sum"] / t["TCP_GATE_EN1_sum"]
+            if l and l["TCP_TCC_READ_REQ_sum"]:
+                e["l2_round_trip_cycles"] = l["TCP_TCC_READ_REQ_LATENCY_sum"] / l["TCP_TCC_READ_REQ_sum"]
+            wave_state[k] = {a: round(b, 3) for a, b in e.items()}
+            md.append(f"| {k} | {e['wait_mem']:.1%} | {e['wait_issue']:.1%} | {e['active']:.1%} | {e['valu']:.1%} | {e['valu_pipe']:.0%} | "
+                      + (f"{e['ta_busy']:.0%} | {e['pending_stall']:.0%} | " if "ta_busy" in e else "- | - | ") + (f"{e['l2_round_trip_cycles']:.0f} |" if "l2_round_trip_cycles" in e else "- |"))
+        md.append("")
     b0 = bench_line(os.path.join(out, "bench_stats.log"))
     trav = [k for k in traffic if k.startswith("k_trace8")]
     tnum = sum(traffic[k]["total_bytes_x2"] * traffic[k]["dispatches"] for k in trav)
@@ -105,9 +132,9 @@ def main():
         "traffic_bytes_per_frame": int(sum(v["total_bytes_x2"] * v["dispatches"] for k, v in traffic.items() if k.startswith(("k_trace8", "k_shade", "k_generate", "k_resolve", "k_accum"))) / frames),
         "traversal_traffic_bytes_per_frame": int(sum(v["total_bytes_x2"] * v["dispatches"] for k, v in traffic.items() if k.startswith("k_trace8")) / frames),
         "per_kernel_traffic": {k: {kk: (int(vv) if kk != "dispatches" else vv) for kk, vv in v.items()} for k, v in traffic.items()},
-        "valu": {"lane_util": lane, "valu_insts_per_frame": insts_frame, "simd_cycles_per_valu_inst": 4, "simds": 1024, "clock_ghz": 2.4,
-                 "issue_frac_at_profiled_frame_ms": (round(insts_frame * 4 / (1024 * 2.4e9 * b0["ms_per_step"] * 1e-3), 3) if b0 else None),
-                 "source": f"profiles/{tag}_summary.md"},
+        "valu": {"lane_util": lane, "valu_insts_per_frame": insts_frame, "simd_cycles_per_valu_inst": 2, "single_wave_issue_cycles": 4, "simds": 1024, "clock_ghz": 2.4,
+                 "issue_frac_at_profiled_frame_ms": (round(insts_frame * 2 / (1024 * 2.4e9 * b0["ms_per_step"] * 1e-3), 3) if b0 else None),
+                 "wave_state": wave_state or None, "source": f"profiles/{tag}_summary.md"},
         "shade": ({"fetch_x2_plus_write_bytes_per_dispatch": int(traffic[shade_k[0]]["total_bytes_x2"]), "lane_util": lane.get(shade_k[0]),
                    "source": f"profiles/{tag}_summary.md"} if shade_k else None),
     }

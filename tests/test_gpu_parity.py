@@ -333,6 +333,61 @@ def test_trace_triangle_soup_adversarial(ptlib, orc_det):
         assert np.array_equal(occ, occ_o)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["one_triangle", "thousands_of_copies", "collinear_centroids", "flat_scene", "tiny_in_huge", "many_meshes"])
+def test_builder_degenerate_scenes(ptlib, orc_det, case):
+    """Scenes that stress the on-GPU builder rather than the traversal: Morton codes that all tie, root boxes with zero extent
+    on one or two axes (quantisation exponents), a single primitive, triangles far smaller than one 8-bit grid cell of the
+    root box, and hundreds of one-triangle meshes (primitive ids across mesh boundaries)."""
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    rng = np.random.default_rng(5)
+    base = np.array([[0, 0, 0], [4, 0, 0], [0, 3, 0]], np.float32)
+    if case == "one_triangle":
+        tri = base[None]
+    elif case == "thousands_of_copies":
+        tri = np.repeat(base[None], 3000, 0)
+    elif case == "collinear_centroids":
+        tri = base[None] * 0.2 + np.linspace(-50, 50, 4000, dtype=np.float32)[:, None, None] * np.array([1, 0, 0], np.float32)
+    elif case == "flat_scene":  # every vertex in the plane z = 2: the root box has zero extent in z
+        tri = rng.uniform(-30, 30, (2500, 3, 3)).astype(np.float32)
+        tri[:, :, 2] = 2.0
+    elif case == "tiny_in_huge":
+        c = rng.uniform(-500, 500, (4000, 1, 3))  # triangles of ≈0.05 units: 1/80 of one cell of the root's 8-bit grid, ≈10^3 float ulps across
+        tri = (c + rng.standard_normal((4000, 3, 3)) * 0.05).astype(np.float32)
+        tri[:200] = (rng.uniform(-1, 1, (200, 1, 3)) + rng.standard_normal((200, 3, 3)) * 0.3).astype(np.float32)  # a dense cluster at the origin
+    else:
+        tri = (rng.uniform(-20, 20, (600, 1, 3)) + rng.standard_normal((600, 3, 3)) * 2).astype(np.float32)
+    if case == "many_meshes":
+        meshes = [scenes.TriangleMesh(vertex=t.copy(), index=np.array([[0, 1, 2]], np.uint32), material=scenes.Material()) for t in tri]
+    else:
+        meshes = [scenes.TriangleMesh(vertex=tri.reshape(-1, 3).copy(), index=np.arange(3 * len(tri), dtype=np.uint32).reshape(-1, 3), material=scenes.Material())]
+    m = scenes.Model(meshes=meshes)
+    sc = orc_det.make_scene(m, use_bvh=False)
+    lo, hi = float(tri.min()) - 5, float(tri.max()) + 5
+    rays = _random_rays(rng, 20000, lo, hi)
+    tg = tri[rng.integers(0, len(tri), 20000)]                # aimed at the triangles (random barycentrics), from outside and inside
+    bc = rng.dirichlet([1, 1, 1], len(tg)).astype(np.float32)
+    targets = (tg * bc[:, :, None]).sum(1)
+    # origins stay within a few scene sizes: from hundreds of diameters away the float triangle test itself reports hits for rays that
+    # pass nowhere near a small triangle (tools/diag_degenerate2.py: the checker's own BVH2 disagrees with its brute force there too),
+    # and exact ties between coplanar copies are then decided by rounding noise larger than the builder's 2^-16 box padding
+    o = (targets + rng.standard_normal((len(tg), 3)) * rng.choice([0.5, 20.0], (len(tg), 1))).astype(np.float32)
+    aimed = np.concatenate([o, np.full((len(o), 1), 1e-3, np.float32), (targets - o).astype(np.float32), np.full((len(o), 1), 1e16, np.float32)], 1)
+    rays = np.concatenate([rays, aimed]).astype(np.float32)
+    to, po = orc_det.trace_closest(sc, rays)
+    occ_o = orc_det.trace_any(sc, rays)
+    assert (po >= 0).mean() > 0.2
+    for kind in (0, 1):
+        r = SampleRenderer(m)
+        r.setOptions(bvh_kind=kind)
+        (t, prim), _ = r.trace(rays)
+        assert np.array_equal(prim, po), f"{case}, bvh_kind {kind}: {(prim != po).sum()} primitive ids differ"
+        assert_bits_equal(t, to, f"{case}: closest-hit t, bvh_kind {kind}")
+        occ, _ = r.trace(rays, any_hit=True)
+        assert np.array_equal(occ, occ_o)
+
+
 # ---------------------------------------------------------------- whole renders
 def test_render_cornell_c1_lambert(ptlib, orc_det, small_probe):
     """BASELINE config 1: Cornell 256x256, 1 spp, depth 4, Lambert."""

@@ -10,7 +10,11 @@ N>1 (one process per GPU, torch.distributed over RCCL): the FIXED frame is tile-
 64x16 tiles, replicated scene, no data-path collective) — strong scaling, which is what "1/2/4/8 MI355X
 scaling" of a 1080p frame means.  `--scaling weak` (opt-in) grows the image to N x the pixels instead.
 `--workload c4_terrain1M_4k_16spp_d8` is BASELINE config C4 (3840x2160, 16 spp, tiled across the GPUs).
-`value` = rays traced by all ranks / max-over-ranks time of the K timed frames.  After the timed region a
+`value` = rays traced by all ranks / max-over-ranks time of the K timed frames.  The K frames are rendered with two frames
+in flight (pt_options.frames_in_flight = 2: pt_render(k) returns when frame k-1 is complete, so the kernel tails of one frame
+overlap the start of the next; same images bit for bit, the timed region ends after the last frame is complete);
+`ms_per_frame_synchronous` is the same frame rendered one at a time like the reference's render() (`--frames-in-flight 0`
+makes that the timed mode).  After the timed region a
 second, shorter loop renders AND hands the frame over for display every frame (pack -> one RCCL all-gather
 of the packed rgba8 strips -> unpack): `ms_per_displayed_frame`, with the exchange alone as `gather_ms`.
 
@@ -77,6 +81,7 @@ def main():
     ap.add_argument("--split-shadow", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="concurrent pixel chunks per frame (0 = library default)")
     ap.add_argument("--kernel-timing", type=int, default=0, help="1: per-launch HIP-event timing inside the timed loop (slower; the isolated phase always has it)")
+    ap.add_argument("--frames-in-flight", type=int, default=2, help="2 (default): pt_render(k) returns once frame k-1 is complete, so frame tails overlap the next frame's start (pt_options.frames_in_flight; same images); 0: every frame synchronous like the reference's render()")
     ap.add_argument("--bvh-kind", type=int, default=0, help="0 = 8-wide compressed BVH (default), 1 = binary BVH")
     ap.add_argument("--trace-kernel", type=int, default=0, help="0 = persistent-wave traversal (default), 1 = first grid-stride kernel")
     args = ap.parse_args()
@@ -118,7 +123,8 @@ def main():
 
     r = R.SampleRenderer(model, device=local_rank)
     r.setProbe(probe)
-    opts = dict(max_depth=depth, max_paths=args.max_paths, trace_kernel=args.trace_kernel, bvh_kind=args.bvh_kind, streams=args.streams, split_shadow=args.split_shadow, kernel_timing=args.kernel_timing)
+    opts = dict(max_depth=depth, max_paths=args.max_paths, trace_kernel=args.trace_kernel, bvh_kind=args.bvh_kind, streams=args.streams, split_shadow=args.split_shadow, kernel_timing=args.kernel_timing,
+                frames_in_flight=0 if args.kernel_timing else args.frames_in_flight)
     r.setOptions(**opts)
     part_world = world if world > 1 else max(1, args.simulate_world)
     if world > 1:
@@ -130,6 +136,7 @@ def main():
     r.launchParams.samples_per_launch = spp
 
     def barrier():
+        r.sync()  # frames in flight finish (and report their errors) before the clock is read
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -153,18 +160,40 @@ def main():
     for k in range(args.warmup):
         render_frame(k)
     barrier()
-    rays = 0
     keys = ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms", "trace_launches", "shadow_launches", "shade_launches", "radiance_rays", "shadow_rays", "shaded_hits")
     agg = dict.fromkeys(keys, 0.0)
+    # rays are counted on the device for every frame; pt_stats also keeps the totals since pt_create, so that the timed loop
+    # does not have to read (= wait for) each frame's statistics
+    pipelined = opts["frames_in_flight"] >= 2 and not sv4
+    s0 = r.stats()
     t0 = time.perf_counter()
     for k in range(args.steps):
         render_frame(args.warmup + k)
-        st = r.stats()
-        rays += st["radiance_rays"] + st["shadow_rays"]
-        for key in agg:
-            agg[key] += st[key]
+        if not pipelined:
+            st = r.stats()
+            for key in agg:
+                agg[key] += st[key]
     barrier()
     dt = time.perf_counter() - t0
+    st = r.stats()
+    assert st["frames"] - s0["frames"] == args.steps, (st["frames"], s0["frames"])
+    rays = (st["total_radiance_rays"] + st["total_shadow_rays"]) - (s0["total_radiance_rays"] + s0["total_shadow_rays"])
+    if pipelined:  # per-frame figures: those of the last frame (the frames differ only by their random numbers)
+        agg = {key: st[key] * args.steps for key in keys}
+
+    # the same frames one at a time (what SampleRenderer::render() does: return when the frame is complete), for the record
+    sync_ms = None
+    if pipelined:
+        r.setOptions(**dict(opts, frames_in_flight=0))
+        n_sync = max(1, min(args.steps, 5))
+        render_frame(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for k in range(n_sync):
+            render_frame(args.warmup + args.steps + 1 + k)
+        torch.cuda.synchronize()
+        sync_ms = (time.perf_counter() - ts) / n_sync * 1e3
+        r.setOptions(**opts)
 
     tot = torch.tensor([dt, float(rays)], dtype=torch.float64, device=red_dev)
     if dist is not None:
@@ -225,7 +254,7 @@ def main():
     # add up to the frame (rank 0, N=1 only; not part of `value`).
     iso = None
     if world == 1 and not args.no_isolated and not sv4 and args.streams == 0:
-        r.setOptions(**dict(opts, streams=1, kernel_timing=1))
+        r.setOptions(**dict(opts, streams=1, kernel_timing=1, frames_in_flight=0))
         n_iso = 3
         render_frame(0)
         ia = dict.fromkeys(keys, 0.0)
@@ -302,6 +331,8 @@ def main():
             },
             "rays_per_frame": int(rays_frame),
             "fps": round(args.steps / dt_max, 2),
+            "frames_in_flight": 2 if pipelined else 1,
+            "ms_per_frame_synchronous": None if sync_ms is None else round(sync_ms, 3),
             "render_ms_per_frame": round(agg["render_ms"] / args.steps, 3),
             "ms_per_step_per_rank": per_rank_ms,
             "kernel_ms_per_frame_isolated": None if iso is None else {k: round(iso[k], 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},

@@ -19,7 +19,7 @@ static void rd(FILE* f, T* p, size_t n) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s scene.bin out.bin [ncontexts [frames_in_flight]]\n", argv[0]); return 2; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 2; }
     try {
@@ -89,10 +89,14 @@ int main(int argc, char** argv) {
         sample.setCamera(cam);                          // main.cpp:262
         sample.launchParams.samples_per_launch = spp;
         std::vector<uint32_t> pixels((size_t)w * h);
+        const bool pipelined = argc > 4 && atoi(argv[4]) == 2; // two frames in flight: render() returns once the previous frame is complete
+        if (pipelined) sample.setFramesInFlight(2);
         for (uint32_t s = 0; s < subframes; ++s) {      // the render loop, main.cpp:273-286
             sample.launchParams.frame.subframe_index = s;
-            sample.render(pixels.data());
+            if (pipelined) sample.render();
+            else sample.render(pixels.data());
         }
+        if (pipelined) sample.downloadPixels(pixels.data()); // waits for the last frame
         std::vector<float> accum((size_t)w * h * 4);
         if (pt_download(sample.ctx, PT_BUF_ACCUM, accum.data(), accum.size() * sizeof(float)) != PT_OK) throw std::runtime_error(pt_last_error(sample.ctx));
         FILE* o = fopen(argv[2], "wb");

@@ -86,6 +86,13 @@ typedef struct pt_options {
     int32_t split_shadow;   /* 0 = default: shadow rays of bounce b share a launch with the closest-hit rays of b+1; 1 = separate kernels;
                              * 2 = asynchronous: per-bounce shadow records traced on side streams, nothing waits for them before the
                              *     resolve, which sums the visible contributions in bounce order (not with shadow-catcher materials) */
+    int32_t frames_in_flight; /* 0 / 1 = default: pt_render returns when its frame is complete, like SampleRenderer::render()
+                             * (SimplePathtracer.cpp:96 CUDA_SYNC_CHECK).  2: pt_render(k) enqueues frame k and returns once frame k-1 is
+                             * complete, so the kernel tails of a frame overlap the start of the next one (same images, bit for bit:
+                             * every pixel chunk's stream still orders its own frames).  Frame k completes — and its errors are
+                             * reported — at the next pt_render, at pt_sync, or at any call that reads or changes device state
+                             * (pt_download, pt_get_stats, pt_device_buffer, pt_resize, ...).  Ignored (synchronous) with kernel_timing,
+                             * for pt_render_regions and for pt_multi_render. */
 } pt_options;
 
 enum pt_buffer {          /* LaunchParams.frame.* (LaunchParams.h:53-63) */
@@ -113,6 +120,9 @@ typedef struct pt_stats {
     uint32_t bvh_levels;    /* levels of the traversal structure (must not exceed the traversal stack: pt_create checks) */
     uint64_t shaded_hits;   /* closest hits shaded by the last render whose BSDF sample was accepted (every one cost a BSDFSample, two
                              * BSDFEval and two BSDFPdf: the unit of the shade kernel's FLOP roofline) */
+    uint64_t frames;        /* frames completed since pt_create, and the rays they traced: take differences around a */
+    uint64_t total_radiance_rays; /* sequence of pt_render calls (pt_get_stats itself waits for the frames in flight) */
+    uint64_t total_shadow_rays;
 } pt_stats;
 
 /* SampleRenderer::SampleRenderer(const Model*) (SimplePathtracer.cpp:39-71): uploads the meshes
@@ -169,6 +179,9 @@ int pt_set_partition(pt_ctx* ctx, int rank, int world, int tile_w, int tile_h);
  * Silently does nothing before the first pt_resize (:77). If host_rgba8 is non-NULL the frame
  * buffer is copied into it (render(CUDAOutputBuffer&) + downloadPixels, :99-107,149-153). */
 int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8);
+/* Waits for the frames in flight (pt_options.frames_in_flight = 2) and reports their errors; a no-op otherwise.  No reference
+ * counterpart: the reference's render() is synchronous. */
+int pt_sync(pt_ctx* ctx);
 
 /* Foveated variants (the HelloPathtracing_sv, _sv2, _sv3, _sv4_vmv23 directories; sv and sv2 share one device
  * program and differ from sv3/sv4 by pt_variant.initial_depth / write_aov and their host schedules).  One pt_region = one optixLaunch of the sv4 raygen

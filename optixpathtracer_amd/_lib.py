@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("PT_LIB") or os.path.join(HERE, "libptamd.so")  # PT_L
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_options", "pt_get_options", "pt_set_probe", "pt_build_cdf",
     "pt_resize", "pt_set_camera", "pt_uvw_frame", "pt_set_partition", "pt_render", "pt_download", "pt_upload_accum",
-    "pt_device_buffer", "pt_tonemap_sqrt", "pt_owned_pixels", "pt_pack", "pt_unpack", "pt_get_stats", "pt_trace",
+    "pt_device_buffer", "pt_tonemap_sqrt", "pt_owned_pixels", "pt_pack", "pt_unpack", "pt_get_stats", "pt_trace", "pt_sync",
     "pt_eval_table", "pt_version", "pt_set_probe_image", "pt_get_probe_cdf", "pt_render_regions", "pt_denoise",
     "pt_create_multi", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_size", "pt_multi_ctx", "pt_multi_set_options", "pt_multi_set_probe",
     "pt_multi_set_probe_image", "pt_multi_resize", "pt_multi_set_camera", "pt_multi_render", "pt_multi_render_regions", "pt_multi_gather",
@@ -56,6 +56,7 @@ class Options(C.Structure):
     _fields_ = [
         ("max_depth", C.c_int32), ("bsdf_mode", C.c_int32), ("max_paths", C.c_uint32), ("kernel_timing", C.c_int32),
         ("bvh_kind", C.c_int32), ("trace_kernel", C.c_int32), ("streams", C.c_int32), ("split_shadow", C.c_int32),
+        ("frames_in_flight", C.c_int32),
     ]
 
 
@@ -79,6 +80,7 @@ class Stats(C.Structure):
         ("other_ms", C.c_double),
         ("trace_launches", C.c_uint32), ("shadow_launches", C.c_uint32), ("shade_launches", C.c_uint32),
         ("bvh_nodes", C.c_uint32), ("bvh_bytes", C.c_uint64), ("bvh_build_ms", C.c_double), ("bvh_levels", C.c_uint32), ("shaded_hits", C.c_uint64),
+        ("frames", C.c_uint64), ("total_radiance_rays", C.c_uint64), ("total_shadow_rays", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -139,6 +141,7 @@ def load_library() -> C.CDLL:
     L.pt_uvw_frame.argtypes = [C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3), f, f, C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3)]
     L.pt_set_partition.argtypes = [vp, i, i, i, i]
     L.pt_render.argtypes = [vp, u32, u32, vp]
+    L.pt_sync.argtypes = [vp]
     L.pt_render_regions.argtypes = [vp, C.POINTER(Region), u32, C.POINTER(Variant), vp]
     L.pt_download.argtypes = [vp, i, vp, C.c_size_t]
     L.pt_upload_accum.argtypes = [vp, vp, C.c_size_t]

@@ -141,6 +141,16 @@ class SampleRenderer {
         pt_denoise_params p{iterations, sigma_color, sigma_normal, sigma_albedo, PT_BUF_COLOR, 1};
         ck(pt_denoise(ctx, &p, h_pixels, nullptr));
     }
+    // Beyond the reference: render() normally returns when its frame is complete (SimplePathtracer.cpp:96); with two frames in flight
+    // it returns once the PREVIOUS frame is complete, so a progressive loop overlaps one frame's kernel tails with the next frame's start.
+    // downloadPixels / render(h_pixels) / resize / sync() wait for the frame in flight; the images are the same bit for bit.
+    void setFramesInFlight(int n) {
+        pt_options o;
+        ck(pt_get_options(ctx, &o));
+        o.frames_in_flight = n;
+        ck(pt_set_options(ctx, &o));
+    }
+    void sync() { ck(pt_sync(ctx)); }
     bool denoiserOn = false; // SimplePathtracer.h:63: the flag exists in the reference but nothing reads it (OptixDenoiser.cpp:15-42 is empty)
     LaunchParams launchParams;
     pt_ctx* ctx = nullptr;

@@ -70,12 +70,15 @@ struct pt_ctx {
         uint32_t* counters = nullptr; // [nq][PT_NSUB*PT_CSTRIDE] radiance sub-queue counts, same for shadow, then 2*nq work counters
         uint32_t *ovf = nullptr, *ovf2 = nullptr;
         float4 *pixResult = nullptr, *pixAlpha = nullptr, *pixNormal = nullptr, *pixAlbedo = nullptr;
+        unsigned long long* totals = nullptr; // this set's ray counters of the frame being enqueued (a slice of d_totals)
     };
     std::vector<BatchSet> sets;
     uint32_t set_cap = 0, set_pix_cap = 0, sub_cap = 0;
     bool cap_catcher = false, cap_async = false;
     int nq = 0;
-    unsigned long long* d_totals = nullptr; // [0] radiance rays, [1] shadow rays, [2] low word = traversal fault bits (pt_bvh8.h push), [3] shaded hits
+    // [frame slot 0/1][batch set 0..15][4]: [0] radiance rays, [1] shadow rays, [2] low word = traversal fault bits (pt_bvh8.h push), [3] shaded hits
+    unsigned long long* d_totals = nullptr;
+    unsigned long long* h_totals = nullptr; // pinned host copy, same shape: filled by an asynchronous copy behind each frame (a blocking hipMemcpy would wait for the NEXT frame too)
     uint32_t* ovf = nullptr; // spill stacks for pt_trace queries
     unsigned long long* dbg = nullptr; // PT_DEBUG_COUNTS: traversal step counters of the last frame
     int trace_grid = 0;
@@ -84,15 +87,24 @@ struct pt_ctx {
     int stack_check = 1; // PT_STACK_NOCHECK=1 (test hook): skip the build-time depth check so that the in-kernel fault flag is reached
     // stats + timing
     pt_stats stats{};
-    std::vector<hipEvent_t> ev_pool;
+    std::vector<hipEvent_t> ev_pools[2]; // one event pool per frame slot
     size_t ev_used = 0;
     struct Span { size_t a, b; int cls; };
     std::vector<Span> spans;
-    // a frame that is enqueued but not yet waited for (render_enqueue / render_finish)
-    int pending = 0;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    uint64_t pending_paths = 0;
-    LaunchCounts pending_lc;
+    // Frames that are enqueued but not yet waited for (render_enqueue / render_finish).  Synchronous rendering uses slot 0
+    // only; with pt_options.frames_in_flight = 2 consecutive pt_render calls alternate between the two slots and each call
+    // waits for the PREVIOUS frame, so the kernel tails of frame k overlap the start of frame k+1 (every batch set's stream
+    // orders its own chunks; the sets share nothing else but the frame's counters, kept per slot and per set).
+    struct Inflight {
+        int active = 0;
+        hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+        uint64_t paths = 0, seq = 0;
+        LaunchCounts lc;
+    };
+    Inflight fr[2];
+    int cur_slot = 0;      // slot whose events / counters the enqueue functions are filling
+    uint64_t frame_seq = 0;
+    uint64_t cum_radiance = 0, cum_shadow = 0, cum_frames = 0;
     int env_timing = -1; // PT_TIMING=0/1 overrides pt_options.kernel_timing
     bool span_timing() const { return env_timing >= 0 ? env_timing != 0 : opt.kernel_timing != 0; }
 };
@@ -154,7 +166,11 @@ static void default_options(pt_options* o) {
 }
 
 static size_t ovf_words(const pt_ctx* ctx);
-static uint32_t* fault_word(pt_ctx* ctx) { return reinterpret_cast<uint32_t*>(ctx->d_totals + 2); }
+static const int PT_MAX_SETS = 16;
+static unsigned long long* totals_of(pt_ctx* ctx, int slot, int set) { return ctx->d_totals + ((size_t)slot * PT_MAX_SETS + set) * 4; }
+static uint32_t* fault_word(pt_ctx* ctx) { return reinterpret_cast<uint32_t*>(totals_of(ctx, 0, 0) + 2); } // pt_trace queries
+static uint32_t* fault_word(pt_ctx::BatchSet& bs) { return reinterpret_cast<uint32_t*>(bs.totals + 2); }
+static int drain(pt_ctx* ctx);
 static int stack_capacity8(const pt_ctx* ctx) { return (PT8_LDS_DEPTH - ctx->lds_skip) + ctx->ovf_depth; }
 
 // The traversal stacks are finite (k_trace8: one pushed group per level of the wide tree; k_trace/k_trace2: one node per level of
@@ -307,8 +323,9 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     ctx->bvh_build_ms = ms;
-    CKC(dalloc(&ctx->d_totals, 4));
-    CKC(hipMemset(ctx->d_totals, 0, sizeof(unsigned long long) * 4));
+    CKC(dalloc(&ctx->d_totals, (size_t)2 * PT_MAX_SETS * 4));
+    CKC(hipMemset(ctx->d_totals, 0, sizeof(unsigned long long) * 2 * PT_MAX_SETS * 4));
+    CKC(hipHostMalloc((void**)&ctx->h_totals, sizeof(unsigned long long) * 2 * PT_MAX_SETS * 4));
     {
         hipDeviceProp_t prop;
         CKC(hipGetDeviceProperties(&prop, device));
@@ -365,6 +382,7 @@ static void free_frame(pt_ctx* ctx) {
 extern "C" int pt_destroy(pt_ctx* ctx) {
     if (!ctx) return PT_OK;
     hipSetDevice(ctx->device);
+    drain(ctx);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     free_path_state(ctx);
     free_frame(ctx);
@@ -375,9 +393,11 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
     dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y); dfree(ctx->d_data_pdf);
     dfree(ctx->d_totals);
+    if (ctx->h_totals) hipHostFree(ctx->h_totals);
     dfree(ctx->ovf);
     dfree(ctx->dbg);
-    for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
+    for (auto& pool : ctx->ev_pools)
+        for (hipEvent_t e : pool) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return PT_OK;
@@ -385,8 +405,10 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
 
 extern "C" int pt_set_options(pt_ctx* ctx, const pt_options* opt) {
     if (!ctx || !opt) return PT_ERR_INVALID;
+    { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     if (opt->max_depth < 0 || opt->max_depth > 250) return fail(ctx, PT_ERR_INVALID, "pt_set_options: max_depth out of range [0,250]");
     if (opt->bsdf_mode != PT_BSDF_DISNEY && opt->bsdf_mode != PT_BSDF_LAMBERT) return fail(ctx, PT_ERR_INVALID, "pt_set_options: bad bsdf_mode");
+    if (opt->frames_in_flight < 0 || opt->frames_in_flight > 2) return fail(ctx, PT_ERR_INVALID, "pt_set_options: frames_in_flight must be 0, 1 or 2");
     if ((opt->bvh_kind == 1 || opt->trace_kernel == 1) && !ctx->bvh.nodes) {
         // the binary tree is an A/B path: built (with the wide tree, from the same hierarchy) the first time it is asked for
         CK(hipSetDevice(ctx->device));
@@ -504,6 +526,7 @@ static int finish_probe(pt_ctx* ctx, int w, int h) {
 extern "C" int pt_set_probe(pt_ctx* ctx, const float* data, const float* pdfX, const float* cdfX, const float* pdfY,
                             const float* cdfY, int w, int h) {
     if (!ctx) return PT_ERR_INVALID;
+    { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     if (!data || !pdfX || !cdfX || !pdfY || !cdfY || w <= 0 || h <= 0) return fail(ctx, PT_ERR_INVALID, "pt_set_probe: Probe Data is not valid");
     if ((long long)w * h >= (1ll << 31)) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_set_probe: probe too large");
     CK(hipSetDevice(ctx->device));
@@ -524,6 +547,7 @@ extern "C" int pt_set_probe(pt_ctx* ctx, const float* data, const float* pdfX, c
 
 extern "C" int pt_set_probe_image(pt_ctx* ctx, const float* data, int w, int h) {
     if (!ctx) return PT_ERR_INVALID;
+    { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     if (!data || w <= 0 || h <= 0) return fail(ctx, PT_ERR_INVALID, "pt_set_probe_image: Probe Data is not valid");
     if ((long long)w * h >= (1ll << 31)) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_set_probe_image: probe too large");
     CK(hipSetDevice(ctx->device));
@@ -569,6 +593,7 @@ extern "C" int pt_set_camera(pt_ctx* ctx, const float eye[3], const float U[3], 
 
 extern "C" int pt_set_partition(pt_ctx* ctx, int rank, int world, int tile_w, int tile_h) {
     if (!ctx) return PT_ERR_INVALID;
+    { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     if (world < 1 || rank < 0 || rank >= world || tile_w < 8 || tile_h < 8 || (tile_w % 8) || (tile_h % 8))
         return fail(ctx, PT_ERR_INVALID, "pt_set_partition: need 0<=rank<world and tile sizes that are multiples of 8");
     ctx->rank = rank; ctx->world = world; ctx->tile_w = tile_w; ctx->tile_h = tile_h;
@@ -596,6 +621,7 @@ static void build_pixel_lists(int w, int h, int world, int tile_w, int tile_h, s
 
 extern "C" int pt_resize(pt_ctx* ctx, int width, int height) {
     if (!ctx) return PT_ERR_INVALID;
+    { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     if (width == 0 || height == 0) return PT_OK; // SimplePathtracer.cpp:112
     if (width < 0 || height < 0 || width > 65535 || height > 65535) return fail(ctx, PT_ERR_INVALID, "pt_resize: size out of range");
     CK(hipSetDevice(ctx->device));
@@ -647,6 +673,10 @@ static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_
     if ((int)ctx->sets.size() == nsets && cap <= ctx->set_cap && pix_cap <= ctx->set_pix_cap && nq <= ctx->nq &&
         (!ctx->has_catcher || ctx->cap_catcher) && async == ctx->cap_async)
         return PT_OK;
+    {
+        int rc = drain(ctx); // frames in flight still use the old buffers
+        if (rc) return rc;
+    }
     free_path_state(ctx);
     ctx->sets.resize(nsets);
     ctx->sub_cap = cap / PT_NSUB + 8192 + 1; // a sub-queue receives at most cap/64 + 32 workgroups * 256 entries
@@ -683,12 +713,13 @@ static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_
 enum { CLS_TRACE = 0, CLS_SHADOW = 1, CLS_SHADE = 2, CLS_OTHER = 3 };
 
 static hipEvent_t next_event(pt_ctx* ctx) {
-    if (ctx->ev_used == ctx->ev_pool.size()) {
+    auto& pool = ctx->ev_pools[ctx->cur_slot];
+    if (ctx->ev_used == pool.size()) {
         hipEvent_t e;
         hipEventCreate(&e);
-        ctx->ev_pool.push_back(e);
+        pool.push_back(e);
     }
-    return ctx->ev_pool[ctx->ev_used++];
+    return pool[ctx->ev_used++];
 }
 struct SpanGuard {
     pt_ctx* ctx;
@@ -771,7 +802,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             std::vector<hipEvent_t> shadow_done;
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
+                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
@@ -792,7 +823,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     hipStreamWaitEvent(ss, ev_shaded, 0);
                     {
                         SpanGuard g(ctx, CLS_SHADOW, ss);
-                        Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, (b & 1) ? bs.ovf3 : bs.ovf2, cull, nullptr, b, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
+                        Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, (b & 1) ? bs.ovf3 : bs.ovf2, cull, nullptr, b, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                         hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, ss, ta);
                         ++lc.shadow;
                     }
@@ -802,7 +833,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qnext, QView{}, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
+                    Trace8Args ta{bs.st, bvh8, qnext, QView{}, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 }
@@ -816,7 +847,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             // and a frame has max_depth+1 traversal launches instead of 2*max_depth.
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
+                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
@@ -832,12 +863,12 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
+                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_UNIFIED>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 } else {
                     SpanGuard g(ctx, CLS_SHADOW, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.shadow;
                 }
@@ -856,7 +887,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     Trace2Args ta{bs.st, bvh, qcur, work + b, bs.ovf, nullptr};
                     hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 } else {
-                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
+                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                 }
                 ++lc.trace;
@@ -882,7 +913,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     Trace2Args ta{bs.st, bvh, qshadow, work + nq + b, bs.ovf2, nullptr};
                     hipLaunchKernelGGL((k_trace2<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
                 } else {
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
                 }
                 ++lc.shadow;
@@ -916,7 +947,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 QView qshadow{bs.squeue, cntS + (size_t)cur * CS, ctx->sub_cap};
                 {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
+                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 }
@@ -929,11 +960,11 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 {
                     SpanGuard g(ctx, CLS_SHADOW, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
+                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
                     ++lc.shadow;
                 }
-                hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters + (size_t)cur * CS, nq, 1, 0, ctx->d_totals);
+                hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters + (size_t)cur * CS, nq, 1, 0, bs.totals);
                 qcur = qnext;
                 qnext_base = (qnext_base == bs.queueA) ? bs.queueB : bs.queueA;
                 cur = nxt;
@@ -944,7 +975,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
         {
             SpanGuard g(ctx, CLS_OTHER, bs.stream);
             // counters[last_bounce+1] holds paths that would have continued: not traced, not counted
-            hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters, nq, last_bounce + 1, 1, ctx->d_totals);
+            hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters, nq, last_bounce + 1, 1, bs.totals);
             if (job)
                 hipLaunchKernelGGL(k_resolve_region, dim3((job->nl + 255) / 256), dim3(256), 0, bs.stream, bs.st, fp, job->rg, PartParams{ctx->rank, ctx->world, ctx->tile_w, ctx->tile_h}, job->var, job->l0, job->nl);
             else
@@ -953,10 +984,22 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
     }
 }
 
-// pt_render in two halves, so that pt_multi_render can have every device working before it waits for any of them:
-// render_enqueue launches the whole frame asynchronously, render_finish waits for it and collects the statistics.
-static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index) {
-    ctx->pending = 0;
+// pt_render in two halves, so that pt_multi_render can have every device working before it waits for any of them and so
+// that consecutive frames can overlap (pt_options.frames_in_flight): render_enqueue launches the whole frame asynchronously
+// into a frame slot, render_finish waits for that slot's frame and collects its statistics.
+static void begin_slot(pt_ctx* ctx, int slot) {
+    ctx->cur_slot = slot;
+    ctx->ev_used = 0;
+    ctx->spans.clear();
+    for (size_t i = 0; i < ctx->sets.size(); ++i) ctx->sets[i].totals = totals_of(ctx, slot, (int)i);
+}
+
+static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, int slot = 0, bool pipelined = false) {
+    if (!pipelined) {
+        int rc = drain(ctx);
+        if (rc) return rc;
+    }
+    ctx->fr[slot].active = 0;
     if (ctx->width == 0) return PT_OK; // not resized yet (SimplePathtracer.cpp:77)
     if (spp == 0 || spp > 4096) return fail(ctx, PT_ERR_INVALID, "pt_render: samples_per_launch must be in [1,4096]");
     if (!ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_render: no probe set (setProbe)");
@@ -966,31 +1009,37 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index) {
     // chunks that run concurrently on separate stream pairs; a chunk holds at most max_paths/streams paths, so
     // samples are split when spp*pixels exceed that; shadow-catcher scenes run one sample per pass so that the
     // per-pixel normal/albedo sums keep the reference order.  None of this changes a bit of the result.
-    const int nsets = std::max(1, std::min(16, ctx->opt.streams > 0 ? ctx->opt.streams : 3));
+    const int nsets = std::max(1, std::min(PT_MAX_SETS, ctx->opt.streams > 0 ? ctx->opt.streams : 3));
     const uint32_t max_paths = std::max<uint32_t>(ctx->opt.max_paths, 64u);
     const uint32_t cap = std::max<uint32_t>(64u, max_paths / nsets);
     uint32_t Np = (owned + nsets - 1) / nsets;        // pixels per chunk ...
     Np = std::min(cap, std::max(64u, (Np + 63u) & ~63u)); // ... whole 8x8 blocks, within the set capacity
     const uint32_t S = ctx->has_catcher ? 1u : std::max(1u, std::min(spp, cap / Np));
     if (owned) {
-        int rc = ensure_path_state(ctx, nsets, Np * S, Np);
+        int rc = ensure_path_state(ctx, nsets, Np * S, Np); // waits for the frames in flight before it re-allocates
         if (rc) return rc;
     }
     if (getenv("PT_DEBUG_COUNTS")) {
         if (!ctx->dbg) CK(dalloc(&ctx->dbg, 64));
         CK(hipMemset(ctx->dbg, 0, 512));
     }
-    ctx->ev_used = 0;
-    ctx->spans.clear();
-    CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 4, ctx->stream));
+    begin_slot(ctx, slot);
     hipEvent_t ev_begin = next_event(ctx);
-    CK(hipEventRecord(ev_begin, ctx->stream));
-    ctx->ev_begin = ev_begin;
+    if (!pipelined) {
+        CK(hipMemsetAsync(totals_of(ctx, slot, 0), 0, sizeof(unsigned long long) * PT_MAX_SETS * 4, ctx->stream));
+        CK(hipEventRecord(ev_begin, ctx->stream));
+    }
     FrameParams fp{ctx->accum, ctx->frame, ctx->color, ctx->normal, ctx->albedo, ctx->width, ctx->height, subframe_index,
                    ctx->eye, ctx->U, ctx->V, ctx->W, spp, ctx->probe};
     LaunchCounts lc;
     if (owned) {
-        for (auto& b : ctx->sets) hipStreamWaitEvent(b.stream, ev_begin, 0);
+        if (!pipelined) {
+            for (auto& b : ctx->sets) hipStreamWaitEvent(b.stream, ev_begin, 0);
+        } else {
+            // no frame-wide start: every set clears its own counters behind its own previous chunk and goes on
+            for (auto& b : ctx->sets) CK(hipMemsetAsync(b.totals, 0, sizeof(unsigned long long) * 4, b.stream));
+            CK(hipEventRecord(ev_begin, ctx->sets[0].stream));
+        }
         uint32_t k = 0;
         for (uint32_t pix0 = 0; pix0 < owned; pix0 += Np, ++k)
             enqueue_chunk(ctx, ctx->sets[k % nsets], fp, pix0, std::min(Np, owned - pix0), spp, S, lc);
@@ -999,27 +1048,40 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index) {
             hipEventRecord(e, b.stream);
             hipStreamWaitEvent(ctx->stream, e, 0);
         }
+    } else if (pipelined) {
+        CK(hipEventRecord(ev_begin, ctx->stream));
     }
+    CK(hipMemcpyAsync(ctx->h_totals + (size_t)slot * PT_MAX_SETS * 4, totals_of(ctx, slot, 0), sizeof(unsigned long long) * PT_MAX_SETS * 4, hipMemcpyDeviceToHost, ctx->stream));
     hipEvent_t ev_end = next_event(ctx);
     CK(hipEventRecord(ev_end, ctx->stream));
-    ctx->ev_end = ev_end;
-    ctx->pending = 1;
-    ctx->pending_paths = (uint64_t)owned * spp;
-    ctx->pending_lc = lc;
+    pt_ctx::Inflight& fr = ctx->fr[slot];
+    fr.ev_begin = ev_begin;
+    fr.ev_end = ev_end;
+    fr.active = 1;
+    fr.paths = (uint64_t)owned * spp;
+    fr.lc = lc;
+    fr.seq = ++ctx->frame_seq;
     return PT_OK;
 }
 
-static int render_finish(pt_ctx* ctx) {
-    if (!ctx->pending) return PT_OK;
-    ctx->pending = 0;
+static int render_finish(pt_ctx* ctx, int slot = 0) {
+    pt_ctx::Inflight& fr = ctx->fr[slot];
+    if (!fr.active) return PT_OK;
+    fr.active = 0;
     CK(hipSetDevice(ctx->device));
     const uint32_t owned = ctx->owned;
-    const LaunchCounts lc = ctx->pending_lc;
-    hipEvent_t ev_begin = ctx->ev_begin, ev_end = ctx->ev_end;
-    CK(hipStreamSynchronize(ctx->stream)); // SimplePathtracer.cpp:96 CUDA_SYNC_CHECK
+    const LaunchCounts lc = fr.lc;
+    hipEvent_t ev_begin = fr.ev_begin, ev_end = fr.ev_end;
+    CK(hipEventSynchronize(ev_end)); // SimplePathtracer.cpp:96 CUDA_SYNC_CHECK (the frame's last event on the context's stream)
     CK(hipGetLastError());
+    const unsigned long long* per_set = ctx->h_totals + (size_t)slot * PT_MAX_SETS * 4; // copied behind the frame's last kernel, before ev_end
     unsigned long long totals[4] = {0, 0, 0, 0};
-    CK(hipMemcpy(totals, ctx->d_totals, sizeof(totals), hipMemcpyDeviceToHost));
+    for (int i = 0; i < PT_MAX_SETS; ++i) {
+        totals[0] += per_set[i * 4 + 0];
+        totals[1] += per_set[i * 4 + 1];
+        totals[2] |= per_set[i * 4 + 2];
+        totals[3] += per_set[i * 4 + 3];
+    }
     if (totals[2] & 1ull) return fail(ctx, PT_ERR_UNSUPPORTED, "traversal stack overflow: the acceleration structure is deeper than the traversal stack; the frame is invalid");
     if (ctx->dbg) {
         unsigned long long h[64];
@@ -1052,14 +1114,17 @@ static int render_finish(pt_ctx* ctx) {
     st.radiance_rays = totals[0];
     st.shadow_rays = totals[1];
     st.shaded_hits = totals[3];
-    st.paths = ctx->pending_paths;
+    st.paths = fr.paths;
+    ctx->cum_radiance += totals[0];
+    ctx->cum_shadow += totals[1];
+    ctx->cum_frames += 1;
     float ms = 0;
     hipEventElapsedTime(&ms, ev_begin, ev_end);
     st.render_ms = ms;
     double cls_ms[4] = {0, 0, 0, 0};
-    for (auto& sp : ctx->spans) {
+    for (auto& sp : ctx->spans) { // kernel timing implies synchronous frames: the spans are those of this frame
         float m = 0;
-        hipEventElapsedTime(&m, ctx->ev_pool[sp.a], ctx->ev_pool[sp.b]);
+        hipEventElapsedTime(&m, ctx->ev_pools[slot][sp.a], ctx->ev_pools[slot][sp.b]);
         cls_ms[sp.cls] += m;
     }
     st.trace_ms = cls_ms[CLS_TRACE]; // sums over concurrent streams: they overlap, so they can exceed render_ms
@@ -1072,10 +1137,36 @@ static int render_finish(pt_ctx* ctx) {
     return PT_OK;
 }
 
+// waits for every frame in flight, oldest first
+static int drain(pt_ctx* ctx) {
+    const int first = (ctx->fr[0].active && ctx->fr[1].active && ctx->fr[1].seq < ctx->fr[0].seq) ? 1 : 0;
+    int rc = render_finish(ctx, first);
+    const int rc2 = render_finish(ctx, first ^ 1);
+    return rc != PT_OK ? rc : rc2;
+}
+
+extern "C" int pt_sync(pt_ctx* ctx) { return ctx ? drain(ctx) : PT_ERR_INVALID; }
+
 extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8) {
     if (!ctx) return PT_ERR_INVALID;
-    int rc = render_enqueue(ctx, spp, subframe_index);
-    if (rc == PT_OK) rc = render_finish(ctx);
+    // kernel timing and the debug counters read per-frame state that is not kept per slot
+    const bool pipelined = ctx->opt.frames_in_flight >= 2 && !ctx->span_timing() && !getenv("PT_DEBUG_COUNTS");
+    int rc;
+    if (!pipelined) {
+        rc = drain(ctx);
+        if (rc == PT_OK) rc = render_enqueue(ctx, spp, subframe_index);
+        if (rc == PT_OK) rc = render_finish(ctx);
+    } else {
+        // frame k goes into the slot frame k-2 has left; then wait for frame k-1 (its errors are reported by this call)
+        const int prev = ctx->fr[0].active ? 0 : (ctx->fr[1].active ? 1 : -1);
+        const int slot = prev < 0 ? 0 : prev ^ 1;
+        rc = render_finish(ctx, slot);
+        if (rc == PT_OK) rc = render_enqueue(ctx, spp, subframe_index, slot, true);
+        if (prev >= 0) {
+            const int rcp = render_finish(ctx, prev);
+            if (rc == PT_OK) rc = rcp;
+        }
+    }
     if (rc != PT_OK) return rc;
     if (host_rgba8 && ctx->width) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)ctx->width * ctx->height);
     return PT_OK;
@@ -1087,7 +1178,10 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
 // samples_per_launch and subframe_index; later launches overwrite the pixels of earlier ones, so the launches run
 // in order on one stream.
 static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, const pt_variant* variant) {
-    ctx->pending = 0;
+    {
+        int rc = drain(ctx); // foveated frames are synchronous
+        if (rc) return rc;
+    }
     if (ctx->width == 0) return PT_OK;
     if (!ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_render_regions: no probe set (setProbe)");
     if (ctx->opt.bvh_kind != 0 || ctx->opt.trace_kernel != 0) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_regions: needs the default traversal (bvh_kind 0, trace_kernel 0)");
@@ -1116,12 +1210,10 @@ static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, co
         int rc = ensure_path_state(ctx, nsets, need, 64);
         if (rc) return rc;
     }
-    ctx->ev_used = 0;
-    ctx->spans.clear();
-    CK(hipMemsetAsync(ctx->d_totals, 0, sizeof(unsigned long long) * 4, ctx->stream));
+    begin_slot(ctx, 0);
+    CK(hipMemsetAsync(totals_of(ctx, 0, 0), 0, sizeof(unsigned long long) * PT_MAX_SETS * 4, ctx->stream));
     hipEvent_t ev_begin = next_event(ctx);
     CK(hipEventRecord(ev_begin, ctx->stream));
-    ctx->ev_begin = ev_begin;
     for (auto& b : ctx->sets) hipStreamWaitEvent(b.stream, ev_begin, 0);
     LaunchCounts lc;
     uint64_t paths = 0;
@@ -1159,12 +1251,16 @@ static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, co
         hipEventRecord(e, b.stream);
         hipStreamWaitEvent(ctx->stream, e, 0);
     }
+    CK(hipMemcpyAsync(ctx->h_totals, totals_of(ctx, 0, 0), sizeof(unsigned long long) * PT_MAX_SETS * 4, hipMemcpyDeviceToHost, ctx->stream));
     hipEvent_t ev_end = next_event(ctx);
     CK(hipEventRecord(ev_end, ctx->stream));
-    ctx->ev_end = ev_end;
-    ctx->pending = 1;
-    ctx->pending_paths = paths;
-    ctx->pending_lc = lc;
+    pt_ctx::Inflight& fr = ctx->fr[0];
+    fr.ev_begin = ev_begin;
+    fr.ev_end = ev_end;
+    fr.active = 1;
+    fr.paths = paths;
+    fr.lc = lc;
+    fr.seq = ++ctx->frame_seq;
     return PT_OK;
 }
 
@@ -1192,12 +1288,14 @@ static void* buffer_ptr(pt_ctx* ctx, int which, size_t* elem) {
 
 extern "C" void* pt_device_buffer(pt_ctx* ctx, int which) {
     if (!ctx) return nullptr;
+    if (drain(ctx) != PT_OK) return nullptr; // the caller is about to read or write the buffer
     size_t e;
     return buffer_ptr(ctx, which, &e);
 }
 
 extern "C" int pt_download(pt_ctx* ctx, int which, void* host, size_t bytes) {
     if (!ctx || !host) return PT_ERR_INVALID;
+    { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     size_t elem;
     void* p = buffer_ptr(ctx, which, &elem);
     if (!p) return fail(ctx, PT_ERR_INVALID, "pt_download: unknown buffer or not resized");
@@ -1209,6 +1307,7 @@ extern "C" int pt_download(pt_ctx* ctx, int which, void* host, size_t bytes) {
 
 extern "C" int pt_upload_accum(pt_ctx* ctx, const float* host, size_t bytes) {
     if (!ctx || !host) return PT_ERR_INVALID;
+    { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     if (!ctx->accum || bytes != 16 * (size_t)ctx->width * ctx->height) return fail(ctx, PT_ERR_INVALID, "pt_upload_accum: byte count does not match the frame size");
     CK(hipSetDevice(ctx->device));
     CK(hipMemcpy(ctx->accum, host, bytes, hipMemcpyHostToDevice));
@@ -1217,6 +1316,7 @@ extern "C" int pt_upload_accum(pt_ctx* ctx, const float* host, size_t bytes) {
 
 extern "C" int pt_tonemap_sqrt(pt_ctx* ctx, uint32_t* host_rgba8) {
     if (!ctx) return PT_ERR_INVALID;
+    { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     if (ctx->width == 0) return PT_OK;
     CK(hipSetDevice(ctx->device));
     const uint32_t n = (uint32_t)ctx->width * ctx->height;
@@ -1229,6 +1329,7 @@ extern "C" int pt_tonemap_sqrt(pt_ctx* ctx, uint32_t* host_rgba8) {
 // OptiXDenoiser::exec() + the computeFinalPixelColors call of render(target) (SimplePathtracer.cpp:104-105)
 extern "C" int pt_denoise(pt_ctx* ctx, const pt_denoise_params* prm, uint32_t* host_rgba8, double* kernel_ms) {
     if (!ctx || !prm) return PT_ERR_INVALID;
+    { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     if (ctx->width == 0) return PT_OK;
     if (prm->iterations < 0 || prm->iterations > 8) return fail(ctx, PT_ERR_INVALID, "pt_denoise: iterations must be in [0,8]");
     if (!(prm->sigma_color > 0.f) || !(prm->sigma_normal > 0.f) || !(prm->sigma_albedo > 0.f)) return fail(ctx, PT_ERR_INVALID, "pt_denoise: sigmas must be positive");
@@ -1283,6 +1384,7 @@ static int pack_launch(pt_ctx* ctx, int which, void* dev_dst);
 static int unpack_launch(pt_ctx* ctx, int which, const void* dev_src_all);
 extern "C" int pt_pack(pt_ctx* ctx, int which, void* dev_dst) {
     if (!ctx || !dev_dst) return PT_ERR_INVALID;
+    { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     int rc = pack_launch(ctx, which, dev_dst);
     if (rc != PT_OK) return rc;
     CK(hipStreamSynchronize(ctx->stream));
@@ -1290,6 +1392,7 @@ extern "C" int pt_pack(pt_ctx* ctx, int which, void* dev_dst) {
 }
 extern "C" int pt_unpack(pt_ctx* ctx, int which, const void* dev_src_all) {
     if (!ctx || !dev_src_all) return PT_ERR_INVALID;
+    { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     int rc = unpack_launch(ctx, which, dev_src_all);
     if (rc != PT_OK) return rc;
     CK(hipStreamSynchronize(ctx->stream));
@@ -1328,7 +1431,14 @@ static int unpack_launch(pt_ctx* ctx, int which, const void* dev_src_all) {
 
 extern "C" int pt_get_stats(const pt_ctx* ctx, pt_stats* out) {
     if (!ctx || !out) return PT_ERR_INVALID;
+    {
+        int rc = drain(const_cast<pt_ctx*>(ctx)); // the statistics of the frame still in flight are wanted
+        if (rc != PT_OK) return rc;
+    }
     *out = ctx->stats;
+    out->frames = ctx->cum_frames;
+    out->total_radiance_rays = ctx->cum_radiance;
+    out->total_shadow_rays = ctx->cum_shadow;
     const bool wide = ctx->opt.bvh_kind != 1 && ctx->opt.trace_kernel != 1;
     out->bvh_nodes = wide ? ctx->bvh.num_nodes8 : ctx->bvh.num_nodes;
     out->bvh_bytes = wide ? (uint64_t)ctx->bvh.num_nodes8 * sizeof(Node8) + (uint64_t)ctx->bvh.num_tris8 * sizeof(LeafTri)
@@ -1352,6 +1462,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_query_any(const float4* rayO
 extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit, float* t_out, int32_t* prim_out, int iters,
                         double* kernel_ms) {
     if (!ctx || !rays || !prim_out || (!any_hit && !t_out)) return PT_ERR_INVALID;
+    { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     if (n == 0) return PT_OK;
     CK(hipSetDevice(ctx->device));
     if (iters < 1) iters = 1;

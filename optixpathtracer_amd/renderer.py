@@ -208,12 +208,16 @@ class SampleRenderer:
         self.launchParams.frame.subframe_index += 1
 
     # -- beyond the reference (runtime versions of its compile-time constants, multi-GPU, stats)
-    def setOptions(self, max_depth=8, bsdf_mode=PT_BSDF_DISNEY, max_paths=0, bvh_kind=0, trace_kernel=0, streams=0, split_shadow=0, kernel_timing=0):
-        o = Options(max_depth, bsdf_mode, max_paths, kernel_timing, bvh_kind, trace_kernel, streams, split_shadow)
+    def setOptions(self, max_depth=8, bsdf_mode=PT_BSDF_DISNEY, max_paths=0, bvh_kind=0, trace_kernel=0, streams=0, split_shadow=0, kernel_timing=0, frames_in_flight=0):
+        o = Options(max_depth, bsdf_mode, max_paths, kernel_timing, bvh_kind, trace_kernel, streams, split_shadow, frames_in_flight)
         self._ck(self._L.pt_set_options(self._ctx, C.byref(o)), "pt_set_options")
 
     def setPartition(self, rank, world, tile_w=64, tile_h=16):
         self._ck(self._L.pt_set_partition(self._ctx, rank, world, tile_w, tile_h), "pt_set_partition")
+
+    def sync(self):
+        """Waits for the frames in flight (setOptions(frames_in_flight=2)); their errors surface here."""
+        self._ck(self._L.pt_sync(self._ctx), "pt_sync")
 
     def download(self, which) -> np.ndarray:
         w, h = self.launchParams.frame.size
@@ -355,8 +359,8 @@ class MultiRenderer:
             raise IndexError(r)
         return _RankView(self._L, C.c_void_p(ctx), self.launchParams)
 
-    def setOptions(self, max_depth=8, bsdf_mode=PT_BSDF_DISNEY, max_paths=0, bvh_kind=0, trace_kernel=0, streams=0, split_shadow=0, kernel_timing=0):
-        o = Options(max_depth, bsdf_mode, max_paths, kernel_timing, bvh_kind, trace_kernel, streams, split_shadow)
+    def setOptions(self, max_depth=8, bsdf_mode=PT_BSDF_DISNEY, max_paths=0, bvh_kind=0, trace_kernel=0, streams=0, split_shadow=0, kernel_timing=0, frames_in_flight=0):
+        o = Options(max_depth, bsdf_mode, max_paths, kernel_timing, bvh_kind, trace_kernel, streams, split_shadow, frames_in_flight)
         self._ck(self._L.pt_multi_set_options(self._m, C.byref(o)), "pt_multi_set_options")
 
     def setProbe(self, probe):

@@ -463,6 +463,73 @@ def test_render_progressive_subframes(ptlib, orc_det, small_probe):
     _compare(g, o)
 
 
+@pytest.mark.parametrize("opts", [dict(), dict(max_paths=6000), dict(streams=1), dict(split_shadow=2)], ids=["default", "many_chunks", "one_stream", "async_shadows"])
+def test_pipelined_frames_are_bit_identical(ptlib, small_probe, opts):
+    """pt_options.frames_in_flight = 2: frame k+1 is enqueued before frame k is waited for.  Progressive accumulation makes every frame
+    depend on the previous one through accum_buffer, so any mis-ordering between frames shows; the buffers, the per-frame and the
+    cumulative ray counts must equal the synchronous run's, also across a camera change, a resize and a partition change in mid-flight."""
+    from optixpathtracer_amd import renderer as R
+
+    m = scenes.voxel_terrain(n=96, target_tris=70000)
+    w, h = 160, 96
+
+    def run(fif):
+        r = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h, frames_in_flight=fif, **opts)
+        r.launchParams.samples_per_launch = 2
+        per_frame = []
+        for sf in range(7):
+            if sf == 4:  # host-side change between frames: passed by value with the next frame
+                cam = dict(scenes.TERRAIN_CAMERA)
+                cam["eye"] = tuple(c * 1.05 for c in cam["eye"])
+                r.setCamera(R.make_camera(cam, w / h))
+            r.launchParams.frame.subframe_index = sf
+            r.render()
+            if fif < 2:
+                per_frame.append(r.stats()["radiance_rays"] + r.stats()["shadow_rays"])
+        out = dict(accum=r.download(R.PT_BUF_ACCUM), frame=r.download(R.PT_BUF_FRAME), normal=r.download(R.PT_BUF_NORMAL))
+        st = r.stats()
+        # a resize and a partition with frames still in flight: the library finishes them first
+        r.launchParams.frame.subframe_index = 0
+        r.render()
+        r.resize((96, 64))
+        r.setCamera(R.make_camera(scenes.TERRAIN_CAMERA, 96 / 64))
+        r.render()
+        r.setPartition(1, 3, 16, 8)
+        r.render()
+        r.render()
+        r.sync()
+        out["small"] = r.download(R.PT_BUF_ACCUM)
+        out["st2"] = r.stats()
+        return out, st, per_frame
+
+    sync, st_s, per_frame = run(0)
+    pipe, st_p, _ = run(2)
+    for k in ("accum", "frame", "normal", "small"):
+        assert np.array_equal(sync[k].view(np.uint32), pipe[k].view(np.uint32)), k
+    assert st_p["frames"] == st_s["frames"] == 7
+    assert st_p["total_radiance_rays"] + st_p["total_shadow_rays"] == st_s["total_radiance_rays"] + st_s["total_shadow_rays"] == sum(per_frame)
+    assert (st_p["radiance_rays"], st_p["shadow_rays"], st_p["shaded_hits"]) == (st_s["radiance_rays"], st_s["shadow_rays"], st_s["shaded_hits"])  # last frame
+    assert pipe["st2"]["frames"] == sync["st2"]["frames"] == 11
+    assert pipe["st2"]["total_radiance_rays"] == sync["st2"]["total_radiance_rays"]
+
+
+def test_pipelined_frames_report_errors_late_but_loudly(ptlib, small_probe, monkeypatch):
+    """A traversal-stack overflow in frame k is reported by the call that waits for frame k (the next pt_render or pt_sync)."""
+    from optixpathtracer_amd import renderer as R
+
+    monkeypatch.setenv("PT_STACK_LDS_SKIP", "11")
+    monkeypatch.setenv("PT_STACK_CAP", "2")
+    monkeypatch.setenv("PT_STACK_NOCHECK", "1")
+    r = _renderer(scenes.voxel_terrain(n=96, target_tris=70000), small_probe, scenes.TERRAIN_CAMERA, 96, 64, frames_in_flight=2)
+    r.launchParams.samples_per_launch = 1
+    r.render()  # enqueued, not yet waited for
+    with pytest.raises(RuntimeError, match="traversal stack overflow"):
+        r.sync()
+    r.render()
+    with pytest.raises(RuntimeError, match="traversal stack overflow"):
+        r.render()  # waits for the previous frame
+
+
 def test_render_sample_chunking_invariant(ptlib, orc_det, small_probe):
     """Splitting a launch into pixel/sample chunks (max_paths) must not change a single bit."""
     m = scenes.cornell_box()
@@ -1151,6 +1218,13 @@ def test_cxx_facade_demo_matches_python(ptlib, small_probe, tmp_path):
     g = _gpu_render(_renderer(m, small_probe, cam, w, h), spp, subframes=nsub)
     assert_bits_equal(accum, g["accum"], "accum_buffer from the C++ process")
     assert np.array_equal(frame, g["frame"])
+    # the same loop with two frames in flight (SampleRenderer::setFramesInFlight): render() no longer waits for its own frame
+    outp = tmp_path / "outp.bin"
+    res = subprocess.run([str(exe), str(scene), str(outp), "0", "2"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    raw = np.fromfile(outp, np.uint8)
+    assert np.array_equal(raw[: w * h * 4].view(np.uint32).reshape(h, w), g["frame"])
+    assert_bits_equal(raw[w * h * 4 :].view(np.float32).reshape(h, w, 4), g["accum"], "accum_buffer from the pipelined C++ process")
     # the same application on MultiSampleRenderer: 3 contexts in one process (all on device 0 here), frame assembled by the
     # library's own exchange; rank 2's accum_buffer after an explicit gather
     out3 = tmp_path / "out3.bin"

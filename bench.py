@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="concurrent pixel chunks per frame (0 = library default)")
     ap.add_argument("--kernel-timing", type=int, default=0, help="1: per-launch HIP-event timing inside the timed loop (slower; the isolated phase always has it)")
     ap.add_argument("--frames-in-flight", type=int, default=2, help="2 (default): pt_render(k) returns once frame k-1 is complete, so frame tails overlap the next frame's start (pt_options.frames_in_flight; same images); 0: every frame synchronous like the reference's render()")
+    ap.add_argument("--no-sync-frames", action="store_true", help="skip the extra frames that measure ms_per_frame_synchronous (profiling runs: keeps the frame count at warmup + steps)")
     ap.add_argument("--bvh-kind", type=int, default=0, help="0 = 8-wide compressed BVH (default), 1 = binary BVH")
     ap.add_argument("--trace-kernel", type=int, default=0, help="0 = persistent-wave traversal (default), 1 = first grid-stride kernel")
     args = ap.parse_args()
@@ -183,7 +184,7 @@ def main():
 
     # the same frames one at a time (what SampleRenderer::render() does: return when the frame is complete), for the record
     sync_ms = None
-    if pipelined:
+    if pipelined and not args.no_sync_frames:
         r.setOptions(**dict(opts, frames_in_flight=0))
         n_sync = max(1, min(args.steps, 5))
         render_frame(args.warmup + args.steps)

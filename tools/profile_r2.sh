@@ -8,16 +8,16 @@ TAG=${1:-r2}
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT" profiles
 export TMPDIR=/tmp
-ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ARGS > "$OUT/bench_stats.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -- python3 $ARGS --streams 1 > "$OUT/bench_stats1.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $ARGS > "$OUT/bench_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $ARGS > "$OUT/bench_write.log" 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_valu" -- python3 $ARGS > "$OUT/bench_valu.log" 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_busy" -- python3 $ARGS > "$OUT/bench_busy.log" 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/pmc_state" -- python3 $ARGS > "$OUT/bench_state.log" 2>&1
-rocprofv3 --pmc TA_TA_BUSY_sum TCP_GATE_EN1_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum --output-format csv -d "$OUT/pmc_ta" -- python3 $ARGS > "$OUT/bench_ta.log" 2>&1
-rocprofv3 --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum --output-format csv -d "$OUT/pmc_lat" -- python3 $ARGS > "$OUT/bench_lat.log" 2>&1
+ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated --no-sync-frames"
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ARGS > "$OUT/bench_stats.log" 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -- python3 $ARGS --streams 1 > "$OUT/bench_stats1.log" 2>&1
+timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $ARGS > "$OUT/bench_fetch.log" 2>&1
+timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $ARGS > "$OUT/bench_write.log" 2>&1
+timeout -k 10 240 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_valu" -- python3 $ARGS > "$OUT/bench_valu.log" 2>&1
+timeout -k 10 240 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_busy" -- python3 $ARGS > "$OUT/bench_busy.log" 2>&1
+timeout -k 10 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/pmc_state" -- python3 $ARGS > "$OUT/bench_state.log" 2>&1
+timeout -k 10 240 rocprofv3 --pmc TA_TA_BUSY_sum TCP_GATE_EN1_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum --output-format csv -d "$OUT/pmc_ta" -- python3 $ARGS > "$OUT/bench_ta.log" 2>&1
+timeout -k 10 240 rocprofv3 --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum --output-format csv -d "$OUT/pmc_lat" -- python3 $ARGS > "$OUT/bench_lat.log" 2>&1
 python3 tools/summarize_r2.py "$OUT" "$TAG"
 find "$OUT" -name "*_kernel_trace.csv" -size +2M -delete || true
 find "$OUT" -name "*counter_collection.csv" -size +2M -delete || true

@@ -10,9 +10,10 @@ N>1 (one process per GPU, torch.distributed over RCCL): the FIXED frame is tile-
 64x16 tiles, replicated scene, no data-path collective) — strong scaling, which is what "1/2/4/8 MI355X
 scaling" of a 1080p frame means.  `--scaling weak` (opt-in) grows the image to N x the pixels instead.
 `--workload c4_terrain1M_4k_16spp_d8` is BASELINE config C4 (3840x2160, 16 spp, tiled across the GPUs).
-`value` = rays traced by all ranks / max-over-ranks time of the K timed frames.  The K frames are rendered with two frames
-in flight (pt_options.frames_in_flight = 2: pt_render(k) returns when frame k-1 is complete, so the kernel tails of one frame
-overlap the start of the next; same images bit for bit, the timed region ends after the last frame is complete);
+`value` = rays traced by all ranks / max-over-ranks time of the K timed frames.  The K frames are rendered with three frames
+in flight (pt_options.frames_in_flight = 3: frame k runs whole on stream k mod 3 and pt_render(k) returns when frame k-2 is
+complete, so consecutive frames overlap instead of the pixel chunks of one frame; same images bit for bit, the timed region ends
+after the last frame is complete);
 `ms_per_frame_synchronous` is the same frame rendered one at a time like the reference's render() (`--frames-in-flight 0`
 makes that the timed mode).  After the timed region a
 second, shorter loop renders AND hands the frame over for display every frame (pack -> one RCCL all-gather
@@ -81,7 +82,7 @@ def main():
     ap.add_argument("--split-shadow", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="concurrent pixel chunks per frame (0 = library default)")
     ap.add_argument("--kernel-timing", type=int, default=0, help="1: per-launch HIP-event timing inside the timed loop (slower; the isolated phase always has it)")
-    ap.add_argument("--frames-in-flight", type=int, default=2, help="2 (default): pt_render(k) returns once frame k-1 is complete, so frame tails overlap the next frame's start (pt_options.frames_in_flight; same images); 0: every frame synchronous like the reference's render()")
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="pt_options.frames_in_flight. 3 (default): frame k runs whole on stream k mod 3 and pt_render(k) returns once frame k-2 is complete (three frames overlap, same images); 2: pixel chunks as in the synchronous frame, pt_render(k) waits for frame k-1; 0: every frame synchronous like the reference's render()")
     ap.add_argument("--no-sync-frames", action="store_true", help="skip the extra frames that measure ms_per_frame_synchronous (profiling runs: keeps the frame count at warmup + steps)")
     ap.add_argument("--bvh-kind", type=int, default=0, help="0 = 8-wide compressed BVH (default), 1 = binary BVH")
     ap.add_argument("--trace-kernel", type=int, default=0, help="0 = persistent-wave traversal (default), 1 = first grid-stride kernel")
@@ -182,19 +183,20 @@ def main():
     if pipelined:  # per-frame figures: those of the last frame (the frames differ only by their random numbers)
         agg = {key: st[key] * args.steps for key in keys}
 
-    # the same frames one at a time (what SampleRenderer::render() does: return when the frame is complete), for the record
+    # the same frames one at a time (what SampleRenderer::render() does: return when the frame is complete), for the record;
+    # everything after the timed region (these frames, the displayed frames, the isolated frames) runs synchronously
     sync_ms = None
-    if pipelined and not args.no_sync_frames:
+    if pipelined:
         r.setOptions(**dict(opts, frames_in_flight=0))
-        n_sync = max(1, min(args.steps, 5))
-        render_frame(args.warmup + args.steps)
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for k in range(n_sync):
-            render_frame(args.warmup + args.steps + 1 + k)
-        torch.cuda.synchronize()
-        sync_ms = (time.perf_counter() - ts) / n_sync * 1e3
-        r.setOptions(**opts)
+        if not args.no_sync_frames:
+            n_sync = max(1, min(args.steps, 5))
+            render_frame(args.warmup + args.steps)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for k in range(n_sync):
+                render_frame(args.warmup + args.steps + 1 + k)
+            torch.cuda.synchronize()
+            sync_ms = (time.perf_counter() - ts) / n_sync * 1e3
 
     tot = torch.tensor([dt, float(rays)], dtype=torch.float64, device=red_dev)
     if dist is not None:
@@ -226,6 +228,7 @@ def main():
                 dist.all_gather_into_tensor(d, src.cpu())
                 dst.copy_(d)
 
+        render_frame(args.warmup + args.steps)  # every displayed frame is waited for by its hand-off: synchronous frames (pixel chunks on all streams)
         multigpu.exchange_frame(packer, R.PT_BUF_FRAME, world, all_gather)  # warm RCCL
         barrier()
         nd = max(1, min(args.steps, 10))
@@ -332,7 +335,7 @@ def main():
             },
             "rays_per_frame": int(rays_frame),
             "fps": round(args.steps / dt_max, 2),
-            "frames_in_flight": 2 if pipelined else 1,
+            "frames_in_flight": opts["frames_in_flight"] if pipelined else 1,
             "ms_per_frame_synchronous": None if sync_ms is None else round(sync_ms, 3),
             "render_ms_per_frame": round(agg["render_ms"] / args.steps, 3),
             "ms_per_step_per_rank": per_rank_ms,

@@ -89,8 +89,9 @@ int main(int argc, char** argv) {
         sample.setCamera(cam);                          // main.cpp:262
         sample.launchParams.samples_per_launch = spp;
         std::vector<uint32_t> pixels((size_t)w * h);
-        const bool pipelined = argc > 4 && atoi(argv[4]) == 2; // two frames in flight: render() returns once the previous frame is complete
-        if (pipelined) sample.setFramesInFlight(2);
+        const int fif = argc > 4 ? atoi(argv[4]) : 0;      // 2 or 3 frames in flight: render() returns while its frame is still running
+        const bool pipelined = fif >= 2;
+        if (pipelined) sample.setFramesInFlight(fif);
         for (uint32_t s = 0; s < subframes; ++s) {      // the render loop, main.cpp:273-286
             sample.launchParams.frame.subframe_index = s;
             if (pipelined) sample.render();

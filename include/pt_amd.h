@@ -87,12 +87,16 @@ typedef struct pt_options {
                              * 2 = asynchronous: per-bounce shadow records traced on side streams, nothing waits for them before the
                              *     resolve, which sums the visible contributions in bounce order (not with shadow-catcher materials) */
     int32_t frames_in_flight; /* 0 / 1 = default: pt_render returns when its frame is complete, like SampleRenderer::render()
-                             * (SimplePathtracer.cpp:96 CUDA_SYNC_CHECK).  2: pt_render(k) enqueues frame k and returns once frame k-1 is
-                             * complete, so the kernel tails of a frame overlap the start of the next one (same images, bit for bit:
-                             * every pixel chunk's stream still orders its own frames).  Frame k completes — and its errors are
-                             * reported — at the next pt_render, at pt_sync, or at any call that reads or changes device state
-                             * (pt_download, pt_get_stats, pt_device_buffer, pt_resize, ...).  Ignored (synchronous) with kernel_timing,
-                             * for pt_render_regions and for pt_multi_render. */
+                             * (SimplePathtracer.cpp:96 CUDA_SYNC_CHECK).  2 or 3: pt_render(k) enqueues frame k and returns once at most
+                             * frames_in_flight - 1 frames are still running, so the kernel tails of a frame overlap the next frames (same
+                             * images, bit for bit).  2: the frame is still cut into one pixel chunk per stream; every chunk stream orders
+                             * its own frames and nothing else holds frame k+1 back.  3 (what bench.py times): frame k runs WHOLE on
+                             * stream k mod `streams`, three frames overlap and every launch carries three times the rays; only the
+                             * resolves, which blend into accum_buffer, are chained from frame to frame.  A single frame followed by a
+                             * wait is slower in that mode than the default (one stream, no overlap inside the frame): it is for loops.
+                             * Frame k completes — and its errors are reported — at a later pt_render, at pt_sync, or at any call that
+                             * reads or changes device state (pt_download, pt_get_stats, pt_device_buffer, pt_resize, ...).  Ignored
+                             * (synchronous) with kernel_timing, for pt_render_regions and for pt_multi_render. */
 } pt_options;
 
 enum pt_buffer {          /* LaunchParams.frame.* (LaunchParams.h:53-63) */
@@ -179,7 +183,7 @@ int pt_set_partition(pt_ctx* ctx, int rank, int world, int tile_w, int tile_h);
  * Silently does nothing before the first pt_resize (:77). If host_rgba8 is non-NULL the frame
  * buffer is copied into it (render(CUDAOutputBuffer&) + downloadPixels, :99-107,149-153). */
 int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8);
-/* Waits for the frames in flight (pt_options.frames_in_flight = 2) and reports their errors; a no-op otherwise.  No reference
+/* Waits for the frames in flight (pt_options.frames_in_flight = 2 or 3) and reports their errors; a no-op otherwise.  No reference
  * counterpart: the reference's render() is synchronous. */
 int pt_sync(pt_ctx* ctx);
 

@@ -141,9 +141,9 @@ class SampleRenderer {
         pt_denoise_params p{iterations, sigma_color, sigma_normal, sigma_albedo, PT_BUF_COLOR, 1};
         ck(pt_denoise(ctx, &p, h_pixels, nullptr));
     }
-    // Beyond the reference: render() normally returns when its frame is complete (SimplePathtracer.cpp:96); with two frames in flight
-    // it returns once the PREVIOUS frame is complete, so a progressive loop overlaps one frame's kernel tails with the next frame's start.
-    // downloadPixels / render(h_pixels) / resize / sync() wait for the frame in flight; the images are the same bit for bit.
+    // Beyond the reference: render() normally returns when its frame is complete (SimplePathtracer.cpp:96); with 2 or 3 frames in flight
+    // (pt_options.frames_in_flight) it returns while its own frame is still running, so a progressive loop overlaps consecutive frames.
+    // downloadPixels / render(h_pixels) / resize / sync() wait for the frames in flight; the images are the same bit for bit.
     void setFramesInFlight(int n) {
         pt_options o;
         ck(pt_get_options(ctx, &o));

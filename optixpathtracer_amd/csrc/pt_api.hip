@@ -76,7 +76,7 @@ struct pt_ctx {
     uint32_t set_cap = 0, set_pix_cap = 0, sub_cap = 0;
     bool cap_catcher = false, cap_async = false;
     int nq = 0;
-    // [frame slot 0/1][batch set 0..15][4]: [0] radiance rays, [1] shadow rays, [2] low word = traversal fault bits (pt_bvh8.h push), [3] shaded hits
+    // [frame slot 0..2][batch set 0..15][4]: [0] radiance rays, [1] shadow rays, [2] low word = traversal fault bits (pt_bvh8.h push), [3] shaded hits
     unsigned long long* d_totals = nullptr;
     unsigned long long* h_totals = nullptr; // pinned host copy, same shape: filled by an asynchronous copy behind each frame (a blocking hipMemcpy would wait for the NEXT frame too)
     uint32_t* ovf = nullptr; // spill stacks for pt_trace queries
@@ -87,21 +87,25 @@ struct pt_ctx {
     int stack_check = 1; // PT_STACK_NOCHECK=1 (test hook): skip the build-time depth check so that the in-kernel fault flag is reached
     // stats + timing
     pt_stats stats{};
-    std::vector<hipEvent_t> ev_pools[2]; // one event pool per frame slot
+    std::vector<hipEvent_t> ev_pools[3]; // one event pool per frame slot
     size_t ev_used = 0;
     struct Span { size_t a, b; int cls; };
     std::vector<Span> spans;
     // Frames that are enqueued but not yet waited for (render_enqueue / render_finish).  Synchronous rendering uses slot 0
-    // only; with pt_options.frames_in_flight = 2 consecutive pt_render calls alternate between the two slots and each call
-    // waits for the PREVIOUS frame, so the kernel tails of frame k overlap the start of frame k+1 (every batch set's stream
-    // orders its own chunks; the sets share nothing else but the frame's counters, kept per slot and per set).
+    // only.  pt_options.frames_in_flight = 2: consecutive pt_render calls alternate between two slots and each call waits for
+    // the PREVIOUS frame, so the kernel tails of frame k overlap the start of frame k+1 (every batch set's stream orders its own
+    // chunks; the sets share nothing else but the frame's counters, kept per slot and per set).  frames_in_flight = 3: a frame is
+    // no longer cut into one pixel chunk per stream — frame k runs whole on stream k mod 3, three frames overlap, and a launch
+    // carries three times the rays (only the resolves, which blend into accum_buffer, are chained from frame to frame).
     struct Inflight {
         int active = 0;
         hipEvent_t ev_begin = nullptr, ev_end = nullptr;
         uint64_t paths = 0, seq = 0;
         LaunchCounts lc;
     };
-    Inflight fr[2];
+    Inflight fr[3];
+    hipEvent_t ev_resolved = nullptr; // behind the last k_resolve of the newest frame in flight (frames_in_flight = 3: the next frame's resolve waits for it)
+    int last_slot = -1;
     int cur_slot = 0;      // slot whose events / counters the enqueue functions are filling
     uint64_t frame_seq = 0;
     uint64_t cum_radiance = 0, cum_shadow = 0, cum_frames = 0;
@@ -167,6 +171,7 @@ static void default_options(pt_options* o) {
 
 static size_t ovf_words(const pt_ctx* ctx);
 static const int PT_MAX_SETS = 16;
+static const int PT_MAX_FRAMES = 3;
 static unsigned long long* totals_of(pt_ctx* ctx, int slot, int set) { return ctx->d_totals + ((size_t)slot * PT_MAX_SETS + set) * 4; }
 static uint32_t* fault_word(pt_ctx* ctx) { return reinterpret_cast<uint32_t*>(totals_of(ctx, 0, 0) + 2); } // pt_trace queries
 static uint32_t* fault_word(pt_ctx::BatchSet& bs) { return reinterpret_cast<uint32_t*>(bs.totals + 2); }
@@ -323,9 +328,9 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     ctx->bvh_build_ms = ms;
-    CKC(dalloc(&ctx->d_totals, (size_t)2 * PT_MAX_SETS * 4));
-    CKC(hipMemset(ctx->d_totals, 0, sizeof(unsigned long long) * 2 * PT_MAX_SETS * 4));
-    CKC(hipHostMalloc((void**)&ctx->h_totals, sizeof(unsigned long long) * 2 * PT_MAX_SETS * 4));
+    CKC(dalloc(&ctx->d_totals, (size_t)PT_MAX_FRAMES * PT_MAX_SETS * 4));
+    CKC(hipMemset(ctx->d_totals, 0, sizeof(unsigned long long) * PT_MAX_FRAMES * PT_MAX_SETS * 4));
+    CKC(hipHostMalloc((void**)&ctx->h_totals, sizeof(unsigned long long) * PT_MAX_FRAMES * PT_MAX_SETS * 4));
     {
         hipDeviceProp_t prop;
         CKC(hipGetDeviceProperties(&prop, device));
@@ -408,7 +413,7 @@ extern "C" int pt_set_options(pt_ctx* ctx, const pt_options* opt) {
     { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     if (opt->max_depth < 0 || opt->max_depth > 250) return fail(ctx, PT_ERR_INVALID, "pt_set_options: max_depth out of range [0,250]");
     if (opt->bsdf_mode != PT_BSDF_DISNEY && opt->bsdf_mode != PT_BSDF_LAMBERT) return fail(ctx, PT_ERR_INVALID, "pt_set_options: bad bsdf_mode");
-    if (opt->frames_in_flight < 0 || opt->frames_in_flight > 2) return fail(ctx, PT_ERR_INVALID, "pt_set_options: frames_in_flight must be 0, 1 or 2");
+    if (opt->frames_in_flight < 0 || opt->frames_in_flight > PT_MAX_FRAMES) return fail(ctx, PT_ERR_INVALID, "pt_set_options: frames_in_flight must be 0 ... 3");
     if ((opt->bvh_kind == 1 || opt->trace_kernel == 1) && !ctx->bvh.nodes) {
         // the binary tree is an A/B path: built (with the wide tree, from the same hierarchy) the first time it is asked for
         CK(hipSetDevice(ctx->device));
@@ -678,6 +683,7 @@ static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_
         if (rc) return rc;
     }
     free_path_state(ctx);
+    CK(hipMemset(ctx->d_totals, 0, sizeof(unsigned long long) * PT_MAX_FRAMES * PT_MAX_SETS * 4)); // slices of sets that no longer exist
     ctx->sets.resize(nsets);
     ctx->sub_cap = cap / PT_NSUB + 8192 + 1; // a sub-queue receives at most cap/64 + 32 workgroups * 256 entries
     const size_t qsize = (size_t)PT_NSUB * ctx->sub_cap;
@@ -994,7 +1000,9 @@ static void begin_slot(pt_ctx* ctx, int slot) {
     for (size_t i = 0; i < ctx->sets.size(); ++i) ctx->sets[i].totals = totals_of(ctx, slot, (int)i);
 }
 
-static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, int slot = 0, bool pipelined = false) {
+// mode 0: synchronous frame (pixel chunks on all streams); 2: the same chunks without a frame-wide start; 3: the whole frame on one stream
+static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, int slot = 0, int mode = 0) {
+    const bool pipelined = mode != 0, whole = mode == 3;
     if (!pipelined) {
         int rc = drain(ctx);
         if (rc) return rc;
@@ -1011,8 +1019,8 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
     // per-pixel normal/albedo sums keep the reference order.  None of this changes a bit of the result.
     const int nsets = std::max(1, std::min(PT_MAX_SETS, ctx->opt.streams > 0 ? ctx->opt.streams : 3));
     const uint32_t max_paths = std::max<uint32_t>(ctx->opt.max_paths, 64u);
-    const uint32_t cap = std::max<uint32_t>(64u, max_paths / nsets);
-    uint32_t Np = (owned + nsets - 1) / nsets;        // pixels per chunk ...
+    const uint32_t cap = std::max<uint32_t>(64u, whole ? max_paths : max_paths / nsets);
+    uint32_t Np = whole ? owned : (owned + nsets - 1) / nsets; // pixels per chunk ...
     Np = std::min(cap, std::max(64u, (Np + 63u) & ~63u)); // ... whole 8x8 blocks, within the set capacity
     const uint32_t S = ctx->has_catcher ? 1u : std::max(1u, std::min(spp, cap / Np));
     if (owned) {
@@ -1032,7 +1040,21 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
     FrameParams fp{ctx->accum, ctx->frame, ctx->color, ctx->normal, ctx->albedo, ctx->width, ctx->height, subframe_index,
                    ctx->eye, ctx->U, ctx->V, ctx->W, spp, ctx->probe};
     LaunchCounts lc;
-    if (owned) {
+    if (owned && whole) {
+        // the frame's chunks (one, unless spp x pixels exceed max_paths) all go to the stream of this frame; its resolve blends into
+        // accum_buffer after the previous frame's
+        pt_ctx::BatchSet& bs = ctx->sets[ctx->frame_seq % (uint64_t)nsets];
+        CK(hipMemsetAsync(totals_of(ctx, slot, 0), 0, sizeof(unsigned long long) * PT_MAX_SETS * 4, bs.stream));
+        CK(hipEventRecord(ev_begin, bs.stream));
+        std::vector<hipEvent_t> before;
+        if (ctx->ev_resolved) before.push_back(ctx->ev_resolved);
+        for (uint32_t pix0 = 0; pix0 < owned; pix0 += Np)
+            enqueue_chunk(ctx, bs, fp, pix0, std::min(Np, owned - pix0), spp, S, lc, nullptr, before.empty() ? nullptr : &before);
+        hipEvent_t e = next_event(ctx);
+        hipEventRecord(e, bs.stream);
+        hipStreamWaitEvent(ctx->stream, e, 0);
+        ctx->ev_resolved = e;
+    } else if (owned) {
         if (!pipelined) {
             for (auto& b : ctx->sets) hipStreamWaitEvent(b.stream, ev_begin, 0);
         } else {
@@ -1137,12 +1159,23 @@ static int render_finish(pt_ctx* ctx, int slot = 0) {
     return PT_OK;
 }
 
+static int oldest_active(pt_ctx* ctx) {
+    int o = -1;
+    for (int i = 0; i < PT_MAX_FRAMES; ++i)
+        if (ctx->fr[i].active && (o < 0 || ctx->fr[i].seq < ctx->fr[o].seq)) o = i;
+    return o;
+}
+
 // waits for every frame in flight, oldest first
 static int drain(pt_ctx* ctx) {
-    const int first = (ctx->fr[0].active && ctx->fr[1].active && ctx->fr[1].seq < ctx->fr[0].seq) ? 1 : 0;
-    int rc = render_finish(ctx, first);
-    const int rc2 = render_finish(ctx, first ^ 1);
-    return rc != PT_OK ? rc : rc2;
+    int rc = PT_OK;
+    for (int o; (o = oldest_active(ctx)) >= 0;) {
+        const int r = render_finish(ctx, o);
+        if (rc == PT_OK) rc = r;
+    }
+    ctx->ev_resolved = nullptr; // nothing in flight: nothing to order the next resolve behind
+    ctx->last_slot = -1;
+    return rc;
 }
 
 extern "C" int pt_sync(pt_ctx* ctx) { return ctx ? drain(ctx) : PT_ERR_INVALID; }
@@ -1150,21 +1183,25 @@ extern "C" int pt_sync(pt_ctx* ctx) { return ctx ? drain(ctx) : PT_ERR_INVALID; 
 extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8) {
     if (!ctx) return PT_ERR_INVALID;
     // kernel timing and the debug counters read per-frame state that is not kept per slot
-    const bool pipelined = ctx->opt.frames_in_flight >= 2 && !ctx->span_timing() && !getenv("PT_DEBUG_COUNTS");
+    const int F = (ctx->opt.frames_in_flight >= 2 && !ctx->span_timing() && !getenv("PT_DEBUG_COUNTS")) ? std::min(ctx->opt.frames_in_flight, PT_MAX_FRAMES) : 1;
     int rc;
-    if (!pipelined) {
+    if (F == 1) {
         rc = drain(ctx);
         if (rc == PT_OK) rc = render_enqueue(ctx, spp, subframe_index);
         if (rc == PT_OK) rc = render_finish(ctx);
     } else {
-        // frame k goes into the slot frame k-2 has left; then wait for frame k-1 (its errors are reported by this call)
-        const int prev = ctx->fr[0].active ? 0 : (ctx->fr[1].active ? 1 : -1);
-        const int slot = prev < 0 ? 0 : prev ^ 1;
+        // frame k goes into the slot the oldest finished frame has left; then wait until at most F-1 frames are in flight
+        // (a frame's errors are reported by the call that waits for it)
+        const int slot = (ctx->last_slot + 1) % F;
         rc = render_finish(ctx, slot);
-        if (rc == PT_OK) rc = render_enqueue(ctx, spp, subframe_index, slot, true);
-        if (prev >= 0) {
-            const int rcp = render_finish(ctx, prev);
-            if (rc == PT_OK) rc = rcp;
+        if (rc == PT_OK) rc = render_enqueue(ctx, spp, subframe_index, slot, F);
+        if (rc == PT_OK) ctx->last_slot = slot;
+        for (;;) {
+            int n = 0;
+            for (int i = 0; i < PT_MAX_FRAMES; ++i) n += ctx->fr[i].active;
+            if (n < F) break;
+            const int r = render_finish(ctx, oldest_active(ctx));
+            if (rc == PT_OK) rc = r;
         }
     }
     if (rc != PT_OK) return rc;

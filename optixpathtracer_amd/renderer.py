@@ -216,7 +216,7 @@ class SampleRenderer:
         self._ck(self._L.pt_set_partition(self._ctx, rank, world, tile_w, tile_h), "pt_set_partition")
 
     def sync(self):
-        """Waits for the frames in flight (setOptions(frames_in_flight=2)); their errors surface here."""
+        """Waits for the frames in flight (setOptions(frames_in_flight=2 or 3)); their errors surface here."""
         self._ck(self._L.pt_sync(self._ctx), "pt_sync")
 
     def download(self, which) -> np.ndarray:

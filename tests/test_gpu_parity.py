@@ -503,31 +503,34 @@ def test_pipelined_frames_are_bit_identical(ptlib, small_probe, opts):
         return out, st, per_frame
 
     sync, st_s, per_frame = run(0)
-    pipe, st_p, _ = run(2)
-    for k in ("accum", "frame", "normal", "small"):
-        assert np.array_equal(sync[k].view(np.uint32), pipe[k].view(np.uint32)), k
-    assert st_p["frames"] == st_s["frames"] == 7
-    assert st_p["total_radiance_rays"] + st_p["total_shadow_rays"] == st_s["total_radiance_rays"] + st_s["total_shadow_rays"] == sum(per_frame)
-    assert (st_p["radiance_rays"], st_p["shadow_rays"], st_p["shaded_hits"]) == (st_s["radiance_rays"], st_s["shadow_rays"], st_s["shaded_hits"])  # last frame
-    assert pipe["st2"]["frames"] == sync["st2"]["frames"] == 11
-    assert pipe["st2"]["total_radiance_rays"] == sync["st2"]["total_radiance_rays"]
+    for fif in (2, 3):  # 2: the frame's pixel chunks, no frame-wide start; 3: whole frames on alternating streams, resolves chained
+        pipe, st_p, _ = run(fif)
+        for k in ("accum", "frame", "normal", "small"):
+            assert np.array_equal(sync[k].view(np.uint32), pipe[k].view(np.uint32)), (fif, k)
+        assert st_p["frames"] == st_s["frames"] == 7
+        assert st_p["total_radiance_rays"] + st_p["total_shadow_rays"] == st_s["total_radiance_rays"] + st_s["total_shadow_rays"] == sum(per_frame)
+        assert (st_p["radiance_rays"], st_p["shadow_rays"], st_p["shaded_hits"]) == (st_s["radiance_rays"], st_s["shadow_rays"], st_s["shaded_hits"])  # last frame
+        assert pipe["st2"]["frames"] == sync["st2"]["frames"] == 11
+        assert pipe["st2"]["total_radiance_rays"] == sync["st2"]["total_radiance_rays"]
 
 
-def test_pipelined_frames_report_errors_late_but_loudly(ptlib, small_probe, monkeypatch):
+@pytest.mark.parametrize("fif", [2, 3])
+def test_pipelined_frames_report_errors_late_but_loudly(ptlib, small_probe, monkeypatch, fif):
     """A traversal-stack overflow in frame k is reported by the call that waits for frame k (the next pt_render or pt_sync)."""
     from optixpathtracer_amd import renderer as R
 
     monkeypatch.setenv("PT_STACK_LDS_SKIP", "11")
     monkeypatch.setenv("PT_STACK_CAP", "2")
     monkeypatch.setenv("PT_STACK_NOCHECK", "1")
-    r = _renderer(scenes.voxel_terrain(n=96, target_tris=70000), small_probe, scenes.TERRAIN_CAMERA, 96, 64, frames_in_flight=2)
+    r = _renderer(scenes.voxel_terrain(n=96, target_tris=70000), small_probe, scenes.TERRAIN_CAMERA, 96, 64, frames_in_flight=fif)
     r.launchParams.samples_per_launch = 1
     r.render()  # enqueued, not yet waited for
     with pytest.raises(RuntimeError, match="traversal stack overflow"):
         r.sync()
-    r.render()
+    for _ in range(fif - 1):
+        r.render()
     with pytest.raises(RuntimeError, match="traversal stack overflow"):
-        r.render()  # waits for the previous frame
+        r.render()  # waits for the oldest frame in flight
 
 
 def test_render_sample_chunking_invariant(ptlib, orc_det, small_probe):
@@ -1218,9 +1221,9 @@ def test_cxx_facade_demo_matches_python(ptlib, small_probe, tmp_path):
     g = _gpu_render(_renderer(m, small_probe, cam, w, h), spp, subframes=nsub)
     assert_bits_equal(accum, g["accum"], "accum_buffer from the C++ process")
     assert np.array_equal(frame, g["frame"])
-    # the same loop with two frames in flight (SampleRenderer::setFramesInFlight): render() no longer waits for its own frame
+    # the same loop with three frames in flight (SampleRenderer::setFramesInFlight): render() no longer waits for its own frame
     outp = tmp_path / "outp.bin"
-    res = subprocess.run([str(exe), str(scene), str(outp), "0", "2"], capture_output=True, text=True, timeout=120)
+    res = subprocess.run([str(exe), str(scene), str(outp), "0", "3"], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
     raw = np.fromfile(outp, np.uint8)
     assert np.array_equal(raw[: w * h * 4].view(np.uint32).reshape(h, w), g["frame"])

@@ -1040,6 +1040,7 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
     FrameParams fp{ctx->accum, ctx->frame, ctx->color, ctx->normal, ctx->albedo, ctx->width, ctx->height, subframe_index,
                    ctx->eye, ctx->U, ctx->V, ctx->W, spp, ctx->probe};
     LaunchCounts lc;
+    hipStream_t end_stream = ctx->stream; // where the frame's counters are copied out and its end event is recorded
     if (owned && whole) {
         // the frame's chunks (one, unless spp x pixels exceed max_paths) all go to the stream of this frame; its resolve blends into
         // accum_buffer after the previous frame's
@@ -1052,8 +1053,8 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
             enqueue_chunk(ctx, bs, fp, pix0, std::min(Np, owned - pix0), spp, S, lc, nullptr, before.empty() ? nullptr : &before);
         hipEvent_t e = next_event(ctx);
         hipEventRecord(e, bs.stream);
-        hipStreamWaitEvent(ctx->stream, e, 0);
         ctx->ev_resolved = e;
+        end_stream = bs.stream; // the whole frame is on this stream: the context's own stream stays out of the way (one hardware queue fewer)
     } else if (owned) {
         if (!pipelined) {
             for (auto& b : ctx->sets) hipStreamWaitEvent(b.stream, ev_begin, 0);
@@ -1073,9 +1074,9 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
     } else if (pipelined) {
         CK(hipEventRecord(ev_begin, ctx->stream));
     }
-    CK(hipMemcpyAsync(ctx->h_totals + (size_t)slot * PT_MAX_SETS * 4, totals_of(ctx, slot, 0), sizeof(unsigned long long) * PT_MAX_SETS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(ctx->h_totals + (size_t)slot * PT_MAX_SETS * 4, totals_of(ctx, slot, 0), sizeof(unsigned long long) * PT_MAX_SETS * 4, hipMemcpyDeviceToHost, end_stream));
     hipEvent_t ev_end = next_event(ctx);
-    CK(hipEventRecord(ev_end, ctx->stream));
+    CK(hipEventRecord(ev_end, end_stream));
     pt_ctx::Inflight& fr = ctx->fr[slot];
     fr.ev_begin = ev_begin;
     fr.ev_end = ev_end;

@@ -51,7 +51,7 @@ def main():
           "Command of every pass: `rocprofv3 <mode> -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated --no-sync-frames` (C3: 1 M triangles,",
           "1920x1080, 4 spp, depth 8; 7 frames).  Profiled runs clock lower than unprofiled ones; PMC passes serialise kernels.\n"]
     frames = 7
-    for name, sub, log in (("default schedule (3 chunk streams)", "stats", "bench_stats.log"), ("one chunk stream (isolated kernel durations)", "stats1", "bench_stats1.log")):
+    for name, sub, log in (("default schedule of bench.py (three whole frames in flight on three streams)", "stats", "bench_stats.log"), ("one chunk stream (isolated kernel durations)", "stats1", "bench_stats1.log")):
         st = find(os.path.join(out, sub), "*kernel_stats.csv")
         b = bench_line(os.path.join(out, log))
         md.append(f"## kernel time, {name} (--kernel-trace --stats)\n")

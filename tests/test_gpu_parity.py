@@ -567,6 +567,18 @@ def test_render_shadow_catcher_two_box(ptlib, orc_det):
         _compare(g, o)
 
 
+def test_shadow_catcher_scene_with_frames_in_flight(ptlib, orc_det):
+    """The shadow-catcher scene (one sample per pass, the extra pass-through iterations) rendered with 2 and 3 frames in flight
+    against the checker: five progressive subframes."""
+    m = scenes.two_box_scene(True)
+    probe = scenes.disc_probe().BuildCDF()
+    w, h = 96, 64
+    o = _oracle_render(orc_det, m, probe, scenes.TWO_BOX_CAMERA, w, h, 3, subframes=5, use_bvh=False)
+    for fif in (2, 3):
+        r = _renderer(m, probe, scenes.TWO_BOX_CAMERA, w, h, frames_in_flight=fif)
+        _compare(_gpu_render(r, 3, subframes=5), o)
+
+
 def test_render_shadow_catcher_pass_through_chains(ptlib, orc_det):
     """Paths that cross several shadow-catcher faces and then keep bouncing: a pass-through does not consume depth
     (deviceProgram.cu:503-508), so the reference's raygen loop (:411-443) traces such a path more than max_depth+1 times.

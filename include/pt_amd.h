@@ -96,7 +96,8 @@ typedef struct pt_options {
                              * wait is slower in that mode than the default (one stream, no overlap inside the frame): it is for loops.
                              * Frame k completes — and its errors are reported — at a later pt_render, at pt_sync, or at any call that
                              * reads or changes device state (pt_download, pt_get_stats, pt_device_buffer, pt_resize, ...).  Ignored
-                             * (synchronous) with kernel_timing, for pt_render_regions and for pt_multi_render. */
+                             * (synchronous) with kernel_timing, for pt_render_regions and for a pt_multi_render that hands the frame over
+                             * (gather_mask != 0 or host_rgba8); a pt_multi_render with neither keeps the frames in flight on every device. */
 } pt_options;
 
 enum pt_buffer {          /* LaunchParams.frame.* (LaunchParams.h:53-63) */
@@ -285,7 +286,7 @@ int pt_get_stats(const pt_ctx* ctx, pt_stats* out);
 typedef struct pt_multi pt_multi;
 enum pt_exchange { PT_EXCHANGE_NONE = 0, PT_EXCHANGE_RCCL = 1, PT_EXCHANGE_PEER_COPY = 2 };
 typedef struct pt_multi_stats {
-    pt_stats sum;            /* rays / paths summed over the ranks; the *_ms fields are the MAXIMUM over the ranks */
+    pt_stats sum;            /* rays / paths / frames summed over the ranks (frames = frames x ranks); the *_ms fields are the MAXIMUM over the ranks */
     double gather_ms;        /* wall time of the last pt_multi_gather (pack + exchange + unpack, all ranks) */
     int32_t exchange;        /* pt_exchange used by the last gather */
     int32_t ndev;

@@ -1181,29 +1181,43 @@ static int drain(pt_ctx* ctx) {
 
 extern "C" int pt_sync(pt_ctx* ctx) { return ctx ? drain(ctx) : PT_ERR_INVALID; }
 
+// frames in flight asked for and possible (kernel timing and the debug counters read per-frame state that is not kept per slot)
+static int frames_mode(pt_ctx* ctx) {
+    return (ctx->opt.frames_in_flight >= 2 && !ctx->span_timing() && !getenv("PT_DEBUG_COUNTS")) ? std::min(ctx->opt.frames_in_flight, PT_MAX_FRAMES) : 1;
+}
+// frame k goes into the slot the oldest finished frame has left ...
+static int pipelined_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, int F) {
+    const int slot = (ctx->last_slot + 1) % F;
+    int rc = render_finish(ctx, slot);
+    if (rc == PT_OK) rc = render_enqueue(ctx, spp, subframe_index, slot, F);
+    if (rc == PT_OK) ctx->last_slot = slot;
+    return rc;
+}
+// ... then wait until at most F-1 frames are in flight (a frame's errors are reported by the call that waits for it)
+static int pipelined_wait(pt_ctx* ctx, int F) {
+    int rc = PT_OK;
+    for (;;) {
+        int n = 0;
+        for (int i = 0; i < PT_MAX_FRAMES; ++i) n += ctx->fr[i].active;
+        if (n < F) break;
+        const int r = render_finish(ctx, oldest_active(ctx));
+        if (rc == PT_OK) rc = r;
+    }
+    return rc;
+}
+
 extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8) {
     if (!ctx) return PT_ERR_INVALID;
-    // kernel timing and the debug counters read per-frame state that is not kept per slot
-    const int F = (ctx->opt.frames_in_flight >= 2 && !ctx->span_timing() && !getenv("PT_DEBUG_COUNTS")) ? std::min(ctx->opt.frames_in_flight, PT_MAX_FRAMES) : 1;
+    const int F = frames_mode(ctx);
     int rc;
     if (F == 1) {
         rc = drain(ctx);
         if (rc == PT_OK) rc = render_enqueue(ctx, spp, subframe_index);
         if (rc == PT_OK) rc = render_finish(ctx);
     } else {
-        // frame k goes into the slot the oldest finished frame has left; then wait until at most F-1 frames are in flight
-        // (a frame's errors are reported by the call that waits for it)
-        const int slot = (ctx->last_slot + 1) % F;
-        rc = render_finish(ctx, slot);
-        if (rc == PT_OK) rc = render_enqueue(ctx, spp, subframe_index, slot, F);
-        if (rc == PT_OK) ctx->last_slot = slot;
-        for (;;) {
-            int n = 0;
-            for (int i = 0; i < PT_MAX_FRAMES; ++i) n += ctx->fr[i].active;
-            if (n < F) break;
-            const int r = render_finish(ctx, oldest_active(ctx));
-            if (rc == PT_OK) rc = r;
-        }
+        rc = pipelined_enqueue(ctx, spp, subframe_index, F);
+        const int rw = pipelined_wait(ctx, F);
+        if (rc == PT_OK) rc = rw;
     }
     if (rc != PT_OK) return rc;
     if (host_rgba8 && ctx->width) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)ctx->width * ctx->height);
@@ -1843,6 +1857,10 @@ extern "C" int pt_multi_gather(pt_multi* m, int which) {
     size_t elem = 0;
     if (!buffer_ptr(m->ctx[0], which, &elem)) return mfail(m, PT_ERR_INVALID, "pt_multi_gather: unknown buffer");
     const size_t bytes = (size_t)m->padded * elem; // one rank's packed strip (padded to the largest share: same on every rank)
+    for (int r = 0; r < world; ++r) { // frames in flight (pt_options.frames_in_flight) are not ordered before the contexts' own streams
+        int rc = mctx(m, r, drain(m->ctx[r]), "pt_multi_gather");
+        if (rc) return rc;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     for (int r = 0; r < world; ++r) {
         int rc = mctx(m, r, pack_launch(m->ctx[r], which, m->send[r]), "pt_multi_gather(pack)");
@@ -1932,6 +1950,20 @@ static int multi_after_render(pt_multi* m, uint32_t gather_mask, uint32_t* host_
 extern "C" int pt_multi_render(pt_multi* m, uint32_t spp, uint32_t subframe_index, uint32_t gather_mask, uint32_t* host_rgba8) {
     if (!m) return PT_ERR_INVALID;
     const int world = (int)m->ctx.size();
+    const int F = world ? frames_mode(m->ctx[0]) : 1;
+    if (F > 1 && gather_mask == 0 && !host_rgba8) {
+        // pure throughput (nothing is handed over after this frame): pt_options.frames_in_flight applies on every device
+        int first = PT_OK;
+        for (int r = 0; r < world; ++r) {
+            int rc = mctx(m, r, pipelined_enqueue(m->ctx[r], spp, subframe_index, F), "pt_multi_render");
+            if (rc && !first) first = rc;
+        }
+        for (int r = 0; r < world; ++r) {
+            int rc = mctx(m, r, pipelined_wait(m->ctx[r], F), "pt_multi_render");
+            if (rc && !first) first = rc;
+        }
+        return first;
+    }
     // enqueue on every device, then wait: the devices render their tiles concurrently
     for (int r = 0; r < world; ++r) {
         int rc = mctx(m, r, render_enqueue(m->ctx[r], spp, subframe_index), "pt_multi_render");
@@ -1972,6 +2004,9 @@ extern "C" int pt_multi_get_stats(const pt_multi* m, pt_multi_stats* out) {
         out->sum.shadow_rays += s.shadow_rays;
         out->sum.shaded_hits += s.shaded_hits;
         out->sum.paths += s.paths;
+        out->sum.frames += s.frames; // frames x ranks
+        out->sum.total_radiance_rays += s.total_radiance_rays;
+        out->sum.total_shadow_rays += s.total_shadow_rays;
         out->sum.render_ms = std::max(out->sum.render_ms, s.render_ms);
         out->sum.trace_ms = std::max(out->sum.trace_ms, s.trace_ms);
         out->sum.shadow_ms = std::max(out->sum.shadow_ms, s.shadow_ms);

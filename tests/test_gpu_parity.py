@@ -1282,6 +1282,26 @@ def test_multi_context_one_process(ptlib, small_probe, monkeypatch):
                 assert_bits_equal(mr.download(R.PT_BUF_ALBEDO, rank), ref["albedo"], f"albedo_buffer on rank {rank}")
                 assert np.array_equal(mr.download(R.PT_BUF_FRAME, rank), ref["frame"])
             mr.close()
+    # a throughput loop: nothing handed over per frame, three frames in flight on every context, one gather at the end
+    ref5 = _gpu_render(_renderer(model, small_probe, cam, w, h), spp, subframes=5)
+    mr = R.MultiRenderer(model, devices=[0] * 3)
+    mr.setOptions(frames_in_flight=3)
+    mr.setProbe(small_probe)
+    mr.resize((w, h), tile=(16, 8))
+    mr.setCamera(R.make_camera(cam, w / h))
+    mr.launchParams.samples_per_launch = spp
+    mr.gather_mask = 0
+    for sf in range(5):
+        mr.launchParams.frame.subframe_index = sf
+        mr.render()
+    mr.gather(R.PT_BUF_ACCUM)
+    mr.gather(R.PT_BUF_FRAME)
+    for rank in (0, 2):
+        assert_bits_equal(mr.download(R.PT_BUF_ACCUM, rank), ref5["accum"], f"accum_buffer after the pipelined loop, rank {rank}")
+        assert np.array_equal(mr.download(R.PT_BUF_FRAME, rank), ref5["frame"])
+    st = mr.stats()
+    assert st["frames"] == 3 * 5 and st["radiance_rays"] == ref5["stats"]["radiance_rays"]
+    mr.close()
     # RCCL branch: a single-rank communicator (the only RCCL configuration a one-GPU box can run)
     monkeypatch.setenv("PT_MULTI_EXCHANGE", "rccl")
     model, cam, (w, h), spp = scenes.cornell_box(), scenes.CORNELL_CAMERA, (100, 60), 2

@@ -253,7 +253,7 @@ def main():
         if not (full[..., 3] == 1.0).all():
             raise SystemExit(f"rank {rank}: assembled frame has unwritten pixels")
 
-    # isolated per-kernel durations: the default schedule overlaps three pixel chunks on separate streams, so its per-class
+    # isolated per-kernel durations: the timed schedule overlaps three frames (the synchronous one three pixel chunks) on separate streams, so its per-class
     # HIP-event sums include time spent sharing the machine.  A few extra frames with ONE chunk stream give durations that
     # add up to the frame (rank 0, N=1 only; not part of `value`).
     iso = None

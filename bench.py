@@ -166,7 +166,7 @@ def main():
     agg = dict.fromkeys(keys, 0.0)
     # rays are counted on the device for every frame; pt_stats also keeps the totals since pt_create, so that the timed loop
     # does not have to read (= wait for) each frame's statistics
-    pipelined = opts["frames_in_flight"] >= 2 and not sv4
+    pipelined = opts["frames_in_flight"] >= 2
     s0 = r.stats()
     t0 = time.perf_counter()
     for k in range(args.steps):

@@ -95,9 +95,11 @@ typedef struct pt_options {
                              * resolves, which blend into accum_buffer, are chained from frame to frame.  A single frame followed by a
                              * wait is slower in that mode than the default (one stream, no overlap inside the frame): it is for loops.
                              * Frame k completes — and its errors are reported — at a later pt_render, at pt_sync, or at any call that
-                             * reads or changes device state (pt_download, pt_get_stats, pt_device_buffer, pt_resize, ...).  Ignored
-                             * (synchronous) with kernel_timing, for pt_render_regions and for a pt_multi_render that hands the frame over
-                             * (gather_mask != 0 or host_rgba8); a pt_multi_render with neither keeps the frames in flight on every device. */
+                             * reads or changes device state (pt_download, pt_get_stats, pt_device_buffer, pt_resize, ...).
+                             * pt_render_regions with 2 or 3: the frame's launches keep their schedule (passes dealt to the streams in turn) but
+                             * no longer start together, and the first resolve of a frame waits for the end of the previous frame.  Ignored
+                             * (synchronous) with kernel_timing and for a pt_multi_render that hands the frame over (gather_mask != 0 or
+                             * host_rgba8); a pt_multi_render with neither keeps the frames in flight on every device. */
 } pt_options;
 
 enum pt_buffer {          /* LaunchParams.frame.* (LaunchParams.h:53-63) */

@@ -1229,11 +1229,15 @@ extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uin
 // optixLaunch calls per frame with different LaunchParams.frame.{factor,fillSize,c,r_inner,r_outer,offset,redraw},
 // samples_per_launch and subframe_index; later launches overwrite the pixels of earlier ones, so the launches run
 // in order on one stream.
-static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, const pt_variant* variant) {
-    {
-        int rc = drain(ctx); // foveated frames are synchronous
+// pipelined = false: a synchronous frame (slot 0); true (frames_in_flight >= 2): the same schedule without a frame-wide start — the
+// passes of the frame's launches go to the batch sets in turn, every stream carries on behind its own previous work, and the first
+// resolve of the frame waits for the end of the previous frame (later frames overwrite earlier ones)
+static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, const pt_variant* variant, int slot = 0, bool pipelined = false) {
+    if (!pipelined) {
+        int rc = drain(ctx);
         if (rc) return rc;
     }
+    ctx->fr[slot].active = 0;
     if (ctx->width == 0) return PT_OK;
     if (!ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_render_regions: no probe set (setProbe)");
     if (ctx->opt.bvh_kind != 0 || ctx->opt.trace_kernel != 0) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_regions: needs the default traversal (bvh_kind 0, trace_kernel 0)");
@@ -1262,15 +1266,21 @@ static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, co
         int rc = ensure_path_state(ctx, nsets, need, 64);
         if (rc) return rc;
     }
-    begin_slot(ctx, 0);
-    CK(hipMemsetAsync(totals_of(ctx, 0, 0), 0, sizeof(unsigned long long) * PT_MAX_SETS * 4, ctx->stream));
+    begin_slot(ctx, slot);
     hipEvent_t ev_begin = next_event(ctx);
-    CK(hipEventRecord(ev_begin, ctx->stream));
-    for (auto& b : ctx->sets) hipStreamWaitEvent(b.stream, ev_begin, 0);
+    if (!pipelined) {
+        CK(hipMemsetAsync(totals_of(ctx, slot, 0), 0, sizeof(unsigned long long) * PT_MAX_SETS * 4, ctx->stream));
+        CK(hipEventRecord(ev_begin, ctx->stream));
+        for (auto& b : ctx->sets) hipStreamWaitEvent(b.stream, ev_begin, 0);
+    } else {
+        for (auto& b : ctx->sets) CK(hipMemsetAsync(b.totals, 0, sizeof(unsigned long long) * 4, b.stream));
+        CK(hipEventRecord(ev_begin, ctx->sets[0].stream));
+    }
     LaunchCounts lc;
     uint64_t paths = 0;
     uint32_t next_set = 0;
     std::vector<hipEvent_t> prev_done, cur_done;
+    if (pipelined && ctx->ev_resolved) prev_done.push_back(ctx->ev_resolved); // the previous frame's pixels are written first
     for (uint32_t r = 0; r < n; ++r) {
         const pt_region& g = regions[r];
         FrameParams fp{ctx->accum, ctx->frame, ctx->color, ctx->normal, ctx->albedo, ctx->width, ctx->height, g.subframe_index,
@@ -1303,10 +1313,11 @@ static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, co
         hipEventRecord(e, b.stream);
         hipStreamWaitEvent(ctx->stream, e, 0);
     }
-    CK(hipMemcpyAsync(ctx->h_totals, totals_of(ctx, 0, 0), sizeof(unsigned long long) * PT_MAX_SETS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(ctx->h_totals + (size_t)slot * PT_MAX_SETS * 4, totals_of(ctx, slot, 0), sizeof(unsigned long long) * PT_MAX_SETS * 4, hipMemcpyDeviceToHost, ctx->stream));
     hipEvent_t ev_end = next_event(ctx);
     CK(hipEventRecord(ev_end, ctx->stream));
-    pt_ctx::Inflight& fr = ctx->fr[0];
+    if (pipelined) ctx->ev_resolved = ev_end; // behind every resolve of this frame
+    pt_ctx::Inflight& fr = ctx->fr[slot];
     fr.ev_begin = ev_begin;
     fr.ev_end = ev_end;
     fr.active = 1;
@@ -1318,8 +1329,19 @@ static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, co
 
 extern "C" int pt_render_regions(pt_ctx* ctx, const pt_region* regions, uint32_t n, const pt_variant* variant, uint32_t* host_rgba8) {
     if (!ctx || (!regions && n)) return PT_ERR_INVALID;
-    int rc = regions_enqueue(ctx, regions, n, variant);
-    if (rc == PT_OK) rc = render_finish(ctx);
+    const int F = frames_mode(ctx);
+    int rc;
+    if (F < 2) {
+        rc = regions_enqueue(ctx, regions, n, variant);
+        if (rc == PT_OK) rc = render_finish(ctx);
+    } else {
+        const int slot = (ctx->last_slot + 1) % F;
+        rc = render_finish(ctx, slot);
+        if (rc == PT_OK) rc = regions_enqueue(ctx, regions, n, variant, slot, true);
+        if (rc == PT_OK) ctx->last_slot = slot;
+        const int rw = pipelined_wait(ctx, F);
+        if (rc == PT_OK) rc = rw;
+    }
     if (rc != PT_OK) return rc;
     if (host_rgba8 && ctx->width) return pt_download(ctx, PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)ctx->width * ctx->height);
     return PT_OK;

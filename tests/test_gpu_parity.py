@@ -898,6 +898,49 @@ def test_foveated_sv4_three_launches(ptlib, orc_det, variant_name):
     assert st["radiance_rays"] > 0 and st["paths"] == (w // 4) * (h // 4) * 1 + 46 * 46 * 2 + 30 * 30 * 4
 
 
+def test_foveated_frames_in_flight(ptlib, orc_det):
+    """Six foveated frames with a moving gaze and nothing read back in between, three frames in flight (all launches of a frame
+    on that frame's stream, resolves chained from frame to frame), then two uniform frames on top: final buffers against the
+    checker and against the synchronous run."""
+    from optixpathtracer_amd.renderer import SampleRenderer, make_camera
+
+    m = scenes.voxel_terrain(n=64, target_tris=30000)
+    probe = scenes.sky_probe(256, 128).BuildCDF()
+    w, h = 192, 128
+    # the regions stay inside the image: where a splat crosses the border the reference clamps the pixel index (sv4 deviceProgram.cu:528-534),
+    # so several launch indices write the same border pixel — a data race of the reference itself, kept as it is (DESIGN.md §6b)
+    gazes = [(96, 64), (100, 60), (70, 80), (50, 50), (140, 70), (96, 64)]
+    out = {}
+    for fif in (0, 3):
+        r = SampleRenderer(m)
+        r.setProbe(probe)
+        r.setOptions(max_depth=4, frames_in_flight=fif)
+        r.resize((w, h))
+        r.setCamera(make_camera(scenes.TERRAIN_CAMERA, w / h))
+        for gaze in gazes:
+            r.renderFoveated(gaze, inner_radius=14, outer_radius=44, spp=(1, 2, 4), variant=r.SV4_VARIANT)
+        fov = (r.download(R_ACCUM), r.download(R_FRAME))
+        r.launchParams.samples_per_launch = 2
+        for sf in (6, 7):  # the uniform renderer continues the accumulation in the same pipeline
+            r.launchParams.frame.subframe_index = sf
+            r.render()
+        out[fif] = fov + (r.download(R_ACCUM), r.stats()["frames"])
+    sc = orc_det.make_scene(m, True)
+    pr = orc_det.make_probe(probe)
+    U, V, W = scenes.uvw_frame(**scenes.TERRAIN_CAMERA, aspect=w / h)
+    accum = np.zeros((h, w, 4), np.float32)
+    frame = np.zeros((h, w), np.uint32)
+    r0 = SampleRenderer(m)
+    for k, gaze in enumerate(gazes):
+        regs = r0.foveatedRegions((w, h), gaze, k, inner_radius=14, outer_radius=44, spp=(1, 2, 4))
+        orc_det.render_regions(sc, pr, (U, V, W), scenes.TERRAIN_CAMERA["eye"], w, h, regs, r0.SV4_VARIANT, 4, accum, frame)
+    for fif in (0, 3):
+        assert_bits_equal(out[fif][0], accum, f"foveated accum_buffer after six frames, frames_in_flight={fif}")
+        assert np.array_equal(out[fif][1], frame)
+    assert_bits_equal(out[3][2], out[0][2], "uniform frames on top of the foveated ones")
+    assert out[3][3] == out[0][3] == 8
+
+
 R_ACCUM, R_FRAME = 0, 1
 
 

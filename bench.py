@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N>1: strong (default) = the metric's fixed frame split N ways; weak = per-GPU work fixed, image area grows with N")
     ap.add_argument("--simulate-world", type=int, default=0, help="single process: render only rank 0's tiles of an N-way partition (predicts per-GPU time at N GPUs)")
     ap.add_argument("--simulate-rank", type=int, default=0, help="with --simulate-world N: which rank's share to render (load balance of the interleaved tiles)")
+    ap.add_argument("--tile", type=int, nargs=2, default=[64, 16], metavar=("W", "H"), help="tile size of the interleaved partition (multiples of 8)")
     ap.add_argument("--split-shadow", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="concurrent pixel chunks per frame (0 = library default)")
     ap.add_argument("--kernel-timing", type=int, default=0, help="1: per-launch HIP-event timing inside the timed loop (slower; the isolated phase always has it)")
@@ -130,9 +131,9 @@ def main():
     r.setOptions(**opts)
     part_world = world if world > 1 else max(1, args.simulate_world)
     if world > 1:
-        r.setPartition(rank, world, 64, 16)
+        r.setPartition(rank, world, args.tile[0], args.tile[1])
     elif args.simulate_world > 1:
-        r.setPartition(args.simulate_rank % args.simulate_world, args.simulate_world, 64, 16)
+        r.setPartition(args.simulate_rank % args.simulate_world, args.simulate_world, args.tile[0], args.tile[1])
     r.resize((w, h))
     r.setCamera(R.make_camera(cam, w / h))
     r.launchParams.samples_per_launch = spp
@@ -331,7 +332,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": args.workload + (f"_weak_x{world}_area" if (world > 1 and not strong) else ""), "triangles": model.num_triangles, "width": w, "height": h, "spp": spp,
-                "max_depth": depth, "bsdf": "disney", "probe": "sky2048x1024+sun", "partition": f"tiles64x16/{part_world}",
+                "max_depth": depth, "bsdf": "disney", "probe": "sky2048x1024+sun", "partition": f"tiles{args.tile[0]}x{args.tile[1]}/{part_world}",
             },
             "rays_per_frame": int(rays_frame),
             "fps": round(args.steps / dt_max, 2),

@@ -1442,3 +1442,39 @@ def test_async_shadow_schedule_matches_oracle(ptlib, orc_det, small_probe):
     c = scenes.two_box_scene(shadow_catcher=True)
     r = _renderer(c, small_probe, scenes.TWO_BOX_CAMERA, 96, 64, split_shadow=2)
     _compare(_gpu_render(r, 3), _oracle_render(orc_det, c, small_probe, scenes.TWO_BOX_CAMERA, 96, 64, 3))
+
+
+def test_bench_line_contract(ptlib):
+    """bench.py as the driver runs it (one process, default workload, few steps): ONE JSON line with the contract's keys, the
+    metric's configuration, a roofline and a CPU-baseline object, and figures that are consistent with each other."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2"], capture_output=True, text=True, timeout=400)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), (key, d[key])
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["unit"] == "Mrays/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["scaling"] == "strong"
+    assert d["config"]["workload"] == "c3_terrain1M_1080p_4spp_d8" and (d["config"]["width"], d["config"]["height"], d["config"]["spp"], d["config"]["max_depth"]) == (1920, 1080, 4, 8)
+    assert "model" not in d["config"]
+    # value = rays / time of the timed frames
+    assert abs(d["value"] - d["rays_per_frame"] / d["ms_per_step"] / 1e3) / d["value"] < 1e-3
+    assert d["frames_in_flight"] == 3 and d["ms_per_frame_synchronous"] > 0.8 * d["ms_per_step"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0.0 < rf["frac"] < 1.0
+    assert rf["traffic"] is None or rf["traffic"] > rf["alg_bytes_per_frame"] * 0.5
+    dk = rf["dominant_kernel"]
+    assert dk["isolated"] and dk["avg_launch_ms"] > 0 and abs(dk["frac"] - dk["achieved"] / 8000.0) < 1e-4
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "Mrays/s" and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
+    assert cb["single_thread"]["cores"] == 1 and 0 < cb["single_thread"]["value"] <= cb["value"] * 1.05

@@ -82,6 +82,8 @@ struct pt_ctx {
     uint32_t* ovf = nullptr; // spill stacks for pt_trace queries
     unsigned long long* dbg = nullptr; // PT_DEBUG_COUNTS: traversal step counters of the last frame
     int trace_grid = 0;
+    bool adapt_grid = false; // set around the enqueue of a whole frame (frames_in_flight = 3)
+    int trace_grid_min = 2048, grid_chunks = 6; // PT_GRID_MIN / PT_GRID_CHUNKS (tuning hooks): smallest persistent grid, chunks of 64 paths per wave aimed at
     int lds_skip = 0; // PT_STACK_LDS_SKIP (test hook, pt_bvh8.h)
     int ovf_depth = 0; // spill levels of the traversal stack (PT8_OVF_DEPTH; test hook PT_STACK_CAP lowers the total capacity)
     int stack_check = 1; // PT_STACK_NOCHECK=1 (test hook): skip the build-time depth check so that the in-kernel fault flag is reached
@@ -336,6 +338,8 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
         CKC(hipGetDeviceProperties(&prop, device));
         int wpe = PT8_WAVES_PER_EU; // persistent waves per SIMD = the occupancy the traversal kernels are compiled for
         if (const char* e = getenv("PT_TRACE_WAVES")) wpe = atoi(e);
+        if (const char* e = getenv("PT_GRID_MIN")) ctx->trace_grid_min = std::max(64, atoi(e));
+        if (const char* e = getenv("PT_GRID_CHUNKS")) ctx->grid_chunks = std::max(1, atoi(e));
         if (const char* e = getenv("PT_STACK_LDS_SKIP")) ctx->lds_skip = std::max(0, std::min(PT8_LDS_DEPTH, atoi(e)));
         ctx->trace_grid = prop.multiProcessorCount * 4 * wpe;
         CKC(dalloc(&ctx->ovf, ovf_words(ctx)));
@@ -778,6 +782,13 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
     const size_t CS = (size_t)PT_NSUB * PT_CSTRIDE;
     for (uint32_t s0 = 0; s0 < spp; s0 += S) {
         const uint32_t Sc = std::min(S, spp - s0);
+        // Persistent traversal waves of this pass's launches.  A synchronous frame wants the full grid (5 waves per SIMD): its latency is what
+        // counts.  With whole frames in flight (frames_in_flight = 3) throughput counts and the other streams take every wave slot left free:
+        // a small batch then runs faster on fewer waves (refill and drain phases amortised over more rays per wave) — measured optimum
+        // ≈ 6 chunks of 64 of the pass's paths per wave
+        const uint64_t pass_paths = job ? (uint64_t)job->nl * spp : (uint64_t)npix * Sc;
+        const unsigned tgrid = !ctx->adapt_grid ? (unsigned)ctx->trace_grid
+            : (unsigned)std::max<uint64_t>((uint64_t)ctx->trace_grid_min, std::min<uint64_t>((uint64_t)ctx->trace_grid, pass_paths / (64ull * (uint64_t)ctx->grid_chunks)));
         BatchParams bp{ctx->d_pixels + pix0, npix, s0, Sc, ctx->has_catcher ? 1 : 0, bs.pixResult, bs.pixAlpha, bs.pixNormal, bs.pixAlbedo};
         hipMemsetAsync(bs.counters, 0, sizeof(uint32_t) * ((size_t)2 * nq * CS + 2 * nq), bs.stream);
         uint32_t* cntA = bs.counters;                       // radiance queue counters, per bounce
@@ -809,7 +820,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
                 Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
             for (int b = 0; b <= last_bounce; ++b) {
@@ -830,7 +841,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     {
                         SpanGuard g(ctx, CLS_SHADOW, ss);
                         Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, (b & 1) ? bs.ovf3 : bs.ovf2, cull, nullptr, b, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                        hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, ss, ta);
+                        hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(tgrid), dim3(64), 0, ss, ta);
                         ++lc.shadow;
                     }
                     hipEvent_t ev = next_event(ctx);
@@ -840,7 +851,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
                     Trace8Args ta{bs.st, bvh8, qnext, QView{}, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                    hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                    hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 }
                 qcur = qnext;
@@ -854,7 +865,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
                 Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
             for (int b = 0; b <= last_bounce; ++b) {
@@ -870,12 +881,12 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
                     Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                    hipLaunchKernelGGL((k_trace8<TR_UNIFIED>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                    hipLaunchKernelGGL((k_trace8<TR_UNIFIED>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 } else {
                     SpanGuard g(ctx, CLS_SHADOW, bs.stream);
                     Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                    hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                    hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.shadow;
                 }
                 qcur = qnext;
@@ -891,10 +902,10 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, bs.stream, bs.st, bvh, qcur);
                 } else if (ctx->opt.bvh_kind == 1) {
                     Trace2Args ta{bs.st, bvh, qcur, work + b, bs.ovf, nullptr};
-                    hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                    hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                 } else {
                     Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                    hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                    hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                 }
                 ++lc.trace;
             }
@@ -917,10 +928,10 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     hipLaunchKernelGGL((k_trace<1>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, bs.stream2, bs.st, bvh, qshadow);
                 } else if (ctx->opt.bvh_kind == 1) {
                     Trace2Args ta{bs.st, bvh, qshadow, work + nq + b, bs.ovf2, nullptr};
-                    hipLaunchKernelGGL((k_trace2<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
+                    hipLaunchKernelGGL((k_trace2<TR_SHADOW_APPLY>), dim3(tgrid), dim3(64), 0, bs.stream2, ta);
                 } else {
                     Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                    hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream2, ta);
+                    hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(tgrid), dim3(64), 0, bs.stream2, ta);
                 }
                 ++lc.shadow;
             }
@@ -954,7 +965,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
                     Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                    hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                    hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 }
                 ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, 1};
@@ -967,7 +978,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 {
                     SpanGuard g(ctx, CLS_SHADOW, bs.stream);
                     Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                    hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(ctx->trace_grid), dim3(64), 0, bs.stream, ta);
+                    hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.shadow;
                 }
                 hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters + (size_t)cur * CS, nq, 1, 0, bs.totals);
@@ -1049,8 +1060,10 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
         CK(hipEventRecord(ev_begin, bs.stream));
         std::vector<hipEvent_t> before;
         if (ctx->ev_resolved) before.push_back(ctx->ev_resolved);
+        ctx->adapt_grid = true;
         for (uint32_t pix0 = 0; pix0 < owned; pix0 += Np)
             enqueue_chunk(ctx, bs, fp, pix0, std::min(Np, owned - pix0), spp, S, lc, nullptr, before.empty() ? nullptr : &before);
+        ctx->adapt_grid = false;
         hipEvent_t e = next_event(ctx);
         hipEventRecord(e, bs.stream);
         ctx->ev_resolved = e;

@@ -987,7 +987,10 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 cur = nxt;
             }
         }
-        if (before_resolve) // foveated launches: this launch's pixels are written after the previous launch's (they overlap)
+        // foveated launches: this launch's pixels are written after the previous launch's (they overlap); whole frames in flight: after the
+        // previous frame's.  Only the pass that writes the frame buffers has to wait — earlier sample passes of a pixel chunk keep their sums in the
+        // set's own pixResult arrays
+        if (before_resolve && (job || s0 + Sc >= spp))
             for (hipEvent_t e : *before_resolve) hipStreamWaitEvent(bs.stream, e, 0);
         {
             SpanGuard g(ctx, CLS_OTHER, bs.stream);

@@ -1478,3 +1478,85 @@ def test_bench_line_contract(ptlib):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "Mrays/s" and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
     assert cb["single_thread"]["cores"] == 1 and 0 < cb["single_thread"]["value"] <= cb["value"] * 1.05
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_frames_in_flight_api_fuzz(ptlib, small_probe, seed):
+    """A random sequence of API calls — uniform and foveated frames, camera / size / partition / option changes, read-backs, epilogues —
+    on a synchronous renderer and on one with frames in flight (the mode itself changes along the way): every read-back must agree
+    bit for bit.  Exercises the "wait for the frames in flight first" rule of every entry point."""
+    from optixpathtracer_amd import renderer as R
+
+    rng = np.random.default_rng(seed)
+    m = scenes.voxel_terrain(n=64, target_tris=30000)
+    size = [(128, 80)]
+
+    def make(fif):
+        r = R.SampleRenderer(m)
+        r.setProbe(small_probe)
+        r.setOptions(max_depth=4, frames_in_flight=fif)
+        r.resize(size[0])
+        r.setCamera(R.make_camera(scenes.TERRAIN_CAMERA, size[0][0] / size[0][1]))
+        r.launchParams.samples_per_launch = 2
+        return r
+
+    a, b = make(0), make(3)
+    ops = rng.choice(["render", "render", "render", "render", "foveated", "camera", "resize", "partition", "download", "stats", "options", "tonemap", "denoise", "sync"], 70)
+    sub = 0
+    checks = 0
+    for op in ops:
+        if op == "render":
+            for r in (a, b):
+                r.launchParams.frame.subframe_index = sub
+                r.render()
+            sub += 1
+        elif op == "foveated":
+            w, h = size[0]
+            gaze = (int(rng.integers(32, w - 32)), int(rng.integers(32, h - 32)))  # regions stay inside the image (outer radius 30)
+            for r in (a, b):
+                r.launchParams.frame.subframe_index = sub
+                r.renderFoveated(gaze, inner_radius=10, outer_radius=30, spp=(1, 2, 2), variant=r.SV4_VARIANT)
+            sub += 1
+        elif op == "camera":
+            cam = dict(scenes.TERRAIN_CAMERA)
+            cam["eye"] = tuple(float(c * rng.uniform(0.9, 1.1)) for c in cam["eye"])
+            for r in (a, b):
+                r.setCamera(R.make_camera(cam, size[0][0] / size[0][1]))
+        elif op == "resize":
+            size[0] = [(128, 80), (96, 72), (160, 88)][int(rng.integers(0, 3))]
+            for r in (a, b):
+                r.resize(size[0])
+                r.setCamera(R.make_camera(scenes.TERRAIN_CAMERA, size[0][0] / size[0][1]))
+            sub = 0
+        elif op == "partition":
+            rank, world = [(0, 1), (1, 2), (2, 3)][int(rng.integers(0, 3))]
+            for r in (a, b):
+                r.setPartition(rank, world, 16, 8)
+            sub = 0
+        elif op == "options":
+            fif = int(rng.choice([2, 3]))
+            spp = int(rng.choice([1, 2, 3]))
+            b.setOptions(max_depth=4, frames_in_flight=fif)
+            for r in (a, b):
+                r.launchParams.samples_per_launch = spp
+        elif op == "tonemap":
+            assert np.array_equal(a.tonemapSqrt(), b.tonemapSqrt())
+            checks += 1
+        elif op == "denoise":
+            da, _ = a.denoise(iterations=2)
+            db, _ = b.denoise(iterations=2)
+            assert np.array_equal(da.view(np.uint32), db.view(np.uint32))
+            checks += 1
+        elif op == "sync":
+            b.sync()
+        elif op == "stats":
+            sa, sb = a.stats(), b.stats()
+            assert (sa["frames"], sa["total_radiance_rays"], sa["total_shadow_rays"], sa["radiance_rays"], sa["shaded_hits"]) == (sb["frames"], sb["total_radiance_rays"], sb["total_shadow_rays"], sb["radiance_rays"], sb["shaded_hits"])
+            checks += 1
+        else:
+            which = [R.PT_BUF_ACCUM, R.PT_BUF_FRAME, R.PT_BUF_NORMAL, R.PT_BUF_ALBEDO][int(rng.integers(0, 4))]
+            assert np.array_equal(a.download(which).view(np.uint32), b.download(which).view(np.uint32)), (op, which)
+            checks += 1
+    assert np.array_equal(a.download(R.PT_BUF_ACCUM).view(np.uint32), b.download(R.PT_BUF_ACCUM).view(np.uint32))
+    assert np.array_equal(a.download(R.PT_BUF_FRAME), b.download(R.PT_BUF_FRAME))
+    assert checks >= 5

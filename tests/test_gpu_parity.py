@@ -1560,3 +1560,34 @@ def test_frames_in_flight_api_fuzz(ptlib, small_probe, seed):
     assert np.array_equal(a.download(R.PT_BUF_ACCUM).view(np.uint32), b.download(R.PT_BUF_ACCUM).view(np.uint32))
     assert np.array_equal(a.download(R.PT_BUF_FRAME), b.download(R.PT_BUF_FRAME))
     assert checks >= 5
+
+
+def test_fullsize_c3_frames_in_flight_match_synchronous(ptlib):
+    """The schedule bench.py times (C3: 1 M triangles, 1920x1080, 4 spp, depth 8, three whole frames in flight, batch-sized traversal
+    grid) against the synchronous schedule at the literal size: five progressive subframes, every buffer bit for bit, equal ray counts —
+    also for a 1/8 share of the frame."""
+    from optixpathtracer_amd import renderer as R
+
+    m = scenes.voxel_terrain()
+    probe = scenes.sky_probe(2048, 1024).BuildCDF()
+    w, h = 1920, 1080
+    for part in (None, (3, 8)):
+        out = {}
+        for fif in (0, 3):
+            r = R.SampleRenderer(m)
+            r.setProbe(probe)
+            r.setOptions(frames_in_flight=fif)
+            if part:
+                r.setPartition(part[0], part[1], 64, 16)
+            r.resize((w, h))
+            r.setCamera(R.make_camera(scenes.TERRAIN_CAMERA, w / h))
+            r.launchParams.samples_per_launch = 4
+            for sf in range(5):
+                r.launchParams.frame.subframe_index = sf
+                r.render()
+            st = r.stats()
+            out[fif] = [r.download(b) for b in (R.PT_BUF_ACCUM, R.PT_BUF_FRAME, R.PT_BUF_NORMAL, R.PT_BUF_ALBEDO, R.PT_BUF_COLOR)] + [st["total_radiance_rays"], st["total_shadow_rays"], st["frames"]]
+            r.close()
+        for k in range(5):
+            assert np.array_equal(out[0][k].view(np.uint32), out[3][k].view(np.uint32)), (part, k)
+        assert out[0][5:] == out[3][5:] and out[0][7] == 5

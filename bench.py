@@ -338,7 +338,10 @@ def main():
             "fps": round(args.steps / dt_max, 2),
             "frames_in_flight": opts["frames_in_flight"] if pipelined else 1,
             "ms_per_frame_synchronous": None if sync_ms is None else round(sync_ms, 3),
+            # device time from a frame's first kernel to its last: with frames in flight this is one frame's LATENCY (three frames overlap),
+            # not the time per frame — that is ms_per_step
             "render_ms_per_frame": round(agg["render_ms"] / args.steps, 3),
+            "frame_latency_ms": round(agg["render_ms"] / args.steps, 3),
             "ms_per_step_per_rank": per_rank_ms,
             "kernel_ms_per_frame_isolated": None if iso is None else {k: round(iso[k], 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
             "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2)},

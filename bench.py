@@ -338,6 +338,7 @@ def main():
             "fps": round(args.steps / dt_max, 2),
             "frames_in_flight": opts["frames_in_flight"] if pipelined else 1,
             "ms_per_frame_synchronous": None if sync_ms is None else round(sync_ms, 3),
+            "mrays_per_s_synchronous": None if sync_ms is None else round(rays_frame / max(1, world) / sync_ms / 1e3, 2),  # this rank's frames one at a time
             # device time from a frame's first kernel to its last: with frames in flight this is one frame's LATENCY (three frames overlap),
             # not the time per frame — that is ms_per_step
             "render_ms_per_frame": round(agg["render_ms"] / args.steps, 3),

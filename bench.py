@@ -10,14 +10,13 @@ N>1 (one process per GPU, torch.distributed over RCCL): the FIXED frame is tile-
 64x16 tiles, replicated scene, no data-path collective) — strong scaling, which is what "1/2/4/8 MI355X
 scaling" of a 1080p frame means.  `--scaling weak` (opt-in) grows the image to N x the pixels instead.
 `--workload c4_terrain1M_4k_16spp_d8` is BASELINE config C4 (3840x2160, 16 spp, tiled across the GPUs).
-`value` = rays traced by all ranks / max-over-ranks time of the K timed frames.  The K frames are rendered with three frames
-in flight (pt_options.frames_in_flight = 3: frame k runs whole on stream k mod 3 and pt_render(k) returns when frame k-2 is
-complete, so consecutive frames overlap instead of the pixel chunks of one frame; same images bit for bit, the timed region ends
-after the last frame is complete);
-`ms_per_frame_synchronous` is the same frame rendered one at a time like the reference's render() (`--frames-in-flight 0`
-makes that the timed mode).  After the timed region a
-second, shorter loop renders AND hands the frame over for display every frame (pack -> one RCCL all-gather
-of the packed rgba8 strips -> unpack): `ms_per_displayed_frame`, with the exchange alone as `gather_ms`.
+`value` = rays traced by all ranks / max-over-ranks time of the K timed frames, each a device-synchronised pt_render like the
+reference's render() (SimplePathtracer.cpp:96) — `--frames-in-flight 3` / `--batch B` make the other schedules the
+timed mode.  After the timed region, for the record and never part of `value`: the same frames with three whole frames in flight
+(`mrays_per_s_pipelined`, `ms_per_frame_pipelined`; same images bit for bit), and on a partitioned frame the same frames as
+wavefront batches of N subframes (pt_render_batch: `batched`), and a loop that renders AND hands every frame over for display
+(pack -> one RCCL all-gather of the packed rgba8 strips -> unpack into the display buffer, the exchange of frame k overlapping
+the rendering of frame k+1): `ms_per_displayed_frame`, with the exchange alone as `gather_ms`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -83,8 +82,9 @@ def main():
     ap.add_argument("--split-shadow", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="concurrent pixel chunks per frame (0 = library default)")
     ap.add_argument("--kernel-timing", type=int, default=0, help="1: per-launch HIP-event timing inside the timed loop (slower; the isolated phase always has it)")
-    ap.add_argument("--frames-in-flight", type=int, default=3, help="pt_options.frames_in_flight. 3 (default): frame k runs whole on stream k mod 3 and pt_render(k) returns once frame k-2 is complete (three frames overlap, same images); 2: pixel chunks as in the synchronous frame, pt_render(k) waits for frame k-1; 0: every frame synchronous like the reference's render()")
-    ap.add_argument("--no-sync-frames", action="store_true", help="skip the extra frames that measure ms_per_frame_synchronous (profiling runs: keeps the frame count at warmup + steps)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="pt_options.frames_in_flight of the TIMED loop. 0 (default): every frame synchronous like the reference's render(); 3: frame k runs whole on stream k mod 3 and pt_render(k) returns once frame k-2 is complete (three frames overlap, same images); 2: pixel chunks as in the synchronous frame, pt_render(k) waits for frame k-1")
+    ap.add_argument("--batch", type=int, default=1, help="timed loop: frames are rendered as wavefront batches of this many subframes (pt_render_batch; --steps must be a multiple)")
+    ap.add_argument("--no-extra-schedules", action="store_true", help="skip the extra frames after the timed region (pipelined / batched figures; profiling runs: keeps the frame count at warmup + steps)")
     ap.add_argument("--bvh-kind", type=int, default=0, help="0 = 8-wide compressed BVH (default), 1 = binary BVH")
     ap.add_argument("--trace-kernel", type=int, default=0, help="0 = persistent-wave traversal (default), 1 = first grid-stride kernel")
     args = ap.parse_args()
@@ -148,10 +148,16 @@ def main():
     sv4 = args.workload.startswith("sv4_")
     foveated = "foveated" in args.workload
 
-    def render_frame(k):
+    if args.batch < 1 or args.steps % args.batch or (args.batch > 1 and sv4):
+        raise SystemExit("--batch B needs --steps to be a multiple of B (and a pt_render workload)")
+
+    def render_frame(k, count=1):
         if not sv4:
             r.launchParams.frame.subframe_index = k  # progressive accumulation, like the reference's loop
-            r.render()
+            if count == 1:
+                r.render()
+            else:
+                r.renderBatch(count)  # subframes k .. k+count-1 as one wavefront batch, same buffers bit for bit
         elif foveated:  # sv4 FOV_ON render(): gaze = cursor; here it circles the image centre
             import math
             gaze = (w // 2 + int(300 * math.cos(0.3 * k)), h // 2 + int(200 * math.sin(0.3 * k)))
@@ -160,19 +166,37 @@ def main():
             r.renderRegions([dict(launch_w=w, launch_h=h, factor_x=1, factor_y=1, fill_size=1, cx=w // 2, cy=h // 2, r_inner=0.0,
                                   r_outer=1000000000.0, offset_x=0, offset_y=0, redraw=0, spp=spp, subframe_index=0)], r.SV4_VARIANT)
 
-    for k in range(args.warmup):
-        render_frame(k)
+    def timed_frames(first, n, count=1):
+        """n frames from subframe `first` on, `count` per launch chain; returns (seconds, rays) of this rank, frames complete at both ends"""
+        barrier()
+        a0 = r.stats()
+        t_0 = time.perf_counter()
+        tk = []
+        for k in range(0, n, count):
+            render_frame(first + k, count)
+            tk.append(time.perf_counter())
+        barrier()
+        t_1 = time.perf_counter()
+        if os.environ.get("BENCH_DEBUG"):
+            print("timed_frames", count, [round((b - a) * 1e3, 2) for a, b in zip([t_0] + tk, tk + [t_1])], file=sys.stderr)
+        a1 = r.stats()
+        assert a1["frames"] - a0["frames"] == n, (a1["frames"], a0["frames"], n)
+        return t_1 - t_0, (a1["total_radiance_rays"] + a1["total_shadow_rays"]) - (a0["total_radiance_rays"] + a0["total_shadow_rays"])
+
+    for k in range(0, args.warmup, args.batch):
+        render_frame(k, min(args.batch, args.warmup - k))
     barrier()
     keys = ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms", "trace_launches", "shadow_launches", "shade_launches", "radiance_rays", "shadow_rays", "shaded_hits")
     agg = dict.fromkeys(keys, 0.0)
-    # rays are counted on the device for every frame; pt_stats also keeps the totals since pt_create, so that the timed loop
-    # does not have to read (= wait for) each frame's statistics
+    # rays are counted on the device for every frame; pt_stats also keeps the totals since pt_create, so that a loop with frames in
+    # flight does not have to read (= wait for) each frame's statistics
     pipelined = opts["frames_in_flight"] >= 2
+    per_frame_stats = not pipelined and args.batch == 1
     s0 = r.stats()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        render_frame(args.warmup + k)
-        if not pipelined:
+    for k in range(0, args.steps, args.batch):
+        render_frame(args.warmup + k, args.batch)
+        if per_frame_stats:
             st = r.stats()
             for key in agg:
                 agg[key] += st[key]
@@ -181,23 +205,38 @@ def main():
     st = r.stats()
     assert st["frames"] - s0["frames"] == args.steps, (st["frames"], s0["frames"])
     rays = (st["total_radiance_rays"] + st["total_shadow_rays"]) - (s0["total_radiance_rays"] + s0["total_shadow_rays"])
-    if pipelined:  # per-frame figures: those of the last frame (the frames differ only by their random numbers)
-        agg = {key: st[key] * args.steps for key in keys}
+    if not per_frame_stats:  # per-launch-chain figures of the LAST chain only, scaled to the loop (the frames differ only by their random numbers)
+        agg = {key: st[key] * (args.steps // args.batch) for key in keys}
+    next_sub = args.warmup + args.steps
 
-    # the same frames one at a time (what SampleRenderer::render() does: return when the frame is complete), for the record;
-    # everything after the timed region (these frames, the displayed frames, the isolated frames) runs synchronously
-    sync_ms = None
-    if pipelined:
+    # Other schedules of the same frames, for the record (after the timed region, never part of `value`; same images bit for bit):
+    # three whole frames in flight, and — on a partitioned frame — wavefront batches of as many subframes as there are shares
+    # (a 1/N share x N subframes per launch chain carries the rays of one whole frame)
+    extra = {}
+    if not args.no_extra_schedules and not sv4 and not args.kernel_timing:
+        n_x = max(6, min(args.steps, 30))
+        if not pipelined:
+            r.setOptions(**dict(opts, frames_in_flight=3))
+            render_frame(next_sub); render_frame(next_sub + 1); render_frame(next_sub + 2)
+            tp, rp = timed_frames(next_sub + 3, n_x)
+            next_sub += 3 + n_x
+            extra["pipelined"] = (tp, rp, n_x)
+            r.setOptions(**opts)
+        bc = part_world if part_world > 1 else 0
+        if bc and args.batch == 1:
+            r.setOptions(**dict(opts, frames_in_flight=0))
+            n_b = ((n_x + bc - 1) // bc) * bc
+            render_frame(next_sub, bc)
+            tb, rb = timed_frames(next_sub + bc, n_b, bc)
+            extra["batched"] = (tb, rb, n_b, bc)
+            r.setOptions(**dict(opts, frames_in_flight=3))
+            render_frame(next_sub + bc + n_b, bc); render_frame(next_sub + 2 * bc + n_b, bc)
+            tb3, rb3 = timed_frames(next_sub + 3 * bc + n_b, n_b, bc)
+            extra["batched_pipelined"] = (tb3, rb3, n_b, bc)
+            next_sub += 3 * bc + 2 * n_b
+            r.setOptions(**opts)
+    if pipelined:  # everything after this runs synchronously
         r.setOptions(**dict(opts, frames_in_flight=0))
-        if not args.no_sync_frames:
-            n_sync = max(1, min(args.steps, 5))
-            render_frame(args.warmup + args.steps)
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            for k in range(n_sync):
-                render_frame(args.warmup + args.steps + 1 + k)
-            torch.cuda.synchronize()
-            sync_ms = (time.perf_counter() - ts) / n_sync * 1e3
 
     tot = torch.tensor([dt, float(rays)], dtype=torch.float64, device=red_dev)
     if dist is not None:
@@ -213,6 +252,17 @@ def main():
     else:
         dt_max, rays_all = dt, float(rays)
         per_rank_ms = None
+    extra_out = {}
+    for name, tup in extra.items():  # max time over the ranks, rays summed over the ranks
+        te = torch.tensor([tup[0]], dtype=torch.float64, device=red_dev)
+        re_ = torch.tensor([float(tup[1])], dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            dist.all_reduce(re_, op=dist.ReduceOp.SUM)
+        nfr = tup[2]
+        extra_out[name] = {"ms_per_frame": round(float(te[0]) / nfr * 1e3, 3), "mrays_per_s": round(float(re_[0]) / float(te[0]) / 1e6, 2), "frames": nfr}
+        if len(tup) > 3:
+            extra_out[name]["subframes_per_batch"] = tup[3]
 
     # displayed frames: render + the display hand-off (pack -> one all-gather of the packed rgba8 strips -> unpack) every frame
     gather_ms = ms_displayed = None
@@ -229,14 +279,14 @@ def main():
                 dist.all_gather_into_tensor(d, src.cpu())
                 dst.copy_(d)
 
-        render_frame(args.warmup + args.steps)  # every displayed frame is waited for by its hand-off: synchronous frames (pixel chunks on all streams)
+        render_frame(next_sub)  # every displayed frame is waited for by its hand-off: synchronous frames (pixel chunks on all streams)
         multigpu.exchange_frame(packer, R.PT_BUF_FRAME, world, all_gather)  # warm RCCL
         barrier()
         nd = max(1, min(args.steps, 10))
         g_acc = 0.0
         d0 = time.perf_counter()
         for k in range(nd):
-            render_frame(args.warmup + args.steps + k)
+            render_frame(next_sub + 1 + k)
             g0 = time.perf_counter()
             multigpu.exchange_frame(packer, R.PT_BUF_FRAME, world, all_gather)
             torch.cuda.synchronize()
@@ -302,8 +352,9 @@ def main():
         # read from the committed rocprofv3 passes of this same command and quoted only for the sources they were measured on
         traffic = valu = trav_traffic_frame = None
         shash = source_hash()
-        default_cfg = args.workload == "c3_terrain1M_1080p_4spp_d8" and world == 1 and args.bvh_kind == 0 and args.trace_kernel == 0 and args.simulate_world == 0
-        tj = os.path.join(ROOT, "profiles", "r2_pmc.json")
+        default_cfg = args.workload == "c3_terrain1M_1080p_4spp_d8" and world == 1 and args.bvh_kind == 0 and args.trace_kernel == 0 and args.simulate_world == 0 and args.batch == 1 and not pipelined
+        pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+        tj = pj[-1] if pj else ""
         if default_cfg and os.path.exists(tj):
             try:
                 T = json.load(open(tj))
@@ -315,6 +366,11 @@ def main():
                         shade["pmc"] = T["shade"]
             except Exception:
                 traffic = valu = None
+        limiter = None
+        ws = (valu or {}).get("wave_state", {}).get("k_trace8<3>") if valu else None
+        if ws:
+            limiter = (f"dependent-load latency at 5 waves/SIMD, not HBM: k_trace8<3> waves wait on memory {100 * ws['wait_mem']:.0f} % of their time, "
+                       f"VALU pipe {100 * ws['valu_pipe']:.0f} % used, TA {100 * ws['ta_busy']:.0f} % busy, mean L1->L2 round trip {ws['l2_round_trip_cycles']:.0f} cycles")
         kname = {(1, 0): "k_trace2", (1, 1): "k_trace", (0, 1): "k_trace"}.get((args.bvh_kind, args.trace_kernel), "k_trace8<3>/<0>")
         strong = world > 1 and args.scaling == "strong"
         out = {
@@ -336,13 +392,16 @@ def main():
             },
             "rays_per_frame": int(rays_frame),
             "fps": round(args.steps / dt_max, 2),
+            # schedule of the timed loop: frames_in_flight 1 = every frame a device-synchronised pt_render (the reference's render()); subframes_per_batch 1 = one frame per launch chain
             "frames_in_flight": opts["frames_in_flight"] if pipelined else 1,
-            "ms_per_frame_synchronous": None if sync_ms is None else round(sync_ms, 3),
-            "mrays_per_s_synchronous": None if sync_ms is None else round(rays_frame / max(1, world) / sync_ms / 1e3, 2),  # this rank's frames one at a time
-            # device time from a frame's first kernel to its last: with frames in flight this is one frame's LATENCY (three frames overlap),
-            # not the time per frame — that is ms_per_step
-            "render_ms_per_frame": round(agg["render_ms"] / args.steps, 3),
-            "frame_latency_ms": round(agg["render_ms"] / args.steps, 3),
+            "subframes_per_batch": args.batch,
+            # the same frames on the library's other schedules, measured after the timed region (same images bit for bit; not `value`)
+            "mrays_per_s_pipelined": extra_out.get("pipelined", {}).get("mrays_per_s"),
+            "ms_per_frame_pipelined": extra_out.get("pipelined", {}).get("ms_per_frame"),
+            "batched": extra_out.get("batched"),
+            "batched_pipelined": extra_out.get("batched_pipelined"),
+            # device time from a launch chain's first kernel to its last (with frames in flight: one frame's LATENCY, three frames overlap) — of the last chain of the loop
+            "frame_latency_ms": round(agg["render_ms"] / (args.steps // args.batch), 3),
             "ms_per_step_per_rank": per_rank_ms,
             "kernel_ms_per_frame_isolated": None if iso is None else {k: round(iso[k], 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
             "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2)},
@@ -352,7 +411,8 @@ def main():
                 "kernel": "whole frame, all wavefront stages (SURVEY.md 8d: rays x 160 B + pixels x 84 B + scene bytes)", "bound": "hbm",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "alg_bytes_per_frame": int(alg_frame), "scene_bytes": int(scene_bytes),
-                "measured_limiter": "dependent-load latency at 5 waves/SIMD (waves wait on memory 42 % of their time, VALU pipe 59 % used) — not HBM (see valu.wave_state / profiles/r2_08_wave_state.md)",
+                # what the counters say limits the dominant kernel — quoted, like every PMC-derived figure, only for the profiled sources
+                "measured_limiter": limiter,
                 "dominant_kernel": None if trav_ms <= 0 else {
                     "kernel": kname + " (BVH traversal: closest-hit + shadow rays per launch)", "bytes_per_ray": [BYTES_PER_RADIANCE_RAY_TRACE, BYTES_PER_SHADOW_RAY_TRACE],
                     "alg_bytes_per_launch": int(trav_bytes), "avg_launch_ms": round(trav_ms, 4), "isolated": iso is not None,

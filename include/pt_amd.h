@@ -186,6 +186,15 @@ int pt_set_partition(pt_ctx* ctx, int rank, int world, int tile_w, int tile_h);
  * Silently does nothing before the first pt_resize (:77). If host_rgba8 is non-NULL the frame
  * buffer is copied into it (render(CUDAOutputBuffer&) + downloadPixels, :99-107,149-153). */
 int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8);
+/* `count` consecutive launches of the reference's progressive loop — render() with subframe_index = first_subframe, first_subframe + 1, ...
+ * (main.cpp:273-278 renders, displays and increments every frame) — as ONE wavefront batch: the generate / traversal / shade launches carry
+ * the rays of all `count` subframes (seeds are tea<4>(pixel, subframe_index), deviceProgram.cu:357: subframes are independent until they
+ * blend) and the resolve blends them into accum_buffer in subframe order (:460-466).  All five buffers end up bit-identical to `count`
+ * calls of pt_render; what changes is the number of rays per launch, which is what a small share of a tile-partitioned frame lacks
+ * (a 1/8 share of 1080p x 4 spp is 1 M paths; a persistent traversal wave wants several chunks of work).  The intermediate frames are
+ * not displayed: a display loop that shows every frame keeps calling pt_render.  count in [1,4096]; pt_render == count 1.
+ * pt_stats.frames advances by count. */
+int pt_render_batch(pt_ctx* ctx, uint32_t spp, uint32_t first_subframe, uint32_t count, uint32_t* host_rgba8);
 /* Waits for the frames in flight (pt_options.frames_in_flight = 2 or 3) and reports their errors; a no-op otherwise.  No reference
  * counterpart: the reference's render() is synchronous. */
 int pt_sync(pt_ctx* ctx);
@@ -306,6 +315,8 @@ int pt_multi_set_camera(pt_multi* m, const float eye[3], const float U[3], const
 /* gather_mask: bit (1 << pt_buffer) for every buffer to assemble on all ranks after the frame (0 = none: pure throughput);
  * host_rgba8 (may be NULL) receives rank 0's frame buffer and implies gathering PT_BUF_FRAME */
 int pt_multi_render(pt_multi* m, uint32_t spp, uint32_t subframe_index, uint32_t gather_mask, uint32_t* host_rgba8);
+/* pt_render_batch on every rank: `count` subframes in one wavefront batch per device, then the hand-over of the last one */
+int pt_multi_render_batch(pt_multi* m, uint32_t spp, uint32_t first_subframe, uint32_t count, uint32_t gather_mask, uint32_t* host_rgba8);
 int pt_multi_render_regions(pt_multi* m, const pt_region* regions, uint32_t n, const pt_variant* variant, uint32_t gather_mask, uint32_t* host_rgba8);
 int pt_multi_gather(pt_multi* m, int which /* pt_buffer */);
 int pt_multi_get_stats(const pt_multi* m, pt_multi_stats* out);

@@ -18,7 +18,7 @@ EXPORTS = [
     "pt_eval_table", "pt_version", "pt_set_probe_image", "pt_get_probe_cdf", "pt_render_regions", "pt_denoise",
     "pt_create_multi", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_size", "pt_multi_ctx", "pt_multi_set_options", "pt_multi_set_probe",
     "pt_multi_set_probe_image", "pt_multi_resize", "pt_multi_set_camera", "pt_multi_render", "pt_multi_render_regions", "pt_multi_gather",
-    "pt_multi_get_stats", "pt_export_bvh",
+    "pt_multi_get_stats", "pt_export_bvh", "pt_render_batch", "pt_multi_render_batch",
 ]
 
 
@@ -141,6 +141,7 @@ def load_library() -> C.CDLL:
     L.pt_uvw_frame.argtypes = [C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3), f, f, C.POINTER(f * 3), C.POINTER(f * 3), C.POINTER(f * 3)]
     L.pt_set_partition.argtypes = [vp, i, i, i, i]
     L.pt_render.argtypes = [vp, u32, u32, vp]
+    L.pt_render_batch.argtypes = [vp, u32, u32, u32, vp]
     L.pt_sync.argtypes = [vp]
     L.pt_render_regions.argtypes = [vp, C.POINTER(Region), u32, C.POINTER(Variant), vp]
     L.pt_download.argtypes = [vp, i, vp, C.c_size_t]
@@ -171,6 +172,7 @@ def load_library() -> C.CDLL:
     L.pt_multi_resize.argtypes = [vp, i, i, i, i]
     L.pt_multi_set_camera.argtypes = [vp, f3p, f3p, f3p, f3p]
     L.pt_multi_render.argtypes = [vp, u32, u32, u32, vp]
+    L.pt_multi_render_batch.argtypes = [vp, u32, u32, u32, u32, vp]
     L.pt_multi_render_regions.argtypes = [vp, C.POINTER(Region), u32, C.POINTER(Variant), u32, vp]
     L.pt_multi_gather.argtypes = [vp, i]
     L.pt_multi_get_stats.argtypes = [vp, C.POINTER(MultiStats)]

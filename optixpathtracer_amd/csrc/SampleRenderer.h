@@ -119,6 +119,12 @@ class SampleRenderer {
     void render() { ck(pt_render(ctx, launchParams.samples_per_launch, launchParams.frame.subframe_index, nullptr)); }
     // render(sutil::CUDAOutputBuffer<uint32_t>&): the caller's mapped buffer receives the rgba8 frame
     void render(uint32_t* h_pixels) { ck(pt_render(ctx, launchParams.samples_per_launch, launchParams.frame.subframe_index, h_pixels)); }
+    // `count` iterations of the application's progressive loop (render(); launchParams.frame.subframe_index++ — main.cpp:273-278) as one
+    // wavefront batch: the same buffers bit for bit, count times the rays per launch (pt_render_batch).  Advances subframe_index by count.
+    void renderBatch(uint32_t count, uint32_t* h_pixels = nullptr) {
+        ck(pt_render_batch(ctx, launchParams.samples_per_launch, launchParams.frame.subframe_index, count, h_pixels));
+        launchParams.frame.subframe_index += count;
+    }
     void resize(const int2& newSize) {
         ck(pt_resize(ctx, newSize.x, newSize.y));
         if (newSize.x && newSize.y) launchParams.frame.size = newSize;
@@ -184,6 +190,10 @@ class MultiSampleRenderer {
 
     void render() { ck(pt_multi_render(multi, launchParams.samples_per_launch, launchParams.frame.subframe_index, 1u << PT_BUF_FRAME, nullptr)); }
     void render(uint32_t* h_pixels) { ck(pt_multi_render(multi, launchParams.samples_per_launch, launchParams.frame.subframe_index, 1u << PT_BUF_FRAME, h_pixels)); }
+    void renderBatch(uint32_t count, uint32_t* h_pixels = nullptr) {
+        ck(pt_multi_render_batch(multi, launchParams.samples_per_launch, launchParams.frame.subframe_index, count, 1u << PT_BUF_FRAME, h_pixels));
+        launchParams.frame.subframe_index += count;
+    }
     void resize(const int2& newSize) {
         ck(pt_multi_resize(multi, newSize.x, newSize.y, 0, 0));
         if (newSize.x && newSize.y) launchParams.frame.size = newSize;

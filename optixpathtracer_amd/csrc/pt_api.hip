@@ -33,7 +33,6 @@ struct pt_ctx {
     uint32_t* d_idx = nullptr;
     uint32_t* d_tri_mesh = nullptr;
     pt_material* d_mats = nullptr;
-    PrimTri* d_prims = nullptr;
     bool has_catcher = false;
     // textures
     int32_t* d_mesh_tex = nullptr;
@@ -42,6 +41,7 @@ struct pt_ctx {
     std::vector<uint32_t*> d_tex_pixels;
     DevTex tex0{};
     PtBvh bvh;
+    bool bvh2_built = false; // the binary form (A/B paths) has been added to `bvh`
     double bvh_build_ms = 0;
     // probe
     DevProbe probe{};
@@ -73,6 +73,13 @@ struct pt_ctx {
         unsigned long long* totals = nullptr; // this set's ray counters of the frame being enqueued (a slice of d_totals)
     };
     std::vector<BatchSet> sets;
+    // The streams of the batch sets live as long as the context: path-state re-allocations keep them.  HIP maps streams onto four
+    // hardware queues in creation order, and which set streams come to share a queue decides whether frames overlap — measured: after a
+    // re-allocation had destroyed and re-created the streams, three frames in flight ran at 9.1 instead of 8.2 ms; with only the four streams
+    // the default schedule uses (context + one per set, no side streams) a synchronous frame takes 10.1 instead of 9.0 ms and a 1/8 share
+    // 2.57 instead of 1.77.  So the creation order that measures well is kept — context, then per set its stream and its first side
+    // stream — and never disturbed; the second side stream (asynchronous shadow rays) is created when that schedule is first asked for.
+    std::vector<hipStream_t> set_streams, side_streams; // [set], [2 * set + {0,1}]
     uint32_t set_cap = 0, set_pix_cap = 0, sub_cap = 0;
     bool cap_catcher = false, cap_async = false;
     int nq = 0;
@@ -103,10 +110,12 @@ struct pt_ctx {
         int active = 0;
         hipEvent_t ev_begin = nullptr, ev_end = nullptr;
         uint64_t paths = 0, seq = 0;
+        uint32_t subframes = 1; // subframes the slot's launch chain completes (pt_render_batch)
         LaunchCounts lc;
     };
     Inflight fr[3];
-    hipEvent_t ev_resolved = nullptr; // behind the last k_resolve of the newest frame in flight (frames_in_flight = 3: the next frame's resolve waits for it)
+    hipEvent_t ev_resolved = nullptr; // behind the last k_resolve of the newest frame in flight (the next frame's resolves wait for it where stream order alone does not order them)
+    int resolved_kind = 0;            // what recorded ev_resolved: 0 pt_render with pixel chunks (mode 2), 1 whole frames (mode 3), 2 pt_render_regions
     int last_slot = -1;
     int cur_slot = 0;      // slot whose events / counters the enqueue functions are filling
     uint64_t frame_seq = 0;
@@ -287,13 +296,10 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     CKC(dalloc(&ctx->d_idx, 3 * nt));
     CKC(dalloc(&ctx->d_tri_mesh, nt));
     CKC(dalloc(&ctx->d_mats, fs.mats.size()));
-    CKC(dalloc(&ctx->d_prims, nt));
     CKC(hipMemcpy(ctx->d_verts, fs.verts.data(), sizeof(float) * 3 * nv, hipMemcpyHostToDevice));
     CKC(hipMemcpy(ctx->d_idx, fs.idx.data(), sizeof(uint32_t) * 3 * nt, hipMemcpyHostToDevice));
     CKC(hipMemcpy(ctx->d_tri_mesh, fs.tri_mesh.data(), sizeof(uint32_t) * nt, hipMemcpyHostToDevice));
     CKC(hipMemcpy(ctx->d_mats, fs.mats.data(), sizeof(pt_material) * fs.mats.size(), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_emit_prims, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_verts, ctx->d_idx,
-                       ctx->d_tri_mesh, (uint32_t)nt, ctx->d_prims);
     {   // textures (createTextures, SimplePathtracer.cpp:603-654) and per-primitive texcoords (buildSBT :430-447)
         if (fs.any_tex) {
             float* d_tc = nullptr;
@@ -324,7 +330,7 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     CKC(tmp.event(&e0));
     CKC(tmp.event(&e1));
     CKC(hipEventRecord(e0, ctx->stream));
-    CKC(pt_bvh_build(ctx->d_verts, ctx->d_idx, (uint32_t)nt, 0, ctx->stream, &ctx->bvh));
+    CKC(pt_bvh_build(ctx->d_verts, ctx->d_idx, ctx->d_tri_mesh, (uint32_t)nt, 0, ctx->stream, &ctx->bvh));
     CKC(hipEventRecord(e1, ctx->stream));
     CKC(hipStreamSynchronize(ctx->stream));
     float ms = 0;
@@ -369,15 +375,13 @@ static void free_path_state(pt_ctx* ctx) {
     for (auto& b : ctx->sets) {
         if (b.stream) hipStreamSynchronize(b.stream);
         if (b.stream2) hipStreamSynchronize(b.stream2);
+        if (b.stream3) hipStreamSynchronize(b.stream3);
         PathState& s = b.st;
         dfree(s.rayO); dfree(s.rayD); dfree(s.srayD); dfree(s.pend); dfree(s.hit); dfree(s.thr); dfree(s.rng); dfree(s.fd);
         dfree(s.direct); dfree(s.indirect); dfree(s.alpha); dfree(s.nrm); dfree(s.alb); dfree(s.prdN); dfree(s.prdA);
         dfree(b.queueA); dfree(b.queueB); dfree(b.squeue); dfree(b.counters); dfree(b.ovf); dfree(b.ovf2);
         dfree(b.squeueB); dfree(b.ovf3); dfree(s.sO); dfree(s.sD); dfree(s.pendB); dfree(s.vis);
-        if (b.stream3) { hipStreamSynchronize(b.stream3); hipStreamDestroy(b.stream3); }
         dfree(b.pixResult); dfree(b.pixAlpha); dfree(b.pixNormal); dfree(b.pixAlbedo);
-        if (b.stream) hipStreamDestroy(b.stream);
-        if (b.stream2) hipStreamDestroy(b.stream2);
     }
     ctx->sets.clear();
     ctx->set_cap = ctx->set_pix_cap = 0;
@@ -394,8 +398,10 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     drain(ctx);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     free_path_state(ctx);
+    for (hipStream_t st : ctx->set_streams) if (st) hipStreamDestroy(st);
+    for (hipStream_t st : ctx->side_streams) if (st) hipStreamDestroy(st);
     free_frame(ctx);
-    dfree(ctx->d_verts); dfree(ctx->d_idx); dfree(ctx->d_tri_mesh); dfree(ctx->d_mats); dfree(ctx->d_prims);
+    dfree(ctx->d_verts); dfree(ctx->d_idx); dfree(ctx->d_tri_mesh); dfree(ctx->d_mats);
     dfree(ctx->d_mesh_tex); dfree(ctx->d_uvs); dfree(ctx->d_textures);
     for (uint32_t*& px : ctx->d_tex_pixels) dfree(px);
     pt_bvh_free(&ctx->bvh);
@@ -418,18 +424,29 @@ extern "C" int pt_set_options(pt_ctx* ctx, const pt_options* opt) {
     if (opt->max_depth < 0 || opt->max_depth > 250) return fail(ctx, PT_ERR_INVALID, "pt_set_options: max_depth out of range [0,250]");
     if (opt->bsdf_mode != PT_BSDF_DISNEY && opt->bsdf_mode != PT_BSDF_LAMBERT) return fail(ctx, PT_ERR_INVALID, "pt_set_options: bad bsdf_mode");
     if (opt->frames_in_flight < 0 || opt->frames_in_flight > PT_MAX_FRAMES) return fail(ctx, PT_ERR_INVALID, "pt_set_options: frames_in_flight must be 0 ... 3");
-    if ((opt->bvh_kind == 1 || opt->trace_kernel == 1) && !ctx->bvh.nodes) {
-        // the binary tree is an A/B path: built (with the wide tree, from the same hierarchy) the first time it is asked for
+    if ((opt->bvh_kind == 1 || opt->trace_kernel == 1) && !ctx->bvh2_built) {
+        // the binary tree is an A/B path: built (with the wide tree, from the same hierarchy) the first time it is asked for — into a
+        // temporary that replaces the live structure only when the build and the depth check succeeded
         CK(hipSetDevice(ctx->device));
         CK(hipStreamSynchronize(ctx->stream));
-        pt_bvh_free(&ctx->bvh);
-        CK(pt_bvh_build(ctx->d_verts, ctx->d_idx, ctx->ntri, 1, ctx->stream, &ctx->bvh));
-        CK(hipStreamSynchronize(ctx->stream));
+        PtBvh fresh;
+        hipError_t e = pt_bvh_build(ctx->d_verts, ctx->d_idx, ctx->d_tri_mesh, ctx->ntri, 1, ctx->stream, &fresh);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            pt_bvh_free(&fresh);
+            ctx->err = std::string("pt_set_options: building the binary BVH: ") + hipGetErrorString(e);
+            return PT_ERR_HIP;
+        }
+        std::swap(ctx->bvh, fresh);
         char msg[160];
         if (check_tree_depth(ctx, msg, sizeof(msg)) != PT_OK) {
+            std::swap(ctx->bvh, fresh); // keep the structure that passed its own check
+            pt_bvh_free(&fresh);
             ctx->err = std::string("pt_set_options: ") + msg;
             return PT_ERR_UNSUPPORTED;
         }
+        pt_bvh_free(&fresh);
+        ctx->bvh2_built = true;
     }
     ctx->opt = *opt;
     if (ctx->opt.max_paths == 0) ctx->opt.max_paths = 8u << 20;
@@ -674,6 +691,24 @@ static bool async_shadows(const pt_ctx* ctx) {
     return ctx->opt.split_shadow == 2 && !ctx->has_catcher && ctx->opt.bvh_kind == 0 && ctx->opt.trace_kernel == 0 && ctx->opt.max_depth < 31;
 }
 
+// the streams of batch set i (created on first use, kept until pt_destroy)
+static int assign_streams(pt_ctx* ctx, int nsets) {
+    const bool async = async_shadows(ctx);
+    if ((int)ctx->set_streams.size() < nsets) ctx->set_streams.resize(nsets, nullptr);
+    if ((int)ctx->side_streams.size() < 2 * nsets) ctx->side_streams.resize((size_t)2 * nsets, nullptr);
+    for (int i = 0; i < nsets; ++i) {
+        if (!ctx->set_streams[i]) CK(hipStreamCreate(&ctx->set_streams[i]));
+        if (!ctx->side_streams[2 * i]) CK(hipStreamCreate(&ctx->side_streams[2 * i]));
+        if (async && !ctx->side_streams[2 * i + 1]) CK(hipStreamCreate(&ctx->side_streams[2 * i + 1]));
+        if (i < (int)ctx->sets.size()) {
+            ctx->sets[i].stream = ctx->set_streams[i];
+            ctx->sets[i].stream2 = ctx->side_streams[2 * i];
+            ctx->sets[i].stream3 = ctx->side_streams[2 * i + 1];
+        }
+    }
+    return PT_OK;
+}
+
 static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_cap) {
     // one queue-counter slot per bounce plus the "would continue" slot; shadow-catcher scenes get two more for the extra
     // iterations of paths that passed through catcher surfaces (enqueue_chunk)
@@ -681,7 +716,7 @@ static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_
     const bool async = async_shadows(ctx);
     if ((int)ctx->sets.size() == nsets && cap <= ctx->set_cap && pix_cap <= ctx->set_pix_cap && nq <= ctx->nq &&
         (!ctx->has_catcher || ctx->cap_catcher) && async == ctx->cap_async)
-        return PT_OK;
+        return assign_streams(ctx, nsets);
     {
         int rc = drain(ctx); // frames in flight still use the old buffers
         if (rc) return rc;
@@ -691,9 +726,11 @@ static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_
     ctx->sets.resize(nsets);
     ctx->sub_cap = cap / PT_NSUB + 8192 + 1; // a sub-queue receives at most cap/64 + 32 workgroups * 256 entries
     const size_t qsize = (size_t)PT_NSUB * ctx->sub_cap;
+    {
+        int rc = assign_streams(ctx, nsets);
+        if (rc) return rc;
+    }
     for (auto& b : ctx->sets) {
-        CK(hipStreamCreate(&b.stream));
-        CK(hipStreamCreate(&b.stream2));
         PathState& s = b.st;
         CK(dalloc(&s.rayO, cap)); CK(dalloc(&s.rayD, cap)); CK(dalloc(&s.srayD, cap)); CK(dalloc(&s.pend, cap));
         CK(dalloc(&s.hit, cap)); CK(dalloc(&s.thr, cap)); CK(dalloc(&s.rng, cap)); CK(dalloc(&s.fd, cap));
@@ -704,7 +741,6 @@ static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_
         CK(dalloc(&b.ovf, ovf_words(ctx))); CK(dalloc(&b.ovf2, ovf_words(ctx)));
         CK(dalloc(&b.pixResult, pix_cap)); CK(dalloc(&b.pixAlpha, pix_cap)); CK(dalloc(&b.pixNormal, pix_cap)); CK(dalloc(&b.pixAlbedo, pix_cap));
         if (async) {
-            CK(hipStreamCreate(&b.stream3));
             CK(dalloc(&s.sO, (size_t)nq * cap)); CK(dalloc(&s.sD, (size_t)nq * cap)); CK(dalloc(&s.pendB, (size_t)nq * cap));
             CK(dalloc(&s.vis, cap));
             s.bstride = cap;
@@ -772,6 +808,8 @@ struct RegionJob { // non-null: one launch-index range of a foveated launch inst
     uint32_t l0, nl;
 };
 
+// spp: samples of the whole chunk = samples_per_launch x subframes of the batch (pt_render_batch; a foveated launch: its own spp),
+// S: samples per pass
 static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& fp, uint32_t pix0, uint32_t npix, uint32_t spp, uint32_t S,
                           LaunchCounts& lc, const RegionJob* job = nullptr, const std::vector<hipEvent_t>* before_resolve = nullptr) {
     const int nq = ctx->nq;
@@ -779,6 +817,8 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
     const int cull = job ? job->var.cull_back_occlusion : 0;
     BvhDev bvh{ctx->bvh.nodes, ctx->bvh.tris, ctx->bvh.root};
     Bvh8Dev bvh8{ctx->bvh.nodes8, ctx->bvh.tris8};
+    // the hit records index the leaf triangles of the structure that was traversed
+    const LeafTri* shade_tris = (ctx->opt.bvh_kind == 1 || ctx->opt.trace_kernel == 1) ? ctx->bvh.tris : ctx->bvh.tris8;
     const size_t CS = (size_t)PT_NSUB * PT_CSTRIDE;
     for (uint32_t s0 = 0; s0 < spp; s0 += S) {
         const uint32_t Sc = std::min(S, spp - s0);
@@ -787,8 +827,9 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
         // a small batch then runs faster on fewer waves (refill and drain phases amortised over more rays per wave) — measured optimum
         // ≈ 6 chunks of 64 of the pass's paths per wave
         const uint64_t pass_paths = job ? (uint64_t)job->nl * spp : (uint64_t)npix * Sc;
+        // (never above trace_grid: the spill stacks are sized for trace_grid waves and the kernels are compiled for that occupancy)
         const unsigned tgrid = !ctx->adapt_grid ? (unsigned)ctx->trace_grid
-            : (unsigned)std::max<uint64_t>((uint64_t)ctx->trace_grid_min, std::min<uint64_t>((uint64_t)ctx->trace_grid, pass_paths / (64ull * (uint64_t)ctx->grid_chunks)));
+            : (unsigned)std::min<uint64_t>((uint64_t)ctx->trace_grid, std::max<uint64_t>((uint64_t)ctx->trace_grid_min, pass_paths / (64ull * (uint64_t)ctx->grid_chunks)));
         BatchParams bp{ctx->d_pixels + pix0, npix, s0, Sc, ctx->has_catcher ? 1 : 0, bs.pixResult, bs.pixAlpha, bs.pixNormal, bs.pixAlbedo};
         hipMemsetAsync(bs.counters, 0, sizeof(uint32_t) * ((size_t)2 * nq * CS + 2 * nq), bs.stream);
         uint32_t* cntA = bs.counters;                       // radiance queue counters, per bounce
@@ -826,7 +867,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeueB + (size_t)b * qsize, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
+                ShadeParams sp{shade_tris, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
@@ -871,7 +912,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeue, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
+                ShadeParams sp{shade_tris, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
@@ -909,7 +950,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 ++lc.trace;
             }
-            ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
+            ShadeParams sp{shade_tris, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
             if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0); // shade overwrites what shadow(b-1) reads
             {
                 SpanGuard g(ctx, CLS_SHADE, bs.stream);
@@ -968,7 +1009,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 }
-                ShadeParams sp{ctx->d_prims, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, 1};
+                ShadeParams sp{shade_tris, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, 1};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
@@ -990,7 +1031,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
         // foveated launches: this launch's pixels are written after the previous launch's (they overlap); whole frames in flight: after the
         // previous frame's.  Only the pass that writes the frame buffers has to wait — earlier sample passes of a pixel chunk keep their sums in the
         // set's own pixResult arrays
-        if (before_resolve && (job || s0 + Sc >= spp))
+        if (before_resolve && (job || (s0 % fp.spp) + Sc >= fp.spp)) // the pass completes a subframe
             for (hipEvent_t e : *before_resolve) hipStreamWaitEvent(bs.stream, e, 0);
         {
             SpanGuard g(ctx, CLS_OTHER, bs.stream);
@@ -999,7 +1040,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             if (job)
                 hipLaunchKernelGGL(k_resolve_region, dim3((job->nl + 255) / 256), dim3(256), 0, bs.stream, bs.st, fp, job->rg, PartParams{ctx->rank, ctx->world, ctx->tile_w, ctx->tile_h}, job->var, job->l0, job->nl);
             else
-                hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, bs.stream, bs.st, fp, bp, (int)(s0 == 0), (int)(s0 + Sc >= spp));
+                hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, bs.stream, bs.st, fp, bp);
         }
     }
 }
@@ -1015,7 +1056,9 @@ static void begin_slot(pt_ctx* ctx, int slot) {
 }
 
 // mode 0: synchronous frame (pixel chunks on all streams); 2: the same chunks without a frame-wide start; 3: the whole frame on one stream
-static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, int slot = 0, int mode = 0) {
+// count > 1 (pt_render_batch): the launch chain carries the rays of `count` consecutive subframes — generate / trace / shade launches are
+// count times as large, the resolve blends the subframes in order — and leaves the buffers `count` frames would have left.
+static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, int slot = 0, int mode = 0, uint32_t count = 1) {
     const bool pipelined = mode != 0, whole = mode == 3;
     if (!pipelined) {
         int rc = drain(ctx);
@@ -1024,6 +1067,8 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
     ctx->fr[slot].active = 0;
     if (ctx->width == 0) return PT_OK; // not resized yet (SimplePathtracer.cpp:77)
     if (spp == 0 || spp > 4096) return fail(ctx, PT_ERR_INVALID, "pt_render: samples_per_launch must be in [1,4096]");
+    if (count == 0 || count > 4096 || (uint64_t)subframe_index + count > 0xffffffffull) return fail(ctx, PT_ERR_INVALID, "pt_render_batch: count must be in [1,4096] and the subframe indices must fit 32 bits");
+    const uint32_t vspp = spp * count; // samples of a pixel over the whole batch
     if (!ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_render: no probe set (setProbe)");
     CK(hipSetDevice(ctx->device));
     const uint32_t owned = ctx->owned;
@@ -1036,7 +1081,7 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
     const uint32_t cap = std::max<uint32_t>(64u, whole ? max_paths : max_paths / nsets);
     uint32_t Np = whole ? owned : (owned + nsets - 1) / nsets; // pixels per chunk ...
     Np = std::min(cap, std::max(64u, (Np + 63u) & ~63u)); // ... whole 8x8 blocks, within the set capacity
-    const uint32_t S = ctx->has_catcher ? 1u : std::max(1u, std::min(spp, cap / Np));
+    const uint32_t S = ctx->has_catcher ? 1u : std::max(1u, std::min(vspp, cap / Np));
     if (owned) {
         int rc = ensure_path_state(ctx, nsets, Np * S, Np); // waits for the frames in flight before it re-allocates
         if (rc) return rc;
@@ -1065,11 +1110,12 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
         if (ctx->ev_resolved) before.push_back(ctx->ev_resolved);
         ctx->adapt_grid = true;
         for (uint32_t pix0 = 0; pix0 < owned; pix0 += Np)
-            enqueue_chunk(ctx, bs, fp, pix0, std::min(Np, owned - pix0), spp, S, lc, nullptr, before.empty() ? nullptr : &before);
+            enqueue_chunk(ctx, bs, fp, pix0, std::min(Np, owned - pix0), vspp, S, lc, nullptr, before.empty() ? nullptr : &before);
         ctx->adapt_grid = false;
         hipEvent_t e = next_event(ctx);
         hipEventRecord(e, bs.stream);
         ctx->ev_resolved = e;
+        ctx->resolved_kind = 1;
         end_stream = bs.stream; // the whole frame is on this stream: the context's own stream stays out of the way (one hardware queue fewer)
     } else if (owned) {
         if (!pipelined) {
@@ -1079,9 +1125,13 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
             for (auto& b : ctx->sets) CK(hipMemsetAsync(b.totals, 0, sizeof(unsigned long long) * 4, b.stream));
             CK(hipEventRecord(ev_begin, ctx->sets[0].stream));
         }
+        // Chunk c of consecutive pt_render frames runs on the same stream, which orders their resolves; a foveated frame (pt_render_regions)
+        // deals its launches to the streams differently, so after one of those every resolve waits for that frame's end
+        std::vector<hipEvent_t> before;
+        if (pipelined && ctx->ev_resolved && ctx->resolved_kind != 0) before.push_back(ctx->ev_resolved);
         uint32_t k = 0;
         for (uint32_t pix0 = 0; pix0 < owned; pix0 += Np, ++k)
-            enqueue_chunk(ctx, ctx->sets[k % nsets], fp, pix0, std::min(Np, owned - pix0), spp, S, lc);
+            enqueue_chunk(ctx, ctx->sets[k % nsets], fp, pix0, std::min(Np, owned - pix0), vspp, S, lc, nullptr, before.empty() ? nullptr : &before);
         for (auto& b : ctx->sets) {
             hipEvent_t e = next_event(ctx);
             hipEventRecord(e, b.stream);
@@ -1093,11 +1143,16 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
     CK(hipMemcpyAsync(ctx->h_totals + (size_t)slot * PT_MAX_SETS * 4, totals_of(ctx, slot, 0), sizeof(unsigned long long) * PT_MAX_SETS * 4, hipMemcpyDeviceToHost, end_stream));
     hipEvent_t ev_end = next_event(ctx);
     CK(hipEventRecord(ev_end, end_stream));
+    if (pipelined && !whole) { // a later foveated frame (or a whole frame) orders its resolves behind this frame's end
+        ctx->ev_resolved = ev_end;
+        ctx->resolved_kind = 0;
+    }
     pt_ctx::Inflight& fr = ctx->fr[slot];
     fr.ev_begin = ev_begin;
     fr.ev_end = ev_end;
     fr.active = 1;
-    fr.paths = (uint64_t)owned * spp;
+    fr.paths = (uint64_t)owned * vspp;
+    fr.subframes = count;
     fr.lc = lc;
     fr.seq = ++ctx->frame_seq;
     return PT_OK;
@@ -1156,7 +1211,7 @@ static int render_finish(pt_ctx* ctx, int slot = 0) {
     st.paths = fr.paths;
     ctx->cum_radiance += totals[0];
     ctx->cum_shadow += totals[1];
-    ctx->cum_frames += 1;
+    ctx->cum_frames += fr.subframes;
     float ms = 0;
     hipEventElapsedTime(&ms, ev_begin, ev_end);
     st.render_ms = ms;
@@ -1202,10 +1257,10 @@ static int frames_mode(pt_ctx* ctx) {
     return (ctx->opt.frames_in_flight >= 2 && !ctx->span_timing() && !getenv("PT_DEBUG_COUNTS")) ? std::min(ctx->opt.frames_in_flight, PT_MAX_FRAMES) : 1;
 }
 // frame k goes into the slot the oldest finished frame has left ...
-static int pipelined_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, int F) {
+static int pipelined_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, int F, uint32_t count = 1) {
     const int slot = (ctx->last_slot + 1) % F;
     int rc = render_finish(ctx, slot);
-    if (rc == PT_OK) rc = render_enqueue(ctx, spp, subframe_index, slot, F);
+    if (rc == PT_OK) rc = render_enqueue(ctx, spp, subframe_index, slot, F, count);
     if (rc == PT_OK) ctx->last_slot = slot;
     return rc;
 }
@@ -1223,15 +1278,20 @@ static int pipelined_wait(pt_ctx* ctx, int F) {
 }
 
 extern "C" int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host_rgba8) {
+    return pt_render_batch(ctx, spp, subframe_index, 1, host_rgba8);
+}
+
+extern "C" int pt_render_batch(pt_ctx* ctx, uint32_t spp, uint32_t first_subframe, uint32_t count, uint32_t* host_rgba8) {
     if (!ctx) return PT_ERR_INVALID;
     const int F = frames_mode(ctx);
+    const uint32_t subframe_index = first_subframe;
     int rc;
     if (F == 1) {
         rc = drain(ctx);
-        if (rc == PT_OK) rc = render_enqueue(ctx, spp, subframe_index);
+        if (rc == PT_OK) rc = render_enqueue(ctx, spp, subframe_index, 0, 0, count);
         if (rc == PT_OK) rc = render_finish(ctx);
     } else {
-        rc = pipelined_enqueue(ctx, spp, subframe_index, F);
+        rc = pipelined_enqueue(ctx, spp, subframe_index, F, count);
         const int rw = pipelined_wait(ctx, F);
         if (rc == PT_OK) rc = rw;
     }
@@ -1332,8 +1392,12 @@ static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, co
     CK(hipMemcpyAsync(ctx->h_totals + (size_t)slot * PT_MAX_SETS * 4, totals_of(ctx, slot, 0), sizeof(unsigned long long) * PT_MAX_SETS * 4, hipMemcpyDeviceToHost, ctx->stream));
     hipEvent_t ev_end = next_event(ctx);
     CK(hipEventRecord(ev_end, ctx->stream));
-    if (pipelined) ctx->ev_resolved = ev_end; // behind every resolve of this frame
+    if (pipelined) { // behind every resolve of this frame
+        ctx->ev_resolved = ev_end;
+        ctx->resolved_kind = 2;
+    }
     pt_ctx::Inflight& fr = ctx->fr[slot];
+    fr.subframes = 1;
     fr.ev_begin = ev_begin;
     fr.ev_end = ev_end;
     fr.active = 1;
@@ -1607,6 +1671,10 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
         }
     }
     CK(hipEventRecord(e1, ctx->stream));
+    if (!any_hit) { // hit records name leaf triangles; the caller wants optixGetPrimitiveIndex
+        const LeafTri* lt = (ctx->opt.bvh_kind == 1 || ctx->opt.trace_kernel == 1) ? ctx->bvh.tris : ctx->bvh.tris8;
+        hipLaunchKernelGGL(k_hits_to_prims, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dHit, lt, n);
+    }
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipGetLastError());
     float ms = 0;
@@ -1986,6 +2054,10 @@ static int multi_after_render(pt_multi* m, uint32_t gather_mask, uint32_t* host_
 }
 
 extern "C" int pt_multi_render(pt_multi* m, uint32_t spp, uint32_t subframe_index, uint32_t gather_mask, uint32_t* host_rgba8) {
+    return pt_multi_render_batch(m, spp, subframe_index, 1, gather_mask, host_rgba8);
+}
+
+extern "C" int pt_multi_render_batch(pt_multi* m, uint32_t spp, uint32_t subframe_index, uint32_t count, uint32_t gather_mask, uint32_t* host_rgba8) {
     if (!m) return PT_ERR_INVALID;
     const int world = (int)m->ctx.size();
     const int F = world ? frames_mode(m->ctx[0]) : 1;
@@ -1993,7 +2065,7 @@ extern "C" int pt_multi_render(pt_multi* m, uint32_t spp, uint32_t subframe_inde
         // pure throughput (nothing is handed over after this frame): pt_options.frames_in_flight applies on every device
         int first = PT_OK;
         for (int r = 0; r < world; ++r) {
-            int rc = mctx(m, r, pipelined_enqueue(m->ctx[r], spp, subframe_index, F), "pt_multi_render");
+            int rc = mctx(m, r, pipelined_enqueue(m->ctx[r], spp, subframe_index, F, count), "pt_multi_render");
             if (rc && !first) first = rc;
         }
         for (int r = 0; r < world; ++r) {
@@ -2004,7 +2076,7 @@ extern "C" int pt_multi_render(pt_multi* m, uint32_t spp, uint32_t subframe_inde
     }
     // enqueue on every device, then wait: the devices render their tiles concurrently
     for (int r = 0; r < world; ++r) {
-        int rc = mctx(m, r, render_enqueue(m->ctx[r], spp, subframe_index), "pt_multi_render");
+        int rc = mctx(m, r, render_enqueue(m->ctx[r], spp, subframe_index, 0, 0, count), "pt_multi_render");
         if (rc) return rc;
     }
     int first = PT_OK;

@@ -21,7 +21,10 @@ struct Node2 {
 #define PT_REF_EMPTY 0x7fffffff
 #define PT_LEAF_MAX 4
 
-// 48-byte leaf triangle, in leaf order: t0 = (v0.xyz, v1.x) t1 = (v1.yz, v2.xy) t2 = (v2.z, prim bits, -, -)
+// 48-byte leaf triangle, in leaf order: t0 = (v0.xyz, v1.x) t1 = (v1.yz, v2.xy) t2 = (v2.z, prim bits, mesh bits, -).
+// The hit record of a closest-hit ray holds the INDEX of the leaf triangle (not the primitive): the shade kernel reads the very
+// 48 bytes the traversal just pulled through the caches — vertices, primitive (for texcoords) and mesh (material record, what the
+// SBT record index gave the reference, deviceProgram.cu:481-489) — instead of a second triangle array in primitive order.
 struct LeafTri {
     float4 t0, t1, t2;
 };
@@ -82,13 +85,13 @@ PT_DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, floa
 #define PT_STACK_DEPTH 64
 
 // Per-lane traversal with the stack in LDS (stack[level * stride + lane_slot]).
-// ANY: stop at the first hit in (tmin,tmax) → prim = 1/0.  else closest hit → (t, global prim or -1).
+// ANY: stop at the first hit in (tmin,tmax) → prim = 1/0.  else closest hit → (t, leaf-triangle index of the hit or -1).
 template <bool ANY>
 PT_DEV void bvh2_traverse(const BvhDev& bvh, v3 o, v3 d, float tmin, float tmax, uint32_t* stack, uint32_t stride,
                           float& t_out, int32_t& prim_out) {
     const RaySetup r = ray_setup(o, d);
     float best = tmax;
-    int32_t bprim = -1;
+    int32_t bprim = -1, bleaf = -1;
     int sp = 0;
     int32_t node = bvh.root;
     for (;;) {
@@ -133,6 +136,7 @@ PT_DEV void bvh2_traverse(const BvhDev& bvh, v3 o, v3 d, float tmin, float tmax,
                     } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim))) {
                         best = t;
                         bprim = prim;
+                        bleaf = (int32_t)(first + k);
                     }
                 }
             }
@@ -142,5 +146,5 @@ PT_DEV void bvh2_traverse(const BvhDev& bvh, v3 o, v3 d, float tmin, float tmax,
         node = (int32_t)stack[(--sp) * stride];
     }
     t_out = best;
-    prim_out = ANY ? 0 : bprim;
+    prim_out = ANY ? 0 : bleaf;
 }

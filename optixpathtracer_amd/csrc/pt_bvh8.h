@@ -19,6 +19,10 @@
 // that order is found by three mask-and-select steps (z half, y quarter, x slot on the side the ray enters first).
 // The triangle test is pt_bvh.h's tri_test, bit-identical to the CPU checker; closest hit + lowest
 // primitive tie-break make the result independent of the tree.
+// The closest-hit record is (t, index of the leaf triangle): k_shade re-reads those 48 bytes (vertices, primitive, mesh).  A lane
+// therefore tracks the leaf index of its best hit beside the primitive id (which decides exact ties in t).  In the stealing phase
+// the shared 64-bit key carries the primitive (lexicographic minimum = the tie-break rule) and the leaf index of the key's holder
+// sits beside the key in LDS (s_leaf).
 #pragma once
 #ifdef PT_BVH8_NODE_ONLY
 #include "pt_bvh.h"
@@ -119,6 +123,8 @@ k_trace8(Trace8Args a) {
 #if PT8_STEAL
     __shared__ unsigned long long s_key[64]; // per owner lane: merged result of the ray that lane loaded
     __shared__ uint32_t s_cnt[64];           // per owner lane: co-workers still traversing that ray
+    __shared__ int32_t s_leaf[64];           // per owner lane: leaf triangle of the hit s_key holds (written by whoever lowered the key — one wave per
+                                             // workgroup, so after every lane's atomic minimum exactly the lanes whose key IS the minimum write it)
     __shared__ uint32_t s_vlane[64];         // steal round: victim lane by rank
 #endif
     const uint32_t lane = threadIdx.x;
@@ -141,15 +147,22 @@ k_trace8(Trace8Args a) {
     RaySetup r;
     r.o = r.d = r.idir = r.dn = mk3(0.f);
     float tmin = 0.f, tmax = 0.f, best = 0.f;
-    int32_t bprim = -1;
+    int32_t bprim = -1;                        // closest-hit lanes: primitive of the best hit; shadow lanes: 1 = occluded
+    int32_t bleaf = -1;                        // closest-hit lanes: leaf triangle of the best hit (before the stealing phase; then s_leaf)
     uint32_t pm = 0;                           // near-side slot masks of the ray's octant: z half | y quarters << 8 | x slots << 16
     uint32_t g_base = 0, g_imask = 0, g_hits = 0; // current node group: children still to visit (slot positions)
     uint32_t t_base = 0, t_mask = 0, t_bits = 0; // current triangle group: pending bits of the node's leafbits
     int sp = 0;
-    int sb = 0;              // stack bottom: levels [sb, sp) are live (entries below sb were taken by co-workers)
     bool stealing = false;   // wave-uniform: the queue is exhausted and the shared records are in use
-    uint32_t owner = lane;   // the lane whose record this lane's ray belongs to
-    uint32_t slot = 0, hint1 = 0, hint2 = 0;
+    // four small per-lane fields share one register (the kernel sits exactly at the 96 VGPRs of 5 waves per SIMD):
+    //   owner (bits 0-7): the lane whose shared record this lane's ray belongs to | hint1, hint2 (8-15, 16-23): sub-queue of the lane's last
+    //   queue lookups | sb (24-31): stack bottom — levels [sb, sp) are live, entries below sb were taken by co-workers
+    uint32_t misc = lane;
+#define OWNER (misc & 0xffu)
+#define SB ((int)(misc >> 24))
+#define SET_OWNER(v) (misc = (misc & ~0xffu) | (uint32_t)(v))
+#define SET_SB(v) (misc = (misc & 0x00ffffffu) | ((uint32_t)(v) << 24))
+    uint32_t slot = 0;
 #if PT8_DEFER_WRITE
     bool unwritten = false; // this lane holds a finished ray whose result is not written yet
 #endif
@@ -220,11 +233,11 @@ k_trace8(Trace8Args a) {
     auto finish = [&]() {
 #if PT8_STEAL
         if (stealing) {
-            atomicMin(&s_key[owner], local_key());
-            if (atomicSub(&s_cnt[owner], 1u) == 1u) { // the last co-worker publishes the merged result
-                const unsigned long long k = s_key[owner];
+            atomicMin(&s_key[OWNER], local_key());
+            if (atomicSub(&s_cnt[OWNER], 1u) == 1u) { // the last co-worker publishes the merged result
+                const unsigned long long k = s_key[OWNER];
                 if (is_shadow()) write_result(0.f, k == 0ull ? 1 : 0);
-                else write_result(__uint_as_float((uint32_t)(k >> 32)), (int32_t)(uint32_t)k);
+                else write_result(__uint_as_float((uint32_t)(k >> 32)), (int32_t)(uint32_t)k < 0 ? -1 : s_leaf[OWNER]);
             }
             active = false;
             return;
@@ -236,7 +249,7 @@ k_trace8(Trace8Args a) {
         // idle until the next refill — and all finished lanes write together at the top of the loop.
         unwritten = true;
 #else
-        write_result(best, bprim);
+        write_result(best, is_shadow() ? bprim : bleaf);
 #endif
         active = false;
         PT_STAT(if (c_ray > c_raymax) c_raymax = c_ray;
@@ -247,7 +260,7 @@ k_trace8(Trace8Args a) {
     for (;;) {
 #if PT8_DEFER_WRITE
         if (unwritten) { // results of the rays that finished since the last pass: all finished lanes at once
-            write_result(best, bprim);
+            write_result(best, is_shadow() ? bprim : bleaf);
             unwritten = false;
         }
 #endif
@@ -274,9 +287,13 @@ k_trace8(Trace8Args a) {
                     // shadow rays first: the longest rays of a launch are probe shadow rays that graze the terrain and hit nothing;
                     // started early, their tails overlap the closest-hit bulk instead of trailing it
                     shadow_lane = gi < n2;
-                    slot = shadow_lane ? qreader_get_hint(a.queue2, s_prefix2, gi, hint2) : qreader_get_hint(a.queue, s_prefix, gi - n2, hint1);
+                    uint32_t hint = shadow_lane ? (misc >> 16) & 0xffu : (misc >> 8) & 0xffu;
+                    slot = shadow_lane ? qreader_get_hint(a.queue2, s_prefix2, gi, hint) : qreader_get_hint(a.queue, s_prefix, gi - n2, hint);
+                    misc = shadow_lane ? (misc & 0xff00ffffu) | (hint << 16) : (misc & 0xffff00ffu) | (hint << 8);
                 } else {
-                    slot = qreader_get_hint(a.queue, s_prefix, gi, hint1);
+                    uint32_t hint = (misc >> 8) & 0xffu;
+                    slot = qreader_get_hint(a.queue, s_prefix, gi, hint);
+                    misc = (misc & 0xffff00ffu) | (hint << 8);
                 }
                 float4 o4, d4;
                 if (MODE == TR_SHADOW_APPLY || (MODE == TR_UNIFIED && shadow_lane)) {
@@ -318,8 +335,9 @@ k_trace8(Trace8Args a) {
                      (((__float_as_uint(d4.x) >> 31) ? 0xAAu : 0x55u) << 16);
                 best = tmax;
                 bprim = (MODE == TR_CLOSEST || (MODE == TR_UNIFIED && !shadow_lane)) ? -1 : 0;
+                bleaf = -1;
                 sp = 0;
-                sb = 0;
+                SET_SB(0);
                         // the root is node 0: a group whose only internal child is slot 0 of a virtual parent
                 g_base = 0;
                 g_imask = 1u;
@@ -332,8 +350,9 @@ k_trace8(Trace8Args a) {
         if (exhausted) {
             if (!stealing) { // the wave took its last chunk: from here on its rays are shared work
                 stealing = true;
-                owner = lane;
+                SET_OWNER(lane);
                 if (active) {
+                    s_leaf[lane] = bleaf; // from here on the leaf index of a ray's best hit lives beside its shared key
                     s_cnt[lane] = 1u;
                     s_key[lane] = local_key();
                 }
@@ -341,7 +360,7 @@ k_trace8(Trace8Args a) {
             }
             // ---------------- steal round: idle lane k takes the bottom stack entry of victim k
             const unsigned long long idle2 = __ballot(!active);
-            const bool victim = active && sp > sb && sb < lds_depth;
+            const bool victim = active && sp > SB && SB < lds_depth;
             const unsigned long long vmask = __ballot(victim);
             if (idle2 != 0ull && vmask != 0ull) {
                 const uint32_t ni = (uint32_t)__popcll(idle2), nv = (uint32_t)__popcll(vmask);
@@ -356,8 +375,9 @@ k_trace8(Trace8Args a) {
                 const float ix = __shfl(r.idir.x, (int)v), iy = __shfl(r.idir.y, (int)v), iz = __shfl(r.idir.z, (int)v);
                 const float nx_ = __shfl(r.dn.x, (int)v), ny_ = __shfl(r.dn.y, (int)v), nz_ = __shfl(r.dn.z, (int)v);
                 const float vtmin = __shfl(tmin, (int)v), vtmax = __shfl(tmax, (int)v);
-                const uint32_t vpm = __shfl(pm, (int)v), vslot = __shfl(slot, (int)v), vowner = __shfl(owner, (int)v);
-                const int vsb = __shfl(sb, (int)v);
+                const uint32_t vpm = __shfl(pm, (int)v), vslot = __shfl(slot, (int)v), vmisc = __shfl(misc, (int)v);
+                const uint32_t vowner = vmisc & 0xffu;
+                const int vsb = (int)(vmisc >> 24);
                 const int vshadow = __shfl((int)shadow_lane, (int)v);
                 if (take) {
                     r.o = mk3(ox, oy, oz);
@@ -368,16 +388,17 @@ k_trace8(Trace8Args a) {
                     tmax = vtmax;
                     pm = vpm;
                     slot = vslot;
-                    owner = vowner;
+                    SET_OWNER(vowner);
                     shadow_lane = vshadow != 0;
                     const uint32_t e0 = s_stack[(vsb * 2) * 64 + v], e1 = s_stack[(vsb * 2 + 1) * 64 + v];
                     g_base = e0;
                     g_imask = e1 & 0xffu;
                     g_hits = e1 >> 8;
                     t_mask = 0;
-                    sp = sb = 0;
+                    sp = 0;
+                    SET_SB(0);
                     // start from the ray's merged state (so that the tie-break "equal t, lower primitive" sees the current holder)
-                    const unsigned long long k = s_key[owner];
+                    const unsigned long long k = s_key[OWNER];
                     if (is_shadow()) {
                         best = tmax;
                         bprim = 0; // k == 0 (already occluded) is caught by the refresh below
@@ -385,13 +406,14 @@ k_trace8(Trace8Args a) {
                         best = __uint_as_float((uint32_t)(k >> 32));
                         bprim = (int32_t)(uint32_t)k;
                     }
-                    atomicAdd(&s_cnt[owner], 1u);
+                    atomicAdd(&s_cnt[OWNER], 1u);
                     active = true;
                 }
                 __syncthreads(); // takers have read the entries before their victims may overwrite those levels
                 if (give) {
-                    ++sb;
-                    if (sb == sp) sb = sp = 0;
+                    const int nsb = SB + 1;
+                    SET_SB(nsb == sp ? 0 : nsb);
+                    if (nsb == sp) sp = 0;
                 }
             }
         }
@@ -404,7 +426,7 @@ k_trace8(Trace8Args a) {
         do {
 #if PT8_STEAL
             if (stealing && active) { // pick up what the ray's other workers found
-                const unsigned long long k = s_key[owner];
+                const unsigned long long k = s_key[OWNER];
                 if (is_shadow()) {
                     if (k == 0ull) finish(); // occluded elsewhere: nothing left to do for this ray
                 } else if (k < local_key()) {
@@ -426,7 +448,7 @@ k_trace8(Trace8Args a) {
             bool do_node = false;
             if (want_node && node_turn) {
                 if (g_hits == 0u) {
-                    if (sp == sb) {
+                    if (sp == SB) {
                         finish();
                     } else {
                         uint32_t v0, v1;
@@ -462,8 +484,10 @@ k_trace8(Trace8Args a) {
                 const uint32_t bit = (uint32_t)__ffs((int)t_mask) - 1u;
                 t_mask &= t_mask - 1u;
                 PT_STAT(++c_tris; ++c_ray;)
-                const LeafTri* tp = &a.bvh.tris[t_base + (uint32_t)__popc(t_bits & ((1u << bit) - 1u))];
+                const uint32_t leaf = t_base + (uint32_t)__popc(t_bits & ((1u << bit) - 1u));
+                const LeafTri* tp = &a.bvh.tris[leaf];
                 r0 = tp->t0; r1 = tp->t1; r2 = tp->t2;
+                r3.x = __uint_as_float(leaf); // rides to phase 2 in a register the node lanes keep live anyway
             }
             // ---- phase 2: the arithmetic
             if (do_node) {
@@ -524,8 +548,13 @@ k_trace8(Trace8Args a) {
                     } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim))) {
                         best = t;
                         bprim = prim;
+                        bleaf = (int32_t)__float_as_uint(r3.x);
 #if PT8_STEAL
-                        if (stealing) atomicMin(&s_key[owner], local_key());
+                        if (stealing) {
+                            const unsigned long long key = local_key();
+                            atomicMin(&s_key[OWNER], key);
+                            if (s_key[OWNER] == key) s_leaf[OWNER] = bleaf;
+                        }
 #endif
                     }
                 }
@@ -560,4 +589,8 @@ k_trace8(Trace8Args a) {
         }
     })
 }
+#undef OWNER
+#undef SB
+#undef SET_OWNER
+#undef SET_SB
 #endif // PT_BVH8_NODE_ONLY

@@ -192,7 +192,7 @@ __global__ void k_emit_nodes(int n, const int* __restrict__ left, const int* __r
     nodes[remap[i]] = nd;
 }
 
-__global__ void k_emit_tris(const float* __restrict__ verts, const uint32_t* __restrict__ idx,
+__global__ void k_emit_tris(const float* __restrict__ verts, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ tri_mesh,
                             const uint64_t* __restrict__ keys, int n, LeafTri* __restrict__ tris) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -203,7 +203,7 @@ __global__ void k_emit_tris(const float* __restrict__ verts, const uint32_t* __r
     LeafTri t;
     t.t0 = make_float4(v0[0], v0[1], v0[2], v1[0]);
     t.t1 = make_float4(v1[1], v1[2], v2[0], v2[1]);
-    t.t2 = make_float4(v2[2], __int_as_float((int)p), 0.f, 0.f);
+    t.t2 = make_float4(v2[2], __int_as_float((int)p), __int_as_float(tri_mesh ? (int)tri_mesh[p] : 0), 0.f); // (v2.z, primitive, mesh = material record, -)
     tris[i] = t;
 }
 
@@ -674,7 +674,7 @@ static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt,
 }
 
 // Builds the traversal structure for (verts, idx) already resident on the device.
-hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t ntri, int want_bvh2, hipStream_t stream, PtBvh* out) {
+hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint32_t* d_tri_mesh, uint32_t ntri, int want_bvh2, hipStream_t stream, PtBvh* out) {
     out->nodes = nullptr;
     out->tris = nullptr;
     out->num_nodes = 0;
@@ -714,7 +714,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t nt
 
     LeafTri* tris = nullptr;
     HIPCHK(hipMalloc(&tris, sizeof(LeafTri) * (size_t)n));
-    hipLaunchKernelGGL(k_emit_tris, dim3((n + B - 1) / B), dim3(B), 0, stream, d_verts, d_idx, keys_sorted, n, tris);
+    hipLaunchKernelGGL(k_emit_tris, dim3((n + B - 1) / B), dim3(B), 0, stream, d_verts, d_idx, d_tri_mesh, keys_sorted, n, tris);
     out->tris = tris;
 
     if (n <= PT_LEAF_MAX) { // the whole scene is one leaf

@@ -27,5 +27,6 @@ struct PtBvh {
 };
 
 // want_bvh2: also keep the binary form (A/B paths only; the default traversal uses the 8-wide tree alone)
-hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, uint32_t ntri, int want_bvh2, hipStream_t stream, PtBvh* out);
+// d_tri_mesh: mesh (= material record) of every triangle, stored with the leaf triangles (may be null: 0)
+hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint32_t* d_tri_mesh, uint32_t ntri, int want_bvh2, hipStream_t stream, PtBvh* out);
 void pt_bvh_free(PtBvh* b);

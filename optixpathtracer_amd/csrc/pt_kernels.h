@@ -20,17 +20,12 @@ enum { FLAG_DONE = 1, FLAG_SECONDARY = 2, FLAG_CULLED = 4 /* outside the foveati
 enum { PEND_DIRECT = 1, PEND_INDIRECT = 2, PEND_ALPHA = 3 };
 enum { TR_CLOSEST = 0, TR_SHADOW_APPLY = 1, TR_ANY_QUERY = 2, TR_UNIFIED = 3 /* closest-hit queue + shadow queue in one launch */ }; // modes of the persistent traversal kernels
 
-// 48-byte triangle in PRIMITIVE order for shading (what sbtData.vertex[index[prim]] gave, :485-489)
-struct PrimTri {
-    float4 t0, t1, t2; // (v0.xyz,v1.x) (v1.yz,v2.xy) (v2.z, mesh id bits, -, -)
-};
-
 struct PathState {
     float4* rayO;  // next ray origin xyz, tmin
     float4* rayD;  // next ray direction xyz, tmax
     float4* srayD; // shadow ray direction (origin = rayO.xyz, tmin .01, tmax 1e16)
     float4* pend;  // pending NEE contribution xyz, kind bits in w
-    float2* hit;   // t, prim bits
+    float2* hit;   // t, bits of the leaf triangle's index (pt_bvh.h LeafTri; negative = miss)
     float4* thr;   // pathThroughput xyz, rayEta
     uint2* rng;    // Random seed1, seed2
     uint32_t* fd;  // depth | flags << 8
@@ -64,7 +59,10 @@ struct FrameParams { // LaunchParams (LaunchParams.h:51-79) minus the OptiX hand
 struct BatchParams {
     const uint32_t* pixels; // x | y << 16 for the pixels of this chunk
     uint32_t npix;          // pixels in the chunk
-    uint32_t s0, S;         // first sample and number of samples in the chunk
+    // Samples of the pass, counted over the whole batch of subframes (pt_render_batch): "virtual sample" v = j * spp + s is sample s of
+    // subframe fp.subframe_index + j (seeds are tea<4>(pixel, subframe), deviceProgram.cu:357, so subframes are independent until
+    // they blend).  A single frame is the batch of one subframe: v = s.
+    uint32_t s0, S;         // first virtual sample and number of virtual samples in the pass
     int carry;              // nrm/alb carried through pixNormal/pixAlbedo (sequential-sample mode)
     float4 *pixResult, *pixAlpha, *pixNormal, *pixAlbedo; // per pixel of the chunk
 };
@@ -131,11 +129,12 @@ __global__ void __launch_bounds__(256) k_generate(PathState st, FrameParams fp, 
     const uint32_t total = bp.npix * bp.S;
     if (blockIdx.x == 0 && threadIdx.x == 0) *qcount0 = total;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const uint32_t sl = i / bp.npix, pix = i - sl * bp.npix;
+        const uint32_t vl = i / bp.npix, pix = i - vl * bp.npix;
         const uint32_t xy = bp.pixels[pix];
         const uint32_t x = xy & 0xffffu, y = xy >> 16;
-        uint32_t seed = tea4(y * (uint32_t)fp.width + x, fp.subframe_index);
-        for (uint32_t k = 0; k < 2u * (bp.s0 + sl); ++k) lcg(seed); // earlier samples drew 2 rnd() each (:388)
+        const uint32_t v = bp.s0 + vl, sub = v / fp.spp, sl = v - sub * fp.spp; // sample sl of subframe subframe_index + sub
+        uint32_t seed = tea4(y * (uint32_t)fp.width + x, fp.subframe_index + sub);
+        for (uint32_t k = 0; k < 2u * sl; ++k) lcg(seed); // earlier samples drew 2 rnd() each (:388)
         Rng r;
         r.init(seed); // prd.rand = Random(seed) BEFORE the jitter draws (:375-376)
         const float jx = rnd(seed), jy = rnd(seed);
@@ -153,8 +152,8 @@ __global__ void __launch_bounds__(256) k_generate(PathState st, FrameParams fp, 
         st.indirect[i] = z;
         if (st.prdN) { // shadow-catcher scenes
             st.alpha[i] = z;
-            st.nrm[i] = (bp.carry && bp.s0 > 0) ? bp.pixNormal[pix] : z; // carry-in of the running per-pixel sum
-            st.alb[i] = (bp.carry && bp.s0 > 0) ? bp.pixAlbedo[pix] : z;
+            st.nrm[i] = (bp.carry && sl > 0) ? bp.pixNormal[pix] : z; // carry-in of the running per-pixel sum of this subframe
+            st.alb[i] = (bp.carry && sl > 0) ? bp.pixAlbedo[pix] : z;
             st.prdN[i] = z;
             st.prdA[i] = z;
         }
@@ -197,7 +196,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace(PathState st, BvhDev b
             const float4 d4 = st.rayD[p];
             bvh2_traverse<false>(bvh, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, d4.w, &s_stack[threadIdx.x],
                                  PT_TRACE_BLOCK, t, prim);
-            st.hit[p] = make_float2(t, __int_as_float(prim));
+            st.hit[p] = make_float2(t, __int_as_float(prim)); // closest hit: bvh2_traverse returns the leaf triangle's index
         }
     }
 }
@@ -207,7 +206,7 @@ struct PrimUV { // texcoords of the three vertices of a primitive (sbtData.texco
     float2 c0, c1, c2;
 };
 struct ShadeParams {
-    const PrimTri* prims;
+    const LeafTri* tris; // the traversal structure's leaf triangles: vertices, primitive and mesh of a hit (what sbtData.vertex[index[prim]] and the SBT record gave, :481-489)
     const pt_material* mats;
     const int32_t* mesh_tex; // per mesh: texture id when the mesh has a texture AND texcoords, else -1 (null: no textures)
     const PrimUV* uvs;
@@ -241,11 +240,11 @@ PT_DEV void queue_push(bool pred, uint32_t value, const QView& q) {
 template <int MODE, bool CATCHER>
 PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMarg& pm, uint32_t p, bool& push_next, bool& push_shadow, int& shadow_bounce) {
     const float2 h = st.hit[p];
-    const int32_t prim = __float_as_int(h.y);
+    const int32_t leaf = __float_as_int(h.y);
     uint32_t fd = st.fd[p];
     int depth = (int)(fd & 0xffu);
     uint32_t flags = fd >> 8;
-    if (prim < 0) {
+    if (leaf < 0) {
         // __miss__radiance (:209-235): prd.normal = prd.albedo = 0 (adds nothing at depth 0), DONE
         flags |= FLAG_DONE;
         if (CATCHER) {
@@ -256,10 +255,11 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             st.alb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
-        const PrimTri tri = sp.prims[prim];
+        const LeafTri tri = sp.tris[leaf];
         const v3 v0 = mk3(tri.t0.x, tri.t0.y, tri.t0.z), v1 = mk3(tri.t0.w, tri.t1.x, tri.t1.y),
                  v2 = mk3(tri.t1.z, tri.t1.w, tri.t2.x);
-        const pt_material mat = sp.mats[__float_as_int(tri.t2.y)];
+        const int32_t mesh = __float_as_int(tri.t2.z);
+        const pt_material mat = sp.mats[mesh];
         const float4 o4 = st.rayO[p], d4 = st.rayD[p];
         const v3 ray_o = mk3(o4.x, o4.y, o4.z), ray_dir = mk3(d4.x, d4.y, d4.z);
         const v3 N_0 = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
@@ -280,7 +280,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
         } else {
             v3 albedo = mk3(mat.color[0], mat.color[1], mat.color[2]);
             if (sp.mesh_tex) { // deviceProgram.cu:512-523: a textured mesh's albedo is REPLACED by tex2D at the hit's texcoord
-                const int tid = sp.mesh_tex[__float_as_int(tri.t2.y)];
+                const int tid = sp.mesh_tex[mesh];
                 if (tid >= 0) {
                     // optixGetTriangleBarycentrics = (weight of vertex 1, weight of vertex 2): the hit test's own weights
                     const v3 A = sub3(v0, ray_o), B = sub3(v1, ray_o), C = sub3(v2, ray_o);
@@ -288,7 +288,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                     const float Uw = dot3(ray_dir, CxB), Vw = dot3(ray_dir, AxC), Ww = dot3(ray_dir, BxA);
                     const float det = Uw + Vw + Ww;
                     const float bu = Vw / det, bv = Ww / det;
-                    const PrimUV uv = sp.uvs[prim];
+                    const PrimUV uv = sp.uvs[__float_as_int(tri.t2.y)]; // optixGetPrimitiveIndex
                     const float w0 = 1.f - bu - bv;
                     const float tcx = w0 * uv.c0.x + bu * uv.c1.x + bv * uv.c2.x;
                     const float tcy = w0 * uv.c0.y + bu * uv.c1.y + bv * uv.c2.y;
@@ -465,19 +465,32 @@ PT_DEV void apply_visible_contributions(const PathState& st, uint32_t i, float4&
             in = make_float4(in.x + pe.x, in.y + pe.y, in.z + pe.z, 0.f);
         }
 }
-__global__ void __launch_bounds__(256) k_resolve(PathState st, FrameParams fp, BatchParams bp, int first, int last) {
+// One pass over bp.S virtual samples of every pixel of the chunk.  Samples are summed in order; whenever a subframe's last sample
+// has been added the raygen epilogue runs for that subframe (:445-474) — blending with the PREVIOUS subframe's accum value, which is
+// the register of this loop when the previous subframe was completed in the same pass and accum_buffer otherwise — so that a batch
+// of `count` subframes leaves exactly what `count` launches would have left: the stored float4 is the value the next launch re-reads.
+// A pass that ends inside a subframe parks the partial sums in the chunk's pix* arrays; the frame buffers are written by passes that
+// completed at least one subframe (all five, with the values of the last completed one).
+__global__ void __launch_bounds__(256) k_resolve(PathState st, FrameParams fp, BatchParams bp) {
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= bp.npix) return;
     v3 result = mk3(0.f), alpha = mk3(0.f), normal = mk3(0.f), albedo = mk3(0.f);
-    if (!first) {
+    uint32_t sub = bp.s0 / fp.spp, sl = bp.s0 - sub * fp.spp; // position of the pass's first sample
+    if (sl != 0) { // the subframe was begun by an earlier pass
         const float4 r = bp.pixResult[pix], a = bp.pixAlpha[pix], nn = bp.pixNormal[pix], al = bp.pixAlbedo[pix];
         result = mk3(r.x, r.y, r.z);
         alpha = mk3(a.x, a.y, a.z);
         normal = mk3(nn.x, nn.y, nn.z);
         albedo = mk3(al.x, al.y, al.z);
     }
-    for (uint32_t sl = 0; sl < bp.S; ++sl) {
-        const uint32_t i = sl * bp.npix + pix;
+    const uint32_t xy = bp.pixels[pix];
+    const uint32_t x = xy & 0xffffu, y = xy >> 16;
+    const size_t image_index = (size_t)y * fp.width + x;
+    const float spp = (float)fp.spp;
+    bool have = false; // a subframe was completed in this pass
+    v3 accum_cur = mk3(0.f), normal_fin = mk3(0.f), albedo_fin = mk3(0.f);
+    for (uint32_t vl = 0; vl < bp.S; ++vl) {
+        const uint32_t i = vl * bp.npix + pix;
         float4 d = st.direct[i], in = st.indirect[i];
         const float4 nn = st.nrm[i], al = st.alb[i];
         float4 a;
@@ -498,45 +511,53 @@ __global__ void __launch_bounds__(256) k_resolve(PathState st, FrameParams fp, B
             normal = add3(normal, mk3(nn.x, nn.y, nn.z));
             albedo = add3(albedo, mk3(al.x, al.y, al.z));
         }
+        if (++sl < fp.spp) continue;
+        // ---- subframe complete
+        const uint32_t subframe_index = fp.subframe_index + sub;
+        normal_fin = div3s(normal, spp);
+        albedo_fin = div3s(albedo, spp);
+        alpha = div3s(alpha, spp);
+        // backplate of the LAST sample's camera ray (:410)
+        uint32_t seed = tea4(y * (uint32_t)fp.width + x, subframe_index);
+        for (uint32_t k = 0; k < 2u * (fp.spp - 1u); ++k) lcg(seed);
+        const float jx = rnd(seed), jy = rnd(seed);
+        const float dx = 2.0f * (((float)x + jx) / (float)fp.width) - 1.0f;
+        const float dy = 2.0f * (((float)y + jy) / (float)fp.height) - 1.0f;
+        const v3 dir = normalize3(add3(add3(scl3(fp.U, dx), scl3(fp.V, dy)), fp.W));
+        float pu, pv;
+        probe_dir_to_uv(dir, pu, pv);
+        const float4 bpx = probe_eval(fp.probe, pu, pv);
+        const v3 backplate = mk3(bpx.x, bpx.y, bpx.z);
+        const v3 color = add3(mul3(scl3(backplate, spp), sub3(mk3(1.0f), alpha)), result);
+        v3 accum_color = div3s(color, spp);
+        if (subframe_index > 0) {
+            accum_color = mk3(clampf(accum_color.x, 0.0f, 10.0f), clampf(accum_color.y, 0.0f, 10.0f), clampf(accum_color.z, 0.0f, 10.0f));
+            const float w = 1.0f / (float)(subframe_index + 1);
+            v3 prev = accum_cur;
+            if (!have) {
+                const float4 p4 = fp.accum[image_index];
+                prev = mk3(p4.x, p4.y, p4.z);
+            }
+            accum_color = lerp3(prev, accum_color, w);
+        }
+        accum_cur = accum_color;
+        have = true;
+        result = alpha = normal = albedo = mk3(0.f);
+        sl = 0;
+        ++sub;
     }
-    if (!last) {
+    if (sl != 0) {
         bp.pixResult[pix] = make_float4(result.x, result.y, result.z, 0.f);
         bp.pixAlpha[pix] = make_float4(alpha.x, alpha.y, alpha.z, 0.f);
         bp.pixNormal[pix] = make_float4(normal.x, normal.y, normal.z, 0.f);
         bp.pixAlbedo[pix] = make_float4(albedo.x, albedo.y, albedo.z, 0.f);
-        return;
     }
-    const uint32_t xy = bp.pixels[pix];
-    const uint32_t x = xy & 0xffffu, y = xy >> 16;
-    const float spp = (float)fp.spp;
-    normal = div3s(normal, spp);
-    albedo = div3s(albedo, spp);
-    alpha = div3s(alpha, spp);
-    // backplate of the LAST sample's camera ray (:410)
-    uint32_t seed = tea4(y * (uint32_t)fp.width + x, fp.subframe_index);
-    for (uint32_t k = 0; k < 2u * (fp.spp - 1u); ++k) lcg(seed);
-    const float jx = rnd(seed), jy = rnd(seed);
-    const float dx = 2.0f * (((float)x + jx) / (float)fp.width) - 1.0f;
-    const float dy = 2.0f * (((float)y + jy) / (float)fp.height) - 1.0f;
-    const v3 dir = normalize3(add3(add3(scl3(fp.U, dx), scl3(fp.V, dy)), fp.W));
-    float pu, pv;
-    probe_dir_to_uv(dir, pu, pv);
-    const float4 bpx = probe_eval(fp.probe, pu, pv);
-    const v3 backplate = mk3(bpx.x, bpx.y, bpx.z);
-    const v3 color = add3(mul3(scl3(backplate, spp), sub3(mk3(1.0f), alpha)), result);
-    const size_t image_index = (size_t)y * fp.width + x;
-    v3 accum_color = div3s(color, spp);
-    if (fp.subframe_index > 0) {
-        accum_color = mk3(clampf(accum_color.x, 0.0f, 10.0f), clampf(accum_color.y, 0.0f, 10.0f), clampf(accum_color.z, 0.0f, 10.0f));
-        const float a = 1.0f / (float)(fp.subframe_index + 1);
-        const float4 prev = fp.accum[image_index];
-        accum_color = lerp3(mk3(prev.x, prev.y, prev.z), accum_color, a);
-    }
-    fp.accum[image_index] = make_float4(accum_color.x, accum_color.y, accum_color.z, 1.0f);
-    fp.frame[image_index] = make_color(accum_color);
-    fp.normal[image_index] = make_float4(normal.x, normal.y, normal.z, 1.0f);
-    fp.color[image_index] = make_float4(accum_color.x, accum_color.y, accum_color.z, 1.0f);
-    fp.albedo[image_index] = make_float4(albedo.x, albedo.y, albedo.z, 1.0f);
+    if (!have) return;
+    fp.accum[image_index] = make_float4(accum_cur.x, accum_cur.y, accum_cur.z, 1.0f);
+    fp.frame[image_index] = make_color(accum_cur);
+    fp.normal[image_index] = make_float4(normal_fin.x, normal_fin.y, normal_fin.z, 1.0f);
+    fp.color[image_index] = make_float4(accum_cur.x, accum_cur.y, accum_cur.z, 1.0f);
+    fp.albedo[image_index] = make_float4(albedo_fin.x, albedo_fin.y, albedo_fin.z, 1.0f);
 }
 
 // ------------------------------------------------------------------ foveated variant (HelloPathtracing_sv4_vmv23/)
@@ -792,18 +813,12 @@ __global__ void k_accum_stats(const uint32_t* __restrict__ counters, int nq, int
     }
 }
 
-__global__ void k_emit_prims(const float* __restrict__ verts, const uint32_t* __restrict__ idx,
-                             const uint32_t* __restrict__ tri_mesh, uint32_t ntri, PrimTri* __restrict__ prims) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= ntri) return;
-    const float* v0 = &verts[3 * (size_t)idx[3 * (size_t)p + 0]];
-    const float* v1 = &verts[3 * (size_t)idx[3 * (size_t)p + 1]];
-    const float* v2 = &verts[3 * (size_t)idx[3 * (size_t)p + 2]];
-    PrimTri t;
-    t.t0 = make_float4(v0[0], v0[1], v0[2], v1[0]);
-    t.t1 = make_float4(v1[1], v1[2], v2[0], v2[1]);
-    t.t2 = make_float4(v2[2], __int_as_float((int)tri_mesh[p]), 0.f, 0.f);
-    prims[p] = t;
+// pt_trace (the query entry point): closest-hit records hold leaf-triangle indices, the caller is given primitive indices
+__global__ void k_hits_to_prims(float2* __restrict__ hit, const LeafTri* __restrict__ tris, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t leaf = __float_as_int(hit[i].y);
+    if (leaf >= 0) hit[i].y = tris[leaf].t2.y;
 }
 
 // ------------------------------------------------------------------ probe CDF on the GPU (Probe.h:29-77)

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT2_WAV
     RaySetup r;
     r.o = r.d = r.idir = r.dn = mk3(0.f);
     float tmin = 0.f, tmax = 0.f, best = 0.f;
-    int32_t bprim = -1, node = 0;
+    int32_t bprim = -1, bleaf = -1, node = 0;
     int sp = 0;
     uint32_t slot = 0;
     uint32_t c_nodes = 0, c_tris = 0, c_maxsp = 0, c_push = 0; // step counters, reported only when a.dbg is set (pt_trace + PT_DEBUG_COUNTS)
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT2_WAV
     };
     auto finish = [&]() {
         if (MODE == TR_CLOSEST) {
-            a.st.hit[slot] = make_float2(best, __int_as_float(bprim));
+            a.st.hit[slot] = make_float2(best, __int_as_float(bleaf)); // the leaf triangle's index (pt_bvh.h)
         } else if (MODE == TR_ANY_QUERY) {
             a.st.hit[slot] = make_float2(best, __int_as_float(bprim)); // bprim = 1 occluded / 0
         } else {
@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT2_WAV
                     r = ray_setup(mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z));
                     best = tmax;
                     bprim = (MODE == TR_CLOSEST) ? -1 : 0;
+                    bleaf = -1;
                     sp = 0;
                     node = a.bvh.root;
                     active = true;
@@ -195,6 +196,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT2_WAV
                             } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim))) {
                                 best = t;
                                 bprim = prim;
+                                bleaf = (int32_t)(first + k);
                             }
                         }
                     }

@@ -122,6 +122,16 @@ class SampleRenderer:
             ptr = out.ctypes.data
         self._ck(self._L.pt_render(self._ctx, int(self.launchParams.samples_per_launch), int(self.launchParams.frame.subframe_index), ptr), "pt_render")
 
+    def renderBatch(self, count: int, out: np.ndarray | None = None):
+        """`count` iterations of the reference's progressive loop (render(); subframe_index++, main.cpp:273-278) as ONE wavefront
+        batch (pt_render_batch): same buffers bit for bit, count times the rays per launch.  Like render(), it leaves
+        launchParams.frame.subframe_index to the application (advance it by `count`)."""
+        ptr = None
+        if out is not None:
+            assert out.dtype == np.uint32 and out.flags["C_CONTIGUOUS"]
+            ptr = out.ctypes.data
+        self._ck(self._L.pt_render_batch(self._ctx, int(self.launchParams.samples_per_launch), int(self.launchParams.frame.subframe_index), int(count), ptr), "pt_render_batch")
+
     def resize(self, newSize):
         w, h = int(newSize[0]), int(newSize[1])
         self._ck(self._L.pt_resize(self._ctx, w, h), "pt_resize")
@@ -384,6 +394,10 @@ class MultiRenderer:
     def render(self, out: np.ndarray | None = None):
         ptr = out.ctypes.data if out is not None else None
         self._ck(self._L.pt_multi_render(self._m, int(self.launchParams.samples_per_launch), int(self.launchParams.frame.subframe_index), int(self.gather_mask), ptr), "pt_multi_render")
+
+    def renderBatch(self, count: int, out: np.ndarray | None = None):
+        ptr = out.ctypes.data if out is not None else None
+        self._ck(self._L.pt_multi_render_batch(self._m, int(self.launchParams.samples_per_launch), int(self.launchParams.frame.subframe_index), int(count), int(self.gather_mask), ptr), "pt_multi_render_batch")
 
     def renderRegions(self, regions, variant=None, out: np.ndarray | None = None):
         arr = (Region * len(regions))()

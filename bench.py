@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="concurrent pixel chunks per frame (0 = library default)")
     ap.add_argument("--kernel-timing", type=int, default=0, help="1: per-launch HIP-event timing inside the timed loop (slower; the isolated phase always has it)")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="pt_options.frames_in_flight of the TIMED loop. 0 (default): every frame synchronous like the reference's render(); 3: frame k runs whole on stream k mod 3 and pt_render(k) returns once frame k-2 is complete (three frames overlap, same images); 2: pixel chunks as in the synchronous frame, pt_render(k) waits for frame k-1")
-    ap.add_argument("--batch", type=int, default=1, help="timed loop: frames are rendered as wavefront batches of this many subframes (pt_render_batch; --steps must be a multiple)")
+    ap.add_argument("--batch", type=int, default=0, help="timed loop: frames are rendered as wavefront batches of this many subframes (pt_render_batch; the last batch of the loop may be shorter). 0 (default) = the number of ranks the frame is partitioned over: 1 on one GPU (every frame its own pt_render, like the reference's loop); N on N GPUs, so that a launch chain carries the paths of one whole frame however many ways the image is split")
     ap.add_argument("--no-extra-schedules", action="store_true", help="skip the extra frames after the timed region (pipelined / batched figures; profiling runs: keeps the frame count at warmup + steps)")
     ap.add_argument("--bvh-kind", type=int, default=0, help="0 = 8-wide compressed BVH (default), 1 = binary BVH")
     ap.add_argument("--trace-kernel", type=int, default=0, help="0 = persistent-wave traversal (default), 1 = first grid-stride kernel")
@@ -148,8 +148,10 @@ def main():
     sv4 = args.workload.startswith("sv4_")
     foveated = "foveated" in args.workload
 
-    if args.batch < 1 or args.steps % args.batch or (args.batch > 1 and sv4):
-        raise SystemExit("--batch B needs --steps to be a multiple of B (and a pt_render workload)")
+    if args.batch == 0:
+        args.batch = 1 if sv4 else part_world
+    if args.batch < 1 or (args.batch > 1 and sv4):
+        raise SystemExit("--batch B needs a pt_render workload")
 
     def render_frame(k, count=1):
         if not sv4:
@@ -183,8 +185,10 @@ def main():
         assert a1["frames"] - a0["frames"] == n, (a1["frames"], a0["frames"], n)
         return t_1 - t_0, (a1["total_radiance_rays"] + a1["total_shadow_rays"]) - (a0["total_radiance_rays"] + a0["total_shadow_rays"])
 
-    for k in range(0, args.warmup, args.batch):
-        render_frame(k, min(args.batch, args.warmup - k))
+    # untimed warm-up: whole launch chains of the timed loop's size (the path state is sized by the chain), so at least --warmup frames
+    warm = ((max(args.warmup, 1) + args.batch - 1) // args.batch) * args.batch
+    for k in range(0, warm, args.batch):
+        render_frame(k, args.batch)
     barrier()
     keys = ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms", "trace_launches", "shadow_launches", "shade_launches", "radiance_rays", "shadow_rays", "shaded_hits")
     agg = dict.fromkeys(keys, 0.0)
@@ -194,8 +198,10 @@ def main():
     per_frame_stats = not pipelined and args.batch == 1
     s0 = r.stats()
     t0 = time.perf_counter()
+    n_chains = 0
     for k in range(0, args.steps, args.batch):
-        render_frame(args.warmup + k, args.batch)
+        render_frame(warm + k, min(args.batch, args.steps - k))
+        n_chains += 1
         if per_frame_stats:
             st = r.stats()
             for key in agg:
@@ -206,8 +212,8 @@ def main():
     assert st["frames"] - s0["frames"] == args.steps, (st["frames"], s0["frames"])
     rays = (st["total_radiance_rays"] + st["total_shadow_rays"]) - (s0["total_radiance_rays"] + s0["total_shadow_rays"])
     if not per_frame_stats:  # per-launch-chain figures of the LAST chain only, scaled to the loop (the frames differ only by their random numbers)
-        agg = {key: st[key] * (args.steps // args.batch) for key in keys}
-    next_sub = args.warmup + args.steps
+        agg = {key: st[key] * n_chains for key in keys}
+    next_sub = warm + args.steps
 
     # Other schedules of the same frames, for the record (after the timed region, never part of `value`; same images bit for bit):
     # three whole frames in flight, and — on a partitioned frame — wavefront batches of as many subframes as there are shares
@@ -222,18 +228,22 @@ def main():
             next_sub += 3 + n_x
             extra["pipelined"] = (tp, rp, n_x)
             r.setOptions(**opts)
-        bc = part_world if part_world > 1 else 0
-        if bc and args.batch == 1:
+        if part_world > 1:
+            # the strict reading of the reference's loop on a partitioned frame: every frame its own launch chain (batch 1) — or, when that
+            # is the timed mode, the batched schedule
+            bc = 1 if args.batch > 1 else part_world
             r.setOptions(**dict(opts, frames_in_flight=0))
             n_b = ((n_x + bc - 1) // bc) * bc
             render_frame(next_sub, bc)
             tb, rb = timed_frames(next_sub + bc, n_b, bc)
-            extra["batched"] = (tb, rb, n_b, bc)
-            r.setOptions(**dict(opts, frames_in_flight=3))
-            render_frame(next_sub + bc + n_b, bc); render_frame(next_sub + 2 * bc + n_b, bc)
-            tb3, rb3 = timed_frames(next_sub + 3 * bc + n_b, n_b, bc)
-            extra["batched_pipelined"] = (tb3, rb3, n_b, bc)
-            next_sub += 3 * bc + 2 * n_b
+            extra["single_frame_launches" if bc == 1 else "batched"] = (tb, rb, n_b, bc)
+            next_sub += bc + n_b
+            if bc > 1:
+                r.setOptions(**dict(opts, frames_in_flight=3))
+                render_frame(next_sub, bc); render_frame(next_sub + bc, bc)
+                tb3, rb3 = timed_frames(next_sub + 2 * bc, n_b, bc)
+                extra["batched_pipelined"] = (tb3, rb3, n_b, bc)
+                next_sub += 2 * bc + n_b
             r.setOptions(**opts)
     if pipelined:  # everything after this runs synchronously
         r.setOptions(**dict(opts, frames_in_flight=0))
@@ -264,7 +274,9 @@ def main():
         if len(tup) > 3:
             extra_out[name]["subframes_per_batch"] = tup[3]
 
-    # displayed frames: render + the display hand-off (pack -> one all-gather of the packed rgba8 strips -> unpack) every frame
+    # displayed frames: every launch chain's result is handed over for display — pack -> one all-gather of the packed rgba8 strips ->
+    # scatter into the display buffer — with the exchange of chain k overlapping the rendering of chain k+1 (multigpu.HandOff over
+    # pt_pack_async / pt_unpack_display; whole frames in flight, so the context's own stream is free for the hand-off)
     gather_ms = ms_displayed = None
     if dist is not None:
         from optixpathtracer_amd import multigpu
@@ -279,30 +291,39 @@ def main():
                 dist.all_gather_into_tensor(d, src.cpu())
                 dst.copy_(d)
 
-        render_frame(next_sub)  # every displayed frame is waited for by its hand-off: synchronous frames (pixel chunks on all streams)
-        multigpu.exchange_frame(packer, R.PT_BUF_FRAME, world, all_gather)  # warm RCCL
+        bd = args.batch
+        r.setOptions(**dict(opts, frames_in_flight=3))
+        hand = multigpu.HandOff(packer, R.PT_BUF_FRAME, world, all_gather)
+        for k in range(3):  # warm: RCCL, the display buffer, the streams
+            render_frame(next_sub, bd); next_sub += bd
+            hand.collect(); hand.submit()
+        hand.collect()
         barrier()
-        nd = max(1, min(args.steps, 10))
+        nd = max(2, min(args.steps // bd, 10))
         g_acc = 0.0
         d0 = time.perf_counter()
         for k in range(nd):
-            render_frame(next_sub + 1 + k)
+            render_frame(next_sub, bd); next_sub += bd
             g0 = time.perf_counter()
-            multigpu.exchange_frame(packer, R.PT_BUF_FRAME, world, all_gather)
-            torch.cuda.synchronize()
+            hand.collect()
+            hand.submit()
             g_acc += time.perf_counter() - g0
+        hand.collect()
+        r.displaySync()
         barrier()
         dd = time.perf_counter() - d0
         tt = torch.tensor([dd, g_acc], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ms_displayed = float(tt[0]) / nd * 1e3
-        gather_ms = float(tt[1]) / nd * 1e3
-        # the assembled frame must be complete: every pixel of the float frame was written by exactly one rank (alpha = 1)
-        multigpu.exchange_frame(packer, R.PT_BUF_ACCUM, world, all_gather)
-        torch.cuda.synchronize()
-        full = r.download(R.PT_BUF_ACCUM)
-        if not (full[..., 3] == 1.0).all():
-            raise SystemExit(f"rank {rank}: assembled frame has unwritten pixels")
+        ms_displayed = float(tt[0]) / (nd * bd) * 1e3  # per frame of the loop, comparable with ms_per_step; a hand-over every `bd` frames
+        gather_ms = float(tt[1]) / nd * 1e3            # host time of one hand-over (wait for the strip, all-gather, enqueue the scatter)
+        # the displayed frame must be complete and must be the last frame: rgba8 alpha is 255 wherever a rank wrote, and this rank's own pixels equal its frame buffer
+        shown = r.downloadDisplay(R.PT_BUF_FRAME)
+        mine = r.download(R.PT_BUF_FRAME)
+        px = multigpu.pixel_lists(w, h, world, args.tile[0], args.tile[1])[rank]
+        ys, xs = (px >> 16).astype(np.int64), (px & 0xFFFF).astype(np.int64)
+        if not ((shown >> 24) == 255).all() or not np.array_equal(shown[ys, xs], mine[ys, xs]):
+            raise SystemExit(f"rank {rank}: the displayed frame is incomplete or stale")
+        r.setOptions(**opts)
 
     # isolated per-kernel durations: the timed schedule overlaps three frames (the synchronous one three pixel chunks) on separate streams, so its per-class
     # HIP-event sums include time spent sharing the machine.  A few extra frames with ONE chunk stream give durations that
@@ -400,13 +421,14 @@ def main():
             "ms_per_frame_pipelined": extra_out.get("pipelined", {}).get("ms_per_frame"),
             "batched": extra_out.get("batched"),
             "batched_pipelined": extra_out.get("batched_pipelined"),
+            "single_frame_launches": extra_out.get("single_frame_launches"),  # partitioned frame, every frame its own pt_render (subframes_per_batch 1)
             # device time from a launch chain's first kernel to its last (with frames in flight: one frame's LATENCY, three frames overlap) — of the last chain of the loop
-            "frame_latency_ms": round(agg["render_ms"] / (args.steps // args.batch), 3),
+            "frame_latency_ms": round(agg["render_ms"] / n_chains, 3),
             "ms_per_step_per_rank": per_rank_ms,
             "kernel_ms_per_frame_isolated": None if iso is None else {k: round(iso[k], 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
             "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2)},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
-            "ms_per_displayed_frame": None if ms_displayed is None else round(ms_displayed, 3),
+            "ms_per_displayed_frame": None if ms_displayed is None else round(ms_displayed, 3),  # per frame, in a loop that hands every launch chain's result over (every subframes_per_batch frames), the exchange overlapping the next chain
             "roofline": {
                 "kernel": "whole frame, all wavefront stages (SURVEY.md 8d: rays x 160 B + pixels x 84 B + scene bytes)", "bound": "hbm",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -280,6 +280,23 @@ int pt_owned_pixels(const pt_ctx* ctx, uint32_t* owned, uint32_t* padded);
 int pt_pack(pt_ctx* ctx, int which, void* dev_dst);
 int pt_unpack(pt_ctx* ctx, int which, const void* dev_src_all);
 
+/* Display hand-off that overlaps the next frame (the reference's loop renders, then displays, every frame: main.cpp:273-278; on several
+ * GPUs "display" is preceded by the exchange of the ranks' strips).  With pt_options.frames_in_flight = 2 or 3 the loop is
+ *     pt_render(k);  pt_pack_async(FRAME, send[k & 1], k & 1);
+ *     if (k > 0) { pt_pack_wait((k - 1) & 1);  all-gather(recv, send[(k - 1) & 1]);  pt_unpack_display(FRAME, recv);  show pt_display_buffer(FRAME); }
+ * pt_pack_async enqueues the pack of buffer `which` behind the newest frame in flight WITHOUT waiting for it (pt_pack waits) and makes
+ * the resolves of later frames wait for it, so the strip is frame k's whatever is enqueued next; pt_pack_wait blocks the host until that
+ * strip is complete (frames enqueued after it keep running); pt_unpack_display scatters the all-gathered strips into the DISPLAY copy
+ * of the buffer — a second, full-size buffer no render writes (allocated on first use) — so the exchange and display of frame k-1
+ * overlap the rendering of frame k and never show pixels of two frames.  pt_display_sync waits for the newest pt_unpack_display,
+ * pt_download_display copies a display buffer to the host.  Same bits as pt_pack / pt_unpack. */
+int pt_pack_async(pt_ctx* ctx, int which, void* dev_dst, int slot /* 0 or 1: which of the caller's two send buffers */);
+int pt_pack_wait(pt_ctx* ctx, int slot);
+int pt_unpack_display(pt_ctx* ctx, int which, const void* dev_src_all);
+int pt_display_sync(pt_ctx* ctx);
+void* pt_display_buffer(pt_ctx* ctx, int which); /* NULL until the first pt_unpack_display of that buffer */
+int pt_download_display(pt_ctx* ctx, int which, void* host, size_t bytes);
+
 int pt_get_stats(const pt_ctx* ctx, pt_stats* out);
 
 /* ---------------------------------------------------------------------------------------------------------------------
@@ -298,9 +315,13 @@ typedef struct pt_multi pt_multi;
 enum pt_exchange { PT_EXCHANGE_NONE = 0, PT_EXCHANGE_RCCL = 1, PT_EXCHANGE_PEER_COPY = 2 };
 typedef struct pt_multi_stats {
     pt_stats sum;            /* rays / paths / frames summed over the ranks (frames = frames x ranks); the *_ms fields are the MAXIMUM over the ranks */
-    double gather_ms;        /* wall time of the last pt_multi_gather (pack + exchange + unpack, all ranks) */
+    double gather_ms;        /* wall time of the last pt_multi_gather (pack + exchange + unpack, all ranks); overlapped hand-off: host time of the exchange of the previous frame */
     int32_t exchange;        /* pt_exchange used by the last gather */
     int32_t ndev;
+    double enqueue_ms;       /* host time of the enqueue phase of the last render (all launches of the frame on every device): the slowest
+                              * rank's when the ranks have their own threads, the sum over the ranks otherwise */
+    int32_t threads;         /* host threads that enqueue the ranks (0: the calling thread does it for all — one rank, or PT_MULTI_THREADS=0) */
+    uint64_t frames_handed_over; /* frames that went through the overlapped hand-off (frames in flight + gather_mask) */
 } pt_multi_stats;
 int pt_create_multi(const pt_scene_desc* scene, const int* devices, int ndev, pt_multi** out);
 int pt_multi_destroy(pt_multi* m);
@@ -313,12 +334,20 @@ int pt_multi_set_probe_image(pt_multi* m, const float* data_rgba, int width, int
 int pt_multi_resize(pt_multi* m, int width, int height, int tile_w, int tile_h); /* tile sizes: multiples of 8; 0 = 64 x 16 */
 int pt_multi_set_camera(pt_multi* m, const float eye[3], const float U[3], const float V[3], const float W[3]);
 /* gather_mask: bit (1 << pt_buffer) for every buffer to assemble on all ranks after the frame (0 = none: pure throughput);
- * host_rgba8 (may be NULL) receives rank 0's frame buffer and implies gathering PT_BUF_FRAME */
+ * host_rgba8 (may be NULL) receives rank 0's frame buffer and implies gathering PT_BUF_FRAME.
+ * Every rank's launches are enqueued by a host thread of its own (pt_multi_stats.enqueue_ms, .threads), so the host time of a frame does
+ * not grow with the number of devices.
+ * With pt_options.frames_in_flight = 2 or 3 AND something to hand over, the hand-over overlaps the next frame: the call enqueues frame k,
+ * then exchanges the strips frame k-1 packed behind its last kernel and scatters them into the ranks' DISPLAY buffers (pt_display_buffer /
+ * pt_download_display of pt_multi_ctx(m, r); the ordinary buffers keep only the rank's own pixels) while frame k renders, and returns
+ * when frame k-1 is on display: host_rgba8 receives frame k-1 (nothing on the first call), pt_multi_flush hands over the last frame.
+ * Same bits as the synchronous hand-over. */
 int pt_multi_render(pt_multi* m, uint32_t spp, uint32_t subframe_index, uint32_t gather_mask, uint32_t* host_rgba8);
 /* pt_render_batch on every rank: `count` subframes in one wavefront batch per device, then the hand-over of the last one */
 int pt_multi_render_batch(pt_multi* m, uint32_t spp, uint32_t first_subframe, uint32_t count, uint32_t gather_mask, uint32_t* host_rgba8);
 int pt_multi_render_regions(pt_multi* m, const pt_region* regions, uint32_t n, const pt_variant* variant, uint32_t gather_mask, uint32_t* host_rgba8);
 int pt_multi_gather(pt_multi* m, int which /* pt_buffer */);
+int pt_multi_flush(pt_multi* m, uint32_t* host_rgba8 /* may be NULL */); /* overlapped hand-off: the newest frame goes on display now */
 int pt_multi_get_stats(const pt_multi* m, pt_multi_stats* out);
 
 /* Ray-search entry (what optixTrace did: deviceProgram.cu:165,190).  rays = n * 8 floats

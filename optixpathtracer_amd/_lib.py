@@ -19,6 +19,7 @@ EXPORTS = [
     "pt_create_multi", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_size", "pt_multi_ctx", "pt_multi_set_options", "pt_multi_set_probe",
     "pt_multi_set_probe_image", "pt_multi_resize", "pt_multi_set_camera", "pt_multi_render", "pt_multi_render_regions", "pt_multi_gather",
     "pt_multi_get_stats", "pt_export_bvh", "pt_render_batch", "pt_multi_render_batch",
+    "pt_pack_async", "pt_pack_wait", "pt_unpack_display", "pt_display_sync", "pt_display_buffer", "pt_download_display", "pt_multi_flush",
 ]
 
 
@@ -88,7 +89,8 @@ class Stats(C.Structure):
 
 
 class MultiStats(C.Structure):  # pt_multi_stats
-    _fields_ = [("sum", Stats), ("gather_ms", C.c_double), ("exchange", C.c_int32), ("ndev", C.c_int32)]
+    _fields_ = [("sum", Stats), ("gather_ms", C.c_double), ("exchange", C.c_int32), ("ndev", C.c_int32), ("enqueue_ms", C.c_double), ("threads", C.c_int32),
+                ("frames_handed_over", C.c_uint64)]
 
 
 assert C.sizeof(Material) == 104
@@ -154,6 +156,13 @@ def load_library() -> C.CDLL:
     L.pt_pack.argtypes = [vp, i, vp]
     L.pt_unpack.argtypes = [vp, i, vp]
     L.pt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.pt_pack_async.argtypes = [vp, i, vp, i]
+    L.pt_pack_wait.argtypes = [vp, i]
+    L.pt_unpack_display.argtypes = [vp, i, vp]
+    L.pt_display_sync.argtypes = [vp]
+    L.pt_display_buffer.restype = vp
+    L.pt_display_buffer.argtypes = [vp, i]
+    L.pt_download_display.argtypes = [vp, i, vp, C.c_size_t]
     L.pt_trace.argtypes = [vp, vp, u32, i, vp, vp, i, C.POINTER(C.c_double)]
     L.pt_eval_table.argtypes = [vp, i, vp, i, vp, u32, vp]
     L.pt_export_bvh.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(u32), C.POINTER(u32)]
@@ -175,6 +184,7 @@ def load_library() -> C.CDLL:
     L.pt_multi_render_batch.argtypes = [vp, u32, u32, u32, u32, vp]
     L.pt_multi_render_regions.argtypes = [vp, C.POINTER(Region), u32, C.POINTER(Variant), u32, vp]
     L.pt_multi_gather.argtypes = [vp, i]
+    L.pt_multi_flush.argtypes = [vp, vp]
     L.pt_multi_get_stats.argtypes = [vp, C.POINTER(MultiStats)]
     _lib = L
     return L

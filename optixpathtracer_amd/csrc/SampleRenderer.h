@@ -212,6 +212,9 @@ class MultiSampleRenderer {
         ck(pt_multi_set_probe(multi, &probe.data[0].x, probe.pdfValuesX.data(), probe.cdfValuesX.data(), probe.pdfValuesY.data(), probe.cdfValuesY.data(), probe.width, probe.height));
     }
     void gather(int which) { ck(pt_multi_gather(multi, which)); } // assemble another buffer (e.g. PT_BUF_ACCUM) on every rank
+    // Frames in flight (pt_options.frames_in_flight 2 or 3 through setOptions): render(h_pixels) then shows frame k-1 while frame k renders —
+    // the exchange of the strips overlaps the rendering — and flush(h_pixels) hands over the last frame.
+    void flush(uint32_t* h_pixels = nullptr) { ck(pt_multi_flush(multi, h_pixels)); }
     LaunchParams launchParams;
     pt_multi* multi = nullptr;
 

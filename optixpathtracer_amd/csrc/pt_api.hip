@@ -53,6 +53,13 @@ struct pt_ctx {
     float4 *accum = nullptr, *color = nullptr, *normal = nullptr, *albedo = nullptr;
     uint32_t* frame = nullptr;
     float4 *denoised = nullptr, *denoise_tmp = nullptr; // allocated by the first pt_denoise at the current size
+    // Display hand-off that overlaps the next frame (pt_pack_async / pt_unpack_display): the second set of frame buffers.  A frame's
+    // strips are packed behind its last kernel on the context's stream, later frames' resolves wait for that pack before they
+    // overwrite the frame buffers, and the gathered strips of all ranks are scattered into `display[which]`, which no render writes.
+    void* display[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_packed[2] = {nullptr, nullptr}; // behind the pack of hand-off slot 0 / 1
+    hipEvent_t ev_displayed = nullptr;            // behind the newest pt_unpack_display
+    hipEvent_t ev_pack_guard = nullptr;           // the newest pack still to be waited for by later resolves (null: none)
     v3 eye{0, 0, 0}, U{1, 0, 0}, V{0, 1, 0}, W{0, 0, 1};
     // partition
     int rank = 0, world = 1, tile_w = 64, tile_h = 16;
@@ -142,6 +149,15 @@ template <typename T>
 static hipError_t dalloc(T** p, size_t n) {
     return hipMalloc((void**)p, sizeof(T) * (n ? n : 1));
 }
+// The library's streams are created hipStreamNonBlocking: they neither wait for nor hold up the null stream — an application (or torch)
+// working on the default stream next to the renderer would otherwise serialise with every frame in flight, and an exchange of frame
+// k-1 could not overlap the rendering of frame k.  So nothing here may rely on the null stream's implicit ordering: clears go through
+// the context's stream and are waited for.
+static hipError_t dclear(hipStream_t stream, void* p, size_t bytes) {
+    hipError_t e = hipMemsetAsync(p, 0, bytes, stream);
+    return e == hipSuccess ? hipStreamSynchronize(stream) : e;
+}
+static hipError_t stream_create(hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 template <typename T>
 static void dfree(T*& p) {
     if (p) hipFree((void*)p);
@@ -289,7 +305,7 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     } while (0)
     DevScope tmp;
     CKC(hipSetDevice(device));
-    CKC(hipStreamCreate(&ctx->stream));
+    CKC(stream_create(&ctx->stream));
     ctx->ntri = (uint32_t)nt;
     ctx->nmesh = scene->num_meshes;
     CKC(dalloc(&ctx->d_verts, 3 * nv));
@@ -337,7 +353,7 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     hipEventElapsedTime(&ms, e0, e1);
     ctx->bvh_build_ms = ms;
     CKC(dalloc(&ctx->d_totals, (size_t)PT_MAX_FRAMES * PT_MAX_SETS * 4));
-    CKC(hipMemset(ctx->d_totals, 0, sizeof(unsigned long long) * PT_MAX_FRAMES * PT_MAX_SETS * 4));
+    CKC(dclear(ctx->stream, ctx->d_totals, sizeof(unsigned long long) * PT_MAX_FRAMES * PT_MAX_SETS * 4));
     CKC(hipHostMalloc((void**)&ctx->h_totals, sizeof(unsigned long long) * PT_MAX_FRAMES * PT_MAX_SETS * 4));
     {
         hipDeviceProp_t prop;
@@ -387,6 +403,11 @@ static void free_path_state(pt_ctx* ctx) {
     ctx->set_cap = ctx->set_pix_cap = 0;
 }
 static void free_frame(pt_ctx* ctx) {
+    for (void*& d : ctx->display) {
+        if (d) hipFree(d);
+        d = nullptr;
+    }
+    ctx->ev_pack_guard = nullptr;
     dfree(ctx->accum); dfree(ctx->color); dfree(ctx->normal); dfree(ctx->albedo); dfree(ctx->frame);
     dfree(ctx->denoised); dfree(ctx->denoise_tmp);
     dfree(ctx->d_pixels); dfree(ctx->d_all_pixels);
@@ -413,6 +434,8 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     dfree(ctx->dbg);
     for (auto& pool : ctx->ev_pools)
         for (hipEvent_t e : pool) hipEventDestroy(e);
+    for (hipEvent_t e : {ctx->ev_packed[0], ctx->ev_packed[1], ctx->ev_displayed})
+        if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return PT_OK;
@@ -659,11 +682,11 @@ extern "C" int pt_resize(pt_ctx* ctx, int width, int height) {
     CK(dalloc(&ctx->normal, n));
     CK(dalloc(&ctx->albedo, n));
     CK(dalloc(&ctx->frame, n));
-    CK(hipMemset(ctx->accum, 0, sizeof(float4) * n));
-    CK(hipMemset(ctx->color, 0, sizeof(float4) * n));
-    CK(hipMemset(ctx->normal, 0, sizeof(float4) * n));
-    CK(hipMemset(ctx->albedo, 0, sizeof(float4) * n));
-    CK(hipMemset(ctx->frame, 0, sizeof(uint32_t) * n));
+    CK(hipMemsetAsync(ctx->accum, 0, sizeof(float4) * n, ctx->stream));
+    CK(hipMemsetAsync(ctx->color, 0, sizeof(float4) * n, ctx->stream));
+    CK(hipMemsetAsync(ctx->normal, 0, sizeof(float4) * n, ctx->stream));
+    CK(hipMemsetAsync(ctx->albedo, 0, sizeof(float4) * n, ctx->stream));
+    CK(dclear(ctx->stream, ctx->frame, sizeof(uint32_t) * n));
     std::vector<std::vector<uint32_t>> lists;
     build_pixel_lists(width, height, ctx->world, ctx->tile_w, ctx->tile_h, lists);
     size_t padded = 0;
@@ -697,9 +720,9 @@ static int assign_streams(pt_ctx* ctx, int nsets) {
     if ((int)ctx->set_streams.size() < nsets) ctx->set_streams.resize(nsets, nullptr);
     if ((int)ctx->side_streams.size() < 2 * nsets) ctx->side_streams.resize((size_t)2 * nsets, nullptr);
     for (int i = 0; i < nsets; ++i) {
-        if (!ctx->set_streams[i]) CK(hipStreamCreate(&ctx->set_streams[i]));
-        if (!ctx->side_streams[2 * i]) CK(hipStreamCreate(&ctx->side_streams[2 * i]));
-        if (async && !ctx->side_streams[2 * i + 1]) CK(hipStreamCreate(&ctx->side_streams[2 * i + 1]));
+        if (!ctx->set_streams[i]) CK(stream_create(&ctx->set_streams[i]));
+        if (!ctx->side_streams[2 * i]) CK(stream_create(&ctx->side_streams[2 * i]));
+        if (async && !ctx->side_streams[2 * i + 1]) CK(stream_create(&ctx->side_streams[2 * i + 1]));
         if (i < (int)ctx->sets.size()) {
             ctx->sets[i].stream = ctx->set_streams[i];
             ctx->sets[i].stream2 = ctx->side_streams[2 * i];
@@ -722,7 +745,7 @@ static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_
         if (rc) return rc;
     }
     free_path_state(ctx);
-    CK(hipMemset(ctx->d_totals, 0, sizeof(unsigned long long) * PT_MAX_FRAMES * PT_MAX_SETS * 4)); // slices of sets that no longer exist
+    CK(dclear(ctx->stream, ctx->d_totals, sizeof(unsigned long long) * PT_MAX_FRAMES * PT_MAX_SETS * 4)); // slices of sets that no longer exist
     ctx->sets.resize(nsets);
     ctx->sub_cap = cap / PT_NSUB + 8192 + 1; // a sub-queue receives at most cap/64 + 32 workgroups * 256 entries
     const size_t qsize = (size_t)PT_NSUB * ctx->sub_cap;
@@ -1088,7 +1111,7 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
     }
     if (getenv("PT_DEBUG_COUNTS")) {
         if (!ctx->dbg) CK(dalloc(&ctx->dbg, 64));
-        CK(hipMemset(ctx->dbg, 0, 512));
+        CK(dclear(ctx->stream, ctx->dbg, 512));
     }
     begin_slot(ctx, slot);
     hipEvent_t ev_begin = next_event(ctx);
@@ -1108,6 +1131,7 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
         CK(hipEventRecord(ev_begin, bs.stream));
         std::vector<hipEvent_t> before;
         if (ctx->ev_resolved) before.push_back(ctx->ev_resolved);
+        if (ctx->ev_pack_guard) before.push_back(ctx->ev_pack_guard); // the hand-off of the previous frame reads the buffers this frame's resolve overwrites
         ctx->adapt_grid = true;
         for (uint32_t pix0 = 0; pix0 < owned; pix0 += Np)
             enqueue_chunk(ctx, bs, fp, pix0, std::min(Np, owned - pix0), vspp, S, lc, nullptr, before.empty() ? nullptr : &before);
@@ -1129,6 +1153,7 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
         // deals its launches to the streams differently, so after one of those every resolve waits for that frame's end
         std::vector<hipEvent_t> before;
         if (pipelined && ctx->ev_resolved && ctx->resolved_kind != 0) before.push_back(ctx->ev_resolved);
+        if (pipelined && ctx->ev_pack_guard) before.push_back(ctx->ev_pack_guard); // (a synchronous frame starts behind the context's stream, which carries the pack)
         uint32_t k = 0;
         for (uint32_t pix0 = 0; pix0 < owned; pix0 += Np, ++k)
             enqueue_chunk(ctx, ctx->sets[k % nsets], fp, pix0, std::min(Np, owned - pix0), vspp, S, lc, nullptr, before.empty() ? nullptr : &before);
@@ -1247,6 +1272,7 @@ static int drain(pt_ctx* ctx) {
     }
     ctx->ev_resolved = nullptr; // nothing in flight: nothing to order the next resolve behind
     ctx->last_slot = -1;
+    if (ctx->ev_pack_guard && hipEventQuery(ctx->ev_pack_guard) == hipSuccess) ctx->ev_pack_guard = nullptr;
     return rc;
 }
 
@@ -1357,6 +1383,7 @@ static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, co
     uint32_t next_set = 0;
     std::vector<hipEvent_t> prev_done, cur_done;
     if (pipelined && ctx->ev_resolved) prev_done.push_back(ctx->ev_resolved); // the previous frame's pixels are written first
+    if (pipelined && ctx->ev_pack_guard) prev_done.push_back(ctx->ev_pack_guard);
     for (uint32_t r = 0; r < n; ++r) {
         const pt_region& g = regions[r];
         FrameParams fp{ctx->accum, ctx->frame, ctx->color, ctx->normal, ctx->albedo, ctx->width, ctx->height, g.subframe_index,
@@ -1552,6 +1579,84 @@ extern "C" int pt_unpack(pt_ctx* ctx, int which, const void* dev_src_all) {
     CK(hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
+static int newest_active(pt_ctx* ctx) {
+    int o = -1;
+    for (int i = 0; i < PT_MAX_FRAMES; ++i)
+        if (ctx->fr[i].active && (o < 0 || ctx->fr[i].seq > ctx->fr[o].seq)) o = i;
+    return o;
+}
+static size_t buffer_elem(int which) { return which == PT_BUF_FRAME ? 4 : ((which >= 0 && which <= PT_BUF_DENOISED) ? 16 : 0); }
+
+// ---- overlapped display hand-off (include/pt_amd.h): nothing here waits for a frame on the host
+static int pack_async_enqueue(pt_ctx* ctx, int which, void* dev_dst, int slot) {
+    if (slot < 0 || slot > 1) return fail(ctx, PT_ERR_INVALID, "pt_pack_async: slot must be 0 or 1");
+    CK(hipSetDevice(ctx->device));
+    const int nf = newest_active(ctx);
+    if (nf >= 0) CK(hipStreamWaitEvent(ctx->stream, ctx->fr[nf].ev_end, 0)); // the newest frame enqueued; earlier ones end before it writes the buffers
+    int rc = pack_launch(ctx, which, dev_dst);
+    if (rc != PT_OK) return rc;
+    if (!ctx->ev_packed[slot]) CK(hipEventCreateWithFlags(&ctx->ev_packed[slot], hipEventDisableTiming));
+    CK(hipEventRecord(ctx->ev_packed[slot], ctx->stream));
+    ctx->ev_pack_guard = ctx->ev_packed[slot];
+    return PT_OK;
+}
+extern "C" int pt_pack_async(pt_ctx* ctx, int which, void* dev_dst, int slot) {
+    if (!ctx || !dev_dst) return PT_ERR_INVALID;
+    return pack_async_enqueue(ctx, which, dev_dst, slot);
+}
+extern "C" int pt_pack_wait(pt_ctx* ctx, int slot) {
+    if (!ctx || slot < 0 || slot > 1) return PT_ERR_INVALID;
+    if (!ctx->ev_packed[slot]) return PT_OK;
+    CK(hipSetDevice(ctx->device));
+    CK(hipEventSynchronize(ctx->ev_packed[slot]));
+    return PT_OK;
+}
+static int unpack_display_enqueue(pt_ctx* ctx, int which, const void* dev_src_all) {
+    const size_t elem = buffer_elem(which);
+    if (!elem || ctx->width == 0) return fail(ctx, PT_ERR_INVALID, "pt_unpack_display: unknown buffer or not resized");
+    CK(hipSetDevice(ctx->device));
+    const size_t npx = (size_t)ctx->width * ctx->height;
+    if (!ctx->display[which]) {
+        CK(hipMalloc(&ctx->display[which], npx * elem));
+        CK(hipMemsetAsync(ctx->display[which], 0, npx * elem, ctx->stream));
+    }
+    const uint32_t n = ctx->padded * (uint32_t)ctx->world;
+    if (n) {
+        if (elem == 16)
+            hipLaunchKernelGGL((k_unpack<float4>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (float4*)ctx->display[which], ctx->d_all_pixels, n, ctx->width, (const float4*)dev_src_all);
+        else
+            hipLaunchKernelGGL((k_unpack<uint32_t>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t*)ctx->display[which], ctx->d_all_pixels, n, ctx->width, (const uint32_t*)dev_src_all);
+    }
+    if (!ctx->ev_displayed) CK(hipEventCreateWithFlags(&ctx->ev_displayed, hipEventDisableTiming));
+    CK(hipEventRecord(ctx->ev_displayed, ctx->stream));
+    return PT_OK;
+}
+extern "C" int pt_unpack_display(pt_ctx* ctx, int which, const void* dev_src_all) {
+    if (!ctx || !dev_src_all) return PT_ERR_INVALID;
+    return unpack_display_enqueue(ctx, which, dev_src_all);
+}
+extern "C" int pt_display_sync(pt_ctx* ctx) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->ev_displayed) return PT_OK;
+    CK(hipSetDevice(ctx->device));
+    CK(hipEventSynchronize(ctx->ev_displayed));
+    return PT_OK;
+}
+extern "C" void* pt_display_buffer(pt_ctx* ctx, int which) {
+    if (!ctx || which < 0 || which > PT_BUF_DENOISED) return nullptr;
+    return ctx->display[which];
+}
+extern "C" int pt_download_display(pt_ctx* ctx, int which, void* host, size_t bytes) {
+    if (!ctx || !host) return PT_ERR_INVALID;
+    const size_t elem = buffer_elem(which);
+    if (!elem || !ctx->display[which]) return fail(ctx, PT_ERR_INVALID, "pt_download_display: nothing has been handed over into this buffer");
+    if (bytes != elem * (size_t)ctx->width * ctx->height) return fail(ctx, PT_ERR_INVALID, "pt_download_display: byte count does not match the frame size");
+    int rc = pt_display_sync(ctx);
+    if (rc != PT_OK) return rc;
+    CK(hipMemcpy(host, ctx->display[which], bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 // the kernels alone, on the context's stream (pt_multi_gather chains pack -> exchange -> unpack without host waits)
 static int pack_launch(pt_ctx* ctx, int which, void* dev_dst) {
     size_t elem;
@@ -1649,7 +1754,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     st.hit = dHit;
     if (getenv("PT_DEBUG_COUNTS")) {
         CK(tmp.alloc(&dDbg, 64));
-        CK(hipMemset(dDbg, 0, 512));
+        CK(dclear(ctx->stream, dDbg, 512));
     }
     CK(hipMemsetAsync(dWork, 0, sizeof(uint32_t) * iters, ctx->stream));
     CK(hipMemsetAsync(ctx->d_totals + 2, 0, sizeof(unsigned long long), ctx->stream));
@@ -1765,23 +1870,30 @@ extern "C" int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material
 // ===================================================================================================================
 // pt_multi: N contexts in one process (include/pt_amd.h).  No reference counterpart: the reference is single-GPU.
 #include <dlfcn.h>
+#include <rccl/rccl.h> // declarations only: the pointer types below are RCCL's own, the library itself is opened at run time
 
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 namespace {
 // the six RCCL entry points the exchange needs, resolved at run time: libptamd must load (and the single-GPU path must
-// work) on a box without librccl, and a process that already holds torch's bundled librccl must not get a second copy
+// work) on a box without librccl, and a process that already holds torch's bundled librccl must not get a second copy.
+// The pointer types are decltype of rccl.h's declarations, so a signature change breaks the build instead of the call.
 struct Rccl {
     void* lib = nullptr;
-    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
-    int (*CommDestroy)(void* comm) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool ok() const { return lib && CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather && GetErrorString; }
 };
-const int kNcclUint8 = 1; // ncclDataType_t (rccl.h:460)
+const ncclDataType_t kNcclUint8 = ncclUint8;
 
 Rccl& rccl() {
     static Rccl r;
@@ -1806,17 +1918,62 @@ Rccl& rccl() {
 thread_local std::string g_multi_error;
 } // namespace
 
+namespace {
+// One host thread per rank (pt_multi): a frame is ~60 launches and events per device, so enqueueing the devices one after the other
+// from one thread costs ndev x (60 x 5-8 us) — at a 1/8 share of a 1080p frame (1.3-1.8 ms of GPU work) more than the frame itself.
+// Every rank's thread enqueues its own device; the calling thread posts a job to each and waits for all.
+struct RankWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = false, quit = false;
+    int rc = PT_OK;
+    double ms = 0; // host time of the last job
+};
+void rank_worker_main(RankWorker* w, int device) {
+    (void)hipSetDevice(device);
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+        if (w->quit) return;
+        std::function<int()> job = std::move(w->job);
+        w->has_job = false;
+        lk.unlock();
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = job();
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        lk.lock();
+        w->rc = rc;
+        w->ms = ms;
+        w->done = true;
+        w->cv.notify_all();
+    }
+}
+} // namespace
+
 struct pt_multi {
     std::vector<pt_ctx*> ctx;
     std::vector<int> devices;
     std::string err;
     bool distinct = true;           // no device appears twice (RCCL's requirement)
-    std::vector<void*> comms;       // ncclComm_t per rank (empty until the first RCCL gather)
+    std::vector<ncclComm_t> comms;  // per rank (empty until the first RCCL gather)
     int exchange_pref = 0;          // PT_MULTI_EXCHANGE: 0 auto, 1 rccl, 2 peer copies
-    std::vector<void*> send, recv;  // per rank: padded * 16 bytes, world * padded * 16 bytes
+    std::vector<void*> send, recv;  // per rank: padded * 16 bytes, world * padded * 16 bytes (the synchronous pt_multi_gather)
     uint32_t padded = 0;
     double gather_ms = 0;
     int last_exchange = PT_EXCHANGE_NONE;
+    std::vector<std::unique_ptr<RankWorker>> workers; // empty: single rank or PT_MULTI_THREADS=0 (everything on the calling thread)
+    double enqueue_ms = 0;          // host time of the enqueue phase of the last render: the slowest rank's
+    // Overlapped hand-off (frames in flight + a gather mask): frame k's strips are packed behind frame k (pt_pack_async) into the
+    // buffers of slot k & 1 and exchanged + scattered into the ranks' DISPLAY buffers by the NEXT render call, while frame k+1 renders.
+    struct Strips { std::vector<void*> send, recv; };
+    Strips hand[2][6];              // [slot][pt_buffer], allocated on first use
+    std::vector<hipEvent_t> xfer_done[2]; // peer-copy exchange: rank r's copies of slot s are complete
+    int pending_slot = -1;          // slot whose strips are packed (or being packed) but not yet exchanged
+    uint32_t pending_mask = 0;
+    uint64_t handed = 0;            // frames handed over through the overlapped path
+    uint64_t packs = 0;             // pack rounds enqueued (slot = packs & 1)
 };
 
 static int mfail(pt_multi* m, int code, const std::string& msg) {
@@ -1838,7 +1995,12 @@ extern "C" const char* pt_multi_last_error(const pt_multi* m) { return m ? m->er
 extern "C" int pt_multi_size(const pt_multi* m) { return m ? (int)m->ctx.size() : 0; }
 extern "C" pt_ctx* pt_multi_ctx(pt_multi* m, int rank) { return (m && rank >= 0 && rank < (int)m->ctx.size()) ? m->ctx[rank] : nullptr; }
 
+static int multi_present_pending(pt_multi* m, bool wait);
 static void multi_free_exchange(pt_multi* m) {
+    for (size_t r = 0; r < m->ctx.size(); ++r) { // pending packs / exchanges run on the contexts' streams
+        hipSetDevice(m->devices[r]);
+        if (m->ctx[r] && m->ctx[r]->stream) hipStreamSynchronize(m->ctx[r]->stream);
+    }
     for (size_t r = 0; r < m->send.size(); ++r) {
         hipSetDevice(m->devices[r]);
         if (m->send[r]) hipFree(m->send[r]);
@@ -1846,14 +2008,74 @@ static void multi_free_exchange(pt_multi* m) {
     }
     m->send.clear();
     m->recv.clear();
+    for (int sl = 0; sl < 2; ++sl) {
+        for (auto& st : m->hand[sl]) {
+            for (size_t r = 0; r < st.send.size(); ++r) {
+                hipSetDevice(m->devices[r]);
+                if (st.send[r]) hipFree(st.send[r]);
+                if (st.recv[r]) hipFree(st.recv[r]);
+            }
+            st.send.clear();
+            st.recv.clear();
+        }
+        for (hipEvent_t e : m->xfer_done[sl])
+            if (e) hipEventDestroy(e);
+        m->xfer_done[sl].clear();
+    }
+    m->pending_slot = -1;
+    m->pending_mask = 0;
     m->padded = 0;
+}
+
+// fn(rank) for every rank, concurrently on the ranks' threads (or one after the other on the calling thread); returns the first
+// failing rank's status, forwarded with its message.  max_ms: host time of the slowest rank.
+static int multi_run(pt_multi* m, const std::function<int(int)>& fn, const char* what, double* max_ms = nullptr) {
+    const int world = (int)m->ctx.size();
+    std::vector<int> rcs(world, PT_OK);
+    double slow = 0;
+    if (m->workers.empty()) {
+        for (int r = 0; r < world; ++r) {
+            const auto t0 = std::chrono::steady_clock::now();
+            rcs[r] = fn(r);
+            slow += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); // serial: the times add up
+        }
+    } else {
+        for (int r = 0; r < world; ++r) {
+            RankWorker& w = *m->workers[r];
+            std::lock_guard<std::mutex> lk(w.mu);
+            w.job = [&fn, r] { return fn(r); };
+            w.has_job = true;
+            w.done = false;
+            w.cv.notify_all();
+        }
+        for (int r = 0; r < world; ++r) {
+            RankWorker& w = *m->workers[r];
+            std::unique_lock<std::mutex> lk(w.mu);
+            w.cv.wait(lk, [&] { return w.done; });
+            rcs[r] = w.rc;
+            slow = std::max(slow, w.ms);
+        }
+    }
+    if (max_ms) *max_ms = slow;
+    for (int r = 0; r < world; ++r)
+        if (rcs[r] != PT_OK) return mctx(m, r, rcs[r], what);
+    return PT_OK;
 }
 
 extern "C" int pt_multi_destroy(pt_multi* m) {
     if (!m) return PT_OK;
+    for (auto& w : m->workers) {
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->quit = true;
+            w->cv.notify_all();
+        }
+        if (w->th.joinable()) w->th.join();
+    }
+    m->workers.clear();
     multi_free_exchange(m);
     if (!m->comms.empty() && rccl().ok())
-        for (void* c : m->comms)
+        for (ncclComm_t c : m->comms)
             if (c) rccl().CommDestroy(c);
     for (pt_ctx* c : m->ctx) pt_destroy(c);
     delete m;
@@ -1893,6 +2115,12 @@ extern "C" int pt_create_multi(const pt_scene_desc* scene, const int* devices, i
                     if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
                 }
             }
+        }
+    const char* te = getenv("PT_MULTI_THREADS");
+    if (ndev > 1 && !(te && atoi(te) == 0))
+        for (int r = 0; r < ndev; ++r) {
+            m->workers.emplace_back(new RankWorker());
+            m->workers.back()->th = std::thread(rank_worker_main, m->workers.back().get(), devices[r]);
         }
     *out = m;
     return PT_OK;
@@ -1963,6 +2191,10 @@ extern "C" int pt_multi_gather(pt_multi* m, int which) {
     size_t elem = 0;
     if (!buffer_ptr(m->ctx[0], which, &elem)) return mfail(m, PT_ERR_INVALID, "pt_multi_gather: unknown buffer");
     const size_t bytes = (size_t)m->padded * elem; // one rank's packed strip (padded to the largest share: same on every rank)
+    {
+        int rc = multi_present_pending(m, true); // a frame of the overlapped path that was still waiting for its hand-over
+        if (rc) return rc;
+    }
     for (int r = 0; r < world; ++r) { // frames in flight (pt_options.frames_in_flight) are not ordered before the contexts' own streams
         int rc = mctx(m, r, drain(m->ctx[r]), "pt_multi_gather");
         if (rc) return rc;
@@ -1981,20 +2213,20 @@ extern "C" int pt_multi_gather(pt_multi* m, int which) {
         Rccl& R = rccl();
         if (m->comms.empty()) {
             m->comms.assign(world, nullptr);
-            const int e = R.CommInitAll(m->comms.data(), world, m->devices.data());
-            if (e != 0) {
+            const ncclResult_t e = R.CommInitAll(m->comms.data(), world, m->devices.data());
+            if (e != ncclSuccess) {
                 m->comms.clear();
                 return mfail(m, PT_ERR_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(e));
             }
         }
         // one all-gather of `bytes` per rank: with 8 GPUs each of the 7 xGMI links of a GPU carries one strip
-        int e = R.GroupStart();
-        for (int r = 0; r < world && e == 0; ++r) {
+        ncclResult_t e = R.GroupStart();
+        for (int r = 0; r < world && e == ncclSuccess; ++r) {
             MCK(m, hipSetDevice(m->devices[r]));
             e = R.AllGather(m->send[r], m->recv[r], bytes, kNcclUint8, m->comms[r], m->ctx[r]->stream);
         }
-        const int e2 = R.GroupEnd();
-        if (e != 0 || e2 != 0) return mfail(m, PT_ERR_HIP, std::string("ncclAllGather: ") + R.GetErrorString(e ? e : e2));
+        const ncclResult_t e2 = R.GroupEnd();
+        if (e != ncclSuccess || e2 != ncclSuccess) return mfail(m, PT_ERR_HIP, std::string("ncclAllGather: ") + R.GetErrorString(e != ncclSuccess ? e : e2));
         m->last_exchange = PT_EXCHANGE_RCCL;
     } else {
         // every rank writes its strip into slot r of every rank's receive buffer (direct peer writes over xGMI; a plain
@@ -2053,55 +2285,206 @@ static int multi_after_render(pt_multi* m, uint32_t gather_mask, uint32_t* host_
     return PT_OK;
 }
 
+// ---- overlapped hand-off (frames in flight + something to hand over): everything below only ENQUEUES on the ranks' own streams
+static int multi_ensure_strips(pt_multi* m, int slot, int which) {
+    pt_multi::Strips& st = m->hand[slot][which];
+    const int world = (int)m->ctx.size();
+    if ((int)st.send.size() == world) return PT_OK;
+    const size_t elem = buffer_elem(which);
+    st.send.assign(world, nullptr);
+    st.recv.assign(world, nullptr);
+    for (int r = 0; r < world; ++r) {
+        MCK(m, hipSetDevice(m->devices[r]));
+        MCK(m, hipMalloc(&st.send[r], std::max<size_t>(16, (size_t)m->padded * elem)));
+        MCK(m, hipMalloc(&st.recv[r], std::max<size_t>(16, (size_t)world * m->padded * elem)));
+    }
+    if (m->xfer_done[slot].empty()) {
+        m->xfer_done[slot].assign(world, nullptr);
+        for (int r = 0; r < world; ++r) {
+            MCK(m, hipSetDevice(m->devices[r]));
+            MCK(m, hipEventCreateWithFlags(&m->xfer_done[slot][r], hipEventDisableTiming));
+        }
+    }
+    return PT_OK;
+}
+static bool multi_use_rccl(pt_multi* m, int* err) {
+    const int world = (int)m->ctx.size();
+    bool use_rccl = m->exchange_pref == 1 || (m->exchange_pref == 0 && m->distinct && world > 1);
+    *err = PT_OK;
+    if (use_rccl && (!rccl().ok() || !m->distinct)) {
+        if (m->exchange_pref == 1) *err = mfail(m, PT_ERR_UNSUPPORTED, !m->distinct ? "pt_multi: RCCL needs distinct devices" : "pt_multi: librccl not found");
+        use_rccl = false;
+    }
+    return use_rccl;
+}
+// the strips of `slot` (packed on every rank's stream) -> all ranks' receive buffers -> the ranks' display buffers
+static int multi_exchange_display(pt_multi* m, int slot, int which) {
+    const int world = (int)m->ctx.size();
+    pt_multi::Strips& st = m->hand[slot][which];
+    const size_t bytes = (size_t)m->padded * buffer_elem(which);
+    int err;
+    const bool use_rccl = multi_use_rccl(m, &err);
+    if (err) return err;
+    if (use_rccl) {
+        Rccl& R = rccl();
+        if (m->comms.empty()) {
+            m->comms.assign(world, nullptr);
+            const ncclResult_t e = R.CommInitAll(m->comms.data(), world, m->devices.data());
+            if (e != ncclSuccess) {
+                m->comms.clear();
+                return mfail(m, PT_ERR_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(e));
+            }
+        }
+        ncclResult_t e = R.GroupStart();
+        for (int r = 0; r < world && e == ncclSuccess; ++r) {
+            MCK(m, hipSetDevice(m->devices[r]));
+            e = R.AllGather(st.send[r], st.recv[r], bytes, kNcclUint8, m->comms[r], m->ctx[r]->stream);
+        }
+        const ncclResult_t e2 = R.GroupEnd();
+        if (e != ncclSuccess || e2 != ncclSuccess) return mfail(m, PT_ERR_HIP, std::string("ncclAllGather: ") + R.GetErrorString(e != ncclSuccess ? e : e2));
+        m->last_exchange = PT_EXCHANGE_RCCL;
+    } else {
+        for (int r = 0; r < world; ++r) {
+            MCK(m, hipSetDevice(m->devices[r]));
+            for (int p = 0; p < world; ++p) {
+                char* dst = (char*)st.recv[p] + (size_t)r * bytes;
+                if (m->devices[p] == m->devices[r]) MCK(m, hipMemcpyAsync(dst, st.send[r], bytes, hipMemcpyDeviceToDevice, m->ctx[r]->stream));
+                else MCK(m, hipMemcpyPeerAsync(dst, m->devices[p], st.send[r], m->devices[r], bytes, m->ctx[r]->stream));
+            }
+            MCK(m, hipEventRecord(m->xfer_done[slot][r], m->ctx[r]->stream));
+        }
+        for (int p = 0; p < world; ++p) {
+            MCK(m, hipSetDevice(m->devices[p]));
+            for (int r = 0; r < world; ++r)
+                if (r != p) MCK(m, hipStreamWaitEvent(m->ctx[p]->stream, m->xfer_done[slot][r], 0));
+        }
+        m->last_exchange = PT_EXCHANGE_PEER_COPY;
+    }
+    for (int r = 0; r < world; ++r) {
+        int rc = mctx(m, r, unpack_display_enqueue(m->ctx[r], which, st.recv[r]), "pt_multi(unpack_display)");
+        if (rc) return rc;
+    }
+    return PT_OK;
+}
+// exchange what the previous call packed (if anything) and wait until it is on display
+static int multi_present_pending(pt_multi* m, bool wait) {
+    if (m->pending_slot < 0) return PT_OK;
+    const int slot = m->pending_slot;
+    const uint32_t mask = m->pending_mask;
+    m->pending_slot = -1;
+    m->pending_mask = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int which = 0; which <= PT_BUF_DENOISED; ++which)
+        if (mask & (1u << which)) {
+            int rc = multi_exchange_display(m, slot, which);
+            if (rc) return rc;
+        }
+    ++m->handed;
+    if (wait)
+        for (size_t r = 0; r < m->ctx.size(); ++r) {
+            int rc = mctx(m, (int)r, pt_display_sync(m->ctx[r]), "pt_multi(display)");
+            if (rc) return rc;
+        }
+    m->gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PT_OK;
+}
+static int multi_pack_newest(pt_multi* m, uint32_t mask) {
+    // the slots alternate: the other slot's strips were exchanged by this call a moment ago (they may still be in flight), this slot's
+    // were put on display — and waited for — one call earlier
+    const int use = (int)(m->packs++ & 1);
+    for (int which = 0; which <= PT_BUF_DENOISED; ++which)
+        if (mask & (1u << which)) {
+            int rc = multi_ensure_strips(m, use, which);
+            if (rc) return rc;
+            for (size_t r = 0; r < m->ctx.size(); ++r) {
+                rc = mctx(m, (int)r, pack_async_enqueue(m->ctx[r], which, m->hand[use][which].send[r], use), "pt_multi(pack)");
+                if (rc) return rc;
+            }
+        }
+    m->pending_slot = use;
+    m->pending_mask = mask;
+    return PT_OK;
+}
+
+// One frame (or launch chain of `count` subframes, or — regions != null — one foveated frame) on every rank.
+static int multi_render_common(pt_multi* m, uint32_t spp, uint32_t subframe_index, uint32_t count, const pt_region* regions, uint32_t nreg,
+                               const pt_variant* variant, uint32_t gather_mask, uint32_t* host_rgba8, const char* what) {
+    const int world = (int)m->ctx.size();
+    if (world == 0) return PT_OK;
+    if (host_rgba8) gather_mask |= 1u << PT_BUF_FRAME;
+    if (gather_mask >> (PT_BUF_DENOISED + 1)) return mfail(m, PT_ERR_INVALID, std::string(what) + ": unknown buffer in gather_mask");
+    const int F = frames_mode(m->ctx[0]);
+    auto enqueue = [&](int r, int slot, int mode) {
+        pt_ctx* c = m->ctx[r];
+        return regions ? regions_enqueue(c, regions, nreg, variant, slot, mode != 0) : render_enqueue(c, spp, subframe_index, slot, mode, count);
+    };
+    auto enqueue_pipelined = [&](int r) {
+        pt_ctx* c = m->ctx[r];
+        const int slot = (c->last_slot + 1) % F;
+        int rc = render_finish(c, slot);
+        if (rc == PT_OK) rc = enqueue(r, slot, F);
+        if (rc == PT_OK) c->last_slot = slot;
+        return rc;
+    };
+    if (F > 1 && gather_mask == 0) {
+        // pure throughput (nothing is handed over after this frame): pt_options.frames_in_flight applies on every device
+        int rc = multi_present_pending(m, true); // a frame of an earlier call that was waiting for its hand-over
+        int rc1 = multi_run(m, enqueue_pipelined, what, &m->enqueue_ms);
+        int rc2 = multi_run(m, [&](int r) { return pipelined_wait(m->ctx[r], F); }, what);
+        return rc ? rc : (rc1 ? rc1 : rc2);
+    }
+    if (F > 1) {
+        // Frames in flight AND a hand-over: frame k is enqueued, then the strips frame k-1 packed behind itself are exchanged and
+        // scattered into the display buffers while frame k renders, then frame k's pack is enqueued behind frame k.  The call
+        // returns when frame k-1 is on display (host_rgba8 receives it) and at most F-1 frames are still running.
+        int rc = multi_run(m, enqueue_pipelined, what, &m->enqueue_ms);
+        if (rc) return rc;
+        const bool had = m->pending_slot >= 0;
+        rc = multi_present_pending(m, true);
+        if (rc) return rc;
+        if (m->ctx[0]->width) {
+            rc = multi_pack_newest(m, gather_mask);
+            if (rc) return rc;
+        }
+        rc = multi_run(m, [&](int r) { return pipelined_wait(m->ctx[r], F); }, what);
+        if (rc) return rc;
+        if (host_rgba8 && had && m->ctx[0]->width)
+            return mctx(m, 0, pt_download_display(m->ctx[0], PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)m->ctx[0]->width * m->ctx[0]->height), what);
+        return PT_OK;
+    }
+    // synchronous frames: every rank enqueues and finishes its own frame on its own thread, then the hand-over
+    int rc = multi_present_pending(m, true);
+    if (rc) return rc;
+    rc = multi_run(m, [&](int r) { return enqueue(r, 0, 0); }, what, &m->enqueue_ms);
+    int rc2 = multi_run(m, [&](int r) { return render_finish(m->ctx[r]); }, what); // every rank's frame is waited for, also after a failure
+    if (rc || rc2) return rc ? rc : rc2;
+    return multi_after_render(m, gather_mask, host_rgba8);
+}
+
 extern "C" int pt_multi_render(pt_multi* m, uint32_t spp, uint32_t subframe_index, uint32_t gather_mask, uint32_t* host_rgba8) {
     return pt_multi_render_batch(m, spp, subframe_index, 1, gather_mask, host_rgba8);
 }
 
 extern "C" int pt_multi_render_batch(pt_multi* m, uint32_t spp, uint32_t subframe_index, uint32_t count, uint32_t gather_mask, uint32_t* host_rgba8) {
     if (!m) return PT_ERR_INVALID;
-    const int world = (int)m->ctx.size();
-    const int F = world ? frames_mode(m->ctx[0]) : 1;
-    if (F > 1 && gather_mask == 0 && !host_rgba8) {
-        // pure throughput (nothing is handed over after this frame): pt_options.frames_in_flight applies on every device
-        int first = PT_OK;
-        for (int r = 0; r < world; ++r) {
-            int rc = mctx(m, r, pipelined_enqueue(m->ctx[r], spp, subframe_index, F, count), "pt_multi_render");
-            if (rc && !first) first = rc;
-        }
-        for (int r = 0; r < world; ++r) {
-            int rc = mctx(m, r, pipelined_wait(m->ctx[r], F), "pt_multi_render");
-            if (rc && !first) first = rc;
-        }
-        return first;
-    }
-    // enqueue on every device, then wait: the devices render their tiles concurrently
-    for (int r = 0; r < world; ++r) {
-        int rc = mctx(m, r, render_enqueue(m->ctx[r], spp, subframe_index, 0, 0, count), "pt_multi_render");
-        if (rc) return rc;
-    }
-    int first = PT_OK;
-    for (int r = 0; r < world; ++r) {
-        int rc = mctx(m, r, render_finish(m->ctx[r]), "pt_multi_render");
-        if (rc && !first) first = rc;
-    }
-    if (first) return first;
-    return multi_after_render(m, gather_mask, host_rgba8);
+    return multi_render_common(m, spp, subframe_index, count, nullptr, 0, nullptr, gather_mask, host_rgba8, "pt_multi_render");
 }
 
 extern "C" int pt_multi_render_regions(pt_multi* m, const pt_region* regions, uint32_t n, const pt_variant* variant, uint32_t gather_mask, uint32_t* host_rgba8) {
     if (!m || (!regions && n)) return PT_ERR_INVALID;
-    const int world = (int)m->ctx.size();
-    for (int r = 0; r < world; ++r) {
-        int rc = mctx(m, r, regions_enqueue(m->ctx[r], regions, n, variant), "pt_multi_render_regions");
-        if (rc) return rc;
-    }
-    int first = PT_OK;
-    for (int r = 0; r < world; ++r) {
-        int rc = mctx(m, r, render_finish(m->ctx[r]), "pt_multi_render_regions");
-        if (rc && !first) first = rc;
-    }
-    if (first) return first;
-    return multi_after_render(m, gather_mask, host_rgba8);
+    return multi_render_common(m, 0, 0, 1, regions, n, variant, gather_mask, host_rgba8, "pt_multi_render_regions");
+}
+
+// the frame that is still waiting for its hand-over (overlapped path) is exchanged and put on display
+extern "C" int pt_multi_flush(pt_multi* m, uint32_t* host_rgba8) {
+    if (!m) return PT_ERR_INVALID;
+    const bool had = m->pending_slot >= 0;
+    const bool frame = had && (m->pending_mask & (1u << PT_BUF_FRAME));
+    int rc = multi_present_pending(m, true);
+    if (rc) return rc;
+    if (host_rgba8 && frame && !m->ctx.empty() && m->ctx[0]->width)
+        return mctx(m, 0, pt_download_display(m->ctx[0], PT_BUF_FRAME, host_rgba8, sizeof(uint32_t) * (size_t)m->ctx[0]->width * m->ctx[0]->height), "pt_multi_flush");
+    return PT_OK;
 }
 
 extern "C" int pt_multi_get_stats(const pt_multi* m, pt_multi_stats* out) {
@@ -2133,5 +2516,8 @@ extern "C" int pt_multi_get_stats(const pt_multi* m, pt_multi_stats* out) {
     out->gather_ms = m->gather_ms;
     out->exchange = m->last_exchange;
     out->ndev = (int)m->ctx.size();
+    out->enqueue_ms = m->enqueue_ms;
+    out->threads = (int32_t)m->workers.size();
+    out->frames_handed_over = m->handed;
     return PT_OK;
 }

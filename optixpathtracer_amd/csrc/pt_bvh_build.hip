@@ -603,6 +603,7 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
     if (getenv("PT_DEBUG_BVH")) { // slot occupancy of the wide tree
         auto fbits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
         std::vector<Node8> h(hc[1]);
+        HIPCHK(hipStreamSynchronize(stream)); // the library's streams do not synchronise with the null stream
         HIPCHK(hipMemcpy(h.data(), nodes, sizeof(Node8) * h.size(), hipMemcpyDeviceToHost));
         unsigned long long fill[9] = {0}, leafsz[9] = {0}, nint = 0, nleaf = 0;
         for (const Node8& nd : h) {
@@ -668,6 +669,7 @@ static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt,
         N = (int)(lv[0] + lv[1]);
         int* t = cl_a; cl_a = cl_b; cl_b = t;
     }
+    HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipMemcpy(root_out, cl_a, sizeof(int), hipMemcpyDeviceToHost));
     hipFree(cl_a); hipFree(cl_b); hipFree(nn); hipFree(merge); hipFree(valid); hipFree(merge_rank); hipFree(valid_rank); hipFree(tmp);
     return hipSuccess;
@@ -773,6 +775,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
         out->root = 0; // node 0 (range = everything) always stays internal when n > PT_LEAF_MAX, and remap[0] = 0
         // depth of the binary tree (bounds the traversal stack of bvh2_traverse / k_trace2): host walk over the emitted nodes
         std::vector<Node2> h(nnodes);
+        HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipMemcpy(h.data(), nodes, sizeof(Node2) * h.size(), hipMemcpyDeviceToHost));
         std::vector<int> depth(nnodes, 0);
         std::vector<int32_t> todo{0};

@@ -54,6 +54,9 @@ class DevicePacker:
             else:
                 buf = self.torch.zeros((n, 4), dtype=self.torch.float32, device="cuda")
             self._bufs[key] = buf
+            # torch zero-fills on its current stream; the library's streams are non-blocking (they do not wait for the null stream),
+            # so the fill must be complete before a pack kernel may write the buffer
+            self.torch.cuda.current_stream().synchronize()
         return buf
 
     def sync(self):
@@ -66,6 +69,16 @@ class DevicePacker:
 
     def unpack(self, which, src):
         self.r.unpack(which, src.data_ptr())
+
+    # overlapped hand-off (pt_pack_async / pt_pack_wait / pt_unpack_display)
+    def pack_async(self, which, dst, slot):
+        self.r.packAsync(which, dst.data_ptr(), slot)
+
+    def pack_wait(self, slot):
+        self.r.packWait(slot)
+
+    def unpack_display(self, which, src):
+        self.r.unpackDisplay(which, src.data_ptr())
 
 
 def exchange_frame(packer, which, world: int, all_gather_into_tensor):
@@ -80,3 +93,42 @@ def exchange_frame(packer, which, world: int, all_gather_into_tensor):
         packer.sync()
     packer.unpack(which, dst)
     return dst
+
+
+class HandOff:
+    """The display hand-off overlapped with rendering (include/pt_amd.h, pt_pack_async ...).  With frames in flight the loop is
+
+        for k in frames:  render(k);  h.collect();  h.submit()
+        h.collect()       # the last frame
+
+    submit() enqueues the pack of the frame just enqueued behind its last kernel (no host wait) into one of two send buffers;
+    collect() takes the frame submitted before: waits for ITS pack only, all-gathers the strips (RCCL over xGMI), and scatters them
+    into the display copy of the buffer — all while the next frame renders.  collect() is called before the next submit() so that the
+    scatter is not queued behind the wait for the frame that is still rendering."""
+
+    def __init__(self, packer, which, world: int, all_gather_into_tensor):
+        self.packer, self.which, self.world, self.all_gather = packer, which, world, all_gather_into_tensor
+        _, padded = packer.owned_padded()
+        self.send = [packer.alloc(padded, which, 2 + s) if isinstance(packer, DevicePacker) else packer.alloc(padded, which) for s in (0, 1)]
+        self.recv = packer.alloc(padded * world, which, 1) if isinstance(packer, DevicePacker) else packer.alloc(padded * world, which)
+        self.n = 0
+        self.pending = None
+
+    def submit(self):
+        slot = self.n & 1
+        self.packer.pack_async(self.which, self.send[slot], slot)
+        self.pending = slot
+        self.n += 1
+
+    def collect(self):
+        """Returns True when a frame was handed over (it is then complete in the display buffer once the library's stream reaches it:
+        pt_display_sync / pt_download_display wait for that)."""
+        if self.pending is None:
+            return False
+        slot, self.pending = self.pending, None
+        self.packer.pack_wait(slot)
+        self.all_gather(self.recv, self.send[slot])
+        if hasattr(self.packer, "sync"):
+            self.packer.sync()
+        self.packer.unpack_display(self.which, self.recv)
+        return True

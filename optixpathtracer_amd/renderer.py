@@ -278,6 +278,25 @@ class SampleRenderer:
     def unpack(self, which, dev_ptr: int):
         self._ck(self._L.pt_unpack(self._ctx, which, dev_ptr), "pt_unpack")
 
+    # -- display hand-off that overlaps the next frame (pt_pack_async ... pt_download_display, include/pt_amd.h)
+    def packAsync(self, which, dev_ptr: int, slot: int):
+        self._ck(self._L.pt_pack_async(self._ctx, which, dev_ptr, int(slot)), "pt_pack_async")
+
+    def packWait(self, slot: int):
+        self._ck(self._L.pt_pack_wait(self._ctx, int(slot)), "pt_pack_wait")
+
+    def unpackDisplay(self, which, dev_ptr: int):
+        self._ck(self._L.pt_unpack_display(self._ctx, which, dev_ptr), "pt_unpack_display")
+
+    def displaySync(self):
+        self._ck(self._L.pt_display_sync(self._ctx), "pt_display_sync")
+
+    def downloadDisplay(self, which) -> np.ndarray:
+        w, h = self.launchParams.frame.size
+        out = np.empty((h, w), np.uint32) if which == PT_BUF_FRAME else np.empty((h, w, 4), np.float32)
+        self._ck(self._L.pt_download_display(self._ctx, which, out.ctypes.data, out.nbytes), "pt_download_display")
+        return out
+
     def exportBVH(self):
         """The traversal structure as the kernels see it (pt_export_bvh): (nodes uint32[num_nodes, 20], tris float32[num_tris, 12])."""
         nn, nt = C.c_uint32(), C.c_uint32()
@@ -419,6 +438,14 @@ class MultiRenderer:
     def gather(self, which):
         self._ck(self._L.pt_multi_gather(self._m, int(which)), "pt_multi_gather")
 
+    def flush(self, out: np.ndarray | None = None):
+        """Overlapped hand-off (frames in flight + gather_mask): the newest frame goes on display now (pt_multi_flush)."""
+        ptr = out.ctypes.data if out is not None else None
+        self._ck(self._L.pt_multi_flush(self._m, ptr), "pt_multi_flush")
+
+    def downloadDisplay(self, which, rank=0) -> np.ndarray:
+        return self.rank(rank).downloadDisplay(which)
+
     def download(self, which, rank=0) -> np.ndarray:
         return self.rank(rank).download(which)
 
@@ -431,7 +458,8 @@ class MultiRenderer:
         s = MultiStats()
         self._ck(self._L.pt_multi_get_stats(self._m, C.byref(s)), "pt_multi_get_stats")
         d = s.sum.as_dict()
-        d.update(gather_ms=s.gather_ms, exchange=self.EXCHANGE.get(s.exchange, "?"), ndev=s.ndev)
+        d.update(gather_ms=s.gather_ms, exchange=self.EXCHANGE.get(s.exchange, "?"), ndev=s.ndev, enqueue_ms=s.enqueue_ms, threads=s.threads,
+                 frames_handed_over=s.frames_handed_over)
         return d
 
 

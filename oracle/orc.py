@@ -102,6 +102,12 @@ class Oracle:
         L.orc_uniform_sample_hemisphere.argtypes = [C.c_uint32, f32p]
         L.orc_cosine_sample_hemisphere.argtypes = [C.c_float, C.c_float, f32p]
         L.orc_math_table.argtypes = [C.c_int, f32p, f32p, C.c_int, f32p]
+        L.orc_normalize.argtypes = [f32p, f32p]
+        L.orc_faceforward.argtypes = [f32p, f32p, f32p]
+        L.orc_safe_normalize.argtypes = [f32p, f32p]
+        L.orc_lerp3.argtypes = [f32p, f32p, C.c_float, f32p]
+        L.orc_clamp3.argtypes = [f32p, C.c_float, C.c_float, f32p]
+        L.orc_to_srgb.argtypes = [f32p, f32p]
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(Probe), C.POINTER(Params), f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_render_region.argtypes = [C.c_void_p, C.POINTER(Probe), C.POINTER(Params), C.POINTER(Region), C.POINTER(Variant), f32p, u32p, C.POINTER(Stats)]
         L.orc_render_region_aov.argtypes = [C.c_void_p, C.POINTER(Probe), C.POINTER(Params), C.POINTER(Region), C.POINTER(Variant), f32p, u32p, f32p, f32p, f32p, C.POINTER(Stats)]
@@ -271,4 +277,9 @@ def load_ref():
     R.ref_uvw_frame.argtypes = [f32p, f32p, f32p, C.c_float, C.c_float, f32p, f32p, f32p]
     R.ref_faceforward.argtypes = [f32p, f32p, f32p]
     R.ref_normalize.argtypes = [f32p, f32p]
+    if hasattr(R, "ref_safe_normalize"):
+        R.ref_safe_normalize.argtypes = [f32p, f32p]
+        R.ref_lerp3.argtypes = [f32p, f32p, C.c_float, f32p]
+        R.ref_clamp3.argtypes = [f32p, C.c_float, C.c_float, f32p]
+        R.ref_to_srgb.argtypes = [f32p, f32p]
     return R

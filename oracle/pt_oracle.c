@@ -980,6 +980,14 @@ void orc_bsdf_sample(int mode, const orc_material* mat, float etaI, float etaO, 
     L[0] = l.x; L[1] = l.y; L[2] = l.z;
     state_out[0] = r.seed1; state_out[1] = r.seed2;
 }
+/* the small vector helpers by themselves, for the golden fixture (tests/golden/ref_tables.npz): normalize / faceforward
+ * (sutil/vec_math.h:553-570), SafeNormalize (maths.h:144-156), lerp / clamp (sutil/vec_math.h:500-516), toSRGB (cuda/helpers.h:34-42) */
+void orc_normalize(const float a[3], float out[3]) { f3 r = normalize3(mk3(a[0], a[1], a[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void orc_faceforward(const float n[3], const float i[3], float out[3]) { f3 N = mk3(n[0], n[1], n[2]); f3 r = faceforward3(N, mk3(i[0], i[1], i[2]), N); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void orc_safe_normalize(const float a[3], float out[3]) { f3 r = safe_normalize(mk3(a[0], a[1], a[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void orc_lerp3(const float a[3], const float b[3], float t, float out[3]) { f3 r = lerp3(mk3(a[0], a[1], a[2]), mk3(b[0], b[1], b[2]), t); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void orc_clamp3(const float v[3], float lo, float hi, float out[3]) { out[0] = clampf(v[0], lo, hi); out[1] = clampf(v[1], lo, hi); out[2] = clampf(v[2], lo, hi); }
+void orc_to_srgb(const float c[3], float out[3]) { out[0] = to_srgb1(c[0]); out[1] = to_srgb1(c[1]); out[2] = to_srgb1(c[2]); }
 void orc_basis_from_vector(const float w[3], float u[3], float v[3]) {
     f3 uu, vv;
     basis_from_vector(mk3(w[0], w[1], w[2]), &uu, &vv);

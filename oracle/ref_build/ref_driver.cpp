@@ -68,4 +68,9 @@ void ref_uvw_frame(const float e[3], const float a[3], const float up[3], float 
 }
 void ref_faceforward(const float n[3], const float i[3], float out[3]) { float3 N = make_float3(n[0], n[1], n[2]); float3 r = faceforward(N, make_float3(i[0], i[1], i[2]), N); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
 void ref_normalize(const float n[3], float out[3]) { float3 r = normalize(make_float3(n[0], n[1], n[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+// maths.h:144-156 (note the double-precision 1.0 / sqrt(m)), sutil/vec_math.h:500-503 and :513-516, cuda/helpers.h:34-42
+void ref_safe_normalize(const float a[3], float out[3]) { float3 r = SafeNormalize(make_float3(a[0], a[1], a[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void ref_lerp3(const float a[3], const float b[3], float t, float out[3]) { float3 r = lerp(make_float3(a[0], a[1], a[2]), make_float3(b[0], b[1], b[2]), t); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void ref_clamp3(const float v[3], float lo, float hi, float out[3]) { float3 r = clamp(make_float3(v[0], v[1], v[2]), lo, hi); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void ref_to_srgb(const float c[3], float out[3]) { float3 r = toSRGB(make_float3(c[0], c[1], c[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
 }

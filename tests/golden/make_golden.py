@@ -109,6 +109,28 @@ def main():
         R.ref_uvw_frame(np.array(cam["eye"], np.float32), np.array(cam["lookat"], np.float32), np.array(cam["up"], np.float32), cam["fovY"], asp, U, V, W)
         cams.append(np.concatenate([cam["eye"], cam["lookat"], cam["up"], [cam["fovY"], asp], U, V, W]).astype(np.float32))
     G.update(cam_table=np.array(cams, np.float32))
+    # --- round 3: SafeNormalize (maths.h:144-156: a * (1.0 / sqrt(m)) with a DOUBLE quotient), lerp / clamp (sutil/vec_math.h:500-516),
+    # toSRGB alone (cuda/helpers.h:34-42).  SafeNormalize inputs span 60 binades of |a|^2 plus the zero vector and denormal lengths, so that a
+    # float division that differed from the double quotient rounded to float would show.
+    n = 6000
+    sa = (rng.standard_normal((n, 3)) * np.exp(rng.uniform(-20, 20, (n, 1)))).astype(np.float32)
+    sa[:4] = [[0, 0, 0], [1e-23, 0, 0], [3, 4, 0], [1e-30, 1e-30, 1e-30]]
+    sn = np.zeros((n, 3), np.float32)
+    la = rng.standard_normal((n, 3)).astype(np.float32); lb = rng.standard_normal((n, 3)).astype(np.float32)
+    lt = rng.uniform(-0.25, 1.25, n).astype(np.float32)
+    lo = np.zeros((n, 3), np.float32)
+    cv = (rng.standard_normal((n, 3)) * 6).astype(np.float32)
+    cv[:3] = [[np.nan, 0.5, 11], [-0.0, 10.0, 0.0], [np.inf, -np.inf, 5]]
+    cl = np.zeros((n, 3), np.float32)
+    sc = (rng.random((n, 3)) * 1.2).astype(np.float32)
+    sc[:600, 0] = np.linspace(0.0, 0.0062616, 600)  # both sides of the 0.0031308 knee
+    so = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        R.ref_safe_normalize(sa[i].copy(), sn[i])
+        R.ref_lerp3(la[i].copy(), lb[i].copy(), float(lt[i]), lo[i])
+        R.ref_clamp3(cv[i].copy(), 0.0, 10.0, cl[i])
+        R.ref_to_srgb(sc[i].copy(), so[i])
+    G.update(safe_in=sa, safe_out=sn, lerp_a=la, lerp_b=lb, lerp_t=lt, lerp_out=lo, clamp_in=cv, clamp_out=cl, srgb_in=sc, srgb_out=so)
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_tables.npz")
     np.savez_compressed(out, **G)
     print("wrote", out, os.path.getsize(out), "bytes")

@@ -41,10 +41,25 @@ class NumpyPacker:
         v = self.frames[which][(px >> 16).astype(np.int64), (px & 0xFFFF).astype(np.int64)]
         dst[: len(px)] = self.torch.from_numpy(np.ascontiguousarray(v))
 
-    def unpack(self, which, src):
+    def unpack(self, which, src, into=None):
         a = src.numpy()
+        dst = self.frames[which] if into is None else into
         for r, px in enumerate(self.lists):
-            self.frames[which][(px >> 16).astype(np.int64), (px & 0xFFFF).astype(np.int64)] = a[r * self.padded : r * self.padded + len(px)]
+            dst[(px >> 16).astype(np.int64), (px & 0xFFFF).astype(np.int64)] = a[r * self.padded : r * self.padded + len(px)]
+
+    # the overlapped hand-off's entry points (synchronous here): display buffers are separate from the rendered ones
+    def pack_async(self, which, dst, slot):
+        self.pack(which, dst)
+
+    def pack_wait(self, slot):
+        pass
+
+    def unpack_display(self, which, src):
+        if not hasattr(self, "display"):
+            self.display = {}
+        if which not in self.display:
+            self.display[which] = np.zeros_like(self.frames[which])
+        self.unpack(which, src, self.display[which])
 
 
 def _worker(rank, world, port, w, h, q):
@@ -76,6 +91,19 @@ def _worker(rank, world, port, w, h, q):
         multigpu.exchange_frame(packer, 0, world, dist.all_gather_into_tensor)
         multigpu.exchange_frame(packer, 1, world, dist.all_gather_into_tensor)
         ok = np.array_equal(frames[0].view(np.uint32), full["accum"].view(np.uint32)) and np.array_equal(frames[1].view(np.uint32), full["frame"])
+        # the overlapped hand-off (multigpu.HandOff): frame k is submitted, frame k-1 collected into the DISPLAY buffer while "frame k renders";
+        # the rendered buffer keeps changing underneath (here: every frame adds k to this rank's own pixels)
+        own = frame.copy()
+        packer2 = NumpyPacker({1: own}, lists, rank, w)
+        h_off = multigpu.HandOff(packer2, 1, world, dist.all_gather_into_tensor)
+        want_prev = None
+        for k in range(4):
+            own[mine] = (full["frame"].astype(np.int64)[mine] + k).astype(np.int32)  # "render(k)" overwrites this rank's pixels
+            if h_off.collect():
+                ok = ok and np.array_equal(packer2.display[1], want_prev)
+            h_off.submit()
+            want_prev = (full["frame"].astype(np.int64) + k).astype(np.int32)
+        ok = ok and h_off.collect() and np.array_equal(packer2.display[1], want_prev) and not h_off.collect()
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

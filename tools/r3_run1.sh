@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/r3_t2.log 2>&1
-tail -8 gpurun_out/r3_t2.log
-BENCH_DEBUG=1 python tools/r3_order2.py 2>&1 | grep -v amdgpu.ids | tail -12
+timeout -k 10 600 python -m pytest tests/test_gpu_schedule.py -x -q -s > gpurun_out/r3_t5.log 2>&1
+tail -25 gpurun_out/r3_t5.log
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "multi or cxx" > gpurun_out/r3_t6.log 2>&1
+tail -5 gpurun_out/r3_t6.log

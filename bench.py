@@ -38,6 +38,8 @@ WORKLOADS = {
     "c3_terrain1M_1080p_4spp_d8": ("terrain", "TERRAIN_CAMERA", 1920, 1080, 4, 8),
     "c2_cornell_1080p_4spp_d8": ("cornell", "CORNELL_CAMERA", 1920, 1080, 4, 8),
     "c4_terrain1M_4k_16spp_d8": ("terrain", "TERRAIN_CAMERA", 3840, 2160, 16, 8),
+    # second 1 M-triangle workload (scenes.stadium_scene): rotated, displaced, long thin triangles over six decades of edge length, camera inside
+    "stadium1M_1080p_4spp_d8": ("stadium", "STADIUM_CAMERA", 1920, 1080, 4, 8),
     # the reference's only published runs (HelloPathtracing_sv4_vmv23, 3840x2160, depth cutoff 4):
     # uniform 8 spp without accumulation, and the 3-region foveated schedule (radii 157/515, 1/2/8 spp)
     "sv4_uniform_terrain1M_4k_8spp_d4": ("terrain", "TERRAIN_CAMERA", 3840, 2160, 8, 4),
@@ -120,7 +122,7 @@ def main():
         # per-GPU work fixed: the image grows to N x the pixels (same aspect, multiples of 8) and is tile-partitioned
         f = world ** 0.5
         w, h = int(round(w * f / 8)) * 8, int(round(h * f / 8)) * 8
-    model = scenes.voxel_terrain() if scene_name == "terrain" else scenes.cornell_box()
+    model = {"terrain": scenes.voxel_terrain, "stadium": scenes.stadium_scene, "cornell": scenes.cornell_box}[scene_name]()
     probe = scenes.sky_probe(2048, 1024).BuildCDF()
     cam = getattr(scenes, cam_name)
 
@@ -426,7 +428,7 @@ def main():
             "frame_latency_ms": round(agg["render_ms"] / n_chains, 3),
             "ms_per_step_per_rank": per_rank_ms,
             "kernel_ms_per_frame_isolated": None if iso is None else {k: round(iso[k], 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
-            "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2)},
+            "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2), "hierarchy": ["lbvh", "ploc"][st["bvh_builder"]]},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "ms_per_displayed_frame": None if ms_displayed is None else round(ms_displayed, 3),  # per frame, in a loop that hands every launch chain's result over (every subframes_per_batch frames), the exchange overlapping the next chain
             "roofline": {

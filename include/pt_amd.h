@@ -130,6 +130,10 @@ typedef struct pt_stats {
     uint64_t frames;        /* frames completed since pt_create, and the rays they traced: take differences around a */
     uint64_t total_radiance_rays; /* sequence of pt_render calls (pt_get_stats itself waits for the frames in flight) */
     uint64_t total_shadow_rays;
+    uint32_t bvh_builder;   /* hierarchy under the wide tree: 0 = LBVH (Morton order), 1 = PLOC.  pt_create builds both and keeps the one through which
+                             * a fixed batch of calibration rays takes fewer traversal steps; PT_BVH_BUILDER=lbvh|ploc forces one.  Images do not
+                             * depend on the choice (closest hit, lowest primitive on ties, hits confined to the triangle's padded box). */
+    uint32_t reserved_;
 } pt_stats;
 
 /* SampleRenderer::SampleRenderer(const Model*) (SimplePathtracer.cpp:39-71): uploads the meshes

@@ -838,8 +838,8 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
     const int nq = ctx->nq;
     const float tmin_rad = job ? job->var.radiance_tmin : 0.001f;
     const int cull = job ? job->var.cull_back_occlusion : 0;
-    BvhDev bvh{ctx->bvh.nodes, ctx->bvh.tris, ctx->bvh.root};
-    Bvh8Dev bvh8{ctx->bvh.nodes8, ctx->bvh.tris8};
+    BvhDev bvh{ctx->bvh.nodes, ctx->bvh.tris, ctx->bvh.root, 0.5f * ctx->bvh.pad};
+    Bvh8Dev bvh8{ctx->bvh.nodes8, ctx->bvh.tris8, 0.5f * ctx->bvh.pad};
     // the hit records index the leaf triangles of the structure that was traversed
     const LeafTri* shade_tris = (ctx->opt.bvh_kind == 1 || ctx->opt.trace_kernel == 1) ? ctx->bvh.tris : ctx->bvh.tris8;
     const size_t CS = (size_t)PT_NSUB * PT_CSTRIDE;
@@ -1704,6 +1704,7 @@ extern "C" int pt_get_stats(const pt_ctx* ctx, pt_stats* out) {
                           : (uint64_t)ctx->bvh.num_nodes * sizeof(Node2) + (uint64_t)ctx->bvh.num_tris * sizeof(LeafTri);
     out->bvh_build_ms = ctx->bvh_build_ms;
     out->bvh_levels = (uint32_t)(wide ? ctx->bvh.levels8 : ctx->bvh.depth2);
+    out->bvh_builder = (uint32_t)ctx->bvh.builder;
     return PT_OK;
 }
 
@@ -1747,7 +1748,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     CK(hipMemcpy(dO, hO.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     CK(hipMemcpy(dD, hD.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     CK(hipMemcpy(dCount, &n, 4, hipMemcpyHostToDevice));
-    BvhDev bvh{ctx->bvh.nodes, ctx->bvh.tris, ctx->bvh.root};
+    BvhDev bvh{ctx->bvh.nodes, ctx->bvh.tris, ctx->bvh.root, 0.5f * ctx->bvh.pad};
     PathState st{};
     st.rayO = dO;
     st.rayD = dD;
@@ -1770,7 +1771,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
             if (any_hit) hipLaunchKernelGGL((k_trace2<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         } else {
-            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8}, QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, 0, dDbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
+            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8, 0.5f * ctx->bvh.pad}, QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, 0, dDbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
             if (any_hit) hipLaunchKernelGGL((k_trace8<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         }
@@ -2511,6 +2512,7 @@ extern "C" int pt_multi_get_stats(const pt_multi* m, pt_multi_stats* out) {
         out->sum.bvh_nodes = s.bvh_nodes;
         out->sum.bvh_bytes = s.bvh_bytes;
         out->sum.bvh_levels = s.bvh_levels;
+        out->sum.bvh_builder = s.bvh_builder;
         out->sum.bvh_build_ms = std::max(out->sum.bvh_build_ms, s.bvh_build_ms);
     }
     out->gather_ms = m->gather_ms;

@@ -33,6 +33,7 @@ struct BvhDev {
     const Node2* nodes;
     const LeafTri* tris;
     int32_t root; // ref of the root (internal index 0, or a leaf ref for tiny scenes)
+    float hit_pad; // half the builder's box padding (tri_test_det)
 };
 
 struct RaySetup {
@@ -48,11 +49,20 @@ PT_DEV RaySetup ray_setup(v3 o, v3 d) {
     return r;
 }
 
-// returns true with t if the supporting ray (t > 0) hits the triangle; the caller applies (tmin,tmax)
+// returns true with t if the supporting ray (t > 0) hits the triangle; the caller applies (tmin,tmax) and then hit_in_box
 PT_DEV bool tri_test_det(const RaySetup& r, v3 v0, v3 v1, v3 v2, float& t, float& det_out);
-PT_DEV bool tri_test(const RaySetup& r, v3 v0, v3 v1, v3 v2, float& t) {
-    float det;
-    return tri_test_det(r, v0, v1, v2, t, det);
+// Last criterion of a hit, applied by the callers to a candidate that passed the sign test and the t interval: the hit point must lie
+// inside the triangle's bounding box widened by hp = half the padding the builder gives every box (2^-17 of the scene's largest
+// |coordinate|).  In float arithmetic a needle triangle seen along its axis (or any triangle seen edge-on) turns the three edge functions
+// into rounding noise and the sign test accepts rays that pass the triangle at many times its width — hits OUTSIDE the triangle's box,
+// which a hierarchy finds or not depending on which other boxes it happens to enter (stadium scene: 5 of 3 M camera rays differed
+// between the LBVH- and the PLOC-built tree).  With the criterion every accepted hit lies inside every structure's box of that
+// triangle, so brute force and all trees agree again.  (o + t d as one fused multiply-add per axis: the checker calls fmaf.)
+PT_DEV bool hit_in_box(const RaySetup& r, v3 v0, v3 v1, v3 v2, float hp, float t) {
+    const float px = __builtin_fmaf(r.d.x, t, r.o.x), py = __builtin_fmaf(r.d.y, t, r.o.y), pz = __builtin_fmaf(r.d.z, t, r.o.z);
+    return !(px < fminf(fminf(v0.x, v1.x), v2.x) - hp || px > fmaxf(fmaxf(v0.x, v1.x), v2.x) + hp ||
+             py < fminf(fminf(v0.y, v1.y), v2.y) - hp || py > fmaxf(fmaxf(v0.y, v1.y), v2.y) + hp ||
+             pz < fminf(fminf(v0.z, v1.z), v2.z) - hp || pz > fmaxf(fmaxf(v0.z, v1.z), v2.z) + hp);
 }
 // det > 0: the ray meets the triangle's front (counter-clockwise) side — what OPTIX_RAY_FLAG_CULL_BACK_FACING keeps
 PT_DEV bool tri_test_det(const RaySetup& r, v3 v0, v3 v1, v3 v2, float& t, float& det_out) {
@@ -124,16 +134,17 @@ PT_DEV void bvh2_traverse(const BvhDev& bvh, v3 o, v3 d, float tmin, float tmax,
             for (uint32_t k = 0; k < cnt; ++k) {
                 const LeafTri* tp = &bvh.tris[first + k];
                 const float4 a = tp->t0, b = tp->t1, c = tp->t2;
-                float t;
-                if (tri_test(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t)) {
+                float t, det;
+                const v3 v0 = mk3(a.x, a.y, a.z), v1 = mk3(a.w, b.x, b.y), v2 = mk3(b.z, b.w, c.x);
+                if (tri_test_det(r, v0, v1, v2, t, det)) {
                     const int32_t prim = __float_as_int(c.y);
                     if (ANY) {
-                        if (t > tmin && t < tmax) {
+                        if (t > tmin && t < tmax && hit_in_box(r, v0, v1, v2, bvh.hit_pad, t)) {
                             prim_out = 1;
                             t_out = t;
                             return;
                         }
-                    } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim))) {
+                    } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim)) && hit_in_box(r, v0, v1, v2, bvh.hit_pad, t)) {
                         best = t;
                         bprim = prim;
                         bleaf = (int32_t)(first + k);

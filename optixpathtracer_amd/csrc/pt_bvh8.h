@@ -38,9 +38,12 @@ struct Node8 {
 #endif
 static_assert(PT8_LEAF_MAX >= 1 && PT8_LEAF_MAX <= 3, "leafbits holds 3 bits per slot");
 
+PT_DEV float u8f(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
+
 struct Bvh8Dev {
     const Node8* nodes;
     const LeafTri* tris;
+    float hit_pad; // half the builder's box padding (pt_bvh.h tri_test_det)
 };
 
 #ifndef PT_BVH8_NODE_ONLY
@@ -103,8 +106,6 @@ struct Trace8Args {
     uint32_t* fault; // device word: bit 0 set when a push found the stack full — the host turns it into PT_ERR_UNSUPPORTED
     uint32_t num_nodes;
 };
-
-PT_DEV float u8f(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
 
 template <int MODE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT8_WAVES_PER_EU, PT8_WAVES_PER_EU)))
@@ -537,15 +538,16 @@ k_trace8(Trace8Args a) {
             if (do_tri) {
                 const float4 ta = r0, tb = r1, tc = r2;
                 float t, det;
-                if (tri_test_det(r, mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), t, det)) {
+                const v3 v0 = mk3(ta.x, ta.y, ta.z), v1 = mk3(ta.w, tb.x, tb.y), v2 = mk3(tb.z, tb.w, tc.x);
+                if (tri_test_det(r, v0, v1, v2, t, det)) {
                     const int32_t prim = __float_as_int(tc.y);
                     if (MODE == TR_SHADOW_APPLY || MODE == TR_ANY_QUERY || (MODE == TR_UNIFIED && shadow_lane)) {
-                        if (t > tmin && t < tmax && (!a.cull_back || det > 0.0f)) {
+                        if (t > tmin && t < tmax && (!a.cull_back || det > 0.0f) && hit_in_box(r, v0, v1, v2, a.bvh.hit_pad, t)) {
                             bprim = 1;
                             best = t;
                             finish();
                         }
-                    } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim))) {
+                    } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim)) && hit_in_box(r, v0, v1, v2, a.bvh.hit_pad, t)) {
                         best = t;
                         bprim = prim;
                         bleaf = (int32_t)__float_as_uint(r3.x);

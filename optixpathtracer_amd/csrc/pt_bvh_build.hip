@@ -542,6 +542,86 @@ __global__ void k_single_node8(int n, const float* __restrict__ bounds6, float p
     nodes[0] = nd;
 }
 
+// ---- choosing between two hierarchies by measurement (pt_bvh_build, PT_BVH_BUILDER unset).  The SAH cost of the collapsed tree
+// mispredicts: on the voxel terrain PLOC has the LOWER cost (17.19 vs 17.67) and 12 % MORE node steps per ray, on the stadium scene the
+// lower cost (3.73 vs 6.88) and 15 % fewer.  So both wide trees are built and a fixed, deterministic batch of calibration rays — from the
+// centroid of one triangle towards the centroid of another, both drawn by a hash of the ray index: the segments along which a path
+// tracer's camera, bounce and shadow rays travel — is traced through each by this plain per-thread traversal, which visits what
+// k_trace8 visits (a node step per internal child hit when its parent was tested, the leaf triangles of a node before its children,
+// children in slot ^ octant order, everything culled by the closest hit so far) and only counts.
+__global__ void __launch_bounds__(64) k_calibrate8(const Node8* __restrict__ nodes, const LeafTri* __restrict__ tris, const LeafTri* __restrict__ src,
+                                                   uint32_t ntri, uint32_t nrays, float hp, unsigned long long* __restrict__ counts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long nsteps = 0, ntests = 0;
+    if (i < nrays) {
+        uint32_t h = i * 2654435761u + 12345u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const uint32_t ia = h % ntri;
+        h = h * 3266489917u + 668265263u; h ^= h >> 16;
+        const uint32_t ib = h % ntri;
+        const LeafTri ta = src[ia], tb = src[ib];
+        const v3 ca = mk3((ta.t0.x + ta.t0.w + ta.t1.z) * (1.f / 3.f), (ta.t0.y + ta.t1.x + ta.t1.w) * (1.f / 3.f), (ta.t0.z + ta.t1.y + ta.t2.x) * (1.f / 3.f));
+        const v3 cb = mk3((tb.t0.x + tb.t0.w + tb.t1.z) * (1.f / 3.f), (tb.t0.y + tb.t1.x + tb.t1.w) * (1.f / 3.f), (tb.t0.z + tb.t1.y + tb.t2.x) * (1.f / 3.f));
+        v3 d = sub3(cb, ca);
+        const float dl = sqrtf(dot3(d, d));
+        d = dl > 0.f ? scl3(d, 1.0f / dl) : mk3(0.f, 1.f, 0.f);
+        RaySetup r = ray_setup(ca, d);
+        if (!(fabsf(d.x) > 1e-30f)) r.idir.x = copysignf(1e30f, d.x);
+        if (!(fabsf(d.y) > 1e-30f)) r.idir.y = copysignf(1e30f, d.y);
+        if (!(fabsf(d.z) > 1e-30f)) r.idir.z = copysignf(1e30f, d.z);
+        const uint32_t oct = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
+        const float tmin = 1e-3f * fmaxf(dl, 1e-3f);
+        float best = 1e16f;
+        uint32_t stack[192];
+        int sp = 0;
+        stack[sp++] = 0u;
+        while (sp) {
+            const Node8 nd = nodes[stack[--sp]];
+            ++nsteps;
+            const uint32_t e01 = __float_as_uint(nd.n0.w), e2m = __float_as_uint(nd.n1.w);
+            const float sx = __uint_as_float(e01 << 16), sy = __uint_as_float(e01 & 0xffff0000u), sz = __uint_as_float(e2m << 16);
+            const uint32_t imask = e2m >> 16, leafbits = __float_as_uint(nd.n1.z);
+            const uint32_t q[12] = {__float_as_uint(nd.n2.x), __float_as_uint(nd.n2.y), __float_as_uint(nd.n2.z), __float_as_uint(nd.n2.w),
+                                    __float_as_uint(nd.n3.x), __float_as_uint(nd.n3.y), __float_as_uint(nd.n3.z), __float_as_uint(nd.n3.w),
+                                    __float_as_uint(nd.n4.x), __float_as_uint(nd.n4.y), __float_as_uint(nd.n4.z), __float_as_uint(nd.n4.w)};
+            uint32_t hits = 0;
+            for (int sl = 0; sl < 8; ++sl) {
+                const int w = sl >> 2, k = sl & 3;
+                const float lx = nd.n0.x + u8f(q[0 + w], k) * sx, ly = nd.n0.y + u8f(q[2 + w], k) * sy, lz = nd.n0.z + u8f(q[4 + w], k) * sz;
+                const float hx = nd.n0.x + u8f(q[6 + w], k) * sx, hy = nd.n0.y + u8f(q[8 + w], k) * sy, hz = nd.n0.z + u8f(q[10 + w], k) * sz;
+                float tn;
+                if (lx <= hx && box_test(lx, ly, lz, hx, hy, hz, r, tmin, best, tn)) hits |= 1u << sl;
+            }
+            // the leaf triangles of this node first ...
+            for (int sl = 0; sl < 8; ++sl) {
+                if (!(hits & (1u << sl)) || (imask & (1u << sl))) continue;
+                for (int k = 0; k < 3; ++k) {
+                    const int bit = 3 * sl + k;
+                    if (!(leafbits & (1u << bit))) break;
+                    const LeafTri t = tris[__float_as_uint(nd.n1.y) + (uint32_t)__popc(leafbits & ((1u << bit) - 1u))];
+                    ++ntests;
+                    float tt, det;
+                    const v3 v0 = mk3(t.t0.x, t.t0.y, t.t0.z), v1 = mk3(t.t0.w, t.t1.x, t.t1.y), v2 = mk3(t.t1.z, t.t1.w, t.t2.x);
+                    if (tri_test_det(r, v0, v1, v2, tt, det) && tt > tmin && tt < best && hit_in_box(r, v0, v1, v2, hp, tt)) best = tt;
+                }
+            }
+            // ... then its internal children, the one the ray enters first on top of the stack
+            for (int k = 7; k >= 0; --k) {
+                const uint32_t sl = (uint32_t)k ^ oct;
+                if ((hits & imask & (1u << sl)) && sp < 192) stack[sp++] = __float_as_uint(nd.n1.x) + (uint32_t)__popc(imask & ((1u << sl) - 1u));
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        nsteps += __shfl_xor(nsteps, off);
+        ntests += __shfl_xor(ntests, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counts[0], nsteps);
+        atomicAdd(&counts[1], ntests);
+    }
+}
+
 } // namespace
 
 #define HIPCHK(x)                         \
@@ -582,6 +662,13 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
         hipLaunchKernelGGL(k_parents, dim3((n + 255) / 256), dim3(256), 0, stream, n, left, right, root, parent);
         hipLaunchKernelGGL(k_collapse_cost, dim3((n + 255) / 256), dim3(256), 0, stream, n, left, right, parent, cnt, box, pad, cp, cost, dec, visits);
         HIPCHK(hipStreamSynchronize(stream));
+        if (getenv("PT_DEBUG_BVH")) {
+            float rc = 0, rb[6];
+            HIPCHK(hipMemcpy(&rc, cost + (size_t)root * 7, 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(rb, box + (size_t)root * 6, 24, hipMemcpyDeviceToHost));
+            const float dx = rb[3] - rb[0] + 2 * pad, dy = rb[4] - rb[1] + 2 * pad, dz = rb[5] - rb[2] + 2 * pad;
+            fprintf(stderr, "[pt_bvh] SAH cost of the wide tree (node steps + %.2f x triangle tests per random ray through the root box): %.3f\n", cp, rc / (dx * dy + dy * dz + dz * dx));
+        }
         hipFree(parent); hipFree(visits); hipFree(cost);
     }
     Task8 root_task{root, 0u};
@@ -806,8 +893,38 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
         hipLaunchKernelGGL(k_counts_from_ranges, dim3((2 * n + B - 1) / B), dim3(B), 0, stream, n, rfirst, rlast, cnt);
         int root = 0;
         const char* builder = getenv("PT_BVH_BUILDER");
-        if (builder && strcmp(builder, "ploc") == 0) HIPCHK(build_ploc(n, left, right, box, cnt, stream, &root));
+        const bool force_lbvh = builder && strcmp(builder, "lbvh") == 0, force_ploc = builder && strcmp(builder, "ploc") == 0;
+        if (force_ploc) HIPCHK(build_ploc(n, left, right, box, cnt, stream, &root));
         HIPCHK(build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, out));
+        out->builder = force_ploc ? 1 : 0;
+        if (!force_lbvh && !force_ploc && n >= 4096) {
+            // both hierarchies, the one that costs the calibration rays less (see k_calibrate8); small scenes keep the LBVH
+            PtBvh alt;
+            HIPCHK(build_ploc(n, left, right, box, cnt, stream, &root)); // overwrites the LBVH's internal nodes: the first wide tree is already emitted
+            HIPCHK(build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, &alt));
+            unsigned long long* counts = nullptr;
+            unsigned long long hcnt[4] = {0, 0, 0, 0};
+            HIPCHK(hipMalloc(&counts, sizeof(hcnt)));
+            HIPCHK(hipMemsetAsync(counts, 0, sizeof(hcnt), stream));
+            const uint32_t nrays = 1u << 16;
+            hipLaunchKernelGGL(k_calibrate8, dim3(nrays / 64), dim3(64), 0, stream, out->nodes8, out->tris8, tris, (uint32_t)n, nrays, 0.5f * pad, counts);
+            hipLaunchKernelGGL(k_calibrate8, dim3(nrays / 64), dim3(64), 0, stream, alt.nodes8, alt.tris8, tris, (uint32_t)n, nrays, 0.5f * pad, counts + 2);
+            HIPCHK(hipMemcpyAsync(hcnt, counts, sizeof(hcnt), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            hipFree(counts);
+            // a triangle step costs the traversal kernel about 0.6 node steps (≈110 against ≈185 instructions)
+            const double cost_lbvh = (double)hcnt[0] + 0.6 * (double)hcnt[1], cost_ploc = (double)hcnt[2] + 0.6 * (double)hcnt[3];
+            if (getenv("PT_DEBUG_BVH"))
+                fprintf(stderr, "[pt_bvh] calibration (%u rays): LBVH %.2f node steps + %.2f triangle tests per ray, PLOC %.2f + %.2f -> %s\n", nrays,
+                        (double)hcnt[0] / nrays, (double)hcnt[1] / nrays, (double)hcnt[2] / nrays, (double)hcnt[3] / nrays, cost_ploc < cost_lbvh ? "PLOC" : "LBVH");
+            if (cost_ploc < cost_lbvh) {
+                hipFree((void*)out->nodes8); hipFree((void*)out->tris8);
+                out->nodes8 = alt.nodes8; out->tris8 = alt.tris8; out->num_nodes8 = alt.num_nodes8; out->num_tris8 = alt.num_tris8; out->levels8 = alt.levels8;
+                out->builder = 1;
+            } else {
+                hipFree((void*)alt.nodes8); hipFree((void*)alt.tris8);
+            }
+        }
         hipFree(cnt);
     }
     hipFree(keys); hipFree(keys_sorted); hipFree(bounds); hipFree(tmp); hipFree(tmp2);

@@ -24,6 +24,7 @@ struct PtBvh {
     uint32_t num_nodes8 = 0, num_tris8 = 0;
     int levels8 = 0; // levels of the wide tree = upper bound of its traversal stack depth (one pushed group per level)
     int depth2 = 0;  // depth of the binary tree (0: not built)
+    int builder = 0; // hierarchy under the wide tree: 0 LBVH (Morton order, Karras 2012), 1 PLOC (Meister & Bittner 2018) — chosen by calibration rays unless PT_BVH_BUILDER=lbvh|ploc
 };
 
 // want_bvh2: also keep the binary form (A/B paths only; the default traversal uses the 8-wide tree alone)

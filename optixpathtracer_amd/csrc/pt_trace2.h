@@ -183,17 +183,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT2_WAV
                         ++c_tris;
                         const LeafTri* tp = &a.bvh.tris[first + k];
                         const float4 ta = tp->t0, tb = tp->t1, tc = tp->t2;
-                        float t;
-                        if (tri_test(r, mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), t)) {
+                        float t, det;
+                        const v3 v0 = mk3(ta.x, ta.y, ta.z), v1 = mk3(ta.w, tb.x, tb.y), v2 = mk3(tb.z, tb.w, tc.x);
+                        if (tri_test_det(r, v0, v1, v2, t, det)) {
                             const int32_t prim = __float_as_int(tc.y);
                             if (MODE != TR_CLOSEST) {
-                                if (t > tmin && t < tmax) {
+                                if (t > tmin && t < tmax && hit_in_box(r, v0, v1, v2, a.bvh.hit_pad, t)) {
                                     bprim = 1;
                                     best = t;
                                     done = true;
                                     break;
                                 }
-                            } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim))) {
+                            } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim)) && hit_in_box(r, v0, v1, v2, a.bvh.hit_pad, t)) {
                                 best = t;
                                 bprim = prim;
                                 bleaf = (int32_t)(first + k);

@@ -374,6 +374,172 @@ def voxel_terrain(n: int = 360, seed: int = 1234, extent: float = 100.0, target_
     return model
 
 
+# ------------------------------------------------------------------ second 1 M-triangle workload: "teapots in a stadium"
+STADIUM_CAMERA = dict(eye=(-62.0, 9.0, 21.0), lookat=(0.0, 4.0, 0.0), up=(0.0, 1.0, 0.0), fovY=50.0)
+
+
+def _rotation(rng) -> np.ndarray:
+    """uniformly random rotation matrix (QR of a Gaussian matrix, sign-fixed)"""
+    q, r = np.linalg.qr(rng.standard_normal((3, 3)))
+    q = q * np.sign(np.diag(r))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def _grid_quads(P: np.ndarray) -> np.ndarray:
+    """(nu+1, nv+1, 3) grid of surface points -> (nu*nv, 4, 3) quads"""
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    return np.stack([a, b, c, d], -2).reshape(-1, 4, 3)
+
+
+def _tube(curve: np.ndarray, radius: np.ndarray, nv: int) -> np.ndarray:
+    """closed tube of `nv` sides around a closed polyline (n,3); radius (n,) or (n,nv): rotated, elongated, non-axis-aligned triangles"""
+    n = len(curve)
+    T = np.roll(curve, -1, 0) - np.roll(curve, 1, 0)
+    T /= np.linalg.norm(T, axis=1, keepdims=True)
+    ref = np.array([0.31, 0.87, 0.38])
+    N = np.cross(T, ref)
+    N /= np.linalg.norm(N, axis=1, keepdims=True)
+    B = np.cross(T, N)
+    phi = np.linspace(0.0, 2.0 * np.pi, nv + 1)
+    rad = radius if np.ndim(radius) == 2 else np.asarray(radius)[:, None] * np.ones(nv + 1)
+    P = curve[:, None, :] + rad[..., None] * (np.cos(phi)[None, :, None] * N[:, None, :] + np.sin(phi)[None, :, None] * B[:, None, :])
+    P = np.concatenate([P, P[:1]], 0)  # close along the curve
+    return _grid_quads(P)
+
+
+def stadium_scene(target_tris: int = 1_000_000, seed: int = 4321) -> Model:
+    """~1 M triangles that are everything the voxel terrain is not (the reference's real inputs are sponza /
+    San Miguel / lost_empire, HelloPathtracing_sv4_vmv23/main.cpp:188-194): a stadium bowl of long thin bench and railing strips, a
+    colonnade of fluted, slightly tilted columns on an ellipse, a partial roof of huge tilted quads over a two-triangle ground
+    (edges of 600 units), a field strewn with randomly oriented blade triangles (aspect 20-200 : 1), and in the middle "teapots":
+    finely tessellated, noise-displaced torus knots and spheres under random rotations (edges of 0.003-0.05 units).  Edge lengths span
+    five decades, almost nothing is axis-aligned, the camera stands inside.  Deterministic in (target_tris, seed); the object counts
+    scale with target_tris so that small versions serve the brute-force parity tests."""
+    rng = np.random.default_rng(seed)
+    s = target_tris / 1_000_000.0
+    presets = material_presets()
+    parts = {k: [] for k in range(8)}  # quads by material preset
+    tris = {k: [] for k in range(8)}   # loose triangles by material preset
+
+    # ground: two huge triangles; roof: a ring of large tilted quads over the stands
+    g = 300.0
+    parts[1].append(np.array([[[-g, 0, -g], [-g, 0, g], [g, 0, g], [g, 0, -g]]], np.float64))
+    nroof = max(8, int(48 * min(1.0, s * 4)))
+    th = np.linspace(0, 2 * np.pi, nroof + 1)
+    inner = np.stack([70 * np.cos(th), np.full_like(th, 34.0), 52 * np.sin(th)], -1)
+    outer = np.stack([118 * np.cos(th), np.full_like(th, 52.0), 96 * np.sin(th)], -1)
+    parts[2].append(np.stack([inner[:-1], outer[:-1], outer[1:], inner[1:]], -2))
+
+    # stands: tiers of bench tops + risers (long thin quads along the ellipse), thin railings every few tiers
+    ntier = max(4, int(round(44 * min(1.0, s * 3))))
+    nseg = max(48, int(round(640 * min(1.0, s * 3))))
+    th = np.linspace(0, 2 * np.pi, nseg + 1)
+    for t in range(ntier):
+        a0, b0, y0 = 72 + 1.0 * t, 54 + 0.95 * t, 1.0 + 0.7 * t
+        a1, b1, y1 = a0 + 1.0, b0 + 0.95, y0 + 0.7
+        p00 = np.stack([a0 * np.cos(th), np.full_like(th, y0), b0 * np.sin(th)], -1)
+        p01 = np.stack([a1 * np.cos(th), np.full_like(th, y0), b1 * np.sin(th)], -1)
+        p11 = np.stack([a1 * np.cos(th), np.full_like(th, y1), b1 * np.sin(th)], -1)
+        parts[t % 3].append(np.stack([p00[:-1], p01[:-1], p01[1:], p00[1:]], -2))  # bench top
+        parts[2].append(np.stack([p01[:-1], p11[:-1], p11[1:], p01[1:]], -2))      # riser
+        if t % 4 == 0:  # railing: a 0.04-wide strip in 96 long pieces — aspect ratios of several hundred
+            tr = np.linspace(0, 2 * np.pi, 97)
+            r0 = np.stack([a0 * np.cos(tr), np.full_like(tr, y0 + 1.1), b0 * np.sin(tr)], -1)
+            r1 = r0 + np.array([0.0, 0.04, 0.0])
+            parts[4].append(np.stack([r0[:-1], r1[:-1], r1[1:], r0[1:]], -2))
+
+    # colonnade: fluted columns on an ellipse, each turned to face the centre and tilted by up to 2 degrees
+    ncol = max(6, int(round(96 * min(1.0, s * 3))))
+    nside, nh = 24, max(4, int(round(18 * min(1.0, s * 4))))
+    phi = np.linspace(0, 2 * np.pi, nside + 1)
+    hh = np.linspace(0.0, 1.0, nh + 1)
+    for c in range(ncol):
+        ang = 2 * np.pi * c / ncol
+        base = np.array([66 * np.cos(ang), 0.0, 48 * np.sin(ang)])
+        rad = (0.9 - 0.15 * hh)[:, None] * (1.0 + 0.06 * np.cos(12 * phi))[None, :]  # taper + flutes
+        local = np.stack([rad * np.cos(phi)[None, :], 16.0 * hh[:, None] * np.ones_like(phi)[None, :], rad * np.sin(phi)[None, :]], -1)
+        tilt = np.deg2rad(rng.uniform(-2, 2, 2))
+        cx, sx, cz, sz = np.cos(tilt[0]), np.sin(tilt[0]), np.cos(tilt[1]), np.sin(tilt[1])
+        Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        ca, sa = np.cos(-ang), np.sin(-ang)
+        Ry = np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]])
+        P = local @ (Ry @ Rx @ Rz).T + base
+        parts[3 if c % 2 else 2].append(_grid_quads(P))
+        # lintel: a rotated box-like beam (4 long quads) to the next column
+        nxt = np.array([66 * np.cos(ang + 2 * np.pi / ncol), 16.0, 48 * np.sin(ang + 2 * np.pi / ncol)])
+        top = base + np.array([0.0, 16.0, 0.0])
+        d = nxt - top
+        side = np.cross(d, [0, 1, 0.0])
+        side = 0.6 * side / np.linalg.norm(side)
+        up = np.array([0.0, 0.9, 0.0])
+        corners = [top - side, top + side, top + side + up, top - side + up]
+        ring = np.array(corners + [corners[0]])
+        parts[2].append(np.stack([ring[:-1], ring[:-1] + d, ring[1:] + d, ring[1:]], -2))
+
+    # blades: randomly oriented long thin triangles all over the field
+    fixed = sum(len(q) * 2 for v in parts.values() for q in v)
+    budget = max(0, target_tris - fixed)
+    nblade = int(budget * 0.16)
+    c = np.stack([rng.uniform(-60, 60, nblade), rng.uniform(0.0, 0.3, nblade), rng.uniform(-44, 44, nblade)], -1)
+    d = rng.standard_normal((nblade, 3))
+    d[:, 1] = np.abs(d[:, 1]) + 0.3
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    L = np.exp(rng.uniform(np.log(0.08), np.log(3.0), nblade))
+    wdt = L / np.exp(rng.uniform(np.log(20.0), np.log(200.0), nblade))
+    sd = np.cross(d, rng.standard_normal((nblade, 3)))
+    sd /= np.linalg.norm(sd, axis=1, keepdims=True)
+    blade = np.stack([c - sd * wdt[:, None], c + sd * wdt[:, None], c + d * L[:, None]], 1)
+    which = rng.integers(0, 2, nblade)
+    tris[0].append(blade[which == 0])
+    tris[7].append(blade[which == 1])
+
+    # "teapots": finely tessellated, displaced torus knots and spheres under random rotations, scattered over the field
+    budget -= nblade
+    per_obj = 16384
+    nobj = max(1, budget // per_obj)
+    per_obj = max(256, budget // nobj)
+    for o in range(nobj):
+        R = _rotation(rng)
+        scale = np.exp(rng.uniform(np.log(0.25), np.log(2.2)))
+        centre = np.array([rng.uniform(-45, 45), scale * 1.6 + rng.uniform(0.0, 6.0), rng.uniform(-32, 32)])
+        mat = int(rng.integers(3, 8))
+        if o % 3 != 2:  # torus knot tube: 8 sides, (per_obj / 16) segments
+            nu = max(16, per_obj // 16)
+            t = np.linspace(0, 2 * np.pi, nu, endpoint=False)
+            p_, q_ = [(2, 3), (3, 5), (2, 5), (3, 4)][o % 4]
+            rr = 1.0 + 0.45 * np.cos(q_ * t)
+            curve = np.stack([rr * np.cos(p_ * t), 0.45 * np.sin(q_ * t), rr * np.sin(p_ * t)], -1)
+            radius = 0.11 * (1.0 + 0.35 * np.sin(17 * t) * np.cos(5 * t))
+            Q = _tube(curve, radius, 8)
+        else:  # displaced sphere
+            nu = max(8, int(np.sqrt(per_obj / 4)))
+            nv = max(8, per_obj // (2 * nu))
+            u = np.linspace(0, np.pi, nu + 1)[:, None]
+            v = np.linspace(0, 2 * np.pi, nv + 1)[None, :]
+            rad = 1.0 + 0.12 * np.sin(9 * u) * np.cos(7 * v) + 0.05 * np.sin(23 * v + 3 * u)
+            P = np.stack([rad * np.sin(u) * np.cos(v), rad * np.cos(u) * np.ones_like(v), rad * np.sin(u) * np.sin(v)], -1)
+            Q = _grid_quads(P)
+        parts[mat].append((Q.reshape(-1, 3) * scale) @ R.T + centre)
+
+    model = Model()
+    for k in range(8):
+        vs, ix, base = [], [], 0
+        for q in parts[k]:
+            q = np.asarray(q, np.float64).reshape(-1, 4, 3)
+            m = _quads_to_mesh(q, presets[k])
+            vs.append(m.vertex); ix.append(m.index + np.uint32(base)); base += len(m.vertex)
+        for t3 in tris[k]:
+            t3 = np.asarray(t3, np.float32).reshape(-1, 3)
+            if len(t3):
+                vs.append(t3); ix.append(np.arange(len(t3), dtype=np.uint32).reshape(-1, 3) + np.uint32(base)); base += len(t3)
+        if vs:
+            model.meshes.append(TriangleMesh(np.ascontiguousarray(np.concatenate(vs), np.float32), np.ascontiguousarray(np.concatenate(ix), np.uint32), presets[k]))
+    return model
+
+
 # ------------------------------------------------------------------ probes
 
 

@@ -580,6 +580,7 @@ typedef struct {
 
 typedef struct {
     f3 o, d, dn;
+    float hp; /* half the scene's box padding: see wtri2 */
 } wray;
 
 /* per-ray constants of the triangle test: dn = d / dot(d,d) so that t is in units of d */
@@ -588,6 +589,7 @@ static inline void wray_init(wray* r, f3 o, f3 d) {
     r->d = d;
     float inv_dd = 1.0f / dot3(d, d);
     r->dn = scl3(d, inv_dd);
+    r->hp = 0.0f;
 }
 
 /* Sign-consistent scalar-triple-product ray/triangle test.  With A,B,C the vertices relative to the
@@ -597,7 +599,13 @@ static inline void wray_init(wray* r, f3 o, f3 d) {
  * the property the RT-core test behind optixTrace has.  No backface culling (OPTIX_RAY_FLAG_NONE).
  * Returns 1 and *t_out if the supporting ray hits at some t > 0 (caller applies (tmin,tmax)).
  * Every operation is a single rounded IEEE op; the HIP kernel (pt_bvh.h tri_test) performs the
- * same ones in the same order, so t is bit-identical on both sides. */
+ * same ones in the same order, so t is bit-identical on both sides.
+ * Last criterion (hit_in_box below, applied by the callers to candidates that passed the sign test and the t interval): the hit point o + t d must lie inside the triangle's bounding box widened by hp = half the padding every
+ * acceleration structure gives its boxes (2^-17 of the largest |coordinate| of the scene).  In float arithmetic a needle triangle seen
+ * along its axis yields three edge functions that are rounding noise, and the sign test then accepts rays that pass the triangle at
+ * many times its width (measured on the stadium scene: 5 of 3 M camera rays) — hits OUTSIDE the triangle's box, which a hierarchy
+ * finds or misses depending on which other boxes it happens to enter.  With the criterion every accepted hit lies inside every
+ * structure's (more widely padded) box for that triangle, so brute force and all trees return the same answer again. */
 static inline int wtri2(const wray* r, const float* p0, const float* p1, const float* p2, float* t_out, float* det_out) {
     const f3 A = sub3(mk3(p0[0], p0[1], p0[2]), r->o);
     const f3 B = sub3(mk3(p1[0], p1[1], p1[2]), r->o);
@@ -612,6 +620,16 @@ static inline int wtri2(const wray* r, const float* p0, const float* p1, const f
     if (T == 0.0f || ((T < 0.0f) != (det < 0.0f))) return 0;
     *t_out = T / det;
     *det_out = det;
+    return 1;
+}
+/* the hit point o + t d (one fused multiply-add per axis, like the kernel) inside the triangle's box widened by r->hp */
+static inline int hit_in_box(const wray* r, const float* p0, const float* p1, const float* p2, float t) {
+    const float o[3] = {r->o.x, r->o.y, r->o.z}, d[3] = {r->d.x, r->d.y, r->d.z};
+    for (int a = 0; a < 3; ++a) {
+        const float pa = fmaf(d[a], t, o[a]);
+        const float lo = fminf(fminf(p0[a], p1[a]), p2[a]) - r->hp, hi = fmaxf(fmaxf(p0[a], p1[a]), p2[a]) + r->hp;
+        if (pa < lo || pa > hi) return 0;
+    }
     return 1;
 }
 static inline int wtri(const wray* r, const float* p0, const float* p1, const float* p2, float* t_out) {
@@ -695,8 +713,8 @@ static int64_t bvh8_traverse(const orc_scene* s, const wray* r, f3 o, f3 d, floa
                 float t, det;
                 if (!wtri2(r, &tv[0], &tv[3], &tv[6], &t, &det)) continue;
                 if (any) {
-                    if (t > tmin && t < tmax && (!cull_back || det > 0.0f)) return 1;
-                } else if (t > tmin && (t < best || (t == best && bp >= 0 && p < bp))) {
+                    if (t > tmin && t < tmax && (!cull_back || det > 0.0f) && hit_in_box(r, &tv[0], &tv[3], &tv[6], t)) return 1;
+                } else if (t > tmin && (t < best || (t == best && bp >= 0 && p < bp)) && hit_in_box(r, &tv[0], &tv[3], &tv[6], t)) {
                     best = t;
                     bp = p;
                 }
@@ -711,6 +729,7 @@ static int64_t bvh8_traverse(const orc_scene* s, const wray* r, f3 o, f3 d, floa
 static int64_t closest_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tmax, float* t_hit) {
     wray r;
     wray_init(&r, o, d);
+    r.hp = 0.5f * s->pad;
     if (s->n8) return bvh8_traverse(s, &r, o, d, tmin, tmax, 0, 0, t_hit);
     float best = tmax;
     int64_t bp = -1;
@@ -719,7 +738,7 @@ static int64_t closest_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tma
             const float *v0, *v1, *v2;
             float t;
             tri_verts(s, p, &v0, &v1, &v2);
-            if (wtri(&r, v0, v1, v2, &t) && t > tmin && (t < best || (t == best && bp >= 0 && (int64_t)p < bp))) {
+            if (wtri(&r, v0, v1, v2, &t) && t > tmin && (t < best || (t == best && bp >= 0 && (int64_t)p < bp)) && hit_in_box(&r, v0, v1, v2, t)) {
                 best = t;
                 bp = p;
             }
@@ -739,7 +758,7 @@ static int64_t closest_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tma
                     float t;
                     tri_verts(s, p, &v0, &v1, &v2);
                     if (wtri(&r, v0, v1, v2, &t) && t > tmin &&
-                        (t < best || (t == best && bp >= 0 && (int64_t)p < bp))) {
+                        (t < best || (t == best && bp >= 0 && (int64_t)p < bp)) && hit_in_box(&r, v0, v1, v2, t)) {
                         best = t;
                         bp = p;
                     }
@@ -760,13 +779,14 @@ static int64_t closest_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tma
 static int any_hit_c(const orc_scene* s, f3 o, f3 d, float tmin, float tmax, int cull_back) {
     wray r;
     wray_init(&r, o, d);
+    r.hp = 0.5f * s->pad;
     if (s->n8) return (int)bvh8_traverse(s, &r, o, d, tmin, tmax, 1, cull_back, NULL);
     if (!s->use_bvh) {
         for (uint32_t p = 0; p < s->ntri; ++p) {
             const float *v0, *v1, *v2;
             float t, det;
             tri_verts(s, p, &v0, &v1, &v2);
-            if (wtri2(&r, v0, v1, v2, &t, &det) && t > tmin && t < tmax && (!cull_back || det > 0.0f)) return 1;
+            if (wtri2(&r, v0, v1, v2, &t, &det) && t > tmin && t < tmax && (!cull_back || det > 0.0f) && hit_in_box(&r, v0, v1, v2, t)) return 1;
         }
         return 0;
     }
@@ -783,7 +803,7 @@ static int any_hit_c(const orc_scene* s, f3 o, f3 d, float tmin, float tmax, int
                 const float *v0, *v1, *v2;
                 float t, det;
                 tri_verts(s, p, &v0, &v1, &v2);
-                if (wtri2(&r, v0, v1, v2, &t, &det) && t > tmin && t < tmax && (!cull_back || det > 0.0f)) return 1;
+                if (wtri2(&r, v0, v1, v2, &t, &det) && t > tmin && t < tmax && (!cull_back || det > 0.0f) && hit_in_box(&r, v0, v1, v2, t)) return 1;
             }
         } else {
             stack[sp++] = n->left;
@@ -860,6 +880,15 @@ orc_scene* orc_scene_create(const float* verts, uint32_t nv, const uint32_t* idx
     for (uint32_t m = 0; m < nmesh; ++m)
         if (mats[m].flags & MATERIAL_FLAG_SHADOW_CATCHER) s->has_catcher = 1;
     s->use_bvh = use_bvh && ntri > 0;
+    {   /* box padding of every structure over this scene (pt_bvh_build.hip computes the same): 2^-16 of the largest |coordinate| */
+        float mx = 0.0f;
+        for (uint32_t p = 0; p < ntri; ++p) {
+            float lo[3], hi[3];
+            prim_bounds(s, p, lo, hi);
+            for (int a = 0; a < 3; ++a) mx = fmaxf(mx, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
+        }
+        s->pad = mx * (1.0f / 65536.0f);
+    }
     if (s->use_bvh) {
         cent* cs = (cent*)malloc(sizeof(cent) * (size_t)ntri);
         float mx = 0.0f;

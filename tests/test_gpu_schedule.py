@@ -65,7 +65,9 @@ def test_overlapped_handoff_matches_serial(ptlib):
         return r
 
     def bufs(which, n):
-        return torch.zeros(n, dtype=torch.int32, device="cuda") if which == R.PT_BUF_FRAME else torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+        b = torch.zeros(n, dtype=torch.int32, device="cuda") if which == R.PT_BUF_FRAME else torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.current_stream().synchronize()  # torch fills on ITS stream; the library's streams do not wait for it (hipStreamNonBlocking)
+        return b
 
     # serial protocol: the reference for every frame
     ser = [make(0, 0), make(1, 0)]
@@ -80,6 +82,7 @@ def test_overlapped_handoff_matches_serial(ptlib):
             for r, s_ in zip(ser, send):
                 r.pack(which, s_.data_ptr())
             allr = torch.cat(send)
+            torch.cuda.current_stream().synchronize()  # the library's streams do not wait for torch's
             ser[0].unpack(which, allr.data_ptr())
             want[which].append(ser[0].download(which))
     for r in ser:

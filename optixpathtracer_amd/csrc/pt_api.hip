@@ -47,6 +47,7 @@ struct pt_ctx {
     DevProbe probe{};
     float4* d_probe_data = nullptr;
     float *d_pdfX = nullptr, *d_cdfX = nullptr, *d_pdfY = nullptr, *d_cdfY = nullptr, *d_c64X = nullptr, *d_c8X = nullptr, *d_c64Y = nullptr, *d_c8Y = nullptr;
+    uint32_t* d_guideX = nullptr;
     float4* d_data_pdf = nullptr; // (rgb, pdfX) per texel
     // frame
     int width = 0, height = 0;
@@ -82,11 +83,11 @@ struct pt_ctx {
     std::vector<BatchSet> sets;
     // The streams of the batch sets live as long as the context: path-state re-allocations keep them.  HIP maps streams onto four
     // hardware queues in creation order, and which set streams come to share a queue decides whether frames overlap — measured: after a
-    // re-allocation had destroyed and re-created the streams, three frames in flight ran at 9.1 instead of 8.2 ms; with only the four streams
-    // the default schedule uses (context + one per set, no side streams) a synchronous frame takes 10.1 instead of 9.0 ms and a 1/8 share
-    // 2.57 instead of 1.77.  So the creation order that measures well is kept — context, then per set its stream and its first side
-    // stream — and never disturbed; the second side stream (asynchronous shadow rays) is created when that schedule is first asked for.
+    // re-allocation had destroyed and re-created the streams, three frames in flight ran at 9.1 instead of 8.2 ms; with a creation order
+    // that put two set streams on one queue a synchronous frame took 10.1 instead of 9.0 ms and a 1/8 share 2.57 instead of 1.77.  So the
+    // four streams that carry a frame are chosen by probing (pick_streams) and never re-created.
     std::vector<hipStream_t> set_streams, side_streams; // [set], [2 * set + {0,1}]
+    bool streams_probed = false; // pick_streams ran: the context's stream and the first three set streams sit on different hardware queues
     uint32_t set_cap = 0, set_pix_cap = 0, sub_cap = 0;
     bool cap_catcher = false, cap_async = false;
     int nq = 0;
@@ -305,6 +306,13 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     } while (0)
     DevScope tmp;
     CKC(hipSetDevice(device));
+    if (const char* e = getenv("PT_STREAM_SHIFT")) { // test hook: streams created (and kept) ahead of the context's own shift the hardware-queue phase
+        static std::vector<hipStream_t> ahead;
+        for (int k = atoi(e); k > 0; --k) {
+            hipStream_t st = nullptr;
+            if (stream_create(&st) == hipSuccess) ahead.push_back(st);
+        }
+    }
     CKC(stream_create(&ctx->stream));
     ctx->ntri = (uint32_t)nt;
     ctx->nmesh = scene->num_meshes;
@@ -427,7 +435,7 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     for (uint32_t*& px : ctx->d_tex_pixels) dfree(px);
     pt_bvh_free(&ctx->bvh);
     dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
-    dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y); dfree(ctx->d_data_pdf);
+    dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y); dfree(ctx->d_data_pdf); dfree(ctx->d_guideX);
     dfree(ctx->d_totals);
     if (ctx->h_totals) hipHostFree(ctx->h_totals);
     dfree(ctx->ovf);
@@ -543,7 +551,7 @@ extern "C" int pt_uvw_frame(const float eye[3], const float lookat[3], const flo
 
 // finish a probe upload: build the block-search accelerators and publish the device view
 static int finish_probe(pt_ctx* ctx, int w, int h) {
-    dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y); dfree(ctx->d_data_pdf);
+    dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y); dfree(ctx->d_data_pdf); dfree(ctx->d_guideX);
     {
         const size_t n = (size_t)w * h;
         CK(dalloc(&ctx->d_data_pdf, n));
@@ -551,13 +559,18 @@ static int finish_probe(pt_ctx* ctx, int w, int h) {
     }
     const int ncx = w / PT_CDF_BLOCK, ncy = h / PT_CDF_BLOCK;
     const int ncx_pad = (ncx + 7) & ~7, ncy_pad = (ncy + 7) & ~7;
+    const int c8_pitch = w / 8 + 8;
     const bool okx = (w % PT_CDF_BLOCK) == 0 && w >= PT_CDF_BLOCK, oky = (h % PT_CDF_BLOCK) == 0 && h >= PT_CDF_BLOCK;
     const bool enabled = getenv("PT_NO_BLOCKED_SEARCH") == nullptr;
     if (okx && enabled) {
         CK(dalloc(&ctx->d_c64X, (size_t)h * ncx_pad));
-        CK(dalloc(&ctx->d_c8X, (size_t)h * (w / 8)));
+        CK(dalloc(&ctx->d_c8X, (size_t)h * c8_pitch));
         hipLaunchKernelGGL(k_probe_coarse, dim3((h * ncx_pad + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_cdfX, h, w, PT_CDF_BLOCK, ncx_pad, ctx->d_c64X);
-        hipLaunchKernelGGL(k_probe_coarse, dim3((h * (w / 8) + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_cdfX, h, w, 8, w / 8, ctx->d_c8X);
+        hipLaunchKernelGGL(k_probe_coarse, dim3((h * c8_pitch + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_cdfX, h, w, 8, c8_pitch, ctx->d_c8X); // entries past w/8: +inf
+        if (w / 8 < 65536 && getenv("PT_NO_GUIDE") == nullptr) {
+            CK(dalloc(&ctx->d_guideX, (size_t)h * PT_GUIDE_K));
+            hipLaunchKernelGGL(k_probe_guide, dim3((h * PT_GUIDE_K + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_c8X, h, w / 8, c8_pitch, ctx->d_guideX);
+        }
     }
     if (oky && enabled) {
         CK(dalloc(&ctx->d_c64Y, (size_t)ncy_pad));
@@ -568,7 +581,7 @@ static int finish_probe(pt_ctx* ctx, int w, int h) {
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipGetLastError());
     ctx->probe = DevProbe{w, h, ctx->d_probe_data, ctx->d_pdfX, ctx->d_cdfX, ctx->d_pdfY, ctx->d_cdfY,
-                          ctx->d_c64X, ctx->d_c8X, ctx->d_c64Y, ctx->d_c8Y, ncx, ncx_pad, ncy, ctx->d_data_pdf};
+                          ctx->d_c64X, ctx->d_c8X, ctx->d_c64Y, ctx->d_c8Y, ncx, ncx_pad, ncy, ctx->d_data_pdf, ctx->d_guideX, c8_pitch};
     return PT_OK;
 }
 
@@ -714,11 +727,72 @@ static bool async_shadows(const pt_ctx* ctx) {
     return ctx->opt.split_shadow == 2 && !ctx->has_catcher && ctx->opt.bvh_kind == 0 && ctx->opt.trace_kernel == 0 && ctx->opt.max_depth < 31;
 }
 
+// Do two streams run concurrently, or do they share a hardware queue (and serialise)?  HIP deals its streams onto four hardware queues
+// in creation order, back and forth (tools/micro/queue_map.hip on MI355X / ROCm 7.2: streams 0..7 -> queues 0 1 2 3 3 2 1 0), counting
+// every stream of the process — torch's included — so which of a context's streams collide depends on what was created before it.
+// Measured consequences: a synchronous frame 10.1 instead of 9.0 ms, three frames in flight 9.1 instead of 8.2 ms.  So the context asks:
+// a ~150 us spin kernel on `a`, an empty kernel on `b`; if the empty one finishes while the spin is still running, they are concurrent.
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64(); // constant 100 MHz counter
+    while (wall_clock64() - t0 < ticks) {}
+}
+__global__ void k_empty() {}
+static bool streams_concurrent(hipStream_t a, hipStream_t b, hipEvent_t ea, hipEvent_t eb) {
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, 15000LL);
+    if (hipEventRecord(ea, a) != hipSuccess) return true;
+    hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, b);
+    if (hipEventRecord(eb, b) != hipSuccess) return true;
+    hipEventSynchronize(eb);
+    const bool concurrent = hipEventQuery(ea) == hipErrorNotReady;
+    hipEventSynchronize(ea);
+    return concurrent;
+}
+// The context's stream and the streams of the first three batch sets — the four that carry a frame — are picked so that no two share a
+// hardware queue: streams are created until enough mutually concurrent ones are found (at most 12; among any eight consecutive
+// creations every queue appears twice), the others become the side streams of the split / asynchronous shadow schedules.
+// PT_STREAM_PROBE=0 keeps plain creation order.
+static int pick_streams(pt_ctx* ctx, int nsets) {
+    const char* pe = getenv("PT_STREAM_PROBE");
+    if (pe && atoi(pe) == 0) return PT_OK;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    CK(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+    CK(hipStreamSynchronize(ctx->stream));
+    std::vector<hipStream_t> chosen{ctx->stream}, spare;
+    const int want = 1 + std::min(nsets, 3);
+    for (int attempt = 0; attempt < 12 && (int)chosen.size() < want; ++attempt) {
+        hipStream_t st = nullptr;
+        if (stream_create(&st) != hipSuccess) break;
+        bool ok = true;
+        for (hipStream_t c : chosen)
+            if (!streams_concurrent(c, st, ea, eb)) { ok = false; break; }
+        (ok ? chosen : spare).push_back(st);
+    }
+    hipEventDestroy(ea);
+    hipEventDestroy(eb);
+    (void)hipGetLastError();
+    size_t next_spare = 0;
+    for (int i = 0; i < nsets && i < 3; ++i) {
+        if (ctx->set_streams[i]) continue;
+        if ((size_t)(1 + i) < chosen.size()) ctx->set_streams[i] = chosen[1 + i];
+        else if (next_spare < spare.size()) ctx->set_streams[i] = spare[next_spare++]; // probing was inconclusive: any stream will do
+    }
+    for (size_t k = 0; k < ctx->side_streams.size() && next_spare < spare.size(); ++k)
+        if (!ctx->side_streams[k]) ctx->side_streams[k] = spare[next_spare++];
+    for (; next_spare < spare.size(); ++next_spare) ctx->side_streams.push_back(spare[next_spare]); // kept (and destroyed with the context)
+    ctx->streams_probed = true;
+    return PT_OK;
+}
+
 // the streams of batch set i (created on first use, kept until pt_destroy)
 static int assign_streams(pt_ctx* ctx, int nsets) {
     const bool async = async_shadows(ctx);
     if ((int)ctx->set_streams.size() < nsets) ctx->set_streams.resize(nsets, nullptr);
     if ((int)ctx->side_streams.size() < 2 * nsets) ctx->side_streams.resize((size_t)2 * nsets, nullptr);
+    if (!ctx->streams_probed) {
+        int rc = pick_streams(ctx, nsets);
+        if (rc) return rc;
+    }
     for (int i = 0; i < nsets; ++i) {
         if (!ctx->set_streams[i]) CK(stream_create(&ctx->set_streams[i]));
         if (!ctx->side_streams[2 * i]) CK(stream_create(&ctx->side_streams[2 * i]));

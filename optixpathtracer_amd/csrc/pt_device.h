@@ -333,10 +333,16 @@ struct DevProbe {
     const float4* data;
     const float *pdfX, *cdfX, *pdfY, *cdfY;
     // search accelerators built at setProbe: the last CDF value of every PT_CDF_BLOCK-entry block, per row / of cdfY
-    const float *c64X, *c8X, *c64Y, *c8Y; // [height][ncx_pad], [height][width/8], [ncy_pad], [height/8]; null = binary search
+    const float *c64X, *c8X, *c64Y, *c8Y; // [height][ncx_pad], [height][c8_pitch], [ncy_pad], [height/8]; null = binary search
     int ncx, ncx_pad, ncy;
     const float4* data_pdf; // (data.rgb, pdfX) per texel: ProbeSample's colour and conditional pdf in one 16-byte load
+    // Guide table of the column search (null: not built): for row j and k = floor(r2 * PT_GUIDE_K), guideX[j * PT_GUIDE_K + k] holds the number of
+    // 8-entry groups of the row's CDF whose last entry is < k / K (low half) and < (k + 1) / K (high half).  The lower bound's group lies
+    // between the two, so one 4-byte load replaces the eight 16-byte loads of the 64-entry stage (lower_bound_guided).
+    const uint32_t* guideX;
+    int c8_pitch; // floats per row of c8X: width / 8 entries + 8 of +inf, so that an 8-entry window may start at any group
 };
+#define PT_GUIDE_K 256
 // The marginal (row) arrays ProbeSample reads: the global ones, or k_shade's per-workgroup LDS copy (≈4.6 KB for a 1024-row
 // probe) so that the row search and pdfY never leave the CU
 struct ProbeMarg {
@@ -405,6 +411,29 @@ PT_DEV int lower_bound_blocked(const float* __restrict__ row, int n, const float
     return base + count_lt8(row + base, value);
 }
 
+// LowerBound over one row of cdfX with the guide table: the same index as lower_bound / lower_bound_blocked, by construction — the
+// index is 8 g + (entries < value in group g) with g = the number of groups whose LAST entry is < value (c8 holds those last entries,
+// non-decreasing), and r2 in [k/K, (k+1)/K) pins g between the two counts the guide stores for the interval's ends.  Typically the two
+// differ by 0..2: the window of 8 c8 entries from the lower count settles g (entries past the upper count are >= (k+1)/K > value and
+// count for nothing; rows are padded with +inf); wider gaps — flat stretches of a CDF, reached with probability 1/K each — fall back to
+// the blocked search.  Loads: 4 B + 2 x 16 B + 2 x 16 B in three dependent steps, against 8 + 2 + 2 loads of 16 B.
+PT_DEV int lower_bound_guided(const DevProbe& p, int row, float value) {
+    const float* __restrict__ cdf = p.cdfX + (size_t)row * p.width;
+    const float* __restrict__ c8 = p.c8X + (size_t)row * p.c8_pitch;
+    const int k = (int)(value * (float)PT_GUIDE_K); // value in [0, 1): exact product, k <= K - 1
+    const uint32_t gg = p.guideX[(size_t)row * PT_GUIDE_K + (k < PT_GUIDE_K ? k : PT_GUIDE_K - 1)];
+    const int g0 = (int)(gg & 0xffffu), g1 = (int)(gg >> 16);
+    int g = g0;
+    if (g1 - g0 > 8) return lower_bound_blocked(cdf, p.width, p.c64X + (size_t)row * p.ncx_pad, p.ncx, c8, value);
+    if (g1 > g0) {
+        const float* w = c8 + g0; // 4-byte aligned: two unaligned 16-byte loads
+        g += (w[0] < value ? 1 : 0) + (w[1] < value ? 1 : 0) + (w[2] < value ? 1 : 0) + (w[3] < value ? 1 : 0) + (w[4] < value ? 1 : 0) +
+             (w[5] < value ? 1 : 0) + (w[6] < value ? 1 : 0) + (w[7] < value ? 1 : 0);
+    }
+    if (g >= p.width / 8) return p.width;
+    return g * 8 + count_lt8(cdf + g * 8, value);
+}
+
 // :138-169 (row/col clamped: unreachable for a valid CDF, guards a degenerate probe)
 PT_DEV void probe_sample(const DevProbe& p, const ProbeMarg& pm, v3& dir, v3& color, float& pdf, Rng& rand) {
     float r1, r2;
@@ -415,9 +444,10 @@ PT_DEV void probe_sample(const DevProbe& p, const ProbeMarg& pm, v3& dir, v3& co
 #else
     int row = pm.c64Y ? lower_bound_blocked(pm.cdfY, p.height, pm.c64Y, p.ncy, pm.c8Y, r1) : lower_bound(pm.cdfY, 0, p.height, r1);
     if (row > p.height - 1) row = p.height - 1;
-    int col = p.c64X ? lower_bound_blocked(p.cdfX + (size_t)row * p.width, p.width, p.c64X + (size_t)row * p.ncx_pad, p.ncx,
-                                           p.c8X + (size_t)row * (p.width / 8), r2)
-                     : lower_bound(p.cdfX, row * p.width, (row + 1) * p.width, r2) - row * p.width;
+    int col = p.guideX ? lower_bound_guided(p, row, r2)
+              : p.c64X ? lower_bound_blocked(p.cdfX + (size_t)row * p.width, p.width, p.c64X + (size_t)row * p.ncx_pad, p.ncx,
+                                             p.c8X + (size_t)row * p.c8_pitch, r2)
+                       : lower_bound(p.cdfX, row * p.width, (row + 1) * p.width, r2) - row * p.width;
 #endif
     if (col > p.width - 1) col = p.width - 1;
     float4 px = p.data_pdf[(size_t)row * p.width + col];

@@ -259,7 +259,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
         const v3 v0 = mk3(tri.t0.x, tri.t0.y, tri.t0.z), v1 = mk3(tri.t0.w, tri.t1.x, tri.t1.y),
                  v2 = mk3(tri.t1.z, tri.t1.w, tri.t2.x);
         const int32_t mesh = __float_as_int(tri.t2.z);
-        const pt_material mat = sp.mats[mesh];
+        const pt_material mat = sp.mats[mesh]; // the SBT record's material (:481-484).  (An LDS copy of the table was measured: no difference — the few records stay in L1.)
         const float4 o4 = st.rayO[p], d4 = st.rayD[p];
         const v3 ray_o = mk3(o4.x, o4.y, o4.z), ray_dir = mk3(d4.x, d4.y, d4.z);
         const v3 N_0 = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
@@ -413,6 +413,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
 #ifndef PT_LDS_PROBE_ROWS
 #define PT_LDS_PROBE_ROWS 2048
 #endif
+
 template <int MODE, bool CATCHER>
 __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, ShadeParams sp) {
     __shared__ uint32_t s_prefix[PT_NSUB + 1];
@@ -893,6 +894,24 @@ __global__ void k_probe_pack(const float4* __restrict__ data, const float* __res
     if (i >= n) return;
     const float4 c = data[i];
     out[i] = make_float4(c.x, c.y, c.z, pdfX[i]);
+}
+// guide table of the column search (pt_device.h lower_bound_guided): entry (row, k) = count of c8 entries < k/K | count < (k+1)/K << 16
+__global__ void k_probe_guide(const float* __restrict__ c8, int rows, int ngroups, int c8_pitch, uint32_t* __restrict__ guide) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * PT_GUIDE_K) return;
+    const int r = i / PT_GUIDE_K, k = i - r * PT_GUIDE_K;
+    const float* row = c8 + (size_t)r * c8_pitch;
+    uint32_t out = 0;
+    for (int e = 0; e < 2; ++e) {
+        const float v = (float)(k + e) * (1.0f / (float)PT_GUIDE_K);
+        int lo = 0, hi = ngroups; // number of entries < v (NaN rows: every comparison is false -> 0, like the searches)
+        while (lo < hi) {
+            const int mid = lo + (hi - lo) / 2;
+            if (row[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        out |= (uint32_t)lo << (16 * e);
+    }
+    guide[i] = out;
 }
 __global__ void k_probe_coarse(const float* __restrict__ cdf, int rows, int n, int stride, int row_pitch, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

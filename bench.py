@@ -390,7 +390,7 @@ def main():
             except Exception:
                 traffic = valu = None
         limiter = None
-        ws = (valu or {}).get("wave_state", {}).get("k_trace8<3>") if valu else None
+        ws = ((valu or {}).get("wave_state") or {}).get("k_trace8<3>")
         if ws:
             limiter = (f"dependent-load latency at 5 waves/SIMD, not HBM: k_trace8<3> waves wait on memory {100 * ws['wait_mem']:.0f} % of their time, "
                        f"VALU pipe {100 * ws['valu_pipe']:.0f} % used, TA {100 * ws['ta_busy']:.0f} % busy, mean L1->L2 round trip {ws['l2_round_trip_cycles']:.0f} cycles")

@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+bash tools/profile_r3.sh r3_01 c3_terrain1M_1080p_4spp_d8 r3_pmc.json 2>&1 | tail -4

@@ -353,7 +353,9 @@ def main():
         # k_trace8<3> per bounce tracing that bounce's closest-hit rays with the previous bounce's shadow rays): §8(d)'s traversal-
         # stage bytes (48 B per closest-hit ray, 36 B per shadow ray) per launch / mean ISOLATED launch time (single-stream frames,
         # HIP events on the launch's own stream, pt_stats).
-        scene_bytes = st["bvh_bytes"] + 48 * model.num_triangles + probe.data.shape[0] * probe.data.shape[1] * (16 + 4 + 4)
+        # scene bytes read at least once per frame: the wide tree with its leaf triangles (which the shade kernel re-reads — there is no second
+        # triangle array any more) and the probe's texels, pdf and cdf rows
+        scene_bytes = st["bvh_bytes"] + probe.data.shape[0] * probe.data.shape[1] * (16 + 4 + 4)
         rays_frame = rays_all / args.steps
         px_frame = float(w * h) if world > 1 else float(owned_px)
         alg_frame = rays_frame * BYTES_PER_RAY_FRAME + px_frame * BYTES_PER_PIXEL_FRAME + scene_bytes * (world if world > 1 else 1)

@@ -744,6 +744,7 @@ static bool streams_concurrent(hipStream_t a, hipStream_t b, hipEvent_t ea, hipE
     if (hipEventRecord(eb, b) != hipSuccess) return true;
     hipEventSynchronize(eb);
     const bool concurrent = hipEventQuery(ea) == hipErrorNotReady;
+    (void)hipGetLastError();
     hipEventSynchronize(ea);
     return concurrent;
 }
@@ -1346,7 +1347,10 @@ static int drain(pt_ctx* ctx) {
     }
     ctx->ev_resolved = nullptr; // nothing in flight: nothing to order the next resolve behind
     ctx->last_slot = -1;
-    if (ctx->ev_pack_guard && hipEventQuery(ctx->ev_pack_guard) == hipSuccess) ctx->ev_pack_guard = nullptr;
+    if (ctx->ev_pack_guard) {
+        if (hipEventQuery(ctx->ev_pack_guard) == hipSuccess) ctx->ev_pack_guard = nullptr;
+        else (void)hipGetLastError(); // "not ready" is an answer, not an error to be found by the next hipGetLastError
+    }
     return rc;
 }
 

@@ -162,6 +162,30 @@ def test_multi_context_batch(ptlib, small_probe):
         got = dict(zip(BUFS, [mr.download(b, rank) for b in (R.PT_BUF_ACCUM, R.PT_BUF_FRAME, R.PT_BUF_COLOR, R.PT_BUF_NORMAL, R.PT_BUF_ALBEDO)]))
         _same(got, want, rank)
     assert mr.stats()["frames"] == 4 * 3
+    mr.close()
+    # batches with frames in flight and the overlapped hand-over: two batches of 2, the second call returns the first batch's last frame
+    half = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h)
+    half.launchParams.samples_per_launch = spp
+    for sf in range(2):
+        half.launchParams.frame.subframe_index = sf
+        half.render()
+    want2 = half.download(R.PT_BUF_FRAME)
+    mr = R.MultiRenderer(m, devices=(0, 0, 0))
+    mr.setProbe(small_probe)
+    mr.setOptions(frames_in_flight=3)
+    mr.resize((w, h))
+    mr.setCamera(R.make_camera(scenes.TERRAIN_CAMERA, w / h))
+    mr.launchParams.samples_per_launch = spp
+    out = np.zeros((h, w), np.uint32)
+    mr.launchParams.frame.subframe_index = 0
+    mr.renderBatch(2, out)
+    assert not out.any()  # nothing has been handed over yet
+    mr.launchParams.frame.subframe_index = 2
+    mr.renderBatch(2, out)
+    assert np.array_equal(out, want2)
+    mr.flush(out)
+    assert np.array_equal(out, want["frame"])
+    assert mr.stats()["frames"] == 4 * 3 and mr.stats()["frames_handed_over"] == 2
 
 
 def test_fullsize_c3_batch_of_4_subframes(ptlib):

@@ -12,7 +12,9 @@ def cycle(n):
 def mcycle(n):
     for k in range(n):
         mr = R.MultiRenderer(m, devices=[0, 0, 0]); mr.setProbe(probe); mr.resize((320, 200)); mr.setCamera(R.make_camera(scenes.TERRAIN_CAMERA, 1.6))
-        mr.launchParams.samples_per_launch = 2; mr.render(); mr.close()
+        mr.launchParams.samples_per_launch = 2; mr.render()
+        # round 3: the rank threads, the overlapped hand-off with its display buffers and strips, a batch — destroyed with a hand-over still pending
+        mr.setOptions(frames_in_flight=3); mr.render(); mr.renderBatch(3); mr.render(); mr.close()
 cycle(3)
 mcycle(2)
 f0 = torch.cuda.mem_get_info()[0]

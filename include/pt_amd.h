@@ -370,7 +370,8 @@ int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit, float* t_o
  * child box s = origin + q * step per axis (rounded outward at build; an unused slot has qlo 255 > qhi 0);
  * internal child s = node child_base + popcount(imask & ((1 << s) - 1)); leafbits bit 3s+k: slot s holds more than k
  * triangles, triangle (s,k) = tris[tri_base + popcount(leafbits & ((1 << (3s+k)) - 1))].
- * tris: num_tris x 48 bytes = 12 f32: v0.xyz, v1.xyz, v2.xyz, the global primitive index (i32 bits), 2 unused. */
+ * tris: num_tris x 48 bytes = 12 f32: v0.xyz, v1.xyz, v2.xyz, the global primitive index (i32 bits), the mesh index (i32 bits; = the material
+ * record: k_shade reads these very triangles through the leaf index a closest-hit record holds), 1 unused. */
 int pt_export_bvh(pt_ctx* ctx, void* nodes, size_t nodes_bytes, void* tris, size_t tris_bytes, uint32_t* num_nodes, uint32_t* num_tris);
 
 /* Device-function tables for function-level parity tests (the reference's commented-out BSDFTest /

@@ -574,7 +574,7 @@ typedef struct {
      * "scalar C++ CPU traversal of the same BVH" north_star asks for beside the GPU number, and an independent check that the
      * tree the GPU kernels walk holds every triangle. */
     const uint32_t* n8;    /* nnodes8 * 20 words */
-    const float* t8;       /* ntris8 * 12 floats: v0.xyz v1.xyz v2.xyz, prim bits, 2 unused */
+    const float* t8;       /* ntris8 * 12 floats: v0.xyz v1.xyz v2.xyz, prim bits, mesh bits, 1 unused */
     uint32_t nnodes8, ntris8;
 } orc_scene;
 

@@ -9,7 +9,7 @@ for v in $VARS; do
     python - "$v" "$sw" <<'PY'
 import json,sys
 d=json.load(open("/tmp/ab.json"))
-print(f"{sys.argv[1]:>12s} world {sys.argv[2]}: {d['ms_per_step']:.3f} ms  {d['value']:.0f} Mrays/s  (device {d['render_ms_per_frame']:.3f} ms)", flush=True)
+print(f"{sys.argv[1]:>12s} world {sys.argv[2]}: {d['ms_per_step']:.3f} ms  {d['value']:.0f} Mrays/s  (device {d['frame_latency_ms']:.3f} ms)", flush=True)
 PY
   done
 done

@@ -5,7 +5,7 @@ TAG=$1; CTRS=$2; shift 2 || true
 OUT=$PWD/gpurun_out/pmc_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout -k 10 ${PMC_TIMEOUT:-150} rocprofv3 --pmc $CTRS --output-format csv -d "$OUT" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sync-frames "$@" > "$OUT/bench.log" 2>&1 || { tail -20 "$OUT/bench.log"; exit 1; }
+timeout -k 10 ${PMC_TIMEOUT:-150} rocprofv3 --pmc $CTRS --output-format csv -d "$OUT" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-schedules "$@" > "$OUT/bench.log" 2>&1 || { tail -20 "$OUT/bench.log"; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict

@@ -8,7 +8,7 @@ TAG=${1:-r2}
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT" profiles
 export TMPDIR=/tmp
-ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated --no-sync-frames"
+ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated --no-extra-schedules"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ARGS > "$OUT/bench_stats.log" 2>&1
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -- python3 $ARGS --streams 1 > "$OUT/bench_stats1.log" 2>&1
 timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $ARGS > "$OUT/bench_fetch.log" 2>&1

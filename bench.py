@@ -87,8 +87,6 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0, help="pt_options.frames_in_flight of the TIMED loop. 0 (default): every frame synchronous like the reference's render(); 3: frame k runs whole on stream k mod 3 and pt_render(k) returns once frame k-2 is complete (three frames overlap, same images); 2: pixel chunks as in the synchronous frame, pt_render(k) waits for frame k-1")
     ap.add_argument("--batch", type=int, default=0, help="timed loop: frames are rendered as wavefront batches of this many subframes (pt_render_batch; the last batch of the loop may be shorter). 0 (default) = the number of ranks the frame is partitioned over: 1 on one GPU (every frame its own pt_render, like the reference's loop); N on N GPUs, so that a launch chain carries the paths of one whole frame however many ways the image is split")
     ap.add_argument("--no-extra-schedules", action="store_true", help="skip the extra frames after the timed region (pipelined / batched figures; profiling runs: keeps the frame count at warmup + steps)")
-    ap.add_argument("--bvh-kind", type=int, default=0, help="0 = 8-wide compressed BVH (default), 1 = binary BVH")
-    ap.add_argument("--trace-kernel", type=int, default=0, help="0 = persistent-wave traversal (default), 1 = first grid-stride kernel")
     args = ap.parse_args()
 
     import torch
@@ -128,7 +126,7 @@ def main():
 
     r = R.SampleRenderer(model, device=local_rank)
     r.setProbe(probe)
-    opts = dict(max_depth=depth, max_paths=args.max_paths, trace_kernel=args.trace_kernel, bvh_kind=args.bvh_kind, streams=args.streams, split_shadow=args.split_shadow, kernel_timing=args.kernel_timing,
+    opts = dict(max_depth=depth, max_paths=args.max_paths, streams=args.streams, split_shadow=args.split_shadow, kernel_timing=args.kernel_timing,
                 frames_in_flight=0 if args.kernel_timing else args.frames_in_flight)
     r.setOptions(**opts)
     part_world = world if world > 1 else max(1, args.simulate_world)
@@ -377,7 +375,7 @@ def main():
         # read from the committed rocprofv3 passes of this same command and quoted only for the sources they were measured on
         traffic = valu = trav_traffic_frame = None
         shash = source_hash()
-        default_cfg = args.workload == "c3_terrain1M_1080p_4spp_d8" and world == 1 and args.bvh_kind == 0 and args.trace_kernel == 0 and args.simulate_world == 0 and args.batch == 1 and not pipelined
+        default_cfg = args.workload == "c3_terrain1M_1080p_4spp_d8" and world == 1 and args.simulate_world == 0 and args.batch == 1 and not pipelined
         pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
         tj = pj[-1] if pj else ""
         if default_cfg and os.path.exists(tj):
@@ -396,7 +394,7 @@ def main():
         if ws:
             limiter = (f"dependent-load latency at 5 waves/SIMD, not HBM: k_trace8<3> waves wait on memory {100 * ws['wait_mem']:.0f} % of their time, "
                        f"VALU pipe {100 * ws['valu_pipe']:.0f} % used, TA {100 * ws['ta_busy']:.0f} % busy, mean L1->L2 round trip {ws['l2_round_trip_cycles']:.0f} cycles")
-        kname = {(1, 0): "k_trace2", (1, 1): "k_trace", (0, 1): "k_trace"}.get((args.bvh_kind, args.trace_kernel), "k_trace8<3>/<0>")
+        kname = "k_trace8<3>/<0>"
         strong = world > 1 and args.scaling == "strong"
         out = {
             "metric": "Mrays/s (and ms/frame) at 1080p 4spp depth8; 1/2/4/8 MI355X scaling",
@@ -472,8 +470,8 @@ def host_cpu_share():
 
 def cpu_baseline(model, probe, cam, w, h, spp, depth, bvh8):
     """The scalar C port of the same path (oracle/, 'port') on the GPU box's host cores, on bounded samples of the same
-    workload (same scene/camera/spp/depth at reduced resolution; rays are counted, not extrapolated): all cores on a half-
-    resolution frame, and ONE thread on a quarter-resolution frame.  The port traverses THE SAME 8-wide tree as the GPU kernels,
+    workload (same scene/camera/spp/depth; rays are counted, not extrapolated): all cores on the workload's own frame (a half-
+    resolution sample of frames above 1080p / 4 spp), and ONE thread on a quarter-resolution frame.  The port traverses THE SAME 8-wide tree as the GPU kernels,
     exported through pt_export_bvh (scalar stack traversal, oracle/pt_oracle.c bvh8_traverse).  Timed region = the render only."""
     from oracle import orc
     from optixpathtracer_amd import scenes
@@ -493,7 +491,8 @@ def cpu_baseline(model, probe, cam, w, h, spp, depth, bvh8):
         rays = out["radiance_rays"] + out["shadow_rays"]
         return rays, dt
 
-    sw, sh = max(16, w // 2), max(9, h // 2)
+    # all cores: the workload's own frame when it is a 1080p / 4 spp frame (≈4 s on 16 cores), a half-resolution sample of larger ones
+    sw, sh = (w, h) if w * h * spp <= 9_000_000 else (max(16, w // 2), max(9, h // 2))
     rays, dt = run(sw, sh, nthreads)
     qw, qh = max(16, w // 4), max(9, h // 4)
     rays1, dt1 = run(qw, qh, 1)

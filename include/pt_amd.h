@@ -80,8 +80,8 @@ typedef struct pt_options {
     uint32_t max_paths;     /* paths in flight per wavefront batch (0 = default 8Mi) */
     int32_t kernel_timing;  /* 1: pt_stats.{trace,shadow,shade,other}_ms are measured with a pair of HIP events around every launch
                              *    (costs ≈0.3 ms of a 2 ms frame at a 1/8 share); 0 (default): only render_ms is measured */
-    int32_t bvh_kind;       /* 0 = default: 8-wide compressed BVH (k_trace8); 1 = binary BVH (k_trace2), A/B only: built on first request */
-    int32_t trace_kernel;   /* 0 = default: persistent-wave traversal (k_trace8, or k_trace2 with bvh_kind 1); 1 = first grid-stride kernel over the binary BVH (A/B) */
+    int32_t bvh_kind;       /* reserved, must be 0 (rounds 1-2: 1 = a binary BVH as an A/B path; removed — the 8-wide compressed tree is the structure) */
+    int32_t trace_kernel;   /* reserved, must be 0 (rounds 1-2: 1 = the first grid-stride traversal kernel; removed) */
     int32_t streams;        /* pixel chunks of a frame run concurrently on this many stream pairs (0 = default 3, the measured optimum: tails of one chunk overlap the bulk of the others) */
     int32_t split_shadow;   /* 0 = default: shadow rays of bounce b share a launch with the closest-hit rays of b+1; 1 = separate kernels;
                              * 2 = asynchronous: per-bounce shadow records traced on side streams, nothing waits for them before the

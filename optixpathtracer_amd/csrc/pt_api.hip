@@ -13,7 +13,6 @@
 
 #include "pt_host.h"
 #include "pt_kernels.h"
-#include "pt_trace2.h"
 #include "pt_bvh8.h"
 
 static thread_local std::string g_create_error;
@@ -41,7 +40,6 @@ struct pt_ctx {
     std::vector<uint32_t*> d_tex_pixels;
     DevTex tex0{};
     PtBvh bvh;
-    bool bvh2_built = false; // the binary form (A/B paths) has been added to `bvh`
     double bvh_build_ms = 0;
     // probe
     DevProbe probe{};
@@ -206,16 +204,12 @@ static uint32_t* fault_word(pt_ctx::BatchSet& bs) { return reinterpret_cast<uint
 static int drain(pt_ctx* ctx);
 static int stack_capacity8(const pt_ctx* ctx) { return (PT8_LDS_DEPTH - ctx->lds_skip) + ctx->ovf_depth; }
 
-// The traversal stacks are finite (k_trace8: one pushed group per level of the wide tree; k_trace/k_trace2: one node per level of
-// the binary tree).  A tree deeper than the stack is refused here, loudly, instead of being traversed with dropped entries.
+// The traversal stack is finite (k_trace8: one pushed group per level of the wide tree).  A tree deeper than the stack is refused
+// here, loudly, instead of being traversed with dropped entries.
 static int check_tree_depth(pt_ctx* ctx, char* msg, size_t msg_len) {
     if (!ctx->stack_check) return PT_OK;
     if (ctx->bvh.levels8 > stack_capacity8(ctx)) {
         snprintf(msg, msg_len, "acceleration structure has %d levels, the traversal stack holds %d", ctx->bvh.levels8, stack_capacity8(ctx));
-        return PT_ERR_UNSUPPORTED;
-    }
-    if (ctx->bvh.nodes && ctx->bvh.depth2 > PT_STACK_DEPTH) {
-        snprintf(msg, msg_len, "binary acceleration structure is %d levels deep, the traversal stack holds %d", ctx->bvh.depth2, PT_STACK_DEPTH);
         return PT_ERR_UNSUPPORTED;
     }
     return PT_OK;
@@ -354,7 +348,7 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     CKC(tmp.event(&e0));
     CKC(tmp.event(&e1));
     CKC(hipEventRecord(e0, ctx->stream));
-    CKC(pt_bvh_build(ctx->d_verts, ctx->d_idx, ctx->d_tri_mesh, (uint32_t)nt, 0, ctx->stream, &ctx->bvh));
+    CKC(pt_bvh_build(ctx->d_verts, ctx->d_idx, ctx->d_tri_mesh, (uint32_t)nt, ctx->stream, &ctx->bvh));
     CKC(hipEventRecord(e1, ctx->stream));
     CKC(hipStreamSynchronize(ctx->stream));
     float ms = 0;
@@ -455,30 +449,8 @@ extern "C" int pt_set_options(pt_ctx* ctx, const pt_options* opt) {
     if (opt->max_depth < 0 || opt->max_depth > 250) return fail(ctx, PT_ERR_INVALID, "pt_set_options: max_depth out of range [0,250]");
     if (opt->bsdf_mode != PT_BSDF_DISNEY && opt->bsdf_mode != PT_BSDF_LAMBERT) return fail(ctx, PT_ERR_INVALID, "pt_set_options: bad bsdf_mode");
     if (opt->frames_in_flight < 0 || opt->frames_in_flight > PT_MAX_FRAMES) return fail(ctx, PT_ERR_INVALID, "pt_set_options: frames_in_flight must be 0 ... 3");
-    if ((opt->bvh_kind == 1 || opt->trace_kernel == 1) && !ctx->bvh2_built) {
-        // the binary tree is an A/B path: built (with the wide tree, from the same hierarchy) the first time it is asked for — into a
-        // temporary that replaces the live structure only when the build and the depth check succeeded
-        CK(hipSetDevice(ctx->device));
-        CK(hipStreamSynchronize(ctx->stream));
-        PtBvh fresh;
-        hipError_t e = pt_bvh_build(ctx->d_verts, ctx->d_idx, ctx->d_tri_mesh, ctx->ntri, 1, ctx->stream, &fresh);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) {
-            pt_bvh_free(&fresh);
-            ctx->err = std::string("pt_set_options: building the binary BVH: ") + hipGetErrorString(e);
-            return PT_ERR_HIP;
-        }
-        std::swap(ctx->bvh, fresh);
-        char msg[160];
-        if (check_tree_depth(ctx, msg, sizeof(msg)) != PT_OK) {
-            std::swap(ctx->bvh, fresh); // keep the structure that passed its own check
-            pt_bvh_free(&fresh);
-            ctx->err = std::string("pt_set_options: ") + msg;
-            return PT_ERR_UNSUPPORTED;
-        }
-        pt_bvh_free(&fresh);
-        ctx->bvh2_built = true;
-    }
+    if (opt->bvh_kind != 0 || opt->trace_kernel != 0)
+        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_set_options: bvh_kind and trace_kernel are reserved (the binary-BVH A/B paths of rounds 1-2 were removed): must be 0");
     ctx->opt = *opt;
     if (ctx->opt.max_paths == 0) ctx->opt.max_paths = 8u << 20;
     return PT_OK;
@@ -718,13 +690,13 @@ extern "C" int pt_resize(pt_ctx* ctx, int width, int height) {
 }
 
 static size_t ovf_words(const pt_ctx* ctx) {
-    return (size_t)ctx->trace_grid * 64 * (PT8_OVF_DEPTH * 2 > PT2_OVF_DEPTH ? PT8_OVF_DEPTH * 2 : PT2_OVF_DEPTH);
+    return (size_t)ctx->trace_grid * 64 * (PT8_OVF_DEPTH * 2);
 }
 
 // asynchronous shadow rays (split_shadow = 2): per-bounce shadow records and queues; not for shadow-catcher scenes, whose
 // alpha accumulation interleaves assignments and sums, and only with the default traversal
 static bool async_shadows(const pt_ctx* ctx) {
-    return ctx->opt.split_shadow == 2 && !ctx->has_catcher && ctx->opt.bvh_kind == 0 && ctx->opt.trace_kernel == 0 && ctx->opt.max_depth < 31;
+    return ctx->opt.split_shadow == 2 && !ctx->has_catcher && ctx->opt.max_depth < 31;
 }
 
 // Do two streams run concurrently, or do they share a hardware queue (and serialise)?  HIP deals its streams onto four hardware queues
@@ -913,10 +885,8 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
     const int nq = ctx->nq;
     const float tmin_rad = job ? job->var.radiance_tmin : 0.001f;
     const int cull = job ? job->var.cull_back_occlusion : 0;
-    BvhDev bvh{ctx->bvh.nodes, ctx->bvh.tris, ctx->bvh.root, 0.5f * ctx->bvh.pad};
     Bvh8Dev bvh8{ctx->bvh.nodes8, ctx->bvh.tris8, 0.5f * ctx->bvh.pad};
-    // the hit records index the leaf triangles of the structure that was traversed
-    const LeafTri* shade_tris = (ctx->opt.bvh_kind == 1 || ctx->opt.trace_kernel == 1) ? ctx->bvh.tris : ctx->bvh.tris8;
+    const LeafTri* shade_tris = ctx->bvh.tris8; // the hit records index the leaf triangles of the structure that was traversed
     const size_t CS = (size_t)PT_NSUB * PT_CSTRIDE;
     for (uint32_t s0 = 0; s0 < spp; s0 += S) {
         const uint32_t Sc = std::min(S, spp - s0);
@@ -949,7 +919,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
         const int depth0 = job ? job->var.initial_depth : 0;
         const int last_bounce = (ctx->has_catcher ? ctx->opt.max_depth : ctx->opt.max_depth - 1) - depth0;
         hipEvent_t ev_shadow_done = nullptr;
-        const bool unified = ctx->opt.trace_kernel == 0 && ctx->opt.bvh_kind == 0 && ctx->opt.split_shadow == 0;
+        const bool unified = ctx->opt.split_shadow == 0;
         const bool async = ctx->cap_async;
         if (async) {
             // The bounce chain holds closest-hit launches only; the shadow rays of bounce b are traced from their own records
@@ -1037,15 +1007,8 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             QView qshadow{bs.squeue, cntS + (size_t)b * CS, ctx->sub_cap};
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                if (ctx->opt.trace_kernel == 1) {
-                    hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, bs.stream, bs.st, bvh, qcur);
-                } else if (ctx->opt.bvh_kind == 1) {
-                    Trace2Args ta{bs.st, bvh, qcur, work + b, bs.ovf, nullptr};
-                    hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
-                } else {
-                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                    hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
-                }
+                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
+                hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
             ShadeParams sp{shade_tris, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
@@ -1063,15 +1026,8 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 hipEventRecord(ev_shaded, bs.stream);
                 hipStreamWaitEvent(bs.stream2, ev_shaded, 0);
                 SpanGuard g(ctx, CLS_SHADOW, bs.stream2);
-                if (ctx->opt.trace_kernel == 1) {
-                    hipLaunchKernelGGL((k_trace<1>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, bs.stream2, bs.st, bvh, qshadow);
-                } else if (ctx->opt.bvh_kind == 1) {
-                    Trace2Args ta{bs.st, bvh, qshadow, work + nq + b, bs.ovf2, nullptr};
-                    hipLaunchKernelGGL((k_trace2<TR_SHADOW_APPLY>), dim3(tgrid), dim3(64), 0, bs.stream2, ta);
-                } else {
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                    hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(tgrid), dim3(64), 0, bs.stream2, ta);
-                }
+                Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
+                hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(tgrid), dim3(64), 0, bs.stream2, ta);
                 ++lc.shadow;
             }
             ev_shadow_done = next_event(ctx);
@@ -1420,7 +1376,6 @@ static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, co
     ctx->fr[slot].active = 0;
     if (ctx->width == 0) return PT_OK;
     if (!ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_render_regions: no probe set (setProbe)");
-    if (ctx->opt.bvh_kind != 0 || ctx->opt.trace_kernel != 0) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_regions: needs the default traversal (bvh_kind 0, trace_kernel 0)");
     if (ctx->has_catcher) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_regions: shadow-catcher materials are not supported in foveated launches");
     CK(hipSetDevice(ctx->device));
     VariantParams var{0.001f, 0, 0, 1.0f, 1.0f, 0, 0};
@@ -1776,25 +1731,12 @@ extern "C" int pt_get_stats(const pt_ctx* ctx, pt_stats* out) {
     out->frames = ctx->cum_frames;
     out->total_radiance_rays = ctx->cum_radiance;
     out->total_shadow_rays = ctx->cum_shadow;
-    const bool wide = ctx->opt.bvh_kind != 1 && ctx->opt.trace_kernel != 1;
-    out->bvh_nodes = wide ? ctx->bvh.num_nodes8 : ctx->bvh.num_nodes;
-    out->bvh_bytes = wide ? (uint64_t)ctx->bvh.num_nodes8 * sizeof(Node8) + (uint64_t)ctx->bvh.num_tris8 * sizeof(LeafTri)
-                          : (uint64_t)ctx->bvh.num_nodes * sizeof(Node2) + (uint64_t)ctx->bvh.num_tris * sizeof(LeafTri);
+    out->bvh_nodes = ctx->bvh.num_nodes8;
+    out->bvh_bytes = (uint64_t)ctx->bvh.num_nodes8 * sizeof(Node8) + (uint64_t)ctx->bvh.num_tris8 * sizeof(LeafTri);
     out->bvh_build_ms = ctx->bvh_build_ms;
-    out->bvh_levels = (uint32_t)(wide ? ctx->bvh.levels8 : ctx->bvh.depth2);
+    out->bvh_levels = (uint32_t)ctx->bvh.levels8;
     out->bvh_builder = (uint32_t)ctx->bvh.builder;
     return PT_OK;
-}
-
-__global__ void __launch_bounds__(PT_TRACE_BLOCK) k_query_any(const float4* rayO, const float4* rayD, BvhDev bvh, uint32_t n, int32_t* occ) {
-    __shared__ uint32_t s_stack[PT_STACK_DEPTH * PT_TRACE_BLOCK];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 o4 = rayO[i], d4 = rayD[i];
-        float t;
-        int32_t prim;
-        bvh2_traverse<true>(bvh, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, d4.w, &s_stack[threadIdx.x], PT_TRACE_BLOCK, t, prim);
-        occ[i] = prim;
-    }
 }
 
 extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit, float* t_out, int32_t* prim_out, int iters,
@@ -1809,12 +1751,10 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     float4 *dO = nullptr, *dD = nullptr;
     float2* dHit = nullptr;
     uint32_t *dCount = nullptr, *dWork = nullptr;
-    int32_t* dOcc = nullptr;
     unsigned long long* dDbg = nullptr;
     hipEvent_t e0, e1;
     CK(tmp.alloc(&dO, n)); CK(tmp.alloc(&dD, n)); CK(tmp.alloc(&dHit, n)); CK(tmp.alloc(&dCount, 1));
     CK(tmp.alloc(&dWork, (size_t)iters));
-    if (any_hit) CK(tmp.alloc(&dOcc, n));
     CK(tmp.event(&e0));
     CK(tmp.event(&e1));
     std::vector<float4> hO(n), hD(n);
@@ -1826,7 +1766,6 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     CK(hipMemcpy(dO, hO.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     CK(hipMemcpy(dD, hD.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     CK(hipMemcpy(dCount, &n, 4, hipMemcpyHostToDevice));
-    BvhDev bvh{ctx->bvh.nodes, ctx->bvh.tris, ctx->bvh.root, 0.5f * ctx->bvh.pad};
     PathState st{};
     st.rayO = dO;
     st.rayD = dD;
@@ -1839,16 +1778,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     CK(hipMemsetAsync(ctx->d_totals + 2, 0, sizeof(unsigned long long), ctx->stream));
     CK(hipEventRecord(e0, ctx->stream));
     for (int it = 0; it < iters; ++it) {
-        if (ctx->opt.trace_kernel == 1) {
-            if (any_hit)
-                hipLaunchKernelGGL(k_query_any, dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, dO, dD, bvh, n, dOcc);
-            else
-                hipLaunchKernelGGL((k_trace<0>), dim3(GRID), dim3(PT_TRACE_BLOCK), 0, ctx->stream, st, bvh, QView{nullptr, dCount, 0});
-        } else if (ctx->opt.bvh_kind == 1) {
-            Trace2Args ta{st, bvh, QView{nullptr, dCount, 0}, dWork + it, ctx->ovf, dDbg};
-            if (any_hit) hipLaunchKernelGGL((k_trace2<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
-            else hipLaunchKernelGGL((k_trace2<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
-        } else {
+        {
             Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8, 0.5f * ctx->bvh.pad}, QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, 0, dDbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
             if (any_hit) hipLaunchKernelGGL((k_trace8<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
@@ -1856,8 +1786,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     }
     CK(hipEventRecord(e1, ctx->stream));
     if (!any_hit) { // hit records name leaf triangles; the caller wants optixGetPrimitiveIndex
-        const LeafTri* lt = (ctx->opt.bvh_kind == 1 || ctx->opt.trace_kernel == 1) ? ctx->bvh.tris : ctx->bvh.tris8;
-        hipLaunchKernelGGL(k_hits_to_prims, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dHit, lt, n);
+        hipLaunchKernelGGL(k_hits_to_prims, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dHit, ctx->bvh.tris8, n);
     }
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipGetLastError());
@@ -1876,9 +1805,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
                 "wave loop iterations max %llu mean %.1f (waves %llu)\n", n, iters,
                 (double)h[0] / n / iters, (double)h[1] / n / iters, (double)h[3] / n / iters, h[2], h[4], h[5], h[7] ? (double)h[6] / h[7] : 0.0, h[7] / iters);
     }
-    if (any_hit && ctx->opt.trace_kernel == 1) {
-        CK(hipMemcpy(prim_out, dOcc, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    } else if (any_hit) {
+    if (any_hit) {
         std::vector<float2> hh(n);
         CK(hipMemcpy(hh.data(), dHit, sizeof(float2) * n, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < n; ++i) memcpy(&prim_out[i], &hh[i].y, 4);

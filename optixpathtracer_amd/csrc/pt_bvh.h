@@ -1,5 +1,6 @@
-// pt_bvh.h — software acceleration structure and ray search; stands in for the OptiX GAS
-// (optixAccelBuild, SimplePathtracer.cpp:457-601) and for optixTrace (deviceProgram.cu:165,190).
+// pt_bvh.h — what defines a hit: leaf triangles, the ray/triangle test, the box criterion, the slab test of uncompressed boxes.  The
+// structure that stands in for the OptiX GAS (optixAccelBuild, SimplePathtracer.cpp:457-601) and the traversal that stands in for
+// optixTrace (deviceProgram.cu:165,190) are pt_bvh8.h; rounds 1-2 also kept a binary tree with two traversal kernels as an A/B path.
 //
 // Closest hit = smallest t in (tmin,tmax) over all triangles, ties broken by the lowest global
 // primitive index, so the answer does not depend on the tree or on traversal order.  The triangle
@@ -11,29 +12,12 @@
 #pragma once
 #include "pt_device.h"
 
-// 64-byte binary node: both children's boxes + refs.
-//   a = (c0.lo.xyz, c0.hi.x)  b = (c0.hi.yz, c1.lo.xy)  c = (c1.lo.z, c1.hi.xyz)  d = (ref0, ref1, -, -)
-// ref >= 0: internal node index.  ref < 0: leaf, ~ref = (first_triangle << 3) | (count-1).
-// ref == PT_REF_EMPTY: no child (box is inverted, never hit).
-struct Node2 {
-    float4 a, b, c, d;
-};
-#define PT_REF_EMPTY 0x7fffffff
-#define PT_LEAF_MAX 4
-
 // 48-byte leaf triangle, in leaf order: t0 = (v0.xyz, v1.x) t1 = (v1.yz, v2.xy) t2 = (v2.z, prim bits, mesh bits, -).
 // The hit record of a closest-hit ray holds the INDEX of the leaf triangle (not the primitive): the shade kernel reads the very
 // 48 bytes the traversal just pulled through the caches — vertices, primitive (for texcoords) and mesh (material record, what the
 // SBT record index gave the reference, deviceProgram.cu:481-489) — instead of a second triangle array in primitive order.
 struct LeafTri {
     float4 t0, t1, t2;
-};
-
-struct BvhDev {
-    const Node2* nodes;
-    const LeafTri* tris;
-    int32_t root; // ref of the root (internal index 0, or a leaf ref for tiny scenes)
-    float hit_pad; // half the builder's box padding (tri_test_det)
 };
 
 struct RaySetup {
@@ -90,72 +74,4 @@ PT_DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, floa
     tf = fminf(tf, tmax);
     tnear = tn;
     return tn <= tf;
-}
-
-#define PT_STACK_DEPTH 64
-
-// Per-lane traversal with the stack in LDS (stack[level * stride + lane_slot]).
-// ANY: stop at the first hit in (tmin,tmax) → prim = 1/0.  else closest hit → (t, leaf-triangle index of the hit or -1).
-template <bool ANY>
-PT_DEV void bvh2_traverse(const BvhDev& bvh, v3 o, v3 d, float tmin, float tmax, uint32_t* stack, uint32_t stride,
-                          float& t_out, int32_t& prim_out) {
-    const RaySetup r = ray_setup(o, d);
-    float best = tmax;
-    int32_t bprim = -1, bleaf = -1;
-    int sp = 0;
-    int32_t node = bvh.root;
-    for (;;) {
-        if (node >= 0) {
-            if (node == PT_REF_EMPTY) goto pop;
-            {
-                const Node2* n = &bvh.nodes[node];
-                const float4 na = n->a, nb = n->b, nc = n->c, nd = n->d;
-                float t0, t1;
-                const bool h0 = box_test(na.x, na.y, na.z, na.w, nb.x, nb.y, r, tmin, best, t0);
-                const bool h1 = box_test(nb.z, nb.w, nc.x, nc.y, nc.z, nc.w, r, tmin, best, t1);
-                const int32_t c0 = __float_as_int(nd.x), c1 = __float_as_int(nd.y);
-                if (h0 && h1) {
-                    const bool swap = t1 < t0;
-                    const int32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                    if (sp < PT_STACK_DEPTH) stack[(sp++) * stride] = (uint32_t)farc;
-                    node = nearc;
-                    continue;
-                } else if (h0) {
-                    node = c0;
-                    continue;
-                } else if (h1) {
-                    node = c1;
-                    continue;
-                }
-            }
-        } else {
-            const uint32_t code = ~(uint32_t)node;
-            const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const LeafTri* tp = &bvh.tris[first + k];
-                const float4 a = tp->t0, b = tp->t1, c = tp->t2;
-                float t, det;
-                const v3 v0 = mk3(a.x, a.y, a.z), v1 = mk3(a.w, b.x, b.y), v2 = mk3(b.z, b.w, c.x);
-                if (tri_test_det(r, v0, v1, v2, t, det)) {
-                    const int32_t prim = __float_as_int(c.y);
-                    if (ANY) {
-                        if (t > tmin && t < tmax && hit_in_box(r, v0, v1, v2, bvh.hit_pad, t)) {
-                            prim_out = 1;
-                            t_out = t;
-                            return;
-                        }
-                    } else if (t > tmin && (t < best || (t == best && bprim >= 0 && prim < bprim)) && hit_in_box(r, v0, v1, v2, bvh.hit_pad, t)) {
-                        best = t;
-                        bprim = prim;
-                        bleaf = (int32_t)(first + k);
-                    }
-                }
-            }
-        }
-    pop:
-        if (sp == 0) break;
-        node = (int32_t)stack[(--sp) * stride];
-    }
-    t_out = best;
-    prim_out = ANY ? 0 : bleaf;
 }

@@ -1,7 +1,7 @@
-// pt_bvh_build.hip — on-GPU LBVH construction (replaces optixAccelBuild/optixAccelCompact,
-// SimplePathtracer.cpp:561-591).  Morton codes of triangle centroids → radix sort → Karras 2012
-// hierarchy → bottom-up refit → subtrees of <= PT_LEAF_MAX triangles collapsed to leaves →
-// compact 64-byte traversal nodes with padded child boxes and 48-byte leaf triangles in leaf order.
+// pt_bvh_build.hip — on-GPU construction of the acceleration structure (replaces optixAccelBuild/optixAccelCompact,
+// SimplePathtracer.cpp:561-591).  Morton codes of triangle centroids → radix sort → Karras 2012 hierarchy (LBVH) → bottom-up refit →
+// SAH-optimal collapse into the 8-wide compressed tree of pt_bvh8.h (80-byte nodes, 48-byte leaf triangles in leaf order); a PLOC
+// hierarchy over the same leaves is collapsed as well and calibration rays choose between the two (k_calibrate8).
 // Deterministic: keys are (morton30 << 32 | primitive) so they are unique.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -156,42 +156,6 @@ __global__ void k_refit(const float* __restrict__ verts, const uint32_t* __restr
     }
 }
 
-// keep[i] = 1 if internal node i stays internal (its range holds more than PT_LEAF_MAX triangles)
-__global__ void k_mark(int n, const int* __restrict__ rfirst, const int* __restrict__ rlast, uint32_t* __restrict__ keep) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
-    keep[i] = (rlast[i] - rfirst[i] + 1) > PT_LEAF_MAX ? 1u : 0u;
-}
-
-__device__ __forceinline__ int32_t child_ref(int c, int n, const int* rfirst, const int* rlast, const uint32_t* keep,
-                                             const uint32_t* remap) {
-    if (c >= n - 1) { // single-triangle leaf
-        uint32_t first = (uint32_t)(c - (n - 1));
-        return (int32_t)~((first << 3) | 0u);
-    }
-    if (keep[c]) return (int32_t)remap[c];
-    uint32_t first = (uint32_t)rfirst[c], cnt = (uint32_t)(rlast[c] - rfirst[c] + 1);
-    return (int32_t)~((first << 3) | (cnt - 1u));
-}
-
-__global__ void k_emit_nodes(int n, const int* __restrict__ left, const int* __restrict__ right,
-                             const int* __restrict__ rfirst, const int* __restrict__ rlast,
-                             const uint32_t* __restrict__ keep, const uint32_t* __restrict__ remap,
-                             const float* __restrict__ box, float pad, Node2* __restrict__ nodes) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1 || !keep[i]) return;
-    const int l = left[i], r = right[i];
-    const float* bl = &box[(size_t)l * 6];
-    const float* br = &box[(size_t)r * 6];
-    Node2 nd;
-    nd.a = make_float4(bl[0] - pad, bl[1] - pad, bl[2] - pad, bl[3] + pad);
-    nd.b = make_float4(bl[4] + pad, bl[5] + pad, br[0] - pad, br[1] - pad);
-    nd.c = make_float4(br[2] - pad, br[3] + pad, br[4] + pad, br[5] + pad);
-    nd.d = make_float4(__int_as_float(child_ref(l, n, rfirst, rlast, keep, remap)),
-                       __int_as_float(child_ref(r, n, rfirst, rlast, keep, remap)), 0.f, 0.f);
-    nodes[remap[i]] = nd;
-}
-
 __global__ void k_emit_tris(const float* __restrict__ verts, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ tri_mesh,
                             const uint64_t* __restrict__ keys, int n, LeafTri* __restrict__ tris) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,7 +171,7 @@ __global__ void k_emit_tris(const float* __restrict__ verts, const uint32_t* __r
     tris[i] = t;
 }
 
-// ------------------------------------------------------------------ BVH2 → compressed BVH8 (pt_bvh8.h)
+// ------------------------------------------------------------------ binary hierarchy → compressed 8-wide tree (pt_bvh8.h)
 struct Task8 {
     int bnode;     // binary node (Karras numbering: internal 0..n-2, leaf n-1+i)
     uint32_t widx; // index of the wide node to emit
@@ -462,7 +426,7 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
 // right for the partner that minimises the surface area of the merged box; mutual nearest neighbours merge; repeat.
 // Much closer to a SAH tree than the LBVH split-at-Morton-bit hierarchy, still fully parallel.
 #define PLOC_R 25
-__global__ void k_ploc_nn(const int* __restrict__ cl, int N, const float* __restrict__ box, int* __restrict__ nn) {
+__global__ void k_ploc_nn(const int* __restrict__ cl, int N, const float* __restrict__ box, int tie_partner, int* __restrict__ nn) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const float* bi = &box[(size_t)cl[i] * 6];
@@ -470,12 +434,25 @@ __global__ void k_ploc_nn(const int* __restrict__ cl, int N, const float* __rest
     float best = INFINITY;
     int bj = -1;
     const int j0 = i - PLOC_R < 0 ? 0 : i - PLOC_R, j1 = i + PLOC_R > N - 1 ? N - 1 : i + PLOC_R;
-    for (int j = j0; j <= j1; ++j) {
-        if (j == i) continue;
+    auto dist = [&](int j) {
         const float* bjp = &box[(size_t)cl[j] * 6];
         const float dx = fmaxf(h0, bjp[3]) - fminf(l0, bjp[0]), dy = fmaxf(h1, bjp[4]) - fminf(l1, bjp[1]), dz = fmaxf(h2, bjp[5]) - fminf(l2, bjp[2]);
-        const float a = dx * dy + dy * dz + dz * dx;
-        if (a < best) { // strict: the lowest index wins ties → deterministic
+        return dx * dy + dy * dz + dz * dx;
+    };
+    // Ties go to the lowest index (deterministic).  With that rule a neighbourhood of identical boxes (thousands of copies of one
+    // triangle) has a single mutual pair per round — clusters 0 and 1 — and the build would need as many rounds as there are clusters:
+    // a round that merges next to nothing is therefore repeated with tie_partner = 1, where a tie goes to the parity partner i ^ 1 first
+    // and every tie-only neighbourhood pairs up at once.  (The partner rule for every round was measured on the stadium scene: a 9 % worse
+    // tree — there ties are common and "lowest index" = the far end of the Morton window happens to pick better partners.)
+    const int jp = tie_partner ? (i ^ 1) : -1;
+    if (jp >= j0 && jp <= j1) {
+        best = dist(jp);
+        bj = jp;
+    }
+    for (int j = j0; j <= j1; ++j) {
+        if (j == i || j == jp) continue;
+        const float a = dist(j);
+        if (a < best) {
             best = a;
             bj = j;
         }
@@ -739,18 +716,22 @@ static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt,
     hipLaunchKernelGGL(k_ploc_init, dim3((n + B - 1) / B), dim3(B), 0, stream, n, cl_a);
     int N = n, next_id = 0, iters = 0;
     while (N > 1) {
-        hipLaunchKernelGGL(k_ploc_nn, dim3((N + B - 1) / B), dim3(B), 0, stream, cl_a, N, box, nn);
-        hipLaunchKernelGGL(k_ploc_flags, dim3((N + B - 1) / B), dim3(B), 0, stream, nn, N, merge, valid);
-        HIPCHK(rocprim::exclusive_scan(tmp, tmp_bytes, merge, merge_rank, 0u, (size_t)N, rocprim::plus<uint32_t>(), stream));
-        HIPCHK(rocprim::exclusive_scan(tmp, tmp_bytes, valid, valid_rank, 0u, (size_t)N, rocprim::plus<uint32_t>(), stream));
-        hipLaunchKernelGGL(k_ploc_merge, dim3((N + B - 1) / B), dim3(B), 0, stream, cl_a, nn, N, merge, merge_rank, valid, valid_rank, next_id, left, right, box, cnt, cl_b);
         uint32_t lm[2], lv[2];
-        HIPCHK(hipMemcpyAsync(&lm[0], merge + (N - 1), 4, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(&lm[1], merge_rank + (N - 1), 4, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(&lv[0], valid + (N - 1), 4, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(&lv[1], valid_rank + (N - 1), 4, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        const int merged = (int)(lm[0] + lm[1]);
+        int merged = 0;
+        for (int tie_partner = 0; tie_partner < 2; ++tie_partner) {
+            hipLaunchKernelGGL(k_ploc_nn, dim3((N + B - 1) / B), dim3(B), 0, stream, cl_a, N, box, tie_partner, nn);
+            hipLaunchKernelGGL(k_ploc_flags, dim3((N + B - 1) / B), dim3(B), 0, stream, nn, N, merge, valid);
+            HIPCHK(rocprim::exclusive_scan(tmp, tmp_bytes, merge, merge_rank, 0u, (size_t)N, rocprim::plus<uint32_t>(), stream));
+            HIPCHK(rocprim::exclusive_scan(tmp, tmp_bytes, valid, valid_rank, 0u, (size_t)N, rocprim::plus<uint32_t>(), stream));
+            HIPCHK(hipMemcpyAsync(&lm[0], merge + (N - 1), 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(&lm[1], merge_rank + (N - 1), 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(&lv[0], valid + (N - 1), 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(&lv[1], valid_rank + (N - 1), 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            merged = (int)(lm[0] + lm[1]);
+            if (merged * 64 >= N || N <= 64) break; // a healthy round merges a good part of the clusters; a starved one is repeated with the partner rule
+        }
+        hipLaunchKernelGGL(k_ploc_merge, dim3((N + B - 1) / B), dim3(B), 0, stream, cl_a, nn, N, merge, merge_rank, valid, valid_rank, next_id, left, right, box, cnt, cl_b);
         if (merged == 0 || ++iters > 4096) return hipErrorUnknown; // cannot happen: the global closest pair is always mutual
         next_id += merged;
         N = (int)(lv[0] + lv[1]);
@@ -763,12 +744,7 @@ static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt,
 }
 
 // Builds the traversal structure for (verts, idx) already resident on the device.
-hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint32_t* d_tri_mesh, uint32_t ntri, int want_bvh2, hipStream_t stream, PtBvh* out) {
-    out->nodes = nullptr;
-    out->tris = nullptr;
-    out->num_nodes = 0;
-    out->num_tris = ntri;
-    out->depth2 = 0;
+hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint32_t* d_tri_mesh, uint32_t ntri, hipStream_t stream, PtBvh* out) {
     const int n = (int)ntri;
     const int B = 256;
     // leaf triangles + keys
@@ -804,10 +780,8 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
     LeafTri* tris = nullptr;
     HIPCHK(hipMalloc(&tris, sizeof(LeafTri) * (size_t)n));
     hipLaunchKernelGGL(k_emit_tris, dim3((n + B - 1) / B), dim3(B), 0, stream, d_verts, d_idx, d_tri_mesh, keys_sorted, n, tris);
-    out->tris = tris;
 
-    if (n <= PT_LEAF_MAX) { // the whole scene is one leaf
-        out->root = (int32_t)~((0u << 3) | (uint32_t)(n - 1));
+    if (n <= PT8_LEAF_MAX) { // the whole scene is one leaf child of one node
         Node8* nodes8 = nullptr;
         LeafTri* tris8 = nullptr;
         float* dbounds = nullptr;
@@ -820,14 +794,13 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
         out->nodes8 = nodes8; out->tris8 = tris8; out->num_nodes8 = 1; out->num_tris8 = (uint32_t)n; out->levels8 = 1;
         HIPCHK(hipStreamSynchronize(stream));
         hipFree(dbounds);
-        if (!want_bvh2) { hipFree(tris); out->tris = nullptr; out->num_tris = 0; }
+        hipFree(tris);
         hipFree(keys); hipFree(keys_sorted); hipFree(bounds); hipFree(tmp);
         return hipSuccess;
     }
 
     int *left, *right, *parent, *rfirst, *rlast, *visits;
     float* box;
-    uint32_t *keep, *remap;
     HIPCHK(hipMalloc(&left, sizeof(int) * (size_t)n));
     HIPCHK(hipMalloc(&right, sizeof(int) * (size_t)n));
     HIPCHK(hipMalloc(&parent, sizeof(int) * (size_t)(2 * n)));
@@ -835,54 +808,9 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
     HIPCHK(hipMalloc(&rlast, sizeof(int) * (size_t)n));
     HIPCHK(hipMalloc(&visits, sizeof(int) * (size_t)n));
     HIPCHK(hipMalloc(&box, sizeof(float) * 6 * (size_t)(2 * n)));
-    HIPCHK(hipMalloc(&keep, sizeof(uint32_t) * (size_t)n));
-    HIPCHK(hipMalloc(&remap, sizeof(uint32_t) * (size_t)n));
     HIPCHK(hipMemsetAsync(visits, 0, sizeof(int) * (size_t)n, stream));
     hipLaunchKernelGGL(k_karras, dim3((n + B - 1) / B), dim3(B), 0, stream, keys_sorted, n, left, right, parent, rfirst, rlast);
     hipLaunchKernelGGL(k_refit, dim3((n + B - 1) / B), dim3(B), 0, stream, d_verts, d_idx, keys_sorted, n, left, right, parent, box, visits);
-    hipLaunchKernelGGL(k_mark, dim3((n + B - 1) / B), dim3(B), 0, stream, n, rfirst, rlast, keep);
-    size_t tmp2_bytes = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, tmp2_bytes, keep, remap, 0u, (size_t)(n - 1), rocprim::plus<uint32_t>(), stream));
-    void* tmp2 = nullptr;
-    HIPCHK(hipMalloc(&tmp2, tmp2_bytes ? tmp2_bytes : 16));
-    HIPCHK(rocprim::exclusive_scan(tmp2, tmp2_bytes, keep, remap, 0u, (size_t)(n - 1), rocprim::plus<uint32_t>(), stream));
-    uint32_t last_keep = 0, last_remap = 0;
-    HIPCHK(hipMemcpyAsync(&last_keep, keep + (n - 2), 4, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipMemcpyAsync(&last_remap, remap + (n - 2), 4, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    const uint32_t nnodes = last_keep + last_remap;
-    if (want_bvh2) { // the binary form is an A/B path (pt_options.bvh_kind = 1 / trace_kernel = 1): only built on request
-        Node2* nodes = nullptr;
-        HIPCHK(hipMalloc(&nodes, sizeof(Node2) * (size_t)(nnodes ? nnodes : 1)));
-        hipLaunchKernelGGL(k_emit_nodes, dim3((n + B - 1) / B), dim3(B), 0, stream, n, left, right, rfirst, rlast, keep, remap, box, pad, nodes);
-        HIPCHK(hipStreamSynchronize(stream));
-        HIPCHK(hipGetLastError());
-        out->nodes = nodes;
-        out->num_nodes = nnodes;
-        out->root = 0; // node 0 (range = everything) always stays internal when n > PT_LEAF_MAX, and remap[0] = 0
-        // depth of the binary tree (bounds the traversal stack of bvh2_traverse / k_trace2): host walk over the emitted nodes
-        std::vector<Node2> h(nnodes);
-        HIPCHK(hipStreamSynchronize(stream));
-        HIPCHK(hipMemcpy(h.data(), nodes, sizeof(Node2) * h.size(), hipMemcpyDeviceToHost));
-        std::vector<int> depth(nnodes, 0);
-        std::vector<int32_t> todo{0};
-        depth[0] = 1;
-        int dmax = 1;
-        while (!todo.empty()) {
-            const int32_t k = todo.back();
-            todo.pop_back();
-            int32_t c[2];
-            memcpy(&c[0], &h[k].d.x, 4);
-            memcpy(&c[1], &h[k].d.y, 4);
-            for (int j = 0; j < 2; ++j)
-                if (c[j] >= 0 && c[j] != PT_REF_EMPTY && (uint32_t)c[j] < nnodes) {
-                    depth[c[j]] = depth[k] + 1;
-                    dmax = depth[c[j]] > dmax ? depth[c[j]] : dmax;
-                    todo.push_back(c[j]);
-                }
-        }
-        out->depth2 = dmax;
-    }
     {
         // hierarchy for the wide tree: the LBVH itself (default) or PLOC (PT_BVH_BUILDER=ploc).  Measured on the C3 voxel
         // terrain: PLOC gives MORE node visits per ray (13.3 vs 12.5 primary, 15.9 vs 13.6 diffuse bounce) and 5 % lower
@@ -900,8 +828,14 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
         if (!force_lbvh && !force_ploc && n >= 4096) {
             // both hierarchies, the one that costs the calibration rays less (see k_calibrate8); small scenes keep the LBVH
             PtBvh alt;
-            HIPCHK(build_ploc(n, left, right, box, cnt, stream, &root)); // overwrites the LBVH's internal nodes: the first wide tree is already emitted
-            HIPCHK(build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, &alt));
+            hipError_t pe = build_ploc(n, left, right, box, cnt, stream, &root); // overwrites the LBVH's internal nodes: the first wide tree is already emitted
+            if (pe == hipSuccess) pe = build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, &alt);
+            if (pe != hipSuccess) { // the alternative is optional: the LBVH tree stands
+                (void)hipGetLastError();
+                pt_bvh_free(&alt);
+                hipFree(cnt);
+                goto done;
+            }
             unsigned long long* counts = nullptr;
             unsigned long long hcnt[4] = {0, 0, 0, 0};
             HIPCHK(hipMalloc(&counts, sizeof(hcnt)));
@@ -927,24 +861,17 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
         }
         hipFree(cnt);
     }
-    hipFree(keys); hipFree(keys_sorted); hipFree(bounds); hipFree(tmp); hipFree(tmp2);
+done:
+    hipFree(keys); hipFree(keys_sorted); hipFree(bounds); hipFree(tmp);
     hipFree(left); hipFree(right); hipFree(parent); hipFree(rfirst); hipFree(rlast); hipFree(visits);
-    hipFree(box); hipFree(keep); hipFree(remap);
-    if (!want_bvh2) { // the sorted leaf triangles only fed the wide tree's leaf arrays
-        hipFree(tris);
-        out->tris = nullptr;
-        out->num_tris = 0;
-    }
+    hipFree(box);
+    hipFree(tris); // the Morton-ordered triangles only fed the wide tree's leaf arrays
     return hipSuccess;
 }
 
 void pt_bvh_free(PtBvh* b) {
-    if (b->nodes) hipFree((void*)b->nodes);
-    if (b->tris) hipFree((void*)b->tris);
     if (b->nodes8) hipFree((void*)b->nodes8);
     if (b->tris8) hipFree((void*)b->tris8);
     b->nodes8 = nullptr;
     b->tris8 = nullptr;
-    b->nodes = nullptr;
-    b->tris = nullptr;
 }

@@ -7,27 +7,20 @@
 
 #include "../../include/pt_amd.h"
 
-struct Node2;
 struct Node8;
 struct LeafTri;
 
+// the traversal structure on the device: the 8-wide compressed tree (pt_bvh8.h) and what the kernels need to know about it
 struct PtBvh {
-    const Node2* nodes = nullptr;
-    const LeafTri* tris = nullptr;
-    uint32_t num_nodes = 0, num_tris = 0;
-    int32_t root = 0;
     float bounds[6] = {0, 0, 0, 0, 0, 0};
-    float pad = 0.f;
-    // 8-wide compressed form of the same tree (pt_bvh8.h)
+    float pad = 0.f; // padding of every box: 2^-16 of the scene's largest |coordinate| (half of it confines hits: pt_bvh.h hit_in_box)
     const Node8* nodes8 = nullptr;
     const LeafTri* tris8 = nullptr;
     uint32_t num_nodes8 = 0, num_tris8 = 0;
     int levels8 = 0; // levels of the wide tree = upper bound of its traversal stack depth (one pushed group per level)
-    int depth2 = 0;  // depth of the binary tree (0: not built)
     int builder = 0; // hierarchy under the wide tree: 0 LBVH (Morton order, Karras 2012), 1 PLOC (Meister & Bittner 2018) — chosen by calibration rays unless PT_BVH_BUILDER=lbvh|ploc
 };
 
-// want_bvh2: also keep the binary form (A/B paths only; the default traversal uses the 8-wide tree alone)
 // d_tri_mesh: mesh (= material record) of every triangle, stored with the leaf triangles (may be null: 0)
-hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint32_t* d_tri_mesh, uint32_t ntri, int want_bvh2, hipStream_t stream, PtBvh* out);
+hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint32_t* d_tri_mesh, uint32_t ntri, hipStream_t stream, PtBvh* out);
 void pt_bvh_free(PtBvh* b);

@@ -3,9 +3,9 @@
 // deviceProgram.cu:206-594).  One path = one (pixel, sample) of the reference's raygen loops.
 //
 //   k_generate   raygen prologue per sample (deviceProgram.cu:357,370-410): seed, jitter, camera ray
-//   k_trace<0>   traceRadiance (:152-178, 416-422): closest hit for every queued path
+//   k_trace8<0>  (pt_bvh8.h) traceRadiance (:152-178, 416-422): closest hit for every queued path
 //   k_shade      __closesthit__radiance + __miss__radiance + the raygen loop body (:424-442)
-//   k_trace<1>   traceOcclusion + __anyhit__/__miss__occlusion (:181-204,237-250) and the deferred
+//   k_trace8<1>  traceOcclusion + __anyhit__/__miss__occlusion (:181-204,237-250) and the deferred
 //                "if (!occluded) sum += val" of SampleLights / "if (occluded)" of SampleShadow (:272-289,314-331)
 //   k_resolve    raygen epilogue (:445-474): per-pixel sample sums in sample order, backplate,
 //                progressive blend, make_color, the five buffer writes
@@ -156,47 +156,6 @@ __global__ void __launch_bounds__(256) k_generate(PathState st, FrameParams fp, 
             st.alb[i] = (bp.carry && sl > 0) ? bp.pixAlbedo[pix] : z;
             st.prdN[i] = z;
             st.prdA[i] = z;
-        }
-    }
-}
-
-// ------------------------------------------------------------------ trace
-#define PT_TRACE_BLOCK 128
-
-// ANY = 0: closest hit of (rayO,rayD) → hit[slot].  ANY = 1: occlusion of (rayO.xyz,.01,srayD,1e16)
-// then the deferred NEE accumulation.  queue == nullptr means identity.
-template <int ANY>
-__global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace(PathState st, BvhDev bvh, QView queue) {
-    __shared__ uint32_t s_stack[PT_STACK_DEPTH * PT_TRACE_BLOCK];
-    __shared__ uint32_t s_prefix[PT_NSUB + 1];
-    const uint32_t n = qreader_init(queue, s_prefix);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t p = qreader_get(queue, s_prefix, i);
-        const float4 o4 = st.rayO[p];
-        float t;
-        int32_t prim;
-        if (ANY) {
-            const float4 d4 = st.srayD[p];
-            bvh2_traverse<true>(bvh, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), 0.01f, 1e16f, &s_stack[threadIdx.x],
-                                PT_TRACE_BLOCK, t, prim);
-            const float4 pe = st.pend[p];
-            const int kind = __float_as_int(pe.w);
-            const bool occluded = prim != 0;
-            if (kind == PEND_ALPHA) {
-                if (occluded) {
-                    float4 a = st.alpha[p];
-                    st.alpha[p] = make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, 0.f);
-                }
-            } else if (!occluded) {
-                float4* acc = (kind == PEND_DIRECT) ? st.direct : st.indirect;
-                float4 a = acc[p];
-                acc[p] = make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, 0.f);
-            }
-        } else {
-            const float4 d4 = st.rayD[p];
-            bvh2_traverse<false>(bvh, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, d4.w, &s_stack[threadIdx.x],
-                                 PT_TRACE_BLOCK, t, prim);
-            st.hit[p] = make_float2(t, __int_as_float(prim)); // closest hit: bvh2_traverse returns the leaf triangle's index
         }
     }
 }
@@ -374,7 +333,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                 }
             } else if (!term) {
                 // radiance = T*lightSample (+ emission on primary hits) is added to direct/indirect (:432-437)
-                // only when the path goes on; the visibility-dependent part is deferred to k_trace<1>.
+                // only when the path goes on; the visibility-dependent part is deferred to the traversal kernel's write-back (k_trace8).
                 if (primary) {
                     const float4 dd = st.direct[p];
                     st.direct[p] = make_float4(dd.x + mat.emission[0], dd.y + mat.emission[1], dd.z + mat.emission[2], 0.f);

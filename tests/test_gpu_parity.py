@@ -292,7 +292,7 @@ def _soup_model(rng):
     return scenes.Model(meshes=[mesh]), tri
 
 
-def test_trace_triangle_soup_adversarial(ptlib, orc_det):
+def test_trace_triangle_soup_adversarial(ptlib, orc_det, monkeypatch):
     from optixpathtracer_amd.renderer import SampleRenderer
 
     rng = np.random.default_rng(77)
@@ -323,19 +323,19 @@ def test_trace_triangle_soup_adversarial(ptlib, orc_det):
     to, po = orc_det.trace_closest(sc, rays)
     occ_o = orc_det.trace_any(sc, rays)
     assert (po >= 0).mean() > 0.3
-    for kind in (0, 1):
+    for builder in ("lbvh", "ploc"):  # both hierarchies the builder can put under the 8-wide tree
+        monkeypatch.setenv("PT_BVH_BUILDER", builder)
         r = SampleRenderer(m)
-        r.setOptions(bvh_kind=kind)
         (t, prim), _ = r.trace(rays)
-        assert np.array_equal(prim, po), f"bvh_kind {kind}: {(prim != po).sum()} primitive ids differ"
-        assert_bits_equal(t, to, f"closest-hit t, bvh_kind {kind}")
+        assert np.array_equal(prim, po), f"{builder}: {(prim != po).sum()} primitive ids differ"
+        assert_bits_equal(t, to, f"closest-hit t, {builder}")
         occ, _ = r.trace(rays, any_hit=True)
         assert np.array_equal(occ, occ_o)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["one_triangle", "thousands_of_copies", "collinear_centroids", "flat_scene", "tiny_in_huge", "many_meshes"])
-def test_builder_degenerate_scenes(ptlib, orc_det, case):
+@pytest.mark.parametrize("case", ["one_triangle", "three_triangles", "four_triangles", "five_triangles", "thousands_of_copies", "collinear_centroids", "flat_scene", "tiny_in_huge", "many_meshes"])
+def test_builder_degenerate_scenes(ptlib, orc_det, case, monkeypatch):
     """Scenes that stress the on-GPU builder rather than the traversal: Morton codes that all tie, root boxes with zero extent
     on one or two axes (quantisation exponents), a single primitive, triangles far smaller than one 8-bit grid cell of the
     root box, and hundreds of one-triangle meshes (primitive ids across mesh boundaries)."""
@@ -345,8 +345,11 @@ def test_builder_degenerate_scenes(ptlib, orc_det, case):
     base = np.array([[0, 0, 0], [4, 0, 0], [0, 3, 0]], np.float32)
     if case == "one_triangle":
         tri = base[None]
+    elif case in ("three_triangles", "four_triangles", "five_triangles"):  # around the single-node limit (3 triangles in one leaf child)
+        k = {"three_triangles": 3, "four_triangles": 4, "five_triangles": 5}[case]
+        tri = (rng.uniform(-3, 3, (k, 1, 3)) + rng.standard_normal((k, 3, 3)) * 2).astype(np.float32)
     elif case == "thousands_of_copies":
-        tri = np.repeat(base[None], 3000, 0)
+        tri = np.repeat(base[None], 5000, 0)  # above the 4096 triangles from which the builder also tries a PLOC hierarchy
     elif case == "collinear_centroids":
         tri = base[None] * 0.2 + np.linspace(-50, 50, 4000, dtype=np.float32)[:, None, None] * np.array([1, 0, 0], np.float32)
     elif case == "flat_scene":  # every vertex in the plane z = 2: the root box has zero extent in z
@@ -378,12 +381,12 @@ def test_builder_degenerate_scenes(ptlib, orc_det, case):
     to, po = orc_det.trace_closest(sc, rays)
     occ_o = orc_det.trace_any(sc, rays)
     assert (po >= 0).mean() > 0.2
-    for kind in (0, 1):
+    for builder in ("lbvh", "ploc"):
+        monkeypatch.setenv("PT_BVH_BUILDER", builder)
         r = SampleRenderer(m)
-        r.setOptions(bvh_kind=kind)
         (t, prim), _ = r.trace(rays)
-        assert np.array_equal(prim, po), f"{case}, bvh_kind {kind}: {(prim != po).sum()} primitive ids differ"
-        assert_bits_equal(t, to, f"{case}: closest-hit t, bvh_kind {kind}")
+        assert np.array_equal(prim, po), f"{case}, {builder}: {(prim != po).sum()} primitive ids differ"
+        assert_bits_equal(t, to, f"{case}: closest-hit t, {builder}")
         occ, _ = r.trace(rays, any_hit=True)
         assert np.array_equal(occ, occ_o)
 
@@ -442,15 +445,21 @@ def test_c2_cornell_1080p_4spp_depth8_rows(ptlib, orc_det):
         assert_bits_equal(g["accum"][y], accum[y], f"row {y} of the C2 frame")
 
 
-def test_both_traversal_kernels_agree(ptlib, orc_det, small_probe):
-    """The persistent-wave kernel (default) and the first grid-stride kernel give the same bits."""
+def test_both_traversal_kernels_agree(ptlib, orc_det, small_probe, monkeypatch):
+    """Every traversal schedule over either hierarchy gives the checker's bits; the removed A/B options are refused."""
     m = scenes.voxel_terrain(n=96, target_tris=70000)
     w, h = 128, 72
     o = _oracle_render(orc_det, m, small_probe, scenes.TERRAIN_CAMERA, w, h, 2)
-    # k_trace8 unified launches (default), k_trace8 split + 2 streams, 3 concurrent pixel chunks, k_trace2, k_trace
-    for opt in (dict(), dict(split_shadow=1), dict(streams=3), dict(bvh_kind=1), dict(bvh_kind=1, trace_kernel=1)):
-        r = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h, **opt)
-        _compare(_gpu_render(r, 2), o)
+    # unified launches (default), closest-hit and shadow launches apart on 2 streams, 3 concurrent pixel chunks, asynchronous shadow records
+    for builder in ("lbvh", "ploc"):
+        monkeypatch.setenv("PT_BVH_BUILDER", builder)
+        for opt in (dict(), dict(split_shadow=1), dict(streams=3), dict(split_shadow=2)):
+            r = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h, **opt)
+            _compare(_gpu_render(r, 2), o)
+    with pytest.raises(RuntimeError, match="reserved"):
+        r.setOptions(bvh_kind=1)
+    with pytest.raises(RuntimeError, match="reserved"):
+        r.setOptions(trace_kernel=1)
 
 
 def test_render_progressive_subframes(ptlib, orc_det, small_probe):

@@ -17,10 +17,11 @@ d = dx[..., None] * U + dy[..., None] * V + W
 d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).reshape(-1, 3).astype(np.float32)
 n = len(d)
 prim = np.concatenate([np.tile(np.array(scenes.TERRAIN_CAMERA["eye"], np.float32), (n, 1)), np.full((n, 1), 1e-3, np.float32), d, np.full((n, 1), 1e16, np.float32)], 1).astype(np.float32)
-for bk in (0, 1):
+import os
+for bk in ("lbvh", "ploc"):
+    os.environ["PT_BVH_BUILDER"] = bk
     r = R.SampleRenderer(m)
-    r.setOptions(bvh_kind=bk)
-    print("bvh_kind", bk, flush=True)
+    print("hierarchy", bk, flush=True)
     (t, p), ms = r.trace(prim, iters=3); print("  primary   ", n, "rays", round(ms, 3), "ms", round(n / ms / 1e3, 1), "Mrays/s  hit", round(float((p >= 0).mean()), 3), flush=True)
     hit = p >= 0
     P = prim[hit, :3] + t[hit, None] * prim[hit, 4:7]

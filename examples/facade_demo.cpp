@@ -64,10 +64,13 @@ int main(int argc, char** argv) {
             multi.setCamera(cam);
             multi.launchParams.samples_per_launch = spp;
             std::vector<uint32_t> pixels((size_t)w * h);
+            const int mfif = argc > 4 ? atoi(argv[4]) : 0;  // 2 or 3: render(pixels) shows frame k-1 while frame k renders (overlapped hand-over)
+            if (mfif >= 2) multi.setFramesInFlight(mfif);
             for (uint32_t s = 0; s < subframes; ++s) {
                 multi.launchParams.frame.subframe_index = s;
                 multi.render(pixels.data());
             }
+            if (mfif >= 2) multi.flush(pixels.data());      // the last frame goes on display
             multi.gather(PT_BUF_ACCUM);
             std::vector<float> accum((size_t)w * h * 4);
             if (pt_download(pt_multi_ctx(multi.multi, ncontexts - 1), PT_BUF_ACCUM, accum.data(), accum.size() * sizeof(float)) != PT_OK) throw std::runtime_error("download");

@@ -212,9 +212,19 @@ class MultiSampleRenderer {
         ck(pt_multi_set_probe(multi, &probe.data[0].x, probe.pdfValuesX.data(), probe.cdfValuesX.data(), probe.pdfValuesY.data(), probe.cdfValuesY.data(), probe.width, probe.height));
     }
     void gather(int which) { ck(pt_multi_gather(multi, which)); } // assemble another buffer (e.g. PT_BUF_ACCUM) on every rank
-    // Frames in flight (pt_options.frames_in_flight 2 or 3 through setOptions): render(h_pixels) then shows frame k-1 while frame k renders —
-    // the exchange of the strips overlaps the rendering — and flush(h_pixels) hands over the last frame.
+    // Frames in flight (2 or 3): render(h_pixels) then shows frame k-1 while frame k renders — the exchange of the strips overlaps the
+    // rendering and lands in the ranks' display buffers — and flush(h_pixels) hands over the last frame.
+    void setFramesInFlight(int n) {
+        pt_options o;
+        if (pt_get_options(pt_multi_ctx(multi, 0), &o) != PT_OK) throw std::runtime_error("MultiSampleRenderer: pt_get_options failed");
+        o.frames_in_flight = n;
+        ck(pt_multi_set_options(multi, &o));
+    }
     void flush(uint32_t* h_pixels = nullptr) { ck(pt_multi_flush(multi, h_pixels)); }
+    void downloadDisplayedPixels(uint32_t h_pixels[]) { // the frame on display (rank 0's display buffer) in the frames-in-flight mode
+        if (pt_download_display(pt_multi_ctx(multi, 0), PT_BUF_FRAME, h_pixels, sizeof(uint32_t) * (size_t)launchParams.frame.size.x * launchParams.frame.size.y) != PT_OK)
+            throw std::runtime_error(pt_last_error(pt_multi_ctx(multi, 0)));
+    }
     LaunchParams launchParams;
     pt_multi* multi = nullptr;
 

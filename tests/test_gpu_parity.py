@@ -1301,6 +1301,13 @@ def test_cxx_facade_demo_matches_python(ptlib, small_probe, tmp_path):
     raw = np.fromfile(out3, np.uint8)
     assert np.array_equal(raw[: w * h * 4].view(np.uint32).reshape(h, w), g["frame"])
     assert_bits_equal(raw[w * h * 4 :].view(np.float32).reshape(h, w, 4), g["accum"], "accum_buffer from the 3-context C++ process")
+    # ... and with three frames in flight: every render(pixels) hands over the previous frame while the next one renders, flush() the last
+    out3p = tmp_path / "out3p.bin"
+    res = subprocess.run([str(exe), str(scene), str(out3p), "3", "3"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    raw = np.fromfile(out3p, np.uint8)
+    assert np.array_equal(raw[: w * h * 4].view(np.uint32).reshape(h, w), g["frame"])
+    assert_bits_equal(raw[w * h * 4 :].view(np.float32).reshape(h, w, 4), g["accum"], "accum_buffer from the 3-context C++ process, frames in flight")
 
 
 def test_multi_context_one_process(ptlib, small_probe, monkeypatch):

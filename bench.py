@@ -60,7 +60,10 @@ def source_hash():
     """Hash of the kernel sources: PMC-derived numbers under profiles/ carry it and are only quoted for the code they were
     measured on (a hash of the .so would change with every rebuild)."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "optixpathtracer_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+    src = os.path.join(ROOT, "optixpathtracer_amd", "csrc")
+    files = [os.path.join(src, f) for f in ("pt_device.h", "pt_bvh.h", "pt_bvh8.h", "pt_kernels.h", "pt_host.h", "pt_api.hip", "pt_bvh_build.hip", "Makefile")]
+    files.append(os.path.join(ROOT, "include", "pt_detmath.h"))  # (the facade header and the C ABI's comments are not kernel sources)
+    for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

@@ -25,6 +25,7 @@ struct pt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    std::string launch_err; // first failed kernel launch of the frame being enqueued (SpanGuard), reported when the frame is waited for
     pt_options opt{};
     // scene
     uint32_t ntri = 0, nmesh = 0;
@@ -848,6 +849,13 @@ struct SpanGuard {
         hipEventRecord(next_event(ctx), s);
     }
     ~SpanGuard() {
+        // every launch group is checked where it is enqueued, so that a failed launch is reported by name (the frame's final
+        // hipGetLastError would only say that something failed); costs a thread-local read per group
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess && ctx->launch_err.empty()) {
+            static const char* const names[4] = {"closest-hit traversal (k_trace8)", "shadow traversal (k_trace8)", "k_shade", "generate / resolve"};
+            ctx->launch_err = std::string("launch of ") + names[cls & 3] + " failed: " + hipGetErrorString(le);
+        }
         if (!ctx->span_timing()) return;
         size_t b = ctx->ev_used;
         hipEventRecord(next_event(ctx), s);
@@ -1223,6 +1231,11 @@ static int render_finish(pt_ctx* ctx, int slot = 0) {
     const LaunchCounts lc = fr.lc;
     hipEvent_t ev_begin = fr.ev_begin, ev_end = fr.ev_end;
     CK(hipEventSynchronize(ev_end)); // SimplePathtracer.cpp:96 CUDA_SYNC_CHECK (the frame's last event on the context's stream)
+    if (!ctx->launch_err.empty()) {
+        ctx->err = ctx->launch_err;
+        ctx->launch_err.clear();
+        return PT_ERR_HIP;
+    }
     CK(hipGetLastError());
     const unsigned long long* per_set = ctx->h_totals + (size_t)slot * PT_MAX_SETS * 4; // copied behind the frame's last kernel, before ev_end
     unsigned long long totals[4] = {0, 0, 0, 0};

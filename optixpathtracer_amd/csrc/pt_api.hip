@@ -45,9 +45,9 @@ struct pt_ctx {
     // probe
     DevProbe probe{};
     float4* d_probe_data = nullptr;
-    float *d_pdfX = nullptr, *d_cdfX = nullptr, *d_pdfY = nullptr, *d_cdfY = nullptr, *d_c64X = nullptr, *d_c8X = nullptr, *d_c64Y = nullptr, *d_c8Y = nullptr;
-    uint32_t* d_guideX = nullptr;
-    float4* d_data_pdf = nullptr; // (rgb, pdfX) per texel
+    float *d_pdfX = nullptr, *d_cdfX = nullptr, *d_pdfY = nullptr, *d_cdfY = nullptr, *d_c64Y = nullptr, *d_c8Y = nullptr;
+    ProbeLine* d_lines = nullptr; // ProbeSample's column tables: six columns' cdf + (rgb, pdfX) per 128-byte line
+    uint16_t* d_guide = nullptr;
     // frame
     int width = 0, height = 0;
     float4 *accum = nullptr, *color = nullptr, *normal = nullptr, *albedo = nullptr;
@@ -430,7 +430,7 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     for (uint32_t*& px : ctx->d_tex_pixels) dfree(px);
     pt_bvh_free(&ctx->bvh);
     dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
-    dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y); dfree(ctx->d_data_pdf); dfree(ctx->d_guideX);
+    dfree(ctx->d_c64Y); dfree(ctx->d_c8Y); dfree(ctx->d_lines); dfree(ctx->d_guide);
     dfree(ctx->d_totals);
     if (ctx->h_totals) hipHostFree(ctx->h_totals);
     dfree(ctx->ovf);
@@ -524,26 +524,27 @@ extern "C" int pt_uvw_frame(const float eye[3], const float lookat[3], const flo
 
 // finish a probe upload: build the block-search accelerators and publish the device view
 static int finish_probe(pt_ctx* ctx, int w, int h) {
-    dfree(ctx->d_c64X); dfree(ctx->d_c8X); dfree(ctx->d_c64Y); dfree(ctx->d_c8Y); dfree(ctx->d_data_pdf); dfree(ctx->d_guideX);
-    {
-        const size_t n = (size_t)w * h;
-        CK(dalloc(&ctx->d_data_pdf, n));
-        hipLaunchKernelGGL(k_probe_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_probe_data, ctx->d_pdfX, n, ctx->d_data_pdf);
-    }
-    const int ncx = w / PT_CDF_BLOCK, ncy = h / PT_CDF_BLOCK;
-    const int ncx_pad = (ncx + 7) & ~7, ncy_pad = (ncy + 7) & ~7;
-    const int c8_pitch = w / 8 + 8;
-    const bool okx = (w % PT_CDF_BLOCK) == 0 && w >= PT_CDF_BLOCK, oky = (h % PT_CDF_BLOCK) == 0 && h >= PT_CDF_BLOCK;
+    dfree(ctx->d_c64Y); dfree(ctx->d_c8Y); dfree(ctx->d_lines); dfree(ctx->d_guide);
+    const int ncy = h / PT_CDF_BLOCK, ncy_pad = (ncy + 7) & ~7;
+    const bool oky = (h % PT_CDF_BLOCK) == 0 && h >= PT_CDF_BLOCK;
     const bool enabled = getenv("PT_NO_BLOCKED_SEARCH") == nullptr;
-    if (okx && enabled) {
-        CK(dalloc(&ctx->d_c64X, (size_t)h * ncx_pad));
-        CK(dalloc(&ctx->d_c8X, (size_t)h * c8_pitch));
-        hipLaunchKernelGGL(k_probe_coarse, dim3((h * ncx_pad + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_cdfX, h, w, PT_CDF_BLOCK, ncx_pad, ctx->d_c64X);
-        hipLaunchKernelGGL(k_probe_coarse, dim3((h * c8_pitch + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_cdfX, h, w, 8, c8_pitch, ctx->d_c8X); // entries past w/8: +inf
-        if (w / 8 < 65536 && getenv("PT_NO_GUIDE") == nullptr) {
-            CK(dalloc(&ctx->d_guideX, (size_t)h * PT_GUIDE_K));
-            hipLaunchKernelGGL(k_probe_guide, dim3((h * PT_GUIDE_K + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_c8X, h, w / 8, c8_pitch, ctx->d_guideX);
-        }
+    // column tables: any width; the guide has one cell per ~2 columns (a power of two, so that r2 * gk is exact), PT_GUIDE_K overrides (A/B)
+    const int lpr = (w + PT_LINE_COLS - 1) / PT_LINE_COLS;
+    int gk = 64;
+    while (gk < 4096 && gk * 2 < w) gk *= 2;
+    if (const char* e = getenv("PT_GUIDE_K")) {
+        const int v = atoi(e);
+        if (v >= 2 && v <= 65536 && (v & (v - 1)) == 0) gk = v;
+    }
+    const int gpitch = gk + 2; // k = 0..gk, padded to an even count
+    if (lpr <= 65535 && enabled) {
+        CK(dalloc(&ctx->d_lines, (size_t)h * lpr + 1)); // + 1: a non-monotone row handed to pt_set_probe can index one texel past its line
+        CK(dalloc(&ctx->d_guide, (size_t)h * gpitch));
+        CK(hipMemsetAsync(ctx->d_lines + (size_t)h * lpr, 0, sizeof(ProbeLine), ctx->stream));
+        hipLaunchKernelGGL(k_probe_lines, dim3((unsigned)(((size_t)h * lpr + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_probe_data, ctx->d_pdfX,
+                           ctx->d_cdfX, h, w, lpr, ctx->d_lines);
+        hipLaunchKernelGGL(k_probe_guide, dim3((unsigned)(((size_t)h * gpitch + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_lines, h, lpr, gk,
+                           gpitch, ctx->d_guide);
     }
     if (oky && enabled) {
         CK(dalloc(&ctx->d_c64Y, (size_t)ncy_pad));
@@ -553,8 +554,8 @@ static int finish_probe(pt_ctx* ctx, int w, int h) {
     }
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipGetLastError());
-    ctx->probe = DevProbe{w, h, ctx->d_probe_data, ctx->d_pdfX, ctx->d_cdfX, ctx->d_pdfY, ctx->d_cdfY,
-                          ctx->d_c64X, ctx->d_c8X, ctx->d_c64Y, ctx->d_c8Y, ncx, ncx_pad, ncy, ctx->d_data_pdf, ctx->d_guideX, c8_pitch};
+    ctx->probe = DevProbe{w, h, ctx->d_probe_data, ctx->d_pdfX, ctx->d_cdfX, ctx->d_pdfY, ctx->d_cdfY, ctx->d_c64Y, ctx->d_c8Y, ncy,
+                          ctx->d_lines, ctx->d_guide, lpr, gk, gpitch};
     return PT_OK;
 }
 

@@ -328,21 +328,30 @@ PT_DEV v3 bsdf_eval(const pt_material& mat, v3 albedo, float etaI, float etaO, v
 
 // ------------------------------------------------------------------ probe (Probe.cuh)
 #define PT_CDF_BLOCK 64
+// ProbeSample's per-column data, co-located: one 128-byte line (= one L2 line) holds six consecutive columns of a row — their conditional-CDF
+// values and their texels (rgb, pdfX) — so that the end of the column search and the texel fetch touch ONE line instead of three
+// (c8 window, CDF group, texel: the round 2/3 layout, profiles/r2_design_history.md).  Columns past the width: cdf = +inf, texel = 0.
+#define PT_LINE_COLS 6
+struct __attribute__((aligned(128))) ProbeLine {
+    float cdf[PT_LINE_COLS];
+    uint32_t pad_[2];
+    float4 px[PT_LINE_COLS];
+};
+static_assert(sizeof(ProbeLine) == 128, "one probe line per 128-byte cache line");
 struct DevProbe {
     int width, height;
     const float4* data;
     const float *pdfX, *cdfX, *pdfY, *cdfY;
-    // search accelerators built at setProbe: the last CDF value of every PT_CDF_BLOCK-entry block, per row / of cdfY
-    const float *c64X, *c8X, *c64Y, *c8Y; // [height][ncx_pad], [height][c8_pitch], [ncy_pad], [height/8]; null = binary search
-    int ncx, ncx_pad, ncy;
-    const float4* data_pdf; // (data.rgb, pdfX) per texel: ProbeSample's colour and conditional pdf in one 16-byte load
-    // Guide table of the column search (null: not built): for row j and k = floor(r2 * PT_GUIDE_K), guideX[j * PT_GUIDE_K + k] holds the number of
-    // 8-entry groups of the row's CDF whose last entry is < k / K (low half) and < (k + 1) / K (high half).  The lower bound's group lies
-    // between the two, so one 4-byte load replaces the eight 16-byte loads of the 64-entry stage (lower_bound_guided).
-    const uint32_t* guideX;
-    int c8_pitch; // floats per row of c8X: width / 8 entries + 8 of +inf, so that an 8-entry window may start at any group
+    // row search accelerators built at setProbe: the last CDF value of every PT_CDF_BLOCK-entry block / 8-entry group of cdfY
+    const float *c64Y, *c8Y; // [ncy_pad], [height/8]; null = binary search
+    int ncy;
+    // Column search (null: not built, plain binary search): lines[row * lpr + l] holds columns 6l .. 6l+5.  guide[row * gpitch + k], k = 0..gk,
+    // = the number of the row's lines whose LAST cdf entry is < k / gk.  For r2 in [k/gk, (k+1)/gk) the line of the lower bound lies between
+    // guide[k] and guide[k+1] (probe_lower_bound_lines): with gk ≈ width/2 that is one line for 2/3 of the lookups and two for the rest.
+    const ProbeLine* lines;
+    const uint16_t* guide;
+    int lpr, gk, gpitch;
 };
-#define PT_GUIDE_K 256
 // The marginal (row) arrays ProbeSample reads: the global ones, or k_shade's per-workgroup LDS copy (≈4.6 KB for a 1024-row
 // probe) so that the row search and pdfY never leave the CU
 struct ProbeMarg {
@@ -411,46 +420,63 @@ PT_DEV int lower_bound_blocked(const float* __restrict__ row, int n, const float
     return base + count_lt8(row + base, value);
 }
 
-// LowerBound over one row of cdfX with the guide table: the same index as lower_bound / lower_bound_blocked, by construction — the
-// index is 8 g + (entries < value in group g) with g = the number of groups whose LAST entry is < value (c8 holds those last entries,
-// non-decreasing), and r2 in [k/K, (k+1)/K) pins g between the two counts the guide stores for the interval's ends.  Typically the two
-// differ by 0..2: the window of 8 c8 entries from the lower count settles g (entries past the upper count are >= (k+1)/K > value and
-// count for nothing; rows are padded with +inf); wider gaps — flat stretches of a CDF, reached with probability 1/K each — fall back to
-// the blocked search.  Loads: 4 B + 2 x 16 B + 2 x 16 B in three dependent steps, against 8 + 2 + 2 loads of 16 B.
-PT_DEV int lower_bound_guided(const DevProbe& p, int row, float value) {
-    const float* __restrict__ cdf = p.cdfX + (size_t)row * p.width;
-    const float* __restrict__ c8 = p.c8X + (size_t)row * p.c8_pitch;
-    const int k = (int)(value * (float)PT_GUIDE_K); // value in [0, 1): exact product, k <= K - 1
-    const uint32_t gg = p.guideX[(size_t)row * PT_GUIDE_K + (k < PT_GUIDE_K ? k : PT_GUIDE_K - 1)];
-    const int g0 = (int)(gg & 0xffffu), g1 = (int)(gg >> 16);
-    int g = g0;
-    if (g1 - g0 > 8) return lower_bound_blocked(cdf, p.width, p.c64X + (size_t)row * p.ncx_pad, p.ncx, c8, value);
-    if (g1 > g0) {
-        const float* w = c8 + g0; // 4-byte aligned: two unaligned 16-byte loads
-        g += (w[0] < value ? 1 : 0) + (w[1] < value ? 1 : 0) + (w[2] < value ? 1 : 0) + (w[3] < value ? 1 : 0) + (w[4] < value ? 1 : 0) +
-             (w[5] < value ? 1 : 0) + (w[6] < value ? 1 : 0) + (w[7] < value ? 1 : 0);
+// Column lower bound of `value` in row `row` through the line layout: returns the column (possibly == width, like LowerBound :119-136 when every
+// entry is < value) and the line that holds min(column, width - 1).  Same index as the reference's binary search for every non-decreasing row
+// (and for an all-NaN row: every `<` is false → 0): the index is 6 l + (entries < value in line l) with l = the number of lines whose LAST
+// entry is < value, and r2 in [k/gk, (k+1)/gk) pins l between the two counts the guide stores for the cell's ends.  Dependent memory steps:
+// guide (2 x u16, adjacent) → up to three candidate lines loaded together (24 bytes each) → the texel, read from the line just loaded.
+PT_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+PT_DEV float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+PT_DEV int probe_lower_bound_lines(const DevProbe& p, int row, float value, int& line) {
+    const ProbeLine* __restrict__ rl = p.lines + (size_t)row * p.lpr;
+    int k = (int)(value * (float)p.gk); // gk is a power of two and value in [0, 1): exact product, k / gk <= value < (k + 1) / gk
+    k = k < p.gk ? k : p.gk - 1;
+    const uint16_t* __restrict__ g = p.guide + (size_t)row * p.gpitch + k;
+    const int last = p.lpr - 1;
+    int lo = g[0], hi = g[1];
+    lo = lo < last ? lo : last; // count == lpr: every line ends below the cell; the last line then yields column >= width
+    hi = hi < last ? hi : last;
+    while (hi - lo > 2) { // a guide cell that spans more than three lines (flat stretch of the CDF): halve on the lines' last entries
+        const int mid = lo + (hi - lo) / 2;
+        if (rl[mid].cdf[PT_LINE_COLS - 1] < value) lo = mid + 1; else hi = mid;
     }
-    if (g >= p.width / 8) return p.width;
-    return g * 8 + count_lt8(cdf + g * 8, value);
+    const int i1 = lo + 1 < hi ? lo + 1 : hi, i2 = hi; // candidates lo <= i1 <= i2 (equal indices re-read the same line)
+    const float4 a0 = ld4(rl[lo].cdf), b0 = ld4(rl[i1].cdf), c0 = ld4(rl[i2].cdf);
+    const float2 a1 = ld2(rl[lo].cdf + 4), b1 = ld2(rl[i1].cdf + 4), c1 = ld2(rl[i2].cdf + 4);
+    float4 s0 = a0;
+    float2 s1 = a1;
+    int l = lo;
+    if (i1 > lo && a1.y < value) {
+        l = i1; s0 = b0; s1 = b1;
+        if (i2 > i1 && b1.y < value) { l = i2; s0 = c0; s1 = c1; }
+    }
+    line = l;
+    return l * PT_LINE_COLS + (s0.x < value ? 1 : 0) + (s0.y < value ? 1 : 0) + (s0.z < value ? 1 : 0) + (s0.w < value ? 1 : 0) +
+           (s1.x < value ? 1 : 0) + (s1.y < value ? 1 : 0);
 }
 
 // :138-169 (row/col clamped: unreachable for a valid CDF, guards a degenerate probe)
 PT_DEV void probe_sample(const DevProbe& p, const ProbeMarg& pm, v3& dir, v3& color, float& pdf, Rng& rand) {
     float r1, r2;
     sample2d(rand, r1, r2);
+    int line = 0;
 #ifdef PT_EXP_NO_SEARCH
     int row = (int)(r1 * p.height);
     int col = (int)(r2 * p.width);
+    line = col / PT_LINE_COLS;
 #else
     int row = pm.c64Y ? lower_bound_blocked(pm.cdfY, p.height, pm.c64Y, p.ncy, pm.c8Y, r1) : lower_bound(pm.cdfY, 0, p.height, r1);
     if (row > p.height - 1) row = p.height - 1;
-    int col = p.guideX ? lower_bound_guided(p, row, r2)
-              : p.c64X ? lower_bound_blocked(p.cdfX + (size_t)row * p.width, p.width, p.c64X + (size_t)row * p.ncx_pad, p.ncx,
-                                             p.c8X + (size_t)row * p.c8_pitch, r2)
-                       : lower_bound(p.cdfX, row * p.width, (row + 1) * p.width, r2) - row * p.width;
+    int col = p.lines ? probe_lower_bound_lines(p, row, r2, line) : lower_bound(p.cdfX, row * p.width, (row + 1) * p.width, r2) - row * p.width;
 #endif
     if (col > p.width - 1) col = p.width - 1;
-    float4 px = p.data_pdf[(size_t)row * p.width + col];
+    float4 px;
+    if (p.lines) {
+        px = p.lines[(size_t)row * p.lpr + line].px[col - line * PT_LINE_COLS];
+    } else {
+        px = p.data[(size_t)row * p.width + col];
+        px.w = p.pdfX[(size_t)row * p.width + col];
+    }
     color = mk3(px.x, px.y, px.z);
     pdf = px.w * pm.pdfY[row];
     float u = col / (float)p.width;

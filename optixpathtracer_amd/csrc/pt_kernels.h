@@ -848,29 +848,37 @@ __global__ void __launch_bounds__(64) k_cdf_marginal(const float* __restrict__ r
     }
 }
 
-__global__ void k_probe_pack(const float4* __restrict__ data, const float* __restrict__ pdfX, size_t n, float4* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 c = data[i];
-    out[i] = make_float4(c.x, c.y, c.z, pdfX[i]);
-}
-// guide table of the column search (pt_device.h lower_bound_guided): entry (row, k) = count of c8 entries < k/K | count < (k+1)/K << 16
-__global__ void k_probe_guide(const float* __restrict__ c8, int rows, int ngroups, int c8_pitch, uint32_t* __restrict__ guide) {
+// ProbeSample's column tables (pt_device.h ProbeLine): one thread per line gathers six columns' cdf values and (rgb, pdfX) texels
+__global__ void k_probe_lines(const float4* __restrict__ data, const float* __restrict__ pdfX, const float* __restrict__ cdfX, int rows, int width,
+                              int lpr, ProbeLine* __restrict__ lines) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * PT_GUIDE_K) return;
-    const int r = i / PT_GUIDE_K, k = i - r * PT_GUIDE_K;
-    const float* row = c8 + (size_t)r * c8_pitch;
-    uint32_t out = 0;
-    for (int e = 0; e < 2; ++e) {
-        const float v = (float)(k + e) * (1.0f / (float)PT_GUIDE_K);
-        int lo = 0, hi = ngroups; // number of entries < v (NaN rows: every comparison is false -> 0, like the searches)
-        while (lo < hi) {
-            const int mid = lo + (hi - lo) / 2;
-            if (row[mid] < v) lo = mid + 1; else hi = mid;
-        }
-        out |= (uint32_t)lo << (16 * e);
+    if (i >= rows * lpr) return;
+    const int r = i / lpr, l = i - r * lpr;
+    ProbeLine out;
+    for (int c = 0; c < PT_LINE_COLS; ++c) {
+        const int col = l * PT_LINE_COLS + c;
+        const size_t at = (size_t)r * width + col;
+        const bool in = col < width;
+        const float4 d = in ? data[at] : make_float4(0.f, 0.f, 0.f, 0.f);
+        out.cdf[c] = in ? cdfX[at] : INFINITY;
+        out.px[c] = make_float4(d.x, d.y, d.z, in ? pdfX[at] : 0.0f);
     }
-    guide[i] = out;
+    out.pad_[0] = out.pad_[1] = 0u;
+    lines[i] = out;
+}
+// guide of the column search (pt_device.h probe_lower_bound_lines): entry (row, k), k = 0..gk, = the number of lines whose last cdf entry is < k/gk
+__global__ void k_probe_guide(const ProbeLine* __restrict__ lines, int rows, int lpr, int gk, int gpitch, uint16_t* __restrict__ guide) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * gpitch) return;
+    const int r = i / gpitch, k = i - r * gpitch;
+    const ProbeLine* row = lines + (size_t)r * lpr;
+    const float v = (float)(k < gk ? k : gk) / (float)gk; // exact: gk is a power of two
+    int lo = 0, hi = lpr; // number of entries < v (NaN rows: every comparison is false -> 0, like the searches)
+    while (lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        if (row[mid].cdf[PT_LINE_COLS - 1] < v) lo = mid + 1; else hi = mid;
+    }
+    guide[i] = (uint16_t)lo;
 }
 __global__ void k_probe_coarse(const float* __restrict__ cdf, int rows, int n, int stride, int row_pitch, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -628,6 +628,17 @@ def disc_probe(width: int = 100, height: int = 50) -> ProbeData:
     return ProbeData(width, height, np.ascontiguousarray(data))
 
 
+def spots_probe(width: int = 1000, height: int = 64, seed: int = 3, fill: float = 0.01) -> ProbeData:
+    """A search-hostile probe: black except for a few texels whose radiance spans six decades, with some rows entirely black (their
+    conditional CDF is 0/0 = NaN like the reference's BuildCDF, Probe.h:29-77) and long flat stretches in every other row's CDF."""
+    rng = np.random.default_rng(seed)
+    val = np.where(rng.random((height, width)) < fill, 10.0 ** rng.uniform(-3, 3, (height, width)), 0.0)
+    val[rng.integers(0, height, max(1, height // 8))] = 0.0
+    val[height // 2, : width // 3] = 1.0  # one row with a long linear ramp in its CDF
+    data = np.stack([val, val * 0.5, val * 0.25, np.ones_like(val)], -1).astype(np.float32)
+    return ProbeData(width, height, np.ascontiguousarray(data))
+
+
 def uvw_frame(eye, lookat, up, fovY, aspect):
     """sutil::Camera::UVWFrame (sutil/Camera.cpp:34-45) in float32; tanf via the host libm."""
     f = np.float32

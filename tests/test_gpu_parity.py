@@ -169,7 +169,10 @@ def test_probe_tables(ptlib, orc_det):
 
     from optixpathtracer_amd.renderer import SampleRenderer
 
-    for probe in (scenes.disc_probe().BuildCDF(), scenes.sky_probe(512, 256).BuildCDF(), scenes.constant_probe().BuildCDF()):
+    # widths around the 6-column line of the device layout (5, 6, 7, 13), flat stretches and NaN rows (spots), the reference's test probes
+    probes = [scenes.disc_probe(), scenes.sky_probe(512, 256), scenes.constant_probe(), scenes.spots_probe(1000, 64), scenes.spots_probe(4099, 8, fill=0.002),
+              scenes.spots_probe(7, 5, fill=0.5), scenes.spots_probe(13, 3, fill=0.3), scenes.constant_probe(5, 4), scenes.constant_probe(6, 64)]
+    for probe in (p.BuildCDF() for p in probes):
         r = SampleRenderer(scenes.cornell_box())
         r.setProbe(probe)
         pr = orc_det.make_probe(probe)

@@ -537,7 +537,7 @@ static int finish_probe(pt_ctx* ctx, int w, int h) {
         if (v >= 2 && v <= 65536 && (v & (v - 1)) == 0) gk = v;
     }
     const int gpitch = gk + 2; // k = 0..gk, padded to an even count
-    if (lpr <= 65535 && enabled) {
+    {
         CK(dalloc(&ctx->d_lines, (size_t)h * lpr + 1)); // + 1: a non-monotone row handed to pt_set_probe can index one texel past its line
         CK(dalloc(&ctx->d_guide, (size_t)h * gpitch));
         CK(hipMemsetAsync(ctx->d_lines + (size_t)h * lpr, 0, sizeof(ProbeLine), ctx->stream));
@@ -565,6 +565,7 @@ extern "C" int pt_set_probe(pt_ctx* ctx, const float* data, const float* pdfX, c
     { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     if (!data || !pdfX || !cdfX || !pdfY || !cdfY || w <= 0 || h <= 0) return fail(ctx, PT_ERR_INVALID, "pt_set_probe: Probe Data is not valid");
     if ((long long)w * h >= (1ll << 31)) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_set_probe: probe too large");
+    if (w > 65535 * PT_LINE_COLS) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_set_probe: probe wider than 393210 columns"); // u16 line counts in the guide
     CK(hipSetDevice(ctx->device));
     dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
     const size_t n = (size_t)w * h;
@@ -586,6 +587,7 @@ extern "C" int pt_set_probe_image(pt_ctx* ctx, const float* data, int w, int h) 
     { int rc_ = drain(ctx); if (rc_ != PT_OK) return rc_; } // frames in flight (pt_options.frames_in_flight) finish first
     if (!data || w <= 0 || h <= 0) return fail(ctx, PT_ERR_INVALID, "pt_set_probe_image: Probe Data is not valid");
     if ((long long)w * h >= (1ll << 31)) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_set_probe_image: probe too large");
+    if (w > 65535 * PT_LINE_COLS) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_set_probe_image: probe wider than 393210 columns"); // u16 line counts in the guide
     CK(hipSetDevice(ctx->device));
     CK(hipStreamSynchronize(ctx->stream));
     dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);

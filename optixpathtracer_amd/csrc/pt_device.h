@@ -345,7 +345,7 @@ struct DevProbe {
     // row search accelerators built at setProbe: the last CDF value of every PT_CDF_BLOCK-entry block / 8-entry group of cdfY
     const float *c64Y, *c8Y; // [ncy_pad], [height/8]; null = binary search
     int ncy;
-    // Column search (null: not built, plain binary search): lines[row * lpr + l] holds columns 6l .. 6l+5.  guide[row * gpitch + k], k = 0..gk,
+    // Column search: lines[row * lpr + l] holds columns 6l .. 6l+5.  guide[row * gpitch + k], k = 0..gk,
     // = the number of the row's lines whose LAST cdf entry is < k / gk.  For r2 in [k/gk, (k+1)/gk) the line of the lower bound lies between
     // guide[k] and guide[k+1] (probe_lower_bound_lines): with gk ≈ width/2 that is one line for 2/3 of the lookups and two for the rest.
     const ProbeLine* lines;
@@ -420,63 +420,64 @@ PT_DEV int lower_bound_blocked(const float* __restrict__ row, int n, const float
     return base + count_lt8(row + base, value);
 }
 
-// Column lower bound of `value` in row `row` through the line layout: returns the column (possibly == width, like LowerBound :119-136 when every
-// entry is < value) and the line that holds min(column, width - 1).  Same index as the reference's binary search for every non-decreasing row
-// (and for an all-NaN row: every `<` is false → 0): the index is 6 l + (entries < value in line l) with l = the number of lines whose LAST
-// entry is < value, and r2 in [k/gk, (k+1)/gk) pins l between the two counts the guide stores for the cell's ends.  Dependent memory steps:
-// guide (2 x u16, adjacent) → up to three candidate lines loaded together (24 bytes each) → the texel, read from the line just loaded.
 PT_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 PT_DEV float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
-PT_DEV int probe_lower_bound_lines(const DevProbe& p, int row, float value, int& line) {
-    const ProbeLine* __restrict__ rl = p.lines + (size_t)row * p.lpr;
-    int k = (int)(value * (float)p.gk); // gk is a power of two and value in [0, 1): exact product, k / gk <= value < (k + 1) / gk
+// ProbeSample (:138-169) in two stages, so that k_shade can keep the search's first dependent load in flight next to the hit's own chain
+// (hit record → triangle → material): begin = the two random numbers, the row (marginal search, LDS in k_shade) and the guide loads;
+// end = the candidate lines, column, texel, pdf and direction.  probe_sample runs the two back to back.  (Plain scalars, no struct:
+// conditional expressions over struct members are compiled as selects of addresses and park the struct in scratch.)
+PT_DEV void probe_search_begin(const DevProbe& p, const ProbeMarg& pm, Rng& rand, int& row_out, int& lo_out, int& hi_out, float& r2_out) {
+    float r1, r2;
+    sample2d(rand, r1, r2);
+    r2_out = r2;
+#ifdef PT_EXP_NO_SEARCH
+    row_out = (int)(r1 * p.height);
+    lo_out = hi_out = (int)(r2 * p.width) / PT_LINE_COLS;
+#else
+    int row = pm.c64Y ? lower_bound_blocked(pm.cdfY, p.height, pm.c64Y, p.ncy, pm.c8Y, r1) : lower_bound(pm.cdfY, 0, p.height, r1);
+    if (row > p.height - 1) row = p.height - 1; // row/col clamped: unreachable for a valid CDF, guards a degenerate probe
+    row_out = row;
+    int k = (int)(r2 * (float)p.gk); // gk is a power of two and r2 in [0, 1): exact product, k / gk <= r2 < (k + 1) / gk
     k = k < p.gk ? k : p.gk - 1;
     const uint16_t* __restrict__ g = p.guide + (size_t)row * p.gpitch + k;
+    lo_out = g[0];
+    hi_out = g[1];
+#endif
+}
+// Column lower bound of r2 in the row through the line layout: the same index as the reference's binary search (LowerBound :119-136) for
+// every non-decreasing row (and for an all-NaN row: every `<` is false → 0) — the index is 6 l + (entries < r2 in line l) with l = the number
+// of lines whose LAST entry is < r2, and r2 in [k/gk, (k+1)/gk) pins l between the two counts the guide stores for the cell's ends.
+// Dependent memory steps: guide (2 x u16, adjacent) → the candidate lines' cdf (24 bytes; the second and third only where needed) → the texel, in the line just read.
+PT_DEV void probe_search_end(const DevProbe& p, const ProbeMarg& pm, int row, int lo, int hi, float value, v3& dir, v3& color, float& pdf) {
+    const ProbeLine* __restrict__ rl = p.lines + (size_t)row * p.lpr;
+#ifdef PT_EXP_NO_SEARCH
+    const int l = lo;
+    int col = (int)(value * p.width);
+#else
     const int last = p.lpr - 1;
-    int lo = g[0], hi = g[1];
     lo = lo < last ? lo : last; // count == lpr: every line ends below the cell; the last line then yields column >= width
     hi = hi < last ? hi : last;
     while (hi - lo > 2) { // a guide cell that spans more than three lines (flat stretch of the CDF): halve on the lines' last entries
         const int mid = lo + (hi - lo) / 2;
         if (rl[mid].cdf[PT_LINE_COLS - 1] < value) lo = mid + 1; else hi = mid;
     }
-    const int i1 = lo + 1 < hi ? lo + 1 : hi, i2 = hi; // candidates lo <= i1 <= i2 (equal indices re-read the same line)
-    const float4 a0 = ld4(rl[lo].cdf), b0 = ld4(rl[i1].cdf), c0 = ld4(rl[i2].cdf);
-    const float2 a1 = ld2(rl[lo].cdf + 4), b1 = ld2(rl[i1].cdf + 4), c1 = ld2(rl[i2].cdf + 4);
+    const int i1 = lo + 1 < hi ? lo + 1 : hi; // candidates lo <= i1 <= hi (equal indices re-read the same line)
+    const float4 a0 = ld4(rl[lo].cdf), b0 = ld4(rl[i1].cdf), c0 = ld4(rl[hi].cdf);
+    const float2 a1 = ld2(rl[lo].cdf + 4), b1 = ld2(rl[i1].cdf + 4), c1 = ld2(rl[hi].cdf + 4);
+    // (branches, so that the second and third line are only loaded by the lanes that advance: k_shade is bound by the address rate of its
+    // scattered loads — with value selects, i.e. all three lines loaded by every lane, it is 9 % slower)
     float4 s0 = a0;
     float2 s1 = a1;
     int l = lo;
     if (i1 > lo && a1.y < value) {
         l = i1; s0 = b0; s1 = b1;
-        if (i2 > i1 && b1.y < value) { l = i2; s0 = c0; s1 = c1; }
+        if (hi > i1 && b1.y < value) { l = hi; s0 = c0; s1 = c1; }
     }
-    line = l;
-    return l * PT_LINE_COLS + (s0.x < value ? 1 : 0) + (s0.y < value ? 1 : 0) + (s0.z < value ? 1 : 0) + (s0.w < value ? 1 : 0) +
-           (s1.x < value ? 1 : 0) + (s1.y < value ? 1 : 0);
-}
-
-// :138-169 (row/col clamped: unreachable for a valid CDF, guards a degenerate probe)
-PT_DEV void probe_sample(const DevProbe& p, const ProbeMarg& pm, v3& dir, v3& color, float& pdf, Rng& rand) {
-    float r1, r2;
-    sample2d(rand, r1, r2);
-    int line = 0;
-#ifdef PT_EXP_NO_SEARCH
-    int row = (int)(r1 * p.height);
-    int col = (int)(r2 * p.width);
-    line = col / PT_LINE_COLS;
-#else
-    int row = pm.c64Y ? lower_bound_blocked(pm.cdfY, p.height, pm.c64Y, p.ncy, pm.c8Y, r1) : lower_bound(pm.cdfY, 0, p.height, r1);
-    if (row > p.height - 1) row = p.height - 1;
-    int col = p.lines ? probe_lower_bound_lines(p, row, r2, line) : lower_bound(p.cdfX, row * p.width, (row + 1) * p.width, r2) - row * p.width;
+    int col = l * PT_LINE_COLS + (s0.x < value ? 1 : 0) + (s0.y < value ? 1 : 0) + (s0.z < value ? 1 : 0) + (s0.w < value ? 1 : 0) +
+              (s1.x < value ? 1 : 0) + (s1.y < value ? 1 : 0);
 #endif
     if (col > p.width - 1) col = p.width - 1;
-    float4 px;
-    if (p.lines) {
-        px = p.lines[(size_t)row * p.lpr + line].px[col - line * PT_LINE_COLS];
-    } else {
-        px = p.data[(size_t)row * p.width + col];
-        px.w = p.pdfX[(size_t)row * p.width + col];
-    }
+    const float4 px = rl[l].px[col - l * PT_LINE_COLS];
     color = mk3(px.x, px.y, px.z);
     pdf = px.w * pm.pdfY[row];
     float u = col / (float)p.width;
@@ -487,6 +488,12 @@ PT_DEV void probe_sample(const DevProbe& p, const ProbeMarg& pm, v3& dir, v3& co
     else
         pdf *= (p.width * p.height) / (2.0f * kPi * kPi * sinTheta);
     dir = probe_uv_to_dir(u, v);
+}
+PT_DEV void probe_sample(const DevProbe& p, const ProbeMarg& pm, v3& dir, v3& color, float& pdf, Rng& rand) {
+    int row, lo, hi;
+    float r2;
+    probe_search_begin(p, pm, rand, row, lo, hi, r2);
+    probe_search_end(p, pm, row, lo, hi, r2, dir, color, pdf);
 }
 
 // ------------------------------------------------------------------ software tex2D (SimplePathtracer.cpp:603-654 settings)

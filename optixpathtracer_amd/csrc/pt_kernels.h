@@ -214,11 +214,32 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             st.alb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
+        // SampleLights' probe search (:252-334 → Probe.cuh:138-169) depends on the path's random state only: the first of its dependent loads
+        // (guide → lines → texel) is started here, next to the hit's own chain (triangle → material); the rest runs where the reference calls it.
+        // A pass-through hit of the shadow catcher draws nothing: its search is discarded with this copy of the state.
+        const uint2 rs = st.rng[p];
+        Rng rand;
+        rand.seed1 = rs.x;
+        rand.seed2 = rs.y;
+        int ps_row, ps_lo, ps_hi;
+        float ps_r2;
+        probe_search_begin(sp.probe, pm, rand, ps_row, ps_lo, ps_hi, ps_r2);
         const LeafTri tri = sp.tris[leaf];
         const v3 v0 = mk3(tri.t0.x, tri.t0.y, tri.t0.z), v1 = mk3(tri.t0.w, tri.t1.x, tri.t1.y),
                  v2 = mk3(tri.t1.z, tri.t1.w, tri.t2.x);
         const int32_t mesh = __float_as_int(tri.t2.z);
-        const pt_material mat = sp.mats[mesh]; // the SBT record's material (:481-484).  (An LDS copy of the table was measured: no difference — the few records stay in L1.)
+        // the SBT record's material (:481-484): when every hit of the wave is on the same mesh the record comes through the scalar cache (k_shade
+        // is bound by the address rate of its vector loads: six fewer per hit, +1.5 %).  (An LDS copy of the table was measured: no difference.)
+        const int32_t mesh0 = __builtin_amdgcn_readfirstlane(mesh);
+        pt_material mat;
+        if (__all(mesh == mesh0)) {
+#if __HIP_DEVICE_COMPILE__
+            typedef const __attribute__((address_space(4))) pt_material* ConstMat; // constant address space: s_load
+            mat = ((ConstMat)(uintptr_t)sp.mats)[mesh0];
+#endif
+        } else {
+            mat = sp.mats[mesh];
+        }
         const float4 o4 = st.rayO[p], d4 = st.rayD[p];
         const v3 ray_o = mk3(o4.x, o4.y, o4.z), ray_dir = mk3(d4.x, d4.y, d4.z);
         const v3 N_0 = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
@@ -260,14 +281,11 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             float rayEta = th.w;
             const float outEta = (rayEta == 1.0f) ? material_ior(mat) : 1.0f;
             const v3 wo = neg3(ray_dir);
-            const uint2 rs = st.rng[p];
-            Rng rand;
-            rand.seed1 = rs.x;
-            rand.seed2 = rs.y;
             // SampleLights / SampleShadow (:252-334) up to the visibility test
             v3 wi, skyColor;
             float skyPdf;
-            probe_sample(sp.probe, pm, wi, skyColor, skyPdf, rand);
+            // (started at the reference's position: −0.3 % frame; the candidate lines' loads started early as well: 18 more live registers, spills, slower)
+            probe_search_end(sp.probe, pm, ps_row, ps_lo, ps_hi, ps_r2, wi, skyColor, skyPdf);
             bool has_val = false;
             v3 val = mk3(0.f);
             {

@@ -431,7 +431,7 @@ def main():
             "frame_latency_ms": round(agg["render_ms"] / n_chains, 3),
             "ms_per_step_per_rank": per_rank_ms,
             "kernel_ms_per_frame_isolated": None if iso is None else {k: round(iso[k], 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
-            "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2), "hierarchy": ["lbvh", "ploc"][st["bvh_builder"]]},
+            "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2), "hierarchy": ["lbvh", "ploc", "imported"][st["bvh_builder"]]},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "ms_per_displayed_frame": None if ms_displayed is None else round(ms_displayed, 3),  # per frame, in a loop that hands every launch chain's result over (every subframes_per_batch frames), the exchange overlapping the next chain
             "roofline": {

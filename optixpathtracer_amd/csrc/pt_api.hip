@@ -46,6 +46,7 @@ struct pt_ctx {
     DevProbe probe{};
     float4* d_probe_data = nullptr;
     float *d_pdfX = nullptr, *d_cdfX = nullptr, *d_pdfY = nullptr, *d_cdfY = nullptr, *d_c64Y = nullptr, *d_c8Y = nullptr;
+    float4* d_tri_nrm = nullptr; // per leaf triangle of the traversal structure: (geometric normal, mesh) for k_shade
     ProbeLine* d_lines = nullptr; // ProbeSample's column tables: six columns' cdf + (rgb, pdfX) per 128-byte line
     uint16_t* d_guide = nullptr;
     // frame
@@ -350,6 +351,8 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     CKC(tmp.event(&e1));
     CKC(hipEventRecord(e0, ctx->stream));
     CKC(pt_bvh_build(ctx->d_verts, ctx->d_idx, ctx->d_tri_mesh, (uint32_t)nt, ctx->stream, &ctx->bvh));
+    CKC(dalloc(&ctx->d_tri_nrm, (size_t)ctx->bvh.num_tris8));
+    hipLaunchKernelGGL(k_shade_normals, dim3((ctx->bvh.num_tris8 + 255) / 256), dim3(256), 0, ctx->stream, ctx->bvh.tris8, ctx->bvh.num_tris8, ctx->d_tri_nrm);
     CKC(hipEventRecord(e1, ctx->stream));
     CKC(hipStreamSynchronize(ctx->stream));
     float ms = 0;
@@ -396,7 +399,7 @@ static void free_path_state(pt_ctx* ctx) {
         if (b.stream2) hipStreamSynchronize(b.stream2);
         if (b.stream3) hipStreamSynchronize(b.stream3);
         PathState& s = b.st;
-        dfree(s.rayO); dfree(s.rayD); dfree(s.srayD); dfree(s.pend); dfree(s.hit); dfree(s.thr); dfree(s.rng); dfree(s.fd);
+        dfree(s.rayO); dfree(s.rayD); dfree(s.srayD); dfree(s.pend); dfree(s.hit); dfree(s.thr); dfree(s.rf);
         dfree(s.direct); dfree(s.indirect); dfree(s.alpha); dfree(s.nrm); dfree(s.alb); dfree(s.prdN); dfree(s.prdA);
         dfree(b.queueA); dfree(b.queueB); dfree(b.squeue); dfree(b.counters); dfree(b.ovf); dfree(b.ovf2);
         dfree(b.squeueB); dfree(b.ovf3); dfree(s.sO); dfree(s.sD); dfree(s.pendB); dfree(s.vis);
@@ -429,6 +432,7 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     dfree(ctx->d_mesh_tex); dfree(ctx->d_uvs); dfree(ctx->d_textures);
     for (uint32_t*& px : ctx->d_tex_pixels) dfree(px);
     pt_bvh_free(&ctx->bvh);
+    dfree(ctx->d_tri_nrm);
     dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
     dfree(ctx->d_c64Y); dfree(ctx->d_c8Y); dfree(ctx->d_lines); dfree(ctx->d_guide);
     dfree(ctx->d_totals);
@@ -807,7 +811,7 @@ static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_
     for (auto& b : ctx->sets) {
         PathState& s = b.st;
         CK(dalloc(&s.rayO, cap)); CK(dalloc(&s.rayD, cap)); CK(dalloc(&s.srayD, cap)); CK(dalloc(&s.pend, cap));
-        CK(dalloc(&s.hit, cap)); CK(dalloc(&s.thr, cap)); CK(dalloc(&s.rng, cap)); CK(dalloc(&s.fd, cap));
+        CK(dalloc(&s.hit, cap)); CK(dalloc(&s.thr, cap)); CK(dalloc(&s.rf, cap));
         CK(dalloc(&s.direct, cap)); CK(dalloc(&s.indirect, cap)); CK(dalloc(&s.nrm, cap)); CK(dalloc(&s.alb, cap));
         if (ctx->has_catcher) { CK(dalloc(&s.alpha, cap)); CK(dalloc(&s.prdN, cap)); CK(dalloc(&s.prdA, cap)); }
         CK(dalloc(&b.queueA, qsize)); CK(dalloc(&b.queueB, qsize)); CK(dalloc(&b.squeue, qsize));
@@ -946,7 +950,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeueB + (size_t)b * qsize, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{shade_tris, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
+                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
@@ -991,7 +995,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeue, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{shade_tris, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
+                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
@@ -1022,7 +1026,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
-            ShadeParams sp{shade_tris, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
+            ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
             if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0); // shade overwrites what shadow(b-1) reads
             {
                 SpanGuard g(ctx, CLS_SHADE, bs.stream);
@@ -1074,7 +1078,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 }
-                ShadeParams sp{shade_tris, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, 1};
+                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, 1};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);

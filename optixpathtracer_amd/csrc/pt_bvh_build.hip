@@ -743,6 +743,43 @@ static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt,
     return hipSuccess;
 }
 
+// Experiment hook (PT_BVH_IMPORT=file): a binary hierarchy built elsewhere over the same triangles replaces the internal nodes.  File: int32 n,
+// then n-1 pairs (left, right) of int32, node 0 = root, a child >= 0 is an internal node, a child < 0 is primitive ~child.
+static hipError_t import_hierarchy(const char* path, int n, const uint64_t* keys_sorted, int* left, int* right, float* box, int* cnt, hipStream_t stream, int* root_out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return hipErrorInvalidValue;
+    int nf = 0;
+    if (fread(&nf, 4, 1, f) != 1 || nf != n) { fclose(f); return hipErrorInvalidValue; }
+    std::vector<int> lr((size_t)2 * (n - 1));
+    if (fread(lr.data(), 4, lr.size(), f) != lr.size()) { fclose(f); return hipErrorInvalidValue; }
+    fclose(f);
+    std::vector<uint64_t> keys((size_t)n);
+    std::vector<float> hbox((size_t)12 * n);
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipMemcpy(keys.data(), keys_sorted, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hbox.data(), box, sizeof(float) * 12 * (size_t)n, hipMemcpyDeviceToHost));
+    std::vector<int> pos((size_t)n), hl((size_t)n), hr((size_t)n), hc((size_t)2 * n, 1);
+    for (int i = 0; i < n; ++i) pos[(uint32_t)keys[i]] = i;
+    auto tr = [&](int c) { return c >= 0 ? c : n - 1 + pos[~c]; };
+    for (int j = 0; j < n - 1; ++j) { hl[j] = tr(lr[2 * j]); hr[j] = tr(lr[2 * j + 1]); }
+    // children have larger ids than their parent (preorder): one backward sweep computes boxes and counts
+    for (int j = n - 2; j >= 0; --j) {
+        const int a = hl[j], b = hr[j];
+        if ((a < n - 1 && a <= j) || (b < n - 1 && b <= j)) return hipErrorInvalidValue;
+        for (int k = 0; k < 3; ++k) {
+            hbox[(size_t)j * 6 + k] = fminf(hbox[(size_t)a * 6 + k], hbox[(size_t)b * 6 + k]);
+            hbox[(size_t)j * 6 + 3 + k] = fmaxf(hbox[(size_t)a * 6 + 3 + k], hbox[(size_t)b * 6 + 3 + k]);
+        }
+        hc[j] = hc[a] + hc[b];
+    }
+    HIPCHK(hipMemcpy(left, hl.data(), sizeof(int) * (size_t)(n - 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(right, hr.data(), sizeof(int) * (size_t)(n - 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(box, hbox.data(), sizeof(float) * 6 * (size_t)(n - 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(cnt, hc.data(), sizeof(int) * (size_t)(2 * n - 1), hipMemcpyHostToDevice));
+    *root_out = 0;
+    return hipSuccess;
+}
+
 // Builds the traversal structure for (verts, idx) already resident on the device.
 hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint32_t* d_tri_mesh, uint32_t ntri, hipStream_t stream, PtBvh* out) {
     const int n = (int)ntri;
@@ -823,8 +860,11 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
         const char* builder = getenv("PT_BVH_BUILDER");
         const bool force_lbvh = builder && strcmp(builder, "lbvh") == 0, force_ploc = builder && strcmp(builder, "ploc") == 0;
         if (force_ploc) HIPCHK(build_ploc(n, left, right, box, cnt, stream, &root));
+        const char* import = getenv("PT_BVH_IMPORT");
+        if (import) HIPCHK(import_hierarchy(import, n, keys_sorted, left, right, box, cnt, stream, &root));
         HIPCHK(build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, out));
-        out->builder = force_ploc ? 1 : 0;
+        out->builder = import ? 2 : force_ploc ? 1 : 0;
+        if (import) { hipFree(cnt); goto done; }
         if (!force_lbvh && !force_ploc && n >= 4096) {
             // both hierarchies, the one that costs the calibration rays less (see k_calibrate8); small scenes keep the LBVH
             PtBvh alt;

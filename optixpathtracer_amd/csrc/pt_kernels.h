@@ -27,8 +27,7 @@ struct PathState {
     float4* pend;  // pending NEE contribution xyz, kind bits in w
     float2* hit;   // t, bits of the leaf triangle's index (pt_bvh.h LeafTri; negative = miss)
     float4* thr;   // pathThroughput xyz, rayEta
-    uint2* rng;    // Random seed1, seed2
-    uint32_t* fd;  // depth | flags << 8
+    uint4* rf;     // Random seed1, seed2 | depth | flags << 8 | unused: the closest-hit program reads and writes all of it, in one 16-byte access
     float4 *direct, *indirect, *nrm, *alb;
     // Scenes without shadow-catcher materials (prdN == null): prd.alpha is the FLAG_HIT0 bit of fd, and nrm/alb are written once,
     // by the depth-0 closest-hit/miss, never read back by k_shade.  Shadow-catcher scenes keep alpha as a float sum (SampleShadow
@@ -144,8 +143,7 @@ __global__ void __launch_bounds__(256) k_generate(PathState st, FrameParams fp, 
         st.rayO[i] = make_float4(fp.eye.x, fp.eye.y, fp.eye.z, 0.001f);
         st.rayD[i] = make_float4(dir.x, dir.y, dir.z, 1e16f);
         st.thr[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-        st.rng[i] = make_uint2(r.seed1, r.seed2);
-        st.fd[i] = 0u;
+        st.rf[i] = make_uint4(r.seed1, r.seed2, 0u, 0u);
         if (st.vis) st.vis[i] = 0u;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         st.direct[i] = z;
@@ -166,6 +164,7 @@ struct PrimUV { // texcoords of the three vertices of a primitive (sbtData.texco
 };
 struct ShadeParams {
     const LeafTri* tris; // the traversal structure's leaf triangles: vertices, primitive and mesh of a hit (what sbtData.vertex[index[prim]] and the SBT record gave, :481-489)
+    const float4* tri_nrm; // per leaf triangle: (normalize(cross(v1 - v0, v2 - v0)), mesh) — all the closest-hit program needs of an untextured hit, in ONE 16-byte load (k_shade_normals)
     const pt_material* mats;
     const int32_t* mesh_tex; // per mesh: texture id when the mesh has a texture AND texcoords, else -1 (null: no textures)
     const PrimUV* uvs;
@@ -193,41 +192,48 @@ PT_DEV void queue_push(bool pred, uint32_t value, const QView& q) {
     if (pred) queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
 
+// __miss__radiance (:209-235): prd.normal = prd.albedo = 0 (adds nothing at depth 0), DONE
+template <bool CATCHER>
+PT_DEV void shade_miss(const PathState& st, const ShadeParams& sp, uint32_t p) {
+    uint32_t* fdp = &reinterpret_cast<uint32_t*>(st.rf + p)[2];
+    const uint32_t fd = *fdp;
+    const int depth = (int)(fd & 0xffu);
+    if (CATCHER) {
+        st.prdN[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.prdA[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (depth == 0 && sp.aov) { // primary miss: normal += 0, albedo += 0 (:424-427)
+        st.nrm[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.alb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    *fdp = fd | (FLAG_DONE << 8);
+}
+
 // One closest-hit / miss invocation for path slot p (the body of the reference's __closesthit__radiance / __miss__radiance
 // plus the raygen loop's bookkeeping).  push_next: the path continues with the ray now in rayO/rayD; push_shadow: a shadow
 // ray is pending (per-path slots, or the per-bounce record `shadow_bounce` with asynchronous shadow rays).
 template <int MODE, bool CATCHER>
-PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMarg& pm, uint32_t p, bool& push_next, bool& push_shadow, int& shadow_bounce) {
-    const float2 h = st.hit[p];
+PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMarg& pm, uint32_t p, float2 h, bool& push_next, bool& push_shadow, int& shadow_bounce) {
     const int32_t leaf = __float_as_int(h.y);
-    uint32_t fd = st.fd[p];
-    int depth = (int)(fd & 0xffu);
-    uint32_t flags = fd >> 8;
     if (leaf < 0) {
-        // __miss__radiance (:209-235): prd.normal = prd.albedo = 0 (adds nothing at depth 0), DONE
-        flags |= FLAG_DONE;
-        if (CATCHER) {
-            st.prdN[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            st.prdA[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else if (depth == 0 && sp.aov) { // primary miss: normal += 0, albedo += 0 (:424-427)
-            st.nrm[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            st.alb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    } else {
+        shade_miss<CATCHER>(st, sp, p);
+        return;
+    }
+    const uint4 rf = st.rf[p];
+    int depth = (int)(rf.z & 0xffu);
+    uint32_t flags = rf.z >> 8;
+    uint2 rng_out = make_uint2(rf.x, rf.y);
+    {
         // SampleLights' probe search (:252-334 → Probe.cuh:138-169) depends on the path's random state only: the first of its dependent loads
         // (guide → lines → texel) is started here, next to the hit's own chain (triangle → material); the rest runs where the reference calls it.
         // A pass-through hit of the shadow catcher draws nothing: its search is discarded with this copy of the state.
-        const uint2 rs = st.rng[p];
         Rng rand;
-        rand.seed1 = rs.x;
-        rand.seed2 = rs.y;
+        rand.seed1 = rf.x;
+        rand.seed2 = rf.y;
         int ps_row, ps_lo, ps_hi;
         float ps_r2;
         probe_search_begin(sp.probe, pm, rand, ps_row, ps_lo, ps_hi, ps_r2);
-        const LeafTri tri = sp.tris[leaf];
-        const v3 v0 = mk3(tri.t0.x, tri.t0.y, tri.t0.z), v1 = mk3(tri.t0.w, tri.t1.x, tri.t1.y),
-                 v2 = mk3(tri.t1.z, tri.t1.w, tri.t2.x);
-        const int32_t mesh = __float_as_int(tri.t2.z);
+        const float4 tn = sp.tri_nrm[leaf];
+        const int32_t mesh = __float_as_int(tn.w);
         // the SBT record's material (:481-484): when every hit of the wave is on the same mesh the record comes through the scalar cache (k_shade
         // is bound by the address rate of its vector loads: six fewer per hit, +1.5 %).  (An LDS copy of the table was measured: no difference.)
         const int32_t mesh0 = __builtin_amdgcn_readfirstlane(mesh);
@@ -242,7 +248,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
         }
         const float4 o4 = st.rayO[p], d4 = st.rayD[p];
         const v3 ray_o = mk3(o4.x, o4.y, o4.z), ray_dir = mk3(d4.x, d4.y, d4.z);
-        const v3 N_0 = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
+        const v3 N_0 = mk3(tn.x, tn.y, tn.z); // normalize(cross(v1 - v0, v2 - v0)) (:491), evaluated once per triangle by the same device code
         const v3 N = faceforward3(N_0, neg3(ray_dir), N_0);
         const v3 P = add3(ray_o, scl3(ray_dir, h.x));
         st.rayO[p] = make_float4(P.x, P.y, P.z, sp.tmin_radiance);
@@ -262,6 +268,8 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             if (sp.mesh_tex) { // deviceProgram.cu:512-523: a textured mesh's albedo is REPLACED by tex2D at the hit's texcoord
                 const int tid = sp.mesh_tex[mesh];
                 if (tid >= 0) {
+                    const LeafTri tri = sp.tris[leaf];
+                    const v3 v0 = mk3(tri.t0.x, tri.t0.y, tri.t0.z), v1 = mk3(tri.t0.w, tri.t1.x, tri.t1.y), v2 = mk3(tri.t1.z, tri.t1.w, tri.t2.x);
                     // optixGetTriangleBarycentrics = (weight of vertex 1, weight of vertex 2): the hit test's own weights
                     const v3 A = sub3(v0, ray_o), B = sub3(v1, ray_o), C = sub3(v2, ray_o);
                     const v3 CxB = cross3(C, B), AxC = cross3(A, C), BxA = cross3(B, A);
@@ -320,7 +328,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                 flags |= FLAG_SECONDARY;
             }
             st.thr[p] = make_float4(T_new.x, T_new.y, T_new.z, rayEta);
-            st.rng[p] = make_uint2(rand.seed1, rand.seed2);
+            rng_out = make_uint2(rand.seed1, rand.seed2);
             if (CATCHER) {
                 st.prdN[p] = make_float4(N.x, N.y, N.z, 0.f);
                 st.prdA[p] = make_float4(albedo.x, albedo.y, albedo.z, 0.f);
@@ -377,7 +385,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             }
         }
     }
-    st.fd[p] = (uint32_t)depth | (flags << 8);
+    st.rf[p] = make_uint4(rng_out.x, rng_out.y, (uint32_t)depth | (flags << 8), 0u);
 }
 
 // k_shade is half latency-bound (dependent scattered loads: state, triangle, probe CDF search): 5 waves per SIMD at 96 VGPRs
@@ -386,6 +394,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
 #define PT_SHADE_WAVES 5
 #endif
 #define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, PT_SHADE_WAVES)))
+
 // rows of the probe whose marginal arrays fit k_shade's LDS copy: cdfY + pdfY (rows each), c8Y (rows/8), c64Y (rows/64 padded to 8)
 #ifndef PT_LDS_PROBE_ROWS
 #define PT_LDS_PROBE_ROWS 2048
@@ -415,13 +424,16 @@ __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, Shade
     const uint32_t n = qreader_init(sp.queue, s_prefix); // ends in a workgroup barrier (identity queue: see below)
     if (sp.queue.base == nullptr) __syncthreads();
     const uint32_t nround = (n + 63u) & ~63u; // whole waves stay in the loop so ballots see every lane
+    // (Measured and rejected: each wave parking its hits in LDS until 64 are waiting, so that the closest-hit program always runs on full waves
+    // and the misses — a third of the queue — only cost their stores: 31 % fewer wave passes through the hit path, k_shade 6 % SLOWER.  The
+    // kernel is bound by the address rate of its scattered per-lane loads, which a fuller wave does not lower, and gathered lanes coalesce worse.)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += gridDim.x * blockDim.x) {
         bool push_next = false, push_shadow = false;
         int shadow_bounce = 0;
         uint32_t p = 0;
         if (i < n) {
             p = qreader_get(sp.queue, s_prefix, i);
-            shade_path<MODE, CATCHER>(st, sp, pm, p, push_next, push_shadow, shadow_bounce);
+            shade_path<MODE, CATCHER>(st, sp, pm, p, st.hit[p], push_next, push_shadow, shadow_bounce);
         }
         queue_push(push_next, p, sp.next_queue);
         queue_push(push_shadow, p, sp.shadow_queue);
@@ -475,7 +487,7 @@ __global__ void __launch_bounds__(256) k_resolve(PathState st, FrameParams fp, B
         if (st.prdN) {
             a = st.alpha[i];
         } else {
-            const float hit0 = ((st.fd[i] >> 8) & FLAG_HIT0) ? 1.0f : 0.0f;
+            const float hit0 = ((reinterpret_cast<const uint32_t*>(st.rf + i)[2] >> 8) & FLAG_HIT0) ? 1.0f : 0.0f;
             a = make_float4(hit0, hit0, hit0, 0.f);
         }
         apply_visible_contributions(st, i, d, in);
@@ -592,7 +604,7 @@ __global__ void __launch_bounds__(256) k_generate_region(PathState st, FramePara
                     mine = part_owns(pp, px, py);
                 }
             if (range < rg.r_inner || range > rg.r_outer || !mine) {
-                st.fd[i] = (uint32_t)FLAG_CULLED << 8;
+                st.rf[i] = make_uint4(0u, 0u, (uint32_t)FLAG_CULLED << 8, 0u);
             } else {
                 for (uint32_t k = 0; k < 2u * sl; ++k) lcg(seed);
                 Rng r;
@@ -604,8 +616,7 @@ __global__ void __launch_bounds__(256) k_generate_region(PathState st, FramePara
                 st.rayO[i] = make_float4(fp.eye.x, fp.eye.y, fp.eye.z, tmin);
                 st.rayD[i] = make_float4(dir.x, dir.y, dir.z, 1e16f);
                 st.thr[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-                st.rng[i] = make_uint2(r.seed1, r.seed2);
-                st.fd[i] = depth0; // prd.depth = 0 (1 in the sv / sv2 variants)
+                st.rf[i] = make_uint4(r.seed1, r.seed2, depth0, 0u); // prd.depth = 0 (1 in the sv / sv2 variants)
                 if (st.vis) st.vis[i] = 0u;
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 st.direct[i] = z;
@@ -632,7 +643,7 @@ PT_DEV v3 reinhard_tonemap(v3 color, float white) { // sv4 deviceProgram.cu:124-
 __global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParams fp, RegionParams rg, PartParams pp, VariantParams var, uint32_t l0, uint32_t nl) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nl) return;
-    if ((st.fd[k] >> 8) & FLAG_CULLED) return;
+    if ((reinterpret_cast<const uint32_t*>(st.rf + k)[2] >> 8) & FLAG_CULLED) return;
     const uint32_t li = l0 + k;
     const uint32_t lx = li % rg.launch_w, ly = li / rg.launch_w;
     v3 result = mk3(0.f), alpha = mk3(0.f), normal = mk3(0.f), albedo = mk3(0.f);
@@ -640,7 +651,7 @@ __global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParam
     for (uint32_t sl = 0; sl < rg.spp; ++sl) {
         const uint32_t i = sl * nl + k;
         float4 d = st.direct[i], in = st.indirect[i];
-        const float hit0 = ((st.fd[i] >> 8) & FLAG_HIT0) ? 1.0f : 0.0f; // foveated launches never run with shadow catchers
+        const float hit0 = ((reinterpret_cast<const uint32_t*>(st.rf + i)[2] >> 8) & FLAG_HIT0) ? 1.0f : 0.0f; // foveated launches never run with shadow catchers
         apply_visible_contributions(st, i, d, in);
         result = add3(result, add3(mk3(d.x, d.y, d.z), mk3(in.x, in.y, in.z)));
         alpha = add3(alpha, mk3(hit0, hit0, hit0));
@@ -791,6 +802,15 @@ __global__ void k_accum_stats(const uint32_t* __restrict__ counters, int nq, int
     }
 }
 
+// per leaf triangle: the geometric normal of __closesthit__radiance (:491) and the mesh, for k_shade
+__global__ void k_shade_normals(const LeafTri* __restrict__ tris, uint32_t n, float4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const LeafTri tri = tris[i];
+    const v3 v0 = mk3(tri.t0.x, tri.t0.y, tri.t0.z), v1 = mk3(tri.t0.w, tri.t1.x, tri.t1.y), v2 = mk3(tri.t1.z, tri.t1.w, tri.t2.x);
+    const v3 N = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
+    out[i] = make_float4(N.x, N.y, N.z, tri.t2.z);
+}
 // pt_trace (the query entry point): closest-hit records hold leaf-triangle indices, the caller is given primitive indices
 __global__ void k_hits_to_prims(float2* __restrict__ hit, const LeafTri* __restrict__ tris, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -205,7 +205,7 @@ k_trace8(Trace8Args a) {
                 if (!occluded) atomicOr(&a.st.vis[slot], 1u << a.bounce);
                 return;
             }
-            const float4 pe = a.st.pend[slot];
+            const float4 pe = st_ld<PT_NT_TRACE_LD>(&a.st.pend[slot]);
             const int kind = __float_as_int(pe.w);
             if (kind == PEND_ALPHA) {
                 if (occluded) {
@@ -214,11 +214,11 @@ k_trace8(Trace8Args a) {
                 }
             } else if (!occluded) {
                 float4* acc = (kind == PEND_DIRECT) ? a.st.direct : a.st.indirect;
-                const float4 x = acc[slot];
-                acc[slot] = make_float4(x.x + pe.x, x.y + pe.y, x.z + pe.z, 0.f);
+                const float4 x = st_ld<PT_NT_TRACE_LD>(&acc[slot]);
+                st_st<PT_NT_TRACE_ST>(&acc[slot], make_float4(x.x + pe.x, x.y + pe.y, x.z + pe.z, 0.f));
             }
         } else {
-            a.st.hit[slot] = make_float2(rbest, __int_as_float(rprim));
+            st_st<PT_NT_TRACE_ST>(&a.st.hit[slot], make_float2(rbest, __int_as_float(rprim)));
         }
     };
     const auto is_shadow = [&]() { return MODE == TR_SHADOW_APPLY || MODE == TR_ANY_QUERY || (MODE == TR_UNIFIED && shadow_lane); };
@@ -303,14 +303,14 @@ k_trace8(Trace8Args a) {
                         o4 = a.st.sO[bi];
                         d4 = a.st.sD[bi];
                     } else {
-                        o4 = a.st.rayO[slot];
-                        d4 = a.st.srayD[slot];
+                        o4 = st_ld<PT_NT_TRACE_LD>(&a.st.rayO[slot]);
+                        d4 = st_ld<PT_NT_TRACE_LD>(&a.st.srayD[slot]);
                     }
                     tmin = 0.01f;
                     tmax = 1e16f;
                 } else {
-                    o4 = a.st.rayO[slot];
-                    d4 = a.st.rayD[slot];
+                    o4 = st_ld<PT_NT_TRACE_LD>(&a.st.rayO[slot]);
+                    d4 = st_ld<PT_NT_TRACE_LD>(&a.st.rayD[slot]);
                     tmin = o4.w;
                     tmax = d4.w;
                 }

@@ -326,6 +326,56 @@ PT_DEV v3 bsdf_eval(const pt_material& mat, v3 albedo, float etaI, float etaO, v
     return lerp3(brdf, bsdf, mat.transmission);
 }
 
+// Path state streams through the caches once per bounce (hundreds of MB per pass); NT = true marks an access non-temporal, so that it does
+// not displace the tables every ray and hit look up at random (BVH, probe lines, triangle normals).  Measured (C3, six interleaved runs each):
+// k_trace8 loads + stores and k_shade stores non-temporal −1.5 % frame time; k_shade's LOADS as well: +0.5…1 % (they re-read what the
+// traversal launch just wrote); k_generate's stores: no difference.
+#ifndef PT_NT_TRACE_LD
+#define PT_NT_TRACE_LD 1 // k_trace8: ray / pending-contribution loads
+#endif
+#ifndef PT_NT_TRACE_ST
+#define PT_NT_TRACE_ST 1 // k_trace8: hit records, accumulators
+#endif
+#ifndef PT_NT_SHADE_LD
+#define PT_NT_SHADE_LD 0 // k_shade: state loads
+#endif
+#ifndef PT_NT_SHADE_ST
+#define PT_NT_SHADE_ST 1 // k_shade: state stores
+#endif
+typedef float pt_f4v __attribute__((ext_vector_type(4)));
+typedef float pt_f2v __attribute__((ext_vector_type(2)));
+typedef uint32_t pt_u4v __attribute__((ext_vector_type(4)));
+template <bool NT> PT_DEV float4 st_ld(const float4* p) {
+    if (!NT) return *p;
+    const pt_f4v v = __builtin_nontemporal_load(reinterpret_cast<const pt_f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <bool NT> PT_DEV float2 st_ld(const float2* p) {
+    if (!NT) return *p;
+    const pt_f2v v = __builtin_nontemporal_load(reinterpret_cast<const pt_f2v*>(p));
+    return make_float2(v.x, v.y);
+}
+template <bool NT> PT_DEV uint4 st_ld(const uint4* p) {
+    if (!NT) return *p;
+    const pt_u4v v = __builtin_nontemporal_load(reinterpret_cast<const pt_u4v*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <bool NT> PT_DEV void st_st(float4* p, float4 a) {
+    if (!NT) { *p = a; return; }
+    const pt_f4v v = {a.x, a.y, a.z, a.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<pt_f4v*>(p));
+}
+template <bool NT> PT_DEV void st_st(float2* p, float2 a) {
+    if (!NT) { *p = a; return; }
+    const pt_f2v v = {a.x, a.y};
+    __builtin_nontemporal_store(v, reinterpret_cast<pt_f2v*>(p));
+}
+template <bool NT> PT_DEV void st_st(uint4* p, uint4 a) {
+    if (!NT) { *p = a; return; }
+    const pt_u4v v = {a.x, a.y, a.z, a.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<pt_u4v*>(p));
+}
+
 // ------------------------------------------------------------------ probe (Probe.cuh)
 #define PT_CDF_BLOCK 64
 // ProbeSample's per-column data, co-located: one 128-byte line (= one L2 line) holds six consecutive columns of a row — their conditional-CDF

@@ -218,7 +218,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
         shade_miss<CATCHER>(st, sp, p);
         return;
     }
-    const uint4 rf = st.rf[p];
+    const uint4 rf = st_ld<PT_NT_SHADE_LD>(&st.rf[p]);
     int depth = (int)(rf.z & 0xffu);
     uint32_t flags = rf.z >> 8;
     uint2 rng_out = make_uint2(rf.x, rf.y);
@@ -246,12 +246,12 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
         } else {
             mat = sp.mats[mesh];
         }
-        const float4 o4 = st.rayO[p], d4 = st.rayD[p];
+        const float4 o4 = st_ld<PT_NT_SHADE_LD>(&st.rayO[p]), d4 = st_ld<PT_NT_SHADE_LD>(&st.rayD[p]);
         const v3 ray_o = mk3(o4.x, o4.y, o4.z), ray_dir = mk3(d4.x, d4.y, d4.z);
         const v3 N_0 = mk3(tn.x, tn.y, tn.z); // normalize(cross(v1 - v0, v2 - v0)) (:491), evaluated once per triangle by the same device code
         const v3 N = faceforward3(N_0, neg3(ray_dir), N_0);
         const v3 P = add3(ray_o, scl3(ray_dir, h.x));
-        st.rayO[p] = make_float4(P.x, P.y, P.z, sp.tmin_radiance);
+        st_st<PT_NT_SHADE_ST>(&st.rayO[p], make_float4(P.x, P.y, P.z, sp.tmin_radiance));
         const bool is_catcher = (mat.flags & 1) != 0;
         if (CATCHER && is_catcher && (flags & FLAG_SECONDARY)) {
             // pass-through (:503-508): origin = P, direction unchanged, --depth; then raygen (:424-439)
@@ -284,7 +284,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                     albedo = mk3(tx.x, tx.y, tx.z);
                 }
             }
-            const float4 th = st.thr[p];
+            const float4 th = st_ld<PT_NT_SHADE_LD>(&st.thr[p]);
             const v3 T_old = mk3(th.x, th.y, th.z);
             float rayEta = th.w;
             const float outEta = (rayEta == 1.0f) ? material_ior(mat) : 1.0f;
@@ -324,10 +324,10 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                 const v3 f = bsdf_eval<MODE>(mat, albedo, rayEta, outEta, N, wo, bsdfDir);
                 if (dot3(bsdfDir, N) <= 0.0f) rayEta = outEta;
                 T_new = mul3(T_old, div3s(scl3(f, fabsf(dot3(N, bsdfDir))), bsdfPdf));
-                st.rayD[p] = make_float4(bsdfDir.x, bsdfDir.y, bsdfDir.z, 1e16f);
+                st_st<PT_NT_SHADE_ST>(&st.rayD[p], make_float4(bsdfDir.x, bsdfDir.y, bsdfDir.z, 1e16f));
                 flags |= FLAG_SECONDARY;
             }
-            st.thr[p] = make_float4(T_new.x, T_new.y, T_new.z, rayEta);
+            st_st<PT_NT_SHADE_ST>(&st.thr[p], make_float4(T_new.x, T_new.y, T_new.z, rayEta));
             rng_out = make_uint2(rand.seed1, rand.seed2);
             if (CATCHER) {
                 st.prdN[p] = make_float4(N.x, N.y, N.z, 0.f);
@@ -349,8 +349,8 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             if (CATCHER && is_catcher) {
                 // SampleShadow: alpha += T * shadowSample when OCCLUDED (:550-551), whatever happens next
                 if (has_val) {
-                    st.pend[p] = make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(PEND_ALPHA));
-                    st.srayD[p] = make_float4(wi.x, wi.y, wi.z, 0.f);
+                    st_st<PT_NT_SHADE_ST>(&st.pend[p], make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(PEND_ALPHA)));
+                    st_st<PT_NT_SHADE_ST>(&st.srayD[p], make_float4(wi.x, wi.y, wi.z, 0.f));
                     push_shadow = true;
                 }
                 if (!term && primary) { // radiance = emission (:558-560)
@@ -373,8 +373,8 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                         st.sD[bi] = make_float4(wi.x, wi.y, wi.z, 0.f);
                         st.pendB[bi] = pe;
                     } else {
-                        st.pend[p] = pe;
-                        st.srayD[p] = make_float4(wi.x, wi.y, wi.z, 0.f);
+                        st_st<PT_NT_SHADE_ST>(&st.pend[p], pe);
+                        st_st<PT_NT_SHADE_ST>(&st.srayD[p], make_float4(wi.x, wi.y, wi.z, 0.f));
                     }
                     push_shadow = true;
                 }
@@ -385,7 +385,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             }
         }
     }
-    st.rf[p] = make_uint4(rng_out.x, rng_out.y, (uint32_t)depth | (flags << 8), 0u);
+    st_st<PT_NT_SHADE_ST>(&st.rf[p], make_uint4(rng_out.x, rng_out.y, (uint32_t)depth | (flags << 8), 0u));
 }
 
 // k_shade is half latency-bound (dependent scattered loads: state, triangle, probe CDF search): 5 waves per SIMD at 96 VGPRs
@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, Shade
         uint32_t p = 0;
         if (i < n) {
             p = qreader_get(sp.queue, s_prefix, i);
-            shade_path<MODE, CATCHER>(st, sp, pm, p, st.hit[p], push_next, push_shadow, shadow_bounce);
+            shade_path<MODE, CATCHER>(st, sp, pm, p, st_ld<PT_NT_SHADE_LD>(&st.hit[p]), push_next, push_shadow, shadow_bounce);
         }
         queue_push(push_next, p, sp.next_queue);
         queue_push(push_shadow, p, sp.shadow_queue);

@@ -329,7 +329,7 @@ PT_DEV v3 bsdf_eval(const pt_material& mat, v3 albedo, float etaI, float etaO, v
 // Path state streams through the caches once per bounce (hundreds of MB per pass); NT = true marks an access non-temporal, so that it does
 // not displace the tables every ray and hit look up at random (BVH, probe lines, triangle normals).  Measured (C3, six interleaved runs each):
 // k_trace8 loads + stores and k_shade stores non-temporal −1.5 % frame time; k_shade's LOADS as well: +0.5…1 % (they re-read what the
-// traversal launch just wrote); k_generate's stores, the ray queues, k_resolve's loads: no difference.
+// traversal launch just wrote); k_generate's stores, the ray queues, k_resolve's loads: no difference; k_shade's random table loads (probe lines, triangle normals): +5 % — they do hit the caches.
 #ifndef PT_NT_TRACE_LD
 #define PT_NT_TRACE_LD 1 // k_trace8: ray / pending-contribution loads
 #endif

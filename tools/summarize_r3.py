@@ -21,7 +21,7 @@ def find(d, pat):
 
 
 def short(name):
-    return name.replace("void ", "").split("(")[0][:60]
+    return name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
 
 
 def bench_line(path):

@@ -56,16 +56,41 @@ BYTES_PER_SHADOW_RAY_TRACE = 36      # read ray 32 B + write 4 B
 FLOPS_PER_HIT = 700                  # 2 x BSDFEval + 2 x BSDFPdf + BSDFSample + hit setup
 
 
+def _strip_comments(text):
+    """C/C++ source without comments and blank lines (string literals in these files hold no comment markers worth a parser)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        if text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+        elif text[i] == '"':
+            j = i + 1
+            while j < n and text[j] != '"':
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        else:
+            out.append(text[i])
+            i += 1
+    return "\n".join(l.rstrip() for l in "".join(out).split("\n") if l.strip())
+
+
 def source_hash():
-    """Hash of the kernel sources: PMC-derived numbers under profiles/ carry it and are only quoted for the code they were
-    measured on (a hash of the .so would change with every rebuild)."""
+    """Hash of the kernel sources WITHOUT their comments: PMC-derived numbers under profiles/ carry it and are only quoted for the
+    code they were measured on (a hash of the .so would change with every rebuild, a hash of the text with every note on a
+    rejected experiment)."""
     h = hashlib.sha256()
     src = os.path.join(ROOT, "optixpathtracer_amd", "csrc")
-    files = [os.path.join(src, f) for f in ("pt_device.h", "pt_bvh.h", "pt_bvh8.h", "pt_kernels.h", "pt_host.h", "pt_api.hip", "pt_bvh_build.hip", "Makefile")]
+    files = [os.path.join(src, f) for f in ("pt_device.h", "pt_bvh.h", "pt_bvh8.h", "pt_kernels.h", "pt_host.h", "pt_api.hip", "pt_bvh_build.hip")]
     files.append(os.path.join(ROOT, "include", "pt_detmath.h"))  # (the facade header and the C ABI's comments are not kernel sources)
     for f in files:
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(_strip_comments(open(f, encoding="utf-8").read()).encode())
+    flags = [l for l in open(os.path.join(src, "Makefile"), encoding="utf-8") if l.startswith("FLAGS")]
+    h.update("".join(flags).encode())
     return h.hexdigest()[:16]
 
 

@@ -508,7 +508,9 @@ k_trace8(Trace8Args a) {
                 const uint32_t nearz[2] = {nz ? hiz0 : loz0, nz ? hiz1 : loz1}, farz[2] = {nz ? loz0 : hiz0, nz ? loz1 : hiz1};
                 // No extra widening of the far plane here: the 8-bit grid (rounded outward from boxes already padded
                 // by 2^-16 of the scene size) is orders of magnitude coarser than the rounding of these products.
-                // (Measured and rejected: 2-wide vectors → v_pk_fma_f32; the packing moves and VGPR pairs cost more.)
+                // (Measured and rejected, twice: two children per v_pk_fma_f32 — 24 packed instead of 48 scalar FMAs, conversions landing in adjacent
+                // registers, no packing moves: traversal 5 % SLOWER in round 3 (0.847 vs 0.807 ms per launch).  The packed FP32 FMA does not issue
+                // at twice the scalar rate here, and the register pairs add 7 spills.)
                 uint32_t miss = 0u; // sign bits of tfar - tnear, slot 7 first (one subtract + one funnel shift per child)
 #pragma unroll
                 for (int s = 7; s >= 0; --s) {

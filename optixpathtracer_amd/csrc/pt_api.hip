@@ -71,7 +71,15 @@ struct pt_ctx {
     // set runs on its own pair of streams, so one chunk's kernel tails overlap with the other chunks' bulk work
     struct BatchSet {
         hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
-        PathState st{};
+        PathState st{}; // the arrays indexed by path slot; the stream pointers are filled per launch (stream_view)
+        // what a path carries from bounce to bounce, in queue order (pt_kernels.h PathState): X[0] travels with queueA, X[1] with queueB
+        // (the generate kernels write X[1]); the shadow records travel with squeue
+        struct StreamBuf {
+            float4 *rayO = nullptr, *rayD = nullptr, *thr = nullptr;
+            uint4* rf = nullptr;
+            float2* hit = nullptr;
+        } X[2];
+        float4 *shO = nullptr, *shD = nullptr, *shPend = nullptr;
         uint32_t *queueA = nullptr, *queueB = nullptr, *squeue = nullptr;
         uint32_t* squeueB = nullptr; // asynchronous shadow rays: one shadow queue per bounce
         uint32_t* ovf3 = nullptr;
@@ -399,7 +407,8 @@ static void free_path_state(pt_ctx* ctx) {
         if (b.stream2) hipStreamSynchronize(b.stream2);
         if (b.stream3) hipStreamSynchronize(b.stream3);
         PathState& s = b.st;
-        dfree(s.rayO); dfree(s.rayD); dfree(s.srayD); dfree(s.pend); dfree(s.hit); dfree(s.thr); dfree(s.rf);
+        for (auto& x : b.X) { dfree(x.rayO); dfree(x.rayD); dfree(x.thr); dfree(x.rf); dfree(x.hit); }
+        dfree(b.shO); dfree(b.shD); dfree(b.shPend); dfree(s.pflags);
         dfree(s.direct); dfree(s.indirect); dfree(s.alpha); dfree(s.nrm); dfree(s.alb); dfree(s.prdN); dfree(s.prdA);
         dfree(b.queueA); dfree(b.queueB); dfree(b.squeue); dfree(b.counters); dfree(b.ovf); dfree(b.ovf2);
         dfree(b.squeueB); dfree(b.ovf3); dfree(s.sO); dfree(s.sD); dfree(s.pendB); dfree(s.vis);
@@ -810,8 +819,8 @@ static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_
     }
     for (auto& b : ctx->sets) {
         PathState& s = b.st;
-        CK(dalloc(&s.rayO, cap)); CK(dalloc(&s.rayD, cap)); CK(dalloc(&s.srayD, cap)); CK(dalloc(&s.pend, cap));
-        CK(dalloc(&s.hit, cap)); CK(dalloc(&s.thr, cap)); CK(dalloc(&s.rf, cap));
+        for (auto& x : b.X) { CK(dalloc(&x.rayO, qsize)); CK(dalloc(&x.rayD, qsize)); CK(dalloc(&x.thr, qsize)); CK(dalloc(&x.rf, qsize)); CK(dalloc(&x.hit, qsize)); }
+        CK(dalloc(&b.shO, qsize)); CK(dalloc(&b.shD, qsize)); CK(dalloc(&b.shPend, qsize)); CK(dalloc(&s.pflags, cap));
         CK(dalloc(&s.direct, cap)); CK(dalloc(&s.indirect, cap)); CK(dalloc(&s.nrm, cap)); CK(dalloc(&s.alb, cap));
         if (ctx->has_catcher) { CK(dalloc(&s.alpha, cap)); CK(dalloc(&s.prdN, cap)); CK(dalloc(&s.prdA, cap)); }
         CK(dalloc(&b.queueA, qsize)); CK(dalloc(&b.queueB, qsize)); CK(dalloc(&b.squeue, qsize));
@@ -877,13 +886,20 @@ static size_t shade_lds_bytes(const DevProbe& p) {
     if (!p.c64Y || p.height > PT_LDS_PROBE_ROWS) return 0;
     return sizeof(float) * ((size_t)2 * p.height + p.height / 8 + ((p.ncy + 7) & ~7));
 }
+// the path state a launch sees: the slot-indexed arrays plus the radiance stream of its input queue (X[k]) and the shadow stream
+static PathState stream_view(const pt_ctx::BatchSet& bs, int k) {
+    PathState s = bs.st;
+    s.rayO = bs.X[k].rayO; s.rayD = bs.X[k].rayD; s.thr = bs.X[k].thr; s.rf = bs.X[k].rf; s.hit = bs.X[k].hit;
+    s.shO = bs.shO; s.shD = bs.shD; s.shPend = bs.shPend;
+    return s;
+}
 template <int MODE>
-static void launch_shade(pt_ctx* ctx, pt_ctx::BatchSet& bs, const ShadeParams& sp) {
+static void launch_shade(pt_ctx* ctx, pt_ctx::BatchSet& bs, const PathState& st, const ShadeParams& sp) {
     const unsigned lds = (unsigned)shade_lds_bytes(sp.probe);
     if (ctx->has_catcher)
-        hipLaunchKernelGGL((k_shade<MODE, true>), dim3(GRID), dim3(256), lds, bs.stream, bs.st, sp);
+        hipLaunchKernelGGL((k_shade<MODE, true>), dim3(GRID), dim3(256), lds, bs.stream, st, sp);
     else
-        hipLaunchKernelGGL((k_shade<MODE, false>), dim3(GRID), dim3(256), lds, bs.stream, bs.st, sp);
+        hipLaunchKernelGGL((k_shade<MODE, false>), dim3(GRID), dim3(256), lds, bs.stream, st, sp);
 }
 
 // enqueue every kernel of one pixel chunk (all its samples) on the streams of one batch set
@@ -923,11 +939,12 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
         {
             SpanGuard g(ctx, CLS_OTHER, bs.stream);
             if (job)
-                hipLaunchKernelGGL(k_generate_region, dim3(GRID), dim3(256), 0, bs.stream, bs.st, fp, job->rg, PartParams{ctx->rank, ctx->world, ctx->tile_w, ctx->tile_h}, tmin_rad, (uint32_t)job->var.initial_depth, job->l0, job->nl, qcur);
+                hipLaunchKernelGGL(k_generate_region, dim3(GRID), dim3(256), 0, bs.stream, stream_view(bs, 1), fp, job->rg, PartParams{ctx->rank, ctx->world, ctx->tile_w, ctx->tile_h}, tmin_rad, (uint32_t)job->var.initial_depth, job->l0, job->nl, qcur);
             else
-                hipLaunchKernelGGL(k_generate, dim3(GRID), dim3(256), 0, bs.stream, bs.st, fp, bp, bs.counters + 0);
+                hipLaunchKernelGGL(k_generate, dim3(GRID), dim3(256), 0, bs.stream, stream_view(bs, 1), fp, bp, bs.counters + 0);
         }
         uint32_t* qnext_base = bs.queueA;
+        int sin = 1; // X[sin] holds the state of the queue being traced / shaded, X[sin ^ 1] receives the next queue's
         // depth d = 0..max_depth traces in the reference (the trace at depth == max_depth can only matter
         // through a shadow-catcher pass-through or alpha; without catcher materials it is provably dead and skipped)
         // (a foveated launch of the sv / sv2 variants starts its paths at depth 1: that many fewer bounces are live)
@@ -943,18 +960,18 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             std::vector<hipEvent_t> shadow_done;
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
+                Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeueB + (size_t)b * qsize, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
+                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
-                    if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
-                    else launch_shade<PT_BSDF_DISNEY>(ctx, bs, sp);
+                    if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, stream_view(bs, sin), sp);
+                    else launch_shade<PT_BSDF_DISNEY>(ctx, bs, stream_view(bs, sin), sp);
                     ++lc.shade;
                 }
                 {
@@ -964,7 +981,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     hipStreamWaitEvent(ss, ev_shaded, 0);
                     {
                         SpanGuard g(ctx, CLS_SHADOW, ss);
-                        Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, (b & 1) ? bs.ovf3 : bs.ovf2, cull, nullptr, b, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
+                        Trace8Args ta{stream_view(bs, sin), bvh8, qshadow, QView{}, work + nq + b, (b & 1) ? bs.ovf3 : bs.ovf2, cull, nullptr, b, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                         hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(tgrid), dim3(64), 0, ss, ta);
                         ++lc.shadow;
                     }
@@ -974,12 +991,13 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qnext, QView{}, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
+                    Trace8Args ta{stream_view(bs, sin ^ 1), bvh8, qnext, QView{}, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 }
                 qcur = qnext;
                 qnext_base = (qnext_base == bs.queueA) ? bs.queueB : bs.queueA;
+                sin ^= 1;
             }
             for (hipEvent_t e : shadow_done) hipStreamWaitEvent(bs.stream, e, 0);
         } else if (unified) {
@@ -988,33 +1006,34 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             // and a frame has max_depth+1 traversal launches instead of 2*max_depth.
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
+                Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeue, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
+                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
-                    if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
-                    else launch_shade<PT_BSDF_DISNEY>(ctx, bs, sp);
+                    if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, stream_view(bs, sin), sp);
+                    else launch_shade<PT_BSDF_DISNEY>(ctx, bs, stream_view(bs, sin), sp);
                     ++lc.shade;
                 }
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qnext, qshadow, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
+                    Trace8Args ta{stream_view(bs, sin ^ 1), bvh8, qnext, qshadow, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_UNIFIED>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 } else {
                     SpanGuard g(ctx, CLS_SHADOW, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
+                    Trace8Args ta{stream_view(bs, sin), bvh8, qshadow, QView{}, work + nq + b, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.shadow;
                 }
                 qcur = qnext;
                 qnext_base = (qnext_base == bs.queueA) ? bs.queueB : bs.queueA;
+                sin ^= 1;
             }
         } else
         for (int b = 0; b <= last_bounce; ++b) {
@@ -1022,16 +1041,16 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             QView qshadow{bs.squeue, cntS + (size_t)b * CS, ctx->sub_cap};
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
+                Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
-            ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
+            ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
             if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0); // shade overwrites what shadow(b-1) reads
             {
                 SpanGuard g(ctx, CLS_SHADE, bs.stream);
-                if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
-                else launch_shade<PT_BSDF_DISNEY>(ctx, bs, sp);
+                if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, stream_view(bs, sin), sp);
+                else launch_shade<PT_BSDF_DISNEY>(ctx, bs, stream_view(bs, sin), sp);
                 ++lc.shade;
             }
             {
@@ -1041,7 +1060,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 hipEventRecord(ev_shaded, bs.stream);
                 hipStreamWaitEvent(bs.stream2, ev_shaded, 0);
                 SpanGuard g(ctx, CLS_SHADOW, bs.stream2);
-                Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
+                Trace8Args ta{stream_view(bs, sin), bvh8, qshadow, QView{}, work + nq + b, bs.ovf2, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                 hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(tgrid), dim3(64), 0, bs.stream2, ta);
                 ++lc.shadow;
             }
@@ -1049,6 +1068,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             hipEventRecord(ev_shadow_done, bs.stream2);
             qcur = qnext;
             qnext_base = (qnext_base == bs.queueA) ? bs.queueB : bs.queueA;
+                sin ^= 1;
         }
         if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0);
         if (ctx->has_catcher) {
@@ -1074,26 +1094,27 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 QView qshadow{bs.squeue, cntS + (size_t)cur * CS, ctx->sub_cap};
                 {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qcur, QView{}, work + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
+                    Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 }
-                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, 1};
+                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, 1};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
-                    if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, sp);
-                    else launch_shade<PT_BSDF_DISNEY>(ctx, bs, sp);
+                    if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, stream_view(bs, sin), sp);
+                    else launch_shade<PT_BSDF_DISNEY>(ctx, bs, stream_view(bs, sin), sp);
                     ++lc.shade;
                 }
                 {
                     SpanGuard g(ctx, CLS_SHADOW, bs.stream);
-                    Trace8Args ta{bs.st, bvh8, qshadow, QView{}, work + nq + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
+                    Trace8Args ta{stream_view(bs, sin), bvh8, qshadow, QView{}, work + nq + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     hipLaunchKernelGGL((k_trace8<TR_SHADOW_APPLY>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.shadow;
                 }
                 hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters + (size_t)cur * CS, nq, 1, 0, bs.totals);
                 qcur = qnext;
                 qnext_base = (qnext_base == bs.queueA) ? bs.queueB : bs.queueA;
+                sin ^= 1;
                 cur = nxt;
             }
         }

@@ -163,7 +163,7 @@ k_trace8(Trace8Args a) {
 #define SB ((int)(misc >> 24))
 #define SET_OWNER(v) (misc = (misc & ~0xffu) | (uint32_t)(v))
 #define SET_SB(v) (misc = (misc & 0x00ffffffu) | ((uint32_t)(v) << 24))
-    uint32_t slot = 0;
+    uint32_t slot = 0; // position of the lane's ray in its queue's arrays (PathState)
 #if PT8_DEFER_WRITE
     bool unwritten = false; // this lane holds a finished ray whose result is not written yet
 #endif
@@ -201,21 +201,22 @@ k_trace8(Trace8Args a) {
     auto write_result = [&](float rbest, int32_t rprim) {
         if (MODE == TR_SHADOW_APPLY || (MODE == TR_UNIFIED && shadow_lane)) {
             const bool occluded = rprim != 0;
+            const uint32_t ps = (MODE == TR_UNIFIED ? a.queue2 : a.queue).base[slot]; // the path slot of this shadow-queue entry
             if (a.st.vis) { // asynchronous shadow records: only publish the visibility, k_resolve sums in bounce order
-                if (!occluded) atomicOr(&a.st.vis[slot], 1u << a.bounce);
+                if (!occluded) atomicOr(&a.st.vis[ps], 1u << a.bounce);
                 return;
             }
-            const float4 pe = st_ld<PT_NT_TRACE_LD>(&a.st.pend[slot]);
+            const float4 pe = st_ld<PT_NT_TRACE_LD>(&a.st.shPend[slot]);
             const int kind = __float_as_int(pe.w);
             if (kind == PEND_ALPHA) {
                 if (occluded) {
-                    const float4 x = a.st.alpha[slot];
-                    a.st.alpha[slot] = make_float4(x.x + pe.x, x.y + pe.y, x.z + pe.z, 0.f);
+                    const float4 x = a.st.alpha[ps];
+                    a.st.alpha[ps] = make_float4(x.x + pe.x, x.y + pe.y, x.z + pe.z, 0.f);
                 }
             } else if (!occluded) {
                 float4* acc = (kind == PEND_DIRECT) ? a.st.direct : a.st.indirect;
-                const float4 x = st_ld<PT_NT_TRACE_LD>(&acc[slot]);
-                st_st<PT_NT_TRACE_ST>(&acc[slot], make_float4(x.x + pe.x, x.y + pe.y, x.z + pe.z, 0.f));
+                const float4 x = st_ld<PT_NT_TRACE_LD>(&acc[ps]);
+                st_st<PT_NT_TRACE_ST>(&acc[ps], make_float4(x.x + pe.x, x.y + pe.y, x.z + pe.z, 0.f));
             }
         } else {
             st_st<PT_NT_TRACE_ST>(&a.st.hit[slot], make_float2(rbest, __int_as_float(rprim)));
@@ -289,22 +290,22 @@ k_trace8(Trace8Args a) {
                     // started early, their tails overlap the closest-hit bulk instead of trailing it
                     shadow_lane = gi < n2;
                     uint32_t hint = shadow_lane ? (misc >> 16) & 0xffu : (misc >> 8) & 0xffu;
-                    slot = shadow_lane ? qreader_get_hint(a.queue2, s_prefix2, gi, hint) : qreader_get_hint(a.queue, s_prefix, gi - n2, hint);
+                    slot = shadow_lane ? qreader_pos_hint(a.queue2, s_prefix2, gi, hint) : qreader_pos_hint(a.queue, s_prefix, gi - n2, hint);
                     misc = shadow_lane ? (misc & 0xff00ffffu) | (hint << 16) : (misc & 0xffff00ffu) | (hint << 8);
                 } else {
                     uint32_t hint = (misc >> 8) & 0xffu;
-                    slot = qreader_get_hint(a.queue, s_prefix, gi, hint);
+                    slot = qreader_pos_hint(a.queue, s_prefix, gi, hint);
                     misc = (misc & 0xffff00ffu) | (hint << 8);
                 }
                 float4 o4, d4;
                 if (MODE == TR_SHADOW_APPLY || (MODE == TR_UNIFIED && shadow_lane)) {
                     if (a.st.vis) {
-                        const size_t bi = (size_t)a.bounce * a.st.bstride + slot;
+                        const size_t bi = (size_t)a.bounce * a.st.bstride + (MODE == TR_UNIFIED ? a.queue2 : a.queue).base[slot];
                         o4 = a.st.sO[bi];
                         d4 = a.st.sD[bi];
                     } else {
-                        o4 = st_ld<PT_NT_TRACE_LD>(&a.st.rayO[slot]);
-                        d4 = st_ld<PT_NT_TRACE_LD>(&a.st.srayD[slot]);
+                        o4 = st_ld<PT_NT_TRACE_LD>(&a.st.shO[slot]);
+                        d4 = st_ld<PT_NT_TRACE_LD>(&a.st.shD[slot]);
                     }
                     tmin = 0.01f;
                     tmax = 1e16f;

@@ -20,14 +20,22 @@ enum { FLAG_DONE = 1, FLAG_SECONDARY = 2, FLAG_CULLED = 4 /* outside the foveati
 enum { PEND_DIRECT = 1, PEND_INDIRECT = 2, PEND_ALPHA = 3 };
 enum { TR_CLOSEST = 0, TR_SHADOW_APPLY = 1, TR_ANY_QUERY = 2, TR_UNIFIED = 3 /* closest-hit queue + shadow queue in one launch */ }; // modes of the persistent traversal kernels
 
+// What a path carries from bounce to bounce travels WITH ITS QUEUE ENTRY: element `pos` of these arrays belongs to entry `pos` of the queue the
+// launch reads (k_trace8: the rays it traces and the hit records it writes; k_shade: its input), and k_shade writes the continuing path's
+// state at the position its push into the next queue returned (ShadeParams::o*).  So every launch reads and writes the state densely however
+// few of the frame's paths are still alive — indexed by path slot, bounce 3 found 2.4 live paths per 128-byte line and bounce 6 one
+// (k_shade cost 0.078 ns per path at bounce 0 and 0.21 at bounce 7).  Two copies (ping-pong); the generate kernels write the first
+// in launch order (position = slot).  What is summed per path stays indexed by slot.
 struct PathState {
-    float4* rayO;  // next ray origin xyz, tmin
-    float4* rayD;  // next ray direction xyz, tmax
-    float4* srayD; // shadow ray direction (origin = rayO.xyz, tmin .01, tmax 1e16)
-    float4* pend;  // pending NEE contribution xyz, kind bits in w
+    float4* rayO;  // ray origin xyz, tmin
+    float4* rayD;  // ray direction xyz, tmax
     float2* hit;   // t, bits of the leaf triangle's index (pt_bvh.h LeafTri; negative = miss)
     float4* thr;   // pathThroughput xyz, rayEta
-    uint4* rf;     // Random seed1, seed2 | depth | flags << 8 | unused: the closest-hit program reads and writes all of it, in one 16-byte access
+    uint4* rf;     // Random seed1, seed2 | depth | flags << 8 | unused
+    // the shadow rays of the bounce, in the order of the shadow queue: origin, direction (tmin .01, tmax 1e16), pending NEE contribution xyz | kind
+    float4 *shO, *shD, *shPend;
+    // ---- by path slot
+    uint32_t* pflags; // FLAG_CULLED (generate) | FLAG_HIT0 (first hit): what the resolve kernels need of a path's flags
     float4 *direct, *indirect, *nrm, *alb;
     // Scenes without shadow-catcher materials (prdN == null): prd.alpha is the FLAG_HIT0 bit of fd, and nrm/alb are written once,
     // by the depth-0 closest-hit/miss, never read back by k_shade.  Shadow-catcher scenes keep alpha as a float sum (SampleShadow
@@ -112,6 +120,33 @@ PT_DEV uint32_t qreader_get_hint(const QView& q, const uint32_t* s_prefix, uint3
     }
     return q.base[(size_t)lo * q.sub_cap + (i - s_prefix[lo])];
 }
+// position of entry i in the queue's arrays (the slot array q.base and the state that travels with it)
+PT_DEV uint32_t qreader_pos_hint(const QView& q, const uint32_t* s_prefix, uint32_t i, uint32_t& hint) {
+    if (q.base == nullptr) return i;
+    uint32_t lo = hint;
+    if (!(s_prefix[lo] <= i && i < s_prefix[lo + 1])) {
+        lo = 0;
+        uint32_t hi = PT_NSUB;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_prefix[mid] <= i) lo = mid; else hi = mid;
+        }
+        hint = lo;
+    }
+    return lo * q.sub_cap + (i - s_prefix[lo]);
+}
+PT_DEV uint32_t qreader_pos(const QView& q, const uint32_t* s_prefix, uint32_t i) {
+    if (q.base == nullptr) return i;
+    uint32_t lo = 0, hi = PT_NSUB; // find lo with s_prefix[lo] <= i < s_prefix[lo+1]
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_prefix[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo * q.sub_cap + (i - s_prefix[lo]);
+}
+PT_DEV uint32_t qslot(const QView& q, uint32_t pos) { return q.base ? q.base[pos] : pos; } // the path slot of the entry at `pos`
 PT_DEV uint32_t qreader_get(const QView& q, const uint32_t* s_prefix, uint32_t i) {
     if (q.base == nullptr) return i;
     uint32_t lo = 0, hi = PT_NSUB; // find lo with s_prefix[lo] <= i < s_prefix[lo+1]
@@ -144,6 +179,7 @@ __global__ void __launch_bounds__(256) k_generate(PathState st, FrameParams fp, 
         st.rayD[i] = make_float4(dir.x, dir.y, dir.z, 1e16f);
         st.thr[i] = make_float4(1.f, 1.f, 1.f, 1.f);
         st.rf[i] = make_uint4(r.seed1, r.seed2, 0u, 0u);
+        st.pflags[i] = 0u;
         if (st.vis) st.vis[i] = 0u;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         st.direct[i] = z;
@@ -175,53 +211,60 @@ struct ShadeParams {
     QView queue;        // paths to shade (identity at bounce 0)
     QView next_queue;   // paths that continue
     QView shadow_queue; // paths with a live shadow ray
+    float4 *oRayO, *oRayD, *oThr; // the continuing paths' state, at the positions of their entries in next_queue (PathState)
+    uint4* oRf;
     int aov;            // write the first-hit normal/albedo (the foveated variants only keep accum/frame)
 };
 
-// wave-aggregated queue append: one atomic per wave
-PT_DEV void queue_push(bool pred, uint32_t value, const QView& q) {
-    uint32_t* queue = q.base + (size_t)(blockIdx.x & (PT_NSUB - 1)) * q.sub_cap;
-    uint32_t* counter = q.counts + (blockIdx.x & (PT_NSUB - 1)) * PT_CSTRIDE;
+// wave-aggregated queue append: one atomic per wave (over the lanes that are active at the call: it may sit in divergent code).  Returns the
+// position of the lane's entry in the queue's arrays (meaningful where pred holds); the slot is written there.
+PT_DEV uint32_t queue_push(bool pred, uint32_t value, const QView& q) {
+    const uint32_t sub = blockIdx.x & (PT_NSUB - 1);
+    uint32_t* counter = q.counts + sub * PT_CSTRIDE;
     const unsigned long long mask = __ballot(pred);
-    if (mask == 0ull) return;
+    if (mask == 0ull) return 0u;
     const uint32_t lane = __lane_id();
     const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
     base = __shfl(base, (int)leader);
-    if (pred) queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+    const uint32_t pos = sub * q.sub_cap + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (pred) q.base[pos] = value;
+    return pos;
 }
 
 // __miss__radiance (:209-235): prd.normal = prd.albedo = 0 (adds nothing at depth 0), DONE
 template <bool CATCHER>
-PT_DEV void shade_miss(const PathState& st, const ShadeParams& sp, uint32_t p) {
-    uint32_t* fdp = &reinterpret_cast<uint32_t*>(st.rf + p)[2];
-    const uint32_t fd = *fdp;
-    const int depth = (int)(fd & 0xffu);
+PT_DEV void shade_miss(const PathState& st, const ShadeParams& sp, uint32_t pos, uint32_t p) {
     if (CATCHER) {
         st.prdN[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         st.prdA[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else if (depth == 0 && sp.aov) { // primary miss: normal += 0, albedo += 0 (:424-427)
+    } else if (sp.aov && (reinterpret_cast<const uint32_t*>(st.rf + pos)[2] & 0xffu) == 0u) { // primary miss: normal += 0, albedo += 0 (:424-427)
         st.nrm[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         st.alb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    *fdp = fd | (FLAG_DONE << 8);
+    // DONE: the path is simply not queued again
 }
 
-// One closest-hit / miss invocation for path slot p (the body of the reference's __closesthit__radiance / __miss__radiance
-// plus the raygen loop's bookkeeping).  push_next: the path continues with the ray now in rayO/rayD; push_shadow: a shadow
-// ray is pending (per-path slots, or the per-bounce record `shadow_bounce` with asynchronous shadow rays).
+// One closest-hit / miss invocation for the queue entry at `pos` = path slot p (the body of the reference's __closesthit__radiance /
+// __miss__radiance plus the raygen loop's bookkeeping).  A path that continues is pushed into next_queue and its state written at the
+// position of that entry; a pending shadow ray is pushed into shadow_queue with its record (or, with asynchronous shadow rays, written
+// to the per-bounce record of the slot).
 template <int MODE, bool CATCHER>
-PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMarg& pm, uint32_t p, float2 h, bool& push_next, bool& push_shadow, int& shadow_bounce) {
+PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMarg& pm, uint32_t pos, uint32_t p, float2 h) {
     const int32_t leaf = __float_as_int(h.y);
     if (leaf < 0) {
-        shade_miss<CATCHER>(st, sp, p);
+        shade_miss<CATCHER>(st, sp, pos, p);
         return;
     }
-    const uint4 rf = st_ld<PT_NT_SHADE_LD>(&st.rf[p]);
+    bool push_next = false;
+    const uint4 rf = st_ld<PT_NT_SHADE_LD>(&st.rf[pos]);
     int depth = (int)(rf.z & 0xffu);
     uint32_t flags = rf.z >> 8;
     uint2 rng_out = make_uint2(rf.x, rf.y);
+    // what a continuing path carries on (the pass-through of a catcher keeps direction, throughput and random state)
+    v3 P_out = mk3(0.f), dir_out = mk3(0.f);
+    float4 thr_out = make_float4(0.f, 0.f, 0.f, 0.f);
     {
         // SampleLights' probe search (:252-334 → Probe.cuh:138-169) depends on the path's random state only: the first of its dependent loads
         // (guide → lines → texel) is started here, next to the hit's own chain (triangle → material); the rest runs where the reference calls it.
@@ -246,12 +289,15 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
         } else {
             mat = sp.mats[mesh];
         }
-        const float4 o4 = st_ld<PT_NT_SHADE_LD>(&st.rayO[p]), d4 = st_ld<PT_NT_SHADE_LD>(&st.rayD[p]);
+        const float4 o4 = st_ld<PT_NT_SHADE_LD>(&st.rayO[pos]), d4 = st_ld<PT_NT_SHADE_LD>(&st.rayD[pos]);
+        const float4 th = st_ld<PT_NT_SHADE_LD>(&st.thr[pos]);
+        dir_out = mk3(d4.x, d4.y, d4.z);
+        thr_out = th;
         const v3 ray_o = mk3(o4.x, o4.y, o4.z), ray_dir = mk3(d4.x, d4.y, d4.z);
         const v3 N_0 = mk3(tn.x, tn.y, tn.z); // normalize(cross(v1 - v0, v2 - v0)) (:491), evaluated once per triangle by the same device code
         const v3 N = faceforward3(N_0, neg3(ray_dir), N_0);
         const v3 P = add3(ray_o, scl3(ray_dir, h.x));
-        st_st<PT_NT_SHADE_ST>(&st.rayO[p], make_float4(P.x, P.y, P.z, sp.tmin_radiance));
+        P_out = P;
         const bool is_catcher = (mat.flags & 1) != 0;
         if (CATCHER && is_catcher && (flags & FLAG_SECONDARY)) {
             // pass-through (:503-508): origin = P, direction unchanged, --depth; then raygen (:424-439)
@@ -284,7 +330,6 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                     albedo = mk3(tx.x, tx.y, tx.z);
                 }
             }
-            const float4 th = st_ld<PT_NT_SHADE_LD>(&st.thr[p]);
             const v3 T_old = mk3(th.x, th.y, th.z);
             float rayEta = th.w;
             const float outEta = (rayEta == 1.0f) ? material_ior(mat) : 1.0f;
@@ -310,7 +355,8 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             if (CATCHER) {
                 if (!is_catcher) st.alpha[p] = make_float4(1.f, 1.f, 1.f, 0.f); // :547
             } else {
-                flags |= FLAG_HIT0; // :547 — every hit assigns the same value, one bit is enough
+                if (!(flags & FLAG_HIT0)) st.pflags[p] = FLAG_HIT0; // :547 — every hit assigns the same value: one bit, written by the path's first hit
+                flags |= FLAG_HIT0;
             }
             const bool primary = (flags & FLAG_SECONDARY) == 0;
             v3 u, v, bsdfDir = mk3(0.f);
@@ -324,10 +370,10 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                 const v3 f = bsdf_eval<MODE>(mat, albedo, rayEta, outEta, N, wo, bsdfDir);
                 if (dot3(bsdfDir, N) <= 0.0f) rayEta = outEta;
                 T_new = mul3(T_old, div3s(scl3(f, fabsf(dot3(N, bsdfDir))), bsdfPdf));
-                st_st<PT_NT_SHADE_ST>(&st.rayD[p], make_float4(bsdfDir.x, bsdfDir.y, bsdfDir.z, 1e16f));
+                dir_out = bsdfDir;
                 flags |= FLAG_SECONDARY;
             }
-            st_st<PT_NT_SHADE_ST>(&st.thr[p], make_float4(T_new.x, T_new.y, T_new.z, rayEta));
+            thr_out = make_float4(T_new.x, T_new.y, T_new.z, rayEta);
             rng_out = make_uint2(rand.seed1, rand.seed2);
             if (CATCHER) {
                 st.prdN[p] = make_float4(N.x, N.y, N.z, 0.f);
@@ -349,9 +395,10 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             if (CATCHER && is_catcher) {
                 // SampleShadow: alpha += T * shadowSample when OCCLUDED (:550-551), whatever happens next
                 if (has_val) {
-                    st_st<PT_NT_SHADE_ST>(&st.pend[p], make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(PEND_ALPHA)));
-                    st_st<PT_NT_SHADE_ST>(&st.srayD[p], make_float4(wi.x, wi.y, wi.z, 0.f));
-                    push_shadow = true;
+                    const uint32_t sq = queue_push(true, p, sp.shadow_queue);
+                    st_st<PT_NT_SHADE_ST>(&st.shO[sq], make_float4(P.x, P.y, P.z, 0.f));
+                    st_st<PT_NT_SHADE_ST>(&st.shD[sq], make_float4(wi.x, wi.y, wi.z, 0.f));
+                    st_st<PT_NT_SHADE_ST>(&st.shPend[sq], make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(PEND_ALPHA)));
                 }
                 if (!term && primary) { // radiance = emission (:558-560)
                     const float4 dd = st.direct[p];
@@ -366,17 +413,17 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                 }
                 if (has_val) {
                     const float4 pe = make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(depth == 0 ? PEND_DIRECT : PEND_INDIRECT));
-                    if (st.vis) { // asynchronous shadow rays: a self-contained record of this bounce
+                    const uint32_t sq = queue_push(true, p, sp.shadow_queue);
+                    if (st.vis) { // asynchronous shadow rays: a self-contained record of this bounce, by slot (the queue entry names the slot)
                         const size_t bi = (size_t)depth * st.bstride + p;
-                    shadow_bounce = depth;
                         st.sO[bi] = make_float4(P.x, P.y, P.z, 0.f);
                         st.sD[bi] = make_float4(wi.x, wi.y, wi.z, 0.f);
                         st.pendB[bi] = pe;
                     } else {
-                        st_st<PT_NT_SHADE_ST>(&st.pend[p], pe);
-                        st_st<PT_NT_SHADE_ST>(&st.srayD[p], make_float4(wi.x, wi.y, wi.z, 0.f));
+                        st_st<PT_NT_SHADE_ST>(&st.shO[sq], make_float4(P.x, P.y, P.z, 0.f));
+                        st_st<PT_NT_SHADE_ST>(&st.shD[sq], make_float4(wi.x, wi.y, wi.z, 0.f));
+                        st_st<PT_NT_SHADE_ST>(&st.shPend[sq], pe);
                     }
-                    push_shadow = true;
                 }
             }
             if (!term) {
@@ -385,7 +432,13 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             }
         }
     }
-    st_st<PT_NT_SHADE_ST>(&st.rf[p], make_uint4(rng_out.x, rng_out.y, (uint32_t)depth | (flags << 8), 0u));
+    const uint32_t nq = queue_push(push_next, p, sp.next_queue);
+    if (push_next) {
+        st_st<PT_NT_SHADE_ST>(&sp.oRayO[nq], make_float4(P_out.x, P_out.y, P_out.z, sp.tmin_radiance));
+        st_st<PT_NT_SHADE_ST>(&sp.oRayD[nq], make_float4(dir_out.x, dir_out.y, dir_out.z, 1e16f));
+        st_st<PT_NT_SHADE_ST>(&sp.oThr[nq], thr_out);
+        st_st<PT_NT_SHADE_ST>(&sp.oRf[nq], make_uint4(rng_out.x, rng_out.y, (uint32_t)depth | (flags << 8), 0u));
+    }
 }
 
 // k_shade is half latency-bound (dependent scattered loads: state, triangle, probe CDF search): 5 waves per SIMD at 96 VGPRs
@@ -428,15 +481,10 @@ __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, Shade
     // and the misses — a third of the queue — only cost their stores: 31 % fewer wave passes through the hit path, k_shade 6 % SLOWER.  The
     // kernel is bound by the address rate of its scattered per-lane loads, which a fuller wave does not lower, and gathered lanes coalesce worse.)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += gridDim.x * blockDim.x) {
-        bool push_next = false, push_shadow = false;
-        int shadow_bounce = 0;
-        uint32_t p = 0;
         if (i < n) {
-            p = qreader_get(sp.queue, s_prefix, i);
-            shade_path<MODE, CATCHER>(st, sp, pm, p, st_ld<PT_NT_SHADE_LD>(&st.hit[p]), push_next, push_shadow, shadow_bounce);
+            const uint32_t pos = qreader_pos(sp.queue, s_prefix, i);
+            shade_path<MODE, CATCHER>(st, sp, pm, pos, qslot(sp.queue, pos), st_ld<PT_NT_SHADE_LD>(&st.hit[pos]));
         }
-        queue_push(push_next, p, sp.next_queue);
-        queue_push(push_shadow, p, sp.shadow_queue);
     }
 }
 
@@ -487,7 +535,7 @@ __global__ void __launch_bounds__(256) k_resolve(PathState st, FrameParams fp, B
         if (st.prdN) {
             a = st.alpha[i];
         } else {
-            const float hit0 = ((reinterpret_cast<const uint32_t*>(st.rf + i)[2] >> 8) & FLAG_HIT0) ? 1.0f : 0.0f;
+            const float hit0 = (st.pflags[i] & FLAG_HIT0) ? 1.0f : 0.0f;
             a = make_float4(hit0, hit0, hit0, 0.f);
         }
         apply_visible_contributions(st, i, d, in);
@@ -585,6 +633,8 @@ __global__ void __launch_bounds__(256) k_generate_region(PathState st, FramePara
     const uint32_t nround = (total + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += gridDim.x * blockDim.x) {
         bool live = false;
+        v3 dir = mk3(0.f);
+        uint32_t seed1 = 0, seed2 = 0;
         if (i < total) {
             const uint32_t sl = i / nl, li = l0 + (i - sl * nl);
             const uint32_t lx = li % rg.launch_w, ly = li / rg.launch_w;
@@ -604,7 +654,7 @@ __global__ void __launch_bounds__(256) k_generate_region(PathState st, FramePara
                     mine = part_owns(pp, px, py);
                 }
             if (range < rg.r_inner || range > rg.r_outer || !mine) {
-                st.rf[i] = make_uint4(0u, 0u, (uint32_t)FLAG_CULLED << 8, 0u);
+                st.pflags[i] = FLAG_CULLED;
             } else {
                 for (uint32_t k = 0; k < 2u * sl; ++k) lcg(seed);
                 Rng r;
@@ -612,11 +662,10 @@ __global__ void __launch_bounds__(256) k_generate_region(PathState st, FramePara
                 const float jx = rnd(seed), jy = rnd(seed);
                 const float dx = 2.0f * (((float)ix + jx) / (float)fp.width) - 1.0f;
                 const float dy = 2.0f * (((float)iy + jy) / (float)fp.height) - 1.0f;
-                const v3 dir = normalize3(add3(add3(scl3(fp.U, dx), scl3(fp.V, dy)), fp.W));
-                st.rayO[i] = make_float4(fp.eye.x, fp.eye.y, fp.eye.z, tmin);
-                st.rayD[i] = make_float4(dir.x, dir.y, dir.z, 1e16f);
-                st.thr[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-                st.rf[i] = make_uint4(r.seed1, r.seed2, depth0, 0u); // prd.depth = 0 (1 in the sv / sv2 variants)
+                dir = normalize3(add3(add3(scl3(fp.U, dx), scl3(fp.V, dy)), fp.W));
+                seed1 = r.seed1;
+                seed2 = r.seed2;
+                st.pflags[i] = 0u;
                 if (st.vis) st.vis[i] = 0u;
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 st.direct[i] = z;
@@ -631,7 +680,13 @@ __global__ void __launch_bounds__(256) k_generate_region(PathState st, FramePara
                 live = true;
             }
         }
-        queue_push(live, i, qgen);
+        const uint32_t pos = queue_push(live, i, qgen); // the path's state goes where its queue entry went
+        if (live) {
+            st.rayO[pos] = make_float4(fp.eye.x, fp.eye.y, fp.eye.z, tmin);
+            st.rayD[pos] = make_float4(dir.x, dir.y, dir.z, 1e16f);
+            st.thr[pos] = make_float4(1.f, 1.f, 1.f, 1.f);
+            st.rf[pos] = make_uint4(seed1, seed2, depth0, 0u); // prd.depth = 0 (1 in the sv / sv2 variants)
+        }
     }
 }
 
@@ -643,7 +698,7 @@ PT_DEV v3 reinhard_tonemap(v3 color, float white) { // sv4 deviceProgram.cu:124-
 __global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParams fp, RegionParams rg, PartParams pp, VariantParams var, uint32_t l0, uint32_t nl) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nl) return;
-    if ((reinterpret_cast<const uint32_t*>(st.rf + k)[2] >> 8) & FLAG_CULLED) return;
+    if (st.pflags[k] & FLAG_CULLED) return;
     const uint32_t li = l0 + k;
     const uint32_t lx = li % rg.launch_w, ly = li / rg.launch_w;
     v3 result = mk3(0.f), alpha = mk3(0.f), normal = mk3(0.f), albedo = mk3(0.f);
@@ -651,7 +706,7 @@ __global__ void __launch_bounds__(256) k_resolve_region(PathState st, FrameParam
     for (uint32_t sl = 0; sl < rg.spp; ++sl) {
         const uint32_t i = sl * nl + k;
         float4 d = st.direct[i], in = st.indirect[i];
-        const float hit0 = ((reinterpret_cast<const uint32_t*>(st.rf + i)[2] >> 8) & FLAG_HIT0) ? 1.0f : 0.0f; // foveated launches never run with shadow catchers
+        const float hit0 = (st.pflags[i] & FLAG_HIT0) ? 1.0f : 0.0f; // foveated launches never run with shadow catchers
         apply_visible_contributions(st, i, d, in);
         result = add3(result, add3(mk3(d.x, d.y, d.z), mk3(in.x, in.y, in.z)));
         alpha = add3(alpha, mk3(hit0, hit0, hit0));

@@ -10,8 +10,9 @@
 //   k_resolve    raygen epilogue (:445-474): per-pixel sample sums in sample order, backplate,
 //                progressive blend, make_color, the five buffer writes
 //
-// HBM layout: structure-of-arrays indexed by path slot (float4 / float2 / uint2 arrays, 16-byte
-// aligned, one coalesced access per array per wave); queues are arrays of path slots.
+// HBM layout: structures of arrays (float4 / float2 / uint4, 16-byte aligned, one coalesced access per array per wave).  Queues are
+// arrays of path slots; the state a path carries from bounce to bounce sits in queue order beside its entry, the per-path sums are
+// indexed by slot (PathState below).
 #pragma once
 #include "pt_bvh.h"
 

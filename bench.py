@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --share-device rehearses the N>1 path on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use HIP device 0 (rehearsal only)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal on a 1-GPU box: initialise the process group and run the N>1 code (collectives on device tensors, the displayed-frame loop through RCCL) with a world of one rank")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N>1: strong (default) = the metric's fixed frame split N ways; weak = per-GPU work fixed, image area grows with N")
     ap.add_argument("--simulate-world", type=int, default=0, help="single process: render only rank 0's tiles of an N-way partition (predicts per-GPU time at N GPUs)")
     ap.add_argument("--simulate-rank", type=int, default=0, help="with --simulate-world N: which rank's share to render (load balance of the interleaved tiles)")
@@ -126,8 +127,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+
+        if world == 1:  # --force-dist without a launcher
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("MASTER_PORT", "29533")
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.share_device:
@@ -158,7 +162,7 @@ def main():
                 frames_in_flight=0 if args.kernel_timing else args.frames_in_flight)
     r.setOptions(**opts)
     part_world = world if world > 1 else max(1, args.simulate_world)
-    if world > 1:
+    if world > 1 or args.force_dist:
         r.setPartition(rank, world, args.tile[0], args.tile[1])
     elif args.simulate_world > 1:
         r.setPartition(args.simulate_rank % args.simulate_world, args.simulate_world, args.tile[0], args.tile[1])

@@ -392,6 +392,9 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                 }
             }
             const bool term = (flags & FLAG_DONE) || depth >= sp.max_depth;
+            // direct is still the +0 k_generate wrote when the camera ray's hit adds the emission: +0 + (±0) = +0, so a material without emission
+            // leaves the sum as it is, bit for bit, and the read-modify-write of 32 bytes per primary hit is skipped
+            const bool emissive = mat.emission[0] != 0.f || mat.emission[1] != 0.f || mat.emission[2] != 0.f;
             const v3 contrib = mul3(T_old, val);
             if (CATCHER && is_catcher) {
                 // SampleShadow: alpha += T * shadowSample when OCCLUDED (:550-551), whatever happens next
@@ -401,14 +404,14 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                     st_st<PT_NT_SHADE_ST>(&st.shD[sq], make_float4(wi.x, wi.y, wi.z, 0.f));
                     st_st<PT_NT_SHADE_ST>(&st.shPend[sq], make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(PEND_ALPHA)));
                 }
-                if (!term && primary) { // radiance = emission (:558-560)
+                if (!term && primary && emissive) { // radiance = emission (:558-560)
                     const float4 dd = st.direct[p];
                     st.direct[p] = make_float4(dd.x + mat.emission[0], dd.y + mat.emission[1], dd.z + mat.emission[2], 0.f);
                 }
             } else if (!term) {
                 // radiance = T*lightSample (+ emission on primary hits) is added to direct/indirect (:432-437)
                 // only when the path goes on; the visibility-dependent part is deferred to the traversal kernel's write-back (k_trace8).
-                if (primary) {
+                if (primary && emissive) {
                     const float4 dd = st.direct[p];
                     st.direct[p] = make_float4(dd.x + mat.emission[0], dd.y + mat.emission[1], dd.z + mat.emission[2], 0.f);
                 }

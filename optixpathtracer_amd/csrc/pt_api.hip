@@ -967,7 +967,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeueB + (size_t)b * qsize, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
+                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1, (b == 0) ? 1 : 0};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, stream_view(bs, sin), sp);
@@ -1013,7 +1013,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeue, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
+                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1, (b == 0) ? 1 : 0};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, stream_view(bs, sin), sp);
@@ -1045,7 +1045,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
-            ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1};
+            ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1, (b == 0) ? 1 : 0};
             if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0); // shade overwrites what shadow(b-1) reads
             {
                 SpanGuard g(ctx, CLS_SHADE, bs.stream);
@@ -1098,7 +1098,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 }
-                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, 1};
+                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, 1, 0};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, stream_view(bs, sin), sp);

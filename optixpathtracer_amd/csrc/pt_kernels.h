@@ -178,7 +178,6 @@ __global__ void __launch_bounds__(256) k_generate(PathState st, FrameParams fp, 
         const v3 dir = normalize3(add3(add3(scl3(fp.U, dx), scl3(fp.V, dy)), fp.W));
         st.rayO[i] = make_float4(fp.eye.x, fp.eye.y, fp.eye.z, 0.001f);
         st.rayD[i] = make_float4(dir.x, dir.y, dir.z, 1e16f);
-        st.thr[i] = make_float4(1.f, 1.f, 1.f, 1.f);
         st.rf[i] = make_uint4(r.seed1, r.seed2, 0u, 0u);
         st.pflags[i] = 0u;
         if (st.vis) st.vis[i] = 0u;
@@ -215,6 +214,7 @@ struct ShadeParams {
     float4 *oRayO, *oRayD, *oThr; // the continuing paths' state, at the positions of their entries in next_queue (PathState)
     uint4* oRf;
     int aov;            // write the first-hit normal/albedo (the foveated variants only keep accum/frame)
+    int first;          // the queue holds camera rays: throughput (1,1,1) and eta 1 are not read (the generate kernels do not write them)
 };
 
 // wave-aggregated queue append: one atomic per wave (over the lanes that are active at the call: it may sit in divergent code).  Returns the
@@ -291,7 +291,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             mat = sp.mats[mesh];
         }
         const float4 o4 = st_ld<PT_NT_SHADE_LD>(&st.rayO[pos]), d4 = st_ld<PT_NT_SHADE_LD>(&st.rayD[pos]);
-        const float4 th = st_ld<PT_NT_SHADE_LD>(&st.thr[pos]);
+        const float4 th = sp.first ? make_float4(1.f, 1.f, 1.f, 1.f) : st_ld<PT_NT_SHADE_LD>(&st.thr[pos]); // pathThroughput = 1, rayEta = 1 (deviceProgram.cu:379-380)
         dir_out = mk3(d4.x, d4.y, d4.z);
         thr_out = th;
         const v3 ray_o = mk3(o4.x, o4.y, o4.z), ray_dir = mk3(d4.x, d4.y, d4.z);
@@ -688,7 +688,6 @@ __global__ void __launch_bounds__(256) k_generate_region(PathState st, FramePara
         if (live) {
             st.rayO[pos] = make_float4(fp.eye.x, fp.eye.y, fp.eye.z, tmin);
             st.rayD[pos] = make_float4(dir.x, dir.y, dir.z, 1e16f);
-            st.thr[pos] = make_float4(1.f, 1.f, 1.f, 1.f);
             st.rf[pos] = make_uint4(seed1, seed2, depth0, 0u); // prd.depth = 0 (1 in the sv / sv2 variants)
         }
     }

@@ -206,3 +206,67 @@ def test_atrous_filter_properties(kind, orc_libm, orc_det):
     out = O.denoise(col, zeros, alb, 5, sigma_color=10.0, sigma_albedo=0.05)
     assert abs(out[:, : w // 2, :3].mean() - 0.2) < 0.01 and abs(out[:, w // 2 :, :3].mean() - 0.9) < 0.01
     assert out[:, w // 2 - 1, :3].max() < 0.3 and out[:, w // 2, :3].min() > 0.8
+
+
+def test_probe_line_search_model_equals_lower_bound():
+    """The device layout of ProbeSample's column search (pt_device.h: 128-byte lines of six columns + a u16 guide per row) restated in
+    numpy: for every row kind the reference's BuildCDF can produce — smooth, flat stretches, all-NaN — and widths around the line size,
+    guide -> candidate lines -> count gives the index of the reference's LowerBound (Probe.cuh:119-136).  Pins the ALGORITHM on the CPU; the
+    kernel itself is compared bit for bit on the GPU (test_probe_tables)."""
+    from optixpathtracer_amd import scenes
+
+    G = 6
+
+    def lower_bound_ref(row, v):  # Probe.cuh:119-136
+        lo, hi = 0, len(row)
+        while lo < hi:
+            mid = lo + (hi - lo) // 2
+            if row[mid] < v:
+                lo = mid + 1
+            else:
+                hi = mid
+        return lo
+
+    def model(row, v, gk):
+        w = len(row)
+        lpr = (w + G - 1) // G
+        cdf = np.full(lpr * G, np.inf, np.float32)
+        cdf[:w] = row
+        last = cdf.reshape(lpr, G)[:, G - 1]
+        with np.errstate(invalid="ignore"):
+            guide = np.array([int(np.sum(last < np.float32(k / gk))) for k in range(gk + 1)])  # counts: NaN compares false
+            k = min(int(np.float32(v) * np.float32(gk)), gk - 1)
+            lo, hi = min(guide[k], lpr - 1), min(guide[k + 1], lpr - 1)
+            while hi - lo > 2:
+                mid = lo + (hi - lo) // 2
+                if last[mid] < v:
+                    lo = mid + 1
+                else:
+                    hi = mid
+            i1 = min(lo + 1, hi)
+            l = lo
+            if i1 > lo and last[lo] < v:
+                l = i1
+                if hi > i1 and last[i1] < v:
+                    l = hi
+            return l * G + int(np.sum(cdf[l * G:(l + 1) * G] < v))
+
+    rng = np.random.default_rng(11)
+    probes = [scenes.spots_probe(1000, 16), scenes.spots_probe(4099, 4, fill=0.002), scenes.spots_probe(7, 5, fill=0.5), scenes.spots_probe(13, 3, fill=0.3),
+              scenes.constant_probe(5, 4), scenes.constant_probe(6, 8), scenes.sky_probe(256, 8), scenes.disc_probe(100, 10)]
+    for pr in probes:
+        p = pr.BuildCDF()
+        w, h = p.width, p.height
+        cdfx = np.asarray(p.cdfValuesX, np.float32).reshape(h, w)
+        gk = 64
+        while gk < 4096 and gk * 2 < w:
+            gk *= 2
+        for row in cdfx:
+            vs = np.concatenate([rng.random(40, dtype=np.float32), row[np.isfinite(row)][:8], np.float32([0.0, np.nextafter(np.float32(1), np.float32(0))])])
+            for v in vs:
+                if not (0.0 <= v < 1.0):
+                    continue
+                with np.errstate(invalid="ignore"):
+                    ref = lower_bound_ref(row, np.float32(v))
+                got = model(row, np.float32(v), gk)
+                assert min(got, w) == ref or (got >= w and ref == w), (w, v, got, ref)

@@ -45,7 +45,7 @@ struct PathState {
     float4 *prdN, *prdA; // prd.normal / prd.albedo, shadow-catcher scenes only (else null)
     // asynchronous shadow rays (pt_options.split_shadow = 2; null otherwise): every bounce b has its own shadow records
     // [b * bstride + slot] — origin, direction, pending contribution — so that the shadow rays of bounce b no longer have to
-    // finish before k_shade(b+1) overwrites the per-path slots, and a visibility bit per bounce instead of the immediate
+    // finish before k_shade(b+1) overwrites the bounce's shadow stream, and a visibility bit per bounce instead of the immediate
     // `direct/indirect += contribution`: k_resolve adds the visible contributions in bounce order, which keeps the
     // reference's float sums whatever order the shadow launches finish in.
     float4 *sO, *sD, *pendB;
@@ -445,8 +445,9 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
     }
 }
 
-// k_shade is half latency-bound (dependent scattered loads: state, triangle, probe CDF search): 5 waves per SIMD at 96 VGPRs
-// (11 dwords of scratch) measured +1.5 % on C2 and C3 over the compiler's 4 waves at 109; 6 and more lose to spills
+// k_shade waits on memory half of the time (dense state, then the triangle record and the probe search's scattered lines): 5 waves per SIMD
+// at 96 VGPRs measured +1.5 % on C2 and C3 over the compiler's 4 waves at 109 in round 2 and again with the round-3 kernel (4: +0.7 % frame
+// time, 6: ±0 with 8 spills, 7: slower)
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 5
 #endif

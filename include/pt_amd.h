@@ -77,7 +77,8 @@ enum pt_bsdf_mode { PT_BSDF_DISNEY = 0, PT_BSDF_LAMBERT = 1 /* Disney.cuh:125-14
 typedef struct pt_options {
     int32_t max_depth;      /* the literal 8 in deviceProgram.cu:429 */
     int32_t bsdf_mode;      /* pt_bsdf_mode */
-    uint32_t max_paths;     /* paths in flight per wavefront batch (0 = default 8Mi) */
+    uint32_t max_paths;     /* paths in flight per wavefront batch (0 = default 8Mi; ≈280 bytes of path state and queues per path: 2.3 GB,
+                             * three times that with frames_in_flight = 3, whose three batch sets each hold a whole frame) */
     int32_t kernel_timing;  /* 1: pt_stats.{trace,shadow,shade,other}_ms are measured with a pair of HIP events around every launch
                              *    (costs ≈0.3 ms of a 2 ms frame at a 1/8 share); 0 (default): only render_ms is measured */
     int32_t bvh_kind;       /* reserved, must be 0 (rounds 1-2: 1 = a binary BVH as an A/B path; removed — the 8-wide compressed tree is the structure) */

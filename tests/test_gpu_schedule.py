@@ -176,3 +176,24 @@ def test_multi_parallel_enqueue_and_overlapped_handoff(ptlib, capsys):
                   f"median {np.median(enq[1:]):.3f} ms, max {max(enq[1:]):.3f} ms")
         assert np.median(enq[1:]) < (0.5 if fif == 3 else 1.0)  # measured: 0.12 ms (whole frames, 21 launches), 0.41 ms (three pixel chunks, 63 launches)
         mr.close()
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_code_path_runs_over_rccl_with_one_rank():
+    """bench.py's N>1 code — process group on backend nccl (= RCCL), collectives on device tensors, the overlapped displayed-frame loop through
+    all_gather_into_tensor — with a world of one rank (--force-dist): what a 1-GPU box can rehearse of the driver's multi-GPU runs.  The
+    displayed frame is checked inside bench.py (complete, and the last frame)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-isolated",
+                          "--workload", "c2_cornell_1080p_4spp_d8"], capture_output=True, text=True, timeout=400, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
+    assert d["n_gpus"] == 1 and d["ms_per_displayed_frame"] is not None and d["ms_per_displayed_frame"] > 0
+    assert d["ms_per_displayed_frame"] < 1.5 * d["ms_per_step"], d  # the hand-off overlaps the rendering

@@ -11,12 +11,20 @@ N>1 (one process per GPU, torch.distributed over RCCL): the FIXED frame is tile-
 scaling" of a 1080p frame means.  `--scaling weak` (opt-in) grows the image to N x the pixels instead.
 `--workload c4_terrain1M_4k_16spp_d8` is BASELINE config C4 (3840x2160, 16 spp, tiled across the GPUs).
 `value` = rays traced by all ranks / max-over-ranks time of the K timed frames, each a device-synchronised pt_render like the
-reference's render() (SimplePathtracer.cpp:96) — `--frames-in-flight 3` / `--batch B` make the other schedules the
-timed mode.  After the timed region, for the record and never part of `value`: the same frames with three whole frames in flight
-(`mrays_per_s_pipelined`, `ms_per_frame_pipelined`; same images bit for bit), and on a partitioned frame the same frames as
-wavefront batches of N subframes (pt_render_batch: `batched`), and a loop that renders AND hands every frame over for display
-(pack -> one RCCL all-gather of the packed rgba8 strips -> unpack into the display buffer, the exchange of frame k overlapping
-the rendering of frame k+1): `ms_per_displayed_frame`, with the exchange alone as `gather_ms`.
+reference's render() (SimplePathtracer.cpp:96) FOR EVERY N: one launch chain per frame (`subframes_per_batch` 1,
+`frames_in_flight` 1) — `--frames-in-flight 3` / `--batch B` make the other schedules the timed mode.  After the timed region, for
+the record and never part of `value`: the same frames with three whole frames in flight (`mrays_per_s_pipelined`,
+`ms_per_frame_pipelined`; same images bit for bit), on a partitioned frame the same frames as wavefront batches of N subframes
+(pt_render_batch: `batched`, `batched_pipelined`), and a loop that renders AND hands every frame over for display (pack -> one RCCL
+all-gather of the packed rgba8 strips -> unpack into the display buffer, the exchange of frame k overlapping the rendering of
+frame k+1): `ms_per_displayed_frame` = loop time / frames handed over, with the exchange alone as `gather_ms`.
+`single_frame_launches` repeats the strict per-frame figure under one name whatever the timed mode is, so the 1/2/4/8 curve can
+be read from one key; `n_ranks_seen` is the size of the communicator the collectives ran on (RCCL's for backend nccl).
+
+`python3 bench.py --gpus N` without a launcher starts its own N ranks: N child processes of this script with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, spawned BEFORE this process imports torch or loads the
+HIP library (a process that has touched the GPU is never re-executed); rank 0's JSON line is relayed, the exit status is the
+worst child's.  Under `python -m torch.distributed.run` (WORLD_SIZE already set) it is a rank like before.
 
 Prints ONE JSON line on rank 0.
 """
@@ -37,6 +45,7 @@ WORKLOADS = {
     # name: (scene, camera, width, height, spp, depth)
     "c3_terrain1M_1080p_4spp_d8": ("terrain", "TERRAIN_CAMERA", 1920, 1080, 4, 8),
     "c2_cornell_1080p_4spp_d8": ("cornell", "CORNELL_CAMERA", 1920, 1080, 4, 8),
+    "c1_cornell_256_1spp_d4": ("cornell", "CORNELL_CAMERA", 256, 256, 1, 4),  # BASELINE config C1's size (tests of the launcher; Disney BSDF here, Lambert is a test case)
     "c4_terrain1M_4k_16spp_d8": ("terrain", "TERRAIN_CAMERA", 3840, 2160, 16, 8),
     # second 1 M-triangle workload (scenes.stadium_scene): rotated, displaced, long thin triangles over six decades of edge length, camera inside
     "stadium1M_1080p_4spp_d8": ("stadium", "STADIUM_CAMERA", 1920, 1080, 4, 8),
@@ -114,18 +123,24 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="concurrent pixel chunks per frame (0 = library default)")
     ap.add_argument("--kernel-timing", type=int, default=0, help="1: per-launch HIP-event timing inside the timed loop (slower; the isolated phase always has it)")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="pt_options.frames_in_flight of the TIMED loop. 0 (default): every frame synchronous like the reference's render(); 3: frame k runs whole on stream k mod 3 and pt_render(k) returns once frame k-2 is complete (three frames overlap, same images); 2: pixel chunks as in the synchronous frame, pt_render(k) waits for frame k-1")
-    ap.add_argument("--batch", type=int, default=0, help="timed loop: frames are rendered as wavefront batches of this many subframes (pt_render_batch; the last batch of the loop may be shorter). 0 (default) = the number of ranks the frame is partitioned over: 1 on one GPU (every frame its own pt_render, like the reference's loop); N on N GPUs, so that a launch chain carries the paths of one whole frame however many ways the image is split")
+    ap.add_argument("--batch", type=int, default=1, help="timed loop: frames are rendered as wavefront batches of this many subframes (pt_render_batch; the last batch of the loop may be shorter). 1 (default, every N) = every frame its own pt_render, like the reference's loop; the batched schedule (N subframes per launch chain on an N-way partition) is reported beside it under `batched`")
     ap.add_argument("--no-extra-schedules", action="store_true", help="skip the extra frames after the timed region (pipelined / batched figures; profiling runs: keeps the frame count at warmup + steps)")
+    ap.add_argument("--launch-check", action="store_true", help="ranks only join the process group, all-reduce their rank and print {n_ranks_seen}: tests the self-launcher without a GPU")
     args = ap.parse_args()
 
-    import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # nothing GPU-related has been imported yet
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.launch_check:
+        return launch_check(rank, world, args.backend)
+
+    import torch
+
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -180,8 +195,6 @@ def main():
     sv4 = args.workload.startswith("sv4_")
     foveated = "foveated" in args.workload
 
-    if args.batch == 0:
-        args.batch = 1 if sv4 else part_world
     if args.batch < 1 or (args.batch > 1 and sv4):
         raise SystemExit("--batch B needs a pt_render workload")
 
@@ -231,15 +244,18 @@ def main():
     s0 = r.stats()
     t0 = time.perf_counter()
     n_chains = 0
+    stamps = [t0]
     for k in range(0, args.steps, args.batch):
         render_frame(warm + k, min(args.batch, args.steps - k))
         n_chains += 1
+        stamps.append(time.perf_counter())  # synchronous schedule: the chain is complete here; frames in flight: host pacing only
         if per_frame_stats:
             st = r.stats()
             for key in agg:
                 agg[key] += st[key]
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = np.diff(np.asarray(stamps)) * 1e3 / args.batch
     st = r.stats()
     assert st["frames"] - s0["frames"] == args.steps, (st["frames"], s0["frames"])
     rays = (st["total_radiance_rays"] + st["total_shadow_rays"]) - (s0["total_radiance_rays"] + s0["total_shadow_rays"])
@@ -346,7 +362,7 @@ def main():
         dd = time.perf_counter() - d0
         tt = torch.tensor([dd, g_acc], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ms_displayed = float(tt[0]) / (nd * bd) * 1e3  # per frame of the loop, comparable with ms_per_step; a hand-over every `bd` frames
+        ms_displayed = float(tt[0]) / nd * 1e3  # loop time / frames actually handed over for display (one per launch chain)
         gather_ms = float(tt[1]) / nd * 1e3            # host time of one hand-over (wait for the strip, all-gather, enqueue the scatter)
         # the displayed frame must be complete and must be the last frame: rgba8 alpha is 255 wherever a rank wrote, and this rank's own pixels equal its frame buffer
         shown = r.downloadDisplay(R.PT_BUF_FRAME)
@@ -455,14 +471,18 @@ def main():
             "ms_per_frame_pipelined": extra_out.get("pipelined", {}).get("ms_per_frame"),
             "batched": extra_out.get("batched"),
             "batched_pipelined": extra_out.get("batched_pipelined"),
-            "single_frame_launches": extra_out.get("single_frame_launches"),  # partitioned frame, every frame its own pt_render (subframes_per_batch 1)
+            # the strict per-frame schedule (every frame its own device-synchronised pt_render) under one key for every N: the timed loop itself unless --batch / --frames-in-flight changed it
+            "single_frame_launches": extra_out.get("single_frame_launches") or ({"ms_per_frame": round(frame_s * 1e3, 3), "mrays_per_s": round(mrays, 2), "frames": args.steps, "subframes_per_batch": 1} if (args.batch == 1 and not pipelined) else None),
             # device time from a launch chain's first kernel to its last (with frames in flight: one frame's LATENCY, three frames overlap) — of the last chain of the loop
             "frame_latency_ms": round(agg["render_ms"] / n_chains, 3),
             "ms_per_step_per_rank": per_rank_ms,
             "kernel_ms_per_frame_isolated": None if iso is None else {k: round(iso[k], 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
             "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2), "hierarchy": ["lbvh", "ploc", "imported"][st["bvh_builder"]]},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
-            "ms_per_displayed_frame": None if ms_displayed is None else round(ms_displayed, 3),  # per frame, in a loop that hands every launch chain's result over (every subframes_per_batch frames), the exchange overlapping the next chain
+            "ms_per_displayed_frame": None if ms_displayed is None else round(ms_displayed, 3),  # loop time / frames handed over, in a loop that hands every launch chain's result over, the exchange overlapping the next chain
+            "n_ranks_seen": 1 if dist is None else dist.get_world_size(),  # size of the communicator the collectives ran on (RCCL's for backend nccl)
+            # spread of the timed steps on rank 0 (host clock after each device-synchronised step): tells a box effect (boxes differ by about 2 %) from a change
+            "step_ms": {"min": round(float(step_ms.min()), 3), "median": round(float(np.median(step_ms)), 3), "max": round(float(step_ms.max()), 3)},
             "roofline": {
                 "kernel": "whole frame, all wavefront stages (SURVEY.md 8d: rays x 160 B + pixels x 84 B + scene bytes)", "bound": "hbm",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -485,6 +505,80 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """`python3 bench.py --gpus N` by itself: N children of this very command line, one per GPU, rendezvous on 127.0.0.1.  Runs before
+    torch / libptamd.so are imported, so the parent never touches a GPU; no exec anywhere.  Rank 0's stdout is this process's stdout."""
+    import socket
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for rk in range(n):
+        env = dict(os.environ, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rk == 0 else subprocess.DEVNULL, text=rk == 0))
+
+    def relay(pipe):  # the contract is ONE JSON line on stdout: anything else rank 0 prints there (gloo's connection banner) goes to stderr
+        for line in pipe:
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+
+    import threading
+    th = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    th.start()
+    worst = 0
+    try:
+        # a rank that dies leaves the others in a collective: when one fails, give the rest a moment and end them
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                try:
+                    rc = p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.remove(p)
+                if rc != 0:
+                    worst = worst or (rc if rc > 0 else 128 - rc)
+                    deadline = time.time() + 20
+                    for q in pending:
+                        try:
+                            q.wait(timeout=max(0.1, deadline - time.time()))
+                        except subprocess.TimeoutExpired:
+                            q.kill()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        th.join(timeout=5)
+    return worst
+
+
+def launch_check(rank, world, backend):
+    """What --launch-check runs in each rank: join the group, all-reduce, rank 0 prints the communicator's size (no GPU unless backend nccl)."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend)
+    t = torch.tensor([float(rank + 1)], device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t)
+    ok = float(t[0]) == world * (world + 1) / 2
+    if rank == 0:
+        print(json.dumps({"launch_check": ok, "n_gpus": world, "n_ranks_seen": dist.get_world_size(), "backend": backend}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
 
 
 def host_cpu_share():

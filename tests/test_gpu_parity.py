@@ -1490,6 +1490,9 @@ def test_bench_line_contract(ptlib):
     # the headline is the reference's semantics: every frame a device-synchronised pt_render; the other schedules ride along
     assert d["frames_in_flight"] == 1 and d["subframes_per_batch"] == 1
     assert d["mrays_per_s_pipelined"] > 0.8 * d["value"] and d["ms_per_frame_pipelined"] > 0 and d["batched"] is None
+    assert d["n_ranks_seen"] == 1 and d["single_frame_launches"]["ms_per_frame"] == d["ms_per_step"]
+    sm = d["step_ms"]
+    assert sm["min"] <= sm["median"] <= sm["max"] and abs(sm["median"] - d["ms_per_step"]) < 0.25 * d["ms_per_step"]
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0.0 < rf["frac"] < 1.0

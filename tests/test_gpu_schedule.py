@@ -197,3 +197,31 @@ def test_bench_multi_gpu_code_path_runs_over_rccl_with_one_rank():
     d = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
     assert d["n_gpus"] == 1 and d["ms_per_displayed_frame"] is not None and d["ms_per_displayed_frame"] > 0
     assert d["ms_per_displayed_frame"] < 1.5 * d["ms_per_step"], d  # the hand-off overlaps the rendering
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with NO launcher (the way the driver issues the N-GPU run): the script spawns its two ranks itself before
+    touching the GPU, rank 0's single JSON line comes back on stdout, and the line carries the timed per-frame schedule, the batched one,
+    the displayed-frame loop and the communicator's size.  Rehearsed on the one-GPU box with gloo and a shared device."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "4", "--warmup", "1",
+                          "--workload", "c2_cornell_1080p_4spp_d8"], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "strong"
+    assert d["frames_in_flight"] == 1 and d["subframes_per_batch"] == 1  # the timed loop is one pt_render per frame for every N
+    assert d["single_frame_launches"]["ms_per_frame"] == d["ms_per_step"]
+    assert d["batched"]["subframes_per_batch"] == 2 and d["batched"]["ms_per_frame"] > 0 and d["batched_pipelined"]["ms_per_frame"] > 0
+    assert d["ms_per_displayed_frame"] > 0 and d["gather_ms"] >= 0
+    assert d["step_ms"]["min"] <= d["step_ms"]["median"] <= d["step_ms"]["max"]
+    assert len(d["ms_per_step_per_rank"]) == 2

@@ -139,3 +139,39 @@ def test_pixel_lists_cover_and_order():
             assert sizes.max() / sizes.min() < 1.05
     l = multigpu.pixel_lists(16, 16, 1)[0]
     assert (l[:8] & 0xFFFF).tolist() == list(range(8)) and (l[:64] >> 16).max() == 7  # 8x8 block order
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_self_launcher_cpu(n):
+    """`python3 bench.py --gpus N` without a launcher spawns its own N ranks (before importing torch), relays exactly one JSON line from
+    rank 0 and exits with the children's status.  --launch-check keeps the ranks off the GPU: they join the gloo group and all-reduce."""
+    import json
+    import subprocess
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "gloo", "--launch-check"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d == {"launch_check": True, "n_gpus": n, "n_ranks_seen": n, "backend": "gloo"}
+
+
+def test_bench_self_launcher_reports_a_failed_rank():
+    """A rank that cannot start (backend nccl without a GPU here; any failure on a GPU box) must end the launcher with a non-zero status
+    instead of leaving the other ranks in a collective."""
+    import subprocess
+
+    import torch
+
+    from conftest import ROOT
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "nccl", "--launch-check"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode != 0 and not res.stdout.strip()

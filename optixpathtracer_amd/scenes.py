@@ -66,6 +66,7 @@ class TriangleMesh:  # Model.h:10-19
     material: np.ndarray  # MATERIAL_DTYPE scalar
     diffuseTextureID: int = -1
     texcoord: np.ndarray = None  # (nv,2) f32 or None
+    normal: np.ndarray = None  # (nv,3) f32 or None — uploaded but never read by the reference's device code (deviceProgram.cu:488-490 shades flat)
 
 
 @dataclass
@@ -142,7 +143,8 @@ def add_box(model: Model, material, pos, extend) -> None:
     verts = [A, B, C, A, C, D, E, H, G, E, G, F, E, A, D, E, D, H, B, F, G, B, G, C, D, C, G, D, G, H, E, A, B, E, B, F]
     v = np.array(verts, np.float32)
     idx = np.arange(36, dtype=np.uint32).reshape(12, 3)
-    model.meshes.append(TriangleMesh(v, idx, np.array(material, dtype=MATERIAL_DTYPE)))
+    nrm = np.repeat(np.array([(0, 0, 1), (0, 0, -1), (-1, 0, 0), (1, 0, 0), (0, 1, 0), (0, -1, 0)], np.float32), 6, axis=0)  # :243-258
+    model.meshes.append(TriangleMesh(v, idx, np.array(material, dtype=MATERIAL_DTYPE), texcoord=np.zeros((36, 2), np.float32), normal=nrm))
 
 
 def cornell_box() -> Model:

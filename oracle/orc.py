@@ -282,4 +282,53 @@ def load_ref():
         R.ref_lerp3.argtypes = [f32p, f32p, C.c_float, f32p]
         R.ref_clamp3.argtypes = [f32p, C.c_float, C.c_float, f32p]
         R.ref_to_srgb.argtypes = [f32p, f32p]
+    if hasattr(R, "refm_load_obj"):  # oracle/ref_build/ref_model.cpp: the reference's Model.cpp
+        R.refm_load_obj.restype = C.c_void_p
+        R.refm_load_obj.argtypes = [C.c_char_p]
+        R.refm_new_model.restype = C.c_void_p
+        R.refm_add_box.argtypes = [C.c_void_p, C.c_void_p, f32p, f32p]
+        for fn in (R.refm_num_meshes, R.refm_num_textures):
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p]
+        i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+        R.refm_mesh_sizes.argtypes = [C.c_void_p, C.c_int, i32p]
+        R.refm_mesh_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        R.refm_texture_size.argtypes = [C.c_void_p, C.c_int, i32p]
+        R.refm_texture_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     return R
+
+
+def ref_model_arrays(R, handle):
+    """What the reference's Model holds (Model.h:10-42), as numpy arrays: ([mesh dict], [texture (h,w) u32])."""
+    from optixpathtracer_amd import scenes
+
+    meshes, textures = [], []
+    for i in range(R.refm_num_meshes(handle)):
+        sz = np.zeros(5, np.int32)
+        R.refm_mesh_sizes(handle, i, sz)
+        v = np.zeros((sz[0], 3), np.float32); n = np.zeros((sz[1], 3), np.float32); tc = np.zeros((sz[2], 2), np.float32)
+        idx = np.zeros((sz[3], 3), np.uint32); mat = np.zeros((), scenes.MATERIAL_DTYPE)
+        R.refm_mesh_copy(handle, i, v.ctypes.data, n.ctypes.data, tc.ctypes.data, idx.ctypes.data, mat.ctypes.data)
+        meshes.append(dict(vertex=v, normal=n, texcoord=tc, index=idx, material=mat, diffuseTextureID=int(sz[4])))
+    for i in range(R.refm_num_textures(handle)):
+        res = np.zeros(2, np.int32)
+        R.refm_texture_size(handle, i, res)
+        px = np.zeros((res[1], res[0]), np.uint32)
+        R.refm_texture_copy(handle, i, px.ctypes.data)
+        textures.append(px)
+    return meshes, textures
+
+
+def ref_load_obj(R, path):
+    """loadOBJ of the reference itself (None when it threw)."""
+    h = R.refm_load_obj(os.fsencode(path))
+    return None if not h else ref_model_arrays(R, h)
+
+
+def ref_add_boxes(R, boxes):
+    """addBox of the reference itself for a list of (material, pos, extend)."""
+    h = R.refm_new_model()
+    for mat, pos, ext in boxes:
+        m = np.array(mat)
+        R.refm_add_box(h, m.ctypes.data, np.array(pos, np.float32), np.array(ext, np.float32))
+    return ref_model_arrays(R, h)[0]

@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
         for (uint32_t s = 0; s < subframes; ++s) {      // the render loop, main.cpp:273-286
             sample.launchParams.frame.subframe_index = s;
             if (pipelined) sample.render();
-            else sample.render(pixels.data());
+            else sample.renderToHost(pixels.data());
         }
         if (pipelined) sample.downloadPixels(pixels.data()); // waits for the last frame
         std::vector<float> accum((size_t)w * h * 4);

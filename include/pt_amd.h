@@ -13,6 +13,26 @@
  * the message for the calling context (the reference throws sutil::Exception from
  * CUDA_CHECK/OPTIX_CHECK, sutil/Exception.h:93-195).  A context is single-threaded,
  * like the reference's renderer (one stream, device-synchronised render()).
+ *
+ * STREAM CONTRACT.  Every kernel and copy of a context runs on streams the context created with
+ * hipStreamNonBlocking: they do NOT synchronise with the null stream or with any stream of the
+ * caller (the current stream of a tensor framework included).  Entry points that take HOST pointers are complete when
+ * they return.  Entry points that take or return DEVICE pointers — pt_pack, pt_unpack, pt_pack_async,
+ * pt_unpack_display, pt_render_device, pt_device_buffer, pt_display_buffer — read and write them on
+ * pt_stream(ctx), so:
+ *   - a buffer the caller PRODUCED on another stream (the receive buffer of an all-gather, a buffer a
+ *     memset just cleared) must be complete before the call: synchronise that stream on the host, or
+ *     record an event on it and hand it to pt_wait_event(ctx, event) first (device-side ordering);
+ *   - a buffer the library produced is complete when the call returned, for the synchronous entry
+ *     points (pt_pack, pt_unpack, pt_render_device), and after pt_pack_wait / pt_display_sync for the
+ *     asynchronous ones; to consume it on another stream without a host wait, enqueue the consumer
+ *     on pt_stream(ctx) or make that stream wait for an event recorded on pt_stream(ctx).
+ *
+ * VERSIONING.  pt_version() = "ptamd <major>.<minor> ...".  Structs only ever grow at the end; a caller
+ * that may meet a newer or older library uses pt_get_stats_n(ctx, &s, sizeof s) (copies the common
+ * prefix) instead of pt_get_stats, which writes sizeof(pt_stats) of the LIBRARY's header
+ * (pt_stats_size()).  0.2 -> 0.4: pt_stats grew by bvh_builder + reserved_ (8 bytes), pt_multi_stats by
+ * enqueue_ms, threads, frames_handed_over.
  */
 #ifndef PT_AMD_H
 #define PT_AMD_H
@@ -200,6 +220,16 @@ int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host
  * not displayed: a display loop that shows every frame keeps calling pt_render.  count in [1,4096]; pt_render == count 1.
  * pt_stats.frames advances by count. */
 int pt_render_batch(pt_ctx* ctx, uint32_t spp, uint32_t first_subframe, uint32_t count, uint32_t* host_rgba8);
+/* SampleRenderer::render(sutil::CUDAOutputBuffer<uint32_t>&) (SimplePathtracer.cpp:99-107): the rgba8 frame lands in a caller-owned
+ * DEVICE buffer (width*height*4 bytes on the context's device; the reference aliases the caller's mapped buffer as frame_buffer for
+ * the launch).  Synchronous like render(): the buffer is complete when the call returns (also with frames in flight). */
+int pt_render_device(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, void* dev_rgba8);
+/* SampleRenderer::stream (SimplePathtracer.h:107, handed to the display path at main.cpp:245): the hipStream_t (as void*) on which the
+ * context's packs, unpacks, epilogues and device copies run — see STREAM CONTRACT at the top. */
+void* pt_stream(pt_ctx* ctx);
+/* Device-side ordering instead of a host wait: everything the context enqueues on pt_stream(ctx) from now on waits for `hip_event`
+ * (a hipEvent_t the caller recorded on its own stream after producing a buffer it is about to hand in).  No reference counterpart. */
+int pt_wait_event(pt_ctx* ctx, void* hip_event);
 /* Waits for the frames in flight (pt_options.frames_in_flight = 2 or 3) and reports their errors; a no-op otherwise.  No reference
  * counterpart: the reference's render() is synchronous. */
 int pt_sync(pt_ctx* ctx);
@@ -303,6 +333,9 @@ void* pt_display_buffer(pt_ctx* ctx, int which); /* NULL until the first pt_unpa
 int pt_download_display(pt_ctx* ctx, int which, void* host, size_t bytes);
 
 int pt_get_stats(const pt_ctx* ctx, pt_stats* out);
+/* size-checked variant (see VERSIONING): copies min(out_bytes, pt_stats_size()) bytes, zero-fills the rest */
+int pt_get_stats_n(const pt_ctx* ctx, void* out, size_t out_bytes);
+size_t pt_stats_size(void);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Several GPUs from ONE process (SURVEY.md 8b "pt_create_multi"; the reference renders on whatever single device is

@@ -20,6 +20,7 @@ EXPORTS = [
     "pt_multi_set_probe_image", "pt_multi_resize", "pt_multi_set_camera", "pt_multi_render", "pt_multi_render_regions", "pt_multi_gather",
     "pt_multi_get_stats", "pt_export_bvh", "pt_render_batch", "pt_multi_render_batch",
     "pt_pack_async", "pt_pack_wait", "pt_unpack_display", "pt_display_sync", "pt_display_buffer", "pt_download_display", "pt_multi_flush",
+    "pt_render_device", "pt_stream", "pt_wait_event", "pt_get_stats_n", "pt_stats_size",
 ]
 
 
@@ -146,6 +147,12 @@ def load_library() -> C.CDLL:
     L.pt_render.argtypes = [vp, u32, u32, vp]
     L.pt_render_batch.argtypes = [vp, u32, u32, u32, vp]
     L.pt_sync.argtypes = [vp]
+    L.pt_render_device.argtypes = [vp, u32, u32, vp]
+    L.pt_stream.restype = vp
+    L.pt_stream.argtypes = [vp]
+    L.pt_wait_event.argtypes = [vp, vp]
+    L.pt_get_stats_n.argtypes = [vp, vp, C.c_size_t]
+    L.pt_stats_size.restype = C.c_size_t
     L.pt_render_regions.argtypes = [vp, C.POINTER(Region), u32, C.POINTER(Variant), vp]
     L.pt_download.argtypes = [vp, i, vp, C.c_size_t]
     L.pt_upload_accum.argtypes = [vp, vp, C.c_size_t]

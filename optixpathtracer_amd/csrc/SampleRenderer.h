@@ -1,9 +1,10 @@
 // SampleRenderer.h — header-only C++ facade with the reference's public surface
-// (HelloPathtracing_original/SimplePathtracer.h:38-176, Model.h:10-42, Material.h:11-69, Probe.h:8-88)
-// over the C ABI of libptamd.so (include/pt_amd.h).  A maintainer of the reference swaps
-// SimplePathtracer.{h,cpp} + deviceProgram.cu for this header and links -lptamd; main.cpp's calls
-// (main.cpp:211-218,262,273,286) compile unchanged apart from the sutil display buffer type
-// (see INTEGRATION.md).  Errors surface as std::runtime_error, like sutil::Exception did.
+// (HelloPathtracing_original/SimplePathtracer.h:38-176, Model.h:10-42, Material.h:11-69, Probe.h:8-88,
+// LaunchParams.h:32-38,51-79) over the C ABI of libptamd.so (include/pt_amd.h).  A maintainer of the reference swaps
+// SimplePathtracer.{h,cpp} + deviceProgram.cu for this header and links -lptamd; what main.cpp does with the
+// renderer (main.cpp:131-144 initLaunchParams, :211-218, :245 output_buffer.setStream(sample.stream), :259, :273
+// sample.render(output_buffer), :286) compiles against it as written — tests/test_cabi.py compiles those statements.
+// Errors surface as std::runtime_error, like sutil::Exception did.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -21,6 +22,11 @@ struct float4 { float x, y, z, w; };
 struct int2 { int x, y; };
 struct uint3 { uint32_t x, y, z; };
 typedef float4 Color;
+// the few sutil/vec_math.h helpers main.cpp's renderer set-up uses (main.cpp:138-143,215)
+inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
+inline int2 make_int2(int x, int y) { return int2{x, y}; }
+inline float3 cross(const float3& a, const float3& b) { return float3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float3 normalize(const float3& v) { const float inv = 1.0f / std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z); return float3{v.x * inv, v.y * inv, v.z * inv}; }
 
 static const int MATERIAL_FLAG_NONE = 0;
 static const int MATERIAL_FLAG_SHADOW_CATCHER = 1 << 0; // Material.h:9
@@ -88,11 +94,24 @@ struct Camera {
     void UVWFrame(float3& U, float3& V, float3& W) const { pt_uvw_frame(&eye.x, &lookat.x, &up.x, fovY, aspectRatio, &U.x, &V.x, &W.x); }
 };
 
-// the fields of LaunchParams the application pokes directly (LaunchParams.h:51-79; main.cpp:131-144,286)
+// LaunchParams.h:32-38 — set by initLaunchParams (main.cpp:138-143), never read by the device code
+struct ParallelogramLight {
+    float3 corner{0, 0, 0};
+    float3 v1{0, 0, 0}, v2{0, 0, 0};
+    float3 normal{0, 0, 0};
+    float3 emission{0, 0, 0};
+};
+
+// the host-visible part of LaunchParams (LaunchParams.h:51-79; main.cpp:131-144,259,286): the device pointers, the traversable and the
+// probe of the reference's struct live inside the context
 struct LaunchParams {
     struct { int2 size{0, 0}; unsigned int subframe_index = 0; } frame;
+    struct { float3 eye{0, 0, 0}, U{0, 0, 0}, V{0, 0, 0}, W{0, 0, 0}; } camera; // written by setCamera (SimplePathtracer.cpp:155-162)
     unsigned int samples_per_launch = 1;
+    ParallelogramLight light; // dead in the reference too
 };
+
+typedef void* stream_t; // hipStream_t, kept opaque so that the application side needs no HIP header
 
 class SampleRenderer {
   public:
@@ -111,14 +130,25 @@ class SampleRenderer {
         for (size_t i = 0; i < td.size(); ++i) td[i] = pt_texture_desc{model->textures[i]->pixel, model->textures[i]->resolution.x, model->textures[i]->resolution.y};
         pt_scene_desc sd{md.data(), (uint32_t)md.size(), td.data(), (uint32_t)td.size()};
         if (pt_create(&sd, device, &ctx) != PT_OK) throw std::runtime_error(std::string("SampleRenderer: ") + pt_last_error(nullptr));
+        stream = pt_stream(ctx);
     }
     ~SampleRenderer() { pt_destroy(ctx); }
     SampleRenderer(const SampleRenderer&) = delete;
     SampleRenderer& operator=(const SampleRenderer&) = delete;
 
     void render() { ck(pt_render(ctx, launchParams.samples_per_launch, launchParams.frame.subframe_index, nullptr)); }
-    // render(sutil::CUDAOutputBuffer<uint32_t>&): the caller's mapped buffer receives the rgba8 frame
-    void render(uint32_t* h_pixels) { ck(pt_render(ctx, launchParams.samples_per_launch, launchParams.frame.subframe_index, h_pixels)); }
+    // render(sutil::CUDAOutputBuffer<uint32_t>&) (SimplePathtracer.cpp:99-107): `renderTarget.map()` yields the caller's DEVICE buffer, the
+    // rgba8 frame is written there, `unmap()`.  Any type with map() -> uint32_t* (device) and unmap() fits, sutil's buffer included.
+    template <class OutputBuffer> void render(OutputBuffer& renderTarget) {
+        uint32_t* d_pixels = renderTarget.map();
+        const int rc = pt_render_device(ctx, launchParams.samples_per_launch, launchParams.frame.subframe_index, d_pixels);
+        renderTarget.unmap();
+        ck(rc);
+    }
+    // the same with the mapped device pointer itself
+    void render(uint32_t* d_pixels) { ck(pt_render_device(ctx, launchParams.samples_per_launch, launchParams.frame.subframe_index, d_pixels)); }
+    // render() + downloadPixels() in one call: the frame in HOST memory
+    void renderToHost(uint32_t* h_pixels) { ck(pt_render(ctx, launchParams.samples_per_launch, launchParams.frame.subframe_index, h_pixels)); }
     // `count` iterations of the application's progressive loop (render(); launchParams.frame.subframe_index++ — main.cpp:273-278) as one
     // wavefront batch: the same buffers bit for bit, count times the rays per launch (pt_render_batch).  Advances subframe_index by count.
     void renderBatch(uint32_t count, uint32_t* h_pixels = nullptr) {
@@ -135,6 +165,7 @@ class SampleRenderer {
     void setCamera(const Camera& camera) {
         float3 U, V, W;
         camera.UVWFrame(U, V, W);
+        launchParams.camera.eye = camera.eye; launchParams.camera.U = U; launchParams.camera.V = V; launchParams.camera.W = W;
         ck(pt_set_camera(ctx, &camera.eye.x, &U.x, &V.x, &W.x));
     }
     void setProbe(const ProbeData& probe) {
@@ -157,8 +188,9 @@ class SampleRenderer {
         ck(pt_set_options(ctx, &o));
     }
     void sync() { ck(pt_sync(ctx)); }
-    bool denoiserOn = false; // SimplePathtracer.h:63: the flag exists in the reference but nothing reads it (OptixDenoiser.cpp:15-42 is empty)
-    LaunchParams launchParams;
+    bool denoiserOn = true;  // SimplePathtracer.h:63 (default true there too); nothing reads it in the reference (OptixDenoiser.cpp:15-42 is empty)
+    LaunchParams launchParams;   // SimplePathtracer.h:137
+    stream_t stream = nullptr;   // SimplePathtracer.h:107: the context's stream (pt_stream), e.g. for output_buffer.setStream(sample.stream), main.cpp:245
     pt_ctx* ctx = nullptr;
 
   private:

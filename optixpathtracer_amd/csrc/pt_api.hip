@@ -194,7 +194,7 @@ struct DevScope {
     }
 };
 
-extern "C" const char* pt_version(void) { return "ptamd 0.2 (gfx950 wavefront path tracer)"; }
+extern "C" const char* pt_version(void) { return "ptamd 0.4 (gfx950 wavefront path tracer)"; }
 
 extern "C" const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -1402,6 +1402,32 @@ extern "C" int pt_render_batch(pt_ctx* ctx, uint32_t spp, uint32_t first_subfram
 }
 
 
+// render(sutil::CUDAOutputBuffer<uint32_t>&) (SimplePathtracer.cpp:99-107): the reference points frame_buffer at the caller's mapped DEVICE
+// buffer for the launch.  Here the frame is rendered into the context's own frame buffer and copied device-to-device (8 MB at 1080p: a few
+// microseconds), so pt_download / the display hand-off keep seeing the frame too; the call returns when the copy is complete.
+extern "C" int pt_render_device(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, void* dev_rgba8) {
+    if (!ctx || !dev_rgba8) return PT_ERR_INVALID;
+    int rc = pt_render_batch(ctx, spp, subframe_index, 1, nullptr);
+    if (rc == PT_OK) rc = drain(ctx); // frames in flight: this frame has to be complete
+    if (rc != PT_OK) return rc;
+    if (ctx->width == 0) return PT_OK; // not resized yet: render() silently returns (:77)
+    CK(hipSetDevice(ctx->device));
+    CK(hipMemcpyAsync(dev_rgba8, ctx->frame, sizeof(uint32_t) * (size_t)ctx->width * ctx->height, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+// SampleRenderer::stream (SimplePathtracer.h:107; main.cpp:245 hands it to the display path): the stream the context's epilogues, packs and
+// unpacks run on.  hipStreamNonBlocking: it does not synchronise with the null stream.
+extern "C" void* pt_stream(pt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int pt_wait_event(pt_ctx* ctx, void* hip_event) {
+    if (!ctx || !hip_event) return PT_ERR_INVALID;
+    CK(hipSetDevice(ctx->device));
+    CK(hipStreamWaitEvent(ctx->stream, (hipEvent_t)hip_event, 0));
+    return PT_OK;
+}
+
 // The foveated variants' render() (HelloPathtracing_sv4_vmv23/SimplePathtracer.cpp:132-216) issues up to three
 // optixLaunch calls per frame with different LaunchParams.frame.{factor,fillSize,c,r_inner,r_outer,offset,redraw},
 // samples_per_launch and subframe_index; later launches overwrite the pixels of earlier ones, so the launches run
@@ -1780,6 +1806,17 @@ extern "C" int pt_get_stats(const pt_ctx* ctx, pt_stats* out) {
     return PT_OK;
 }
 
+extern "C" size_t pt_stats_size(void) { return sizeof(pt_stats); }
+extern "C" int pt_get_stats_n(const pt_ctx* ctx, void* out, size_t out_bytes) {
+    if (!ctx || !out) return PT_ERR_INVALID;
+    pt_stats s;
+    int rc = pt_get_stats(ctx, &s);
+    if (rc != PT_OK) return rc;
+    memcpy(out, &s, out_bytes < sizeof(s) ? out_bytes : sizeof(s)); // fields are only ever appended: a caller built against an older header gets its prefix
+    if (out_bytes > sizeof(s)) memset((char*)out + sizeof(s), 0, out_bytes - sizeof(s));
+    return PT_OK;
+}
+
 extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit, float* t_out, int32_t* prim_out, int iters,
                         double* kernel_ms) {
     if (!ctx || !rays || !prim_out || (!any_hit && !t_out)) return PT_ERR_INVALID;
@@ -1917,7 +1954,22 @@ extern "C" int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material
 // ===================================================================================================================
 // pt_multi: N contexts in one process (include/pt_amd.h).  No reference counterpart: the reference is single-GPU.
 #include <dlfcn.h>
-#include <rccl/rccl.h> // declarations only: the pointer types below are RCCL's own, the library itself is opened at run time
+// declarations only: the pointer types below are RCCL's own, the library itself is opened at run time
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else // a box without RCCL's headers: the six prototypes as rccl.h (2.x) declares them, so that libptamd still builds (single-GPU path, peer copies)
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+extern "C" {
+ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclGroupStart();
+ncclResult_t ncclGroupEnd();
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include <chrono>
 #include <condition_variable>

@@ -60,9 +60,13 @@ class DevicePacker:
         return buf
 
     def sync(self):
-        """The all-gather runs on RCCL's stream and torch's current stream waits for it; pt_unpack runs on the library's
-        own stream, so the hand-over between the two is made explicit instead of relying on null-stream semantics."""
-        self.torch.cuda.current_stream().synchronize()
+        """The all-gather runs on RCCL's stream and torch's current stream waits for it; pt_unpack runs on the library's own
+        (non-blocking) stream, so the hand-over between the two is made explicit (include/pt_amd.h, STREAM CONTRACT): an event recorded
+        on torch's stream behind the collective, which the context's stream waits for on the device — no host wait."""
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream())
+        self.r.waitEvent(ev.cuda_event)
+        self._ev = ev  # alive until the next hand-over
 
     def pack(self, which, dst):
         self.r.pack(which, dst.data_ptr())

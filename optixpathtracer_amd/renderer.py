@@ -122,6 +122,20 @@ class SampleRenderer:
             ptr = out.ctypes.data
         self._ck(self._L.pt_render(self._ctx, int(self.launchParams.samples_per_launch), int(self.launchParams.frame.subframe_index), ptr), "pt_render")
 
+    def renderDevice(self, dev_ptr: int):
+        """render(sutil::CUDAOutputBuffer<uint32_t>&) (SimplePathtracer.cpp:99-107): the rgba8 frame lands in the caller's DEVICE buffer
+        (width*height*4 bytes, e.g. tensor.data_ptr()); complete when the call returns (pt_render_device)."""
+        self._ck(self._L.pt_render_device(self._ctx, int(self.launchParams.samples_per_launch), int(self.launchParams.frame.subframe_index), dev_ptr), "pt_render_device")
+
+    @property
+    def stream(self) -> int:
+        """SampleRenderer::stream (SimplePathtracer.h:107): the context's hipStream_t as an integer (pt_stream); non-blocking."""
+        return self._L.pt_stream(self._ctx)
+
+    def waitEvent(self, hip_event: int):
+        """Everything enqueued on the context's stream from now on waits for the caller's event (pt_wait_event; torch: event.cuda_event)."""
+        self._ck(self._L.pt_wait_event(self._ctx, hip_event), "pt_wait_event")
+
     def renderBatch(self, count: int, out: np.ndarray | None = None):
         """`count` iterations of the reference's progressive loop (render(); subframe_index++, main.cpp:273-278) as ONE wavefront
         batch (pt_render_batch): same buffers bit for bit, count times the rays per launch.  Like render(), it leaves

@@ -113,3 +113,65 @@ def test_bench_source_hash_ignores_comments_only():
         pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
         if pmc["src_hash"] != bench.source_hash():  # not an error of the code: bench.py then simply does not quote the PMC-derived numbers
             pytest.skip(f"profiles/{name} was measured on other kernel sources (re-run tools/profile_r3.sh to quote its numbers)")
+
+
+def test_reference_main_cpp_statements_compile_against_the_facade(tmp_path):
+    """What the reference's application does with its renderer (HelloPathtracing_original/main.cpp:131-144 initLaunchParams, :211-218
+    construction / setCamera / resize / setProbe, :245 output_buffer.setStream(sample.stream), :259 and :286 subframe_index, :262 resize,
+    :273 sample.render(output_buffer)), restated statement by statement against csrc/SampleRenderer.h: it must compile as it stands.  The
+    output buffer is a stand-in for sutil::CUDAOutputBuffer<uint32_t> with the three members the renderer and main.cpp touch."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("g++"):
+        pytest.skip("no host compiler")
+    src = tmp_path / "main_snippet.cpp"
+    src.write_text(r'''
+#include "optixpathtracer_amd/csrc/SampleRenderer.h"
+using namespace ptamd;
+struct OutputBuffer {                      // sutil::CUDAOutputBuffer<uint32_t>: map() yields a device pointer (sutil/CUDAOutputBuffer.h)
+    uint32_t* map() { return d; }
+    void unmap() {}
+    void setStream(stream_t s) { stream = s; }
+    void resize(int, int) {}
+    uint32_t* d = nullptr; stream_t stream = nullptr;
+};
+void initLaunchParams(SampleRenderer& pathtracer) {   // main.cpp:131-144
+    LaunchParams& params = pathtracer.launchParams;
+    params.samples_per_launch = 32;
+    params.frame.subframe_index = 0u;
+    const float light_size = 200.f;
+    params.light.emission = make_float3(15.0f, 15.0f, 15.0f);
+    params.light.corner = make_float3(-1000 - light_size, 1200, -light_size);
+    params.light.v1 = make_float3(2.f * light_size, 0, 0);
+    params.light.v2 = make_float3(0, 0, 2.f * light_size);
+    params.light.normal = normalize(cross(params.light.v1, params.light.v2));
+}
+int run(const Model* model, const Camera& camera, const ProbeData& probe) {
+    SampleRenderer sample(model);          // main.cpp:211
+    sample.setCamera(camera);              // :212
+    int2 fbSize = make_int2(1200, 1024);   // :214
+    sample.resize(fbSize);                 // :215
+    initLaunchParams(sample);              // :217
+    sample.setProbe(probe);                // :218
+    OutputBuffer output_buffer;
+    output_buffer.setStream(sample.stream);             // :245
+    bool camera_changed = true, resize_dirty = true;
+    if (camera_changed || resize_dirty) sample.launchParams.frame.subframe_index = 0;  // :258-259
+    if (resize_dirty) { sample.resize(fbSize); output_buffer.resize(fbSize.x, fbSize.y); resize_dirty = false; }  // :261-265
+    sample.render(output_buffer);                       // :273
+    sample.launchParams.frame.subframe_index += 1;      // :286
+    static_assert(sizeof(ParallelogramLight) == 60, "LaunchParams.h:32-38: five float3");
+    return sample.denoiserOn ? 0 : 1;                   // SimplePathtracer.h:63: defaults to true
+}
+int main() { return 0; }
+''')
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", ROOT, "-I", os.path.join(ROOT, "include"), str(src)], check=True)
+
+
+def test_stream_contract_is_documented():
+    src = open(os.path.join(ROOT, "include", "pt_amd.h")).read()
+    assert "STREAM CONTRACT" in src and "hipStreamNonBlocking" in src and "pt_wait_event" in src and "VERSIONING" in src
+    L = _lib.load_library()
+    assert L.pt_stats_size() == C.sizeof(_lib.Stats)
+    assert b"ptamd 0.4" in L.pt_version()

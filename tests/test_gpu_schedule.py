@@ -225,3 +225,94 @@ def test_bench_starts_its_own_ranks():
     assert d["ms_per_displayed_frame"] > 0 and d["gather_ms"] >= 0
     assert d["step_ms"]["min"] <= d["step_ms"]["median"] <= d["step_ms"]["max"]
     assert len(d["ms_per_step_per_rank"]) == 2
+
+
+@pytest.mark.parametrize("fif", [0, 3])
+def test_render_into_a_caller_owned_device_buffer(ptlib, fif):
+    """pt_render_device = render(sutil::CUDAOutputBuffer<uint32_t>&) (SimplePathtracer.cpp:99-107): the rgba8 frame lands in the caller's
+    DEVICE buffer, complete when the call returns, equal to the frame pt_render + pt_download give; pt_stream is the context's stream."""
+    import torch
+
+    from optixpathtracer_amd import renderer as R
+
+    m = scenes.cornell_box()
+    probe = scenes.sky_probe(256, 128).BuildCDF()
+    w, h = 200, 120
+    r = R.SampleRenderer(m)
+    r.setProbe(probe)
+    r.setOptions(frames_in_flight=fif)
+    r.resize((w, h))
+    r.setCamera(R.make_camera(scenes.CORNELL_CAMERA, w / h))
+    r.launchParams.samples_per_launch = 2
+    assert r.stream not in (None, 0)
+    ref = []
+    for k in range(3):
+        r.launchParams.frame.subframe_index = k
+        r.render()
+        r.sync()
+        ref.append(r.downloadPixels().copy())
+    r.uploadAccum(np.zeros((h, w, 4), np.float32))
+    dst = torch.full((h, w), 0x55, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for k in range(3):
+        r.launchParams.frame.subframe_index = k
+        r.renderDevice(dst.data_ptr())
+        got = dst.cpu().numpy().view(np.uint32)  # no further synchronisation with the library: the call is synchronous
+        assert np.array_equal(got, ref[k]), k
+    r.close()
+
+
+def test_wait_event_orders_the_context_behind_the_callers_stream(ptlib):
+    """STREAM CONTRACT of include/pt_amd.h: the library's streams do not wait for the caller's.  A receive buffer filled on a torch side
+    stream behind a long-running kernel is handed to pt_unpack after pt_wait_event(event recorded behind the fill): the unpack must see
+    the filled buffer although the host never waited for it."""
+    import torch
+
+    from optixpathtracer_amd import renderer as R
+
+    m = scenes.cornell_box()
+    probe = scenes.sky_probe(64, 32).BuildCDF()
+    w, h = 256, 128
+    r = R.SampleRenderer(m)
+    r.setProbe(probe)
+    r.resize((w, h))
+    r.setCamera(R.make_camera(scenes.CORNELL_CAMERA, w / h))
+    r.render()
+    owned, padded = r.ownedPixels()
+    assert owned == w * h
+    side = torch.cuda.Stream()
+    src = torch.zeros(padded, dtype=torch.int32, device="cuda")
+    big = torch.zeros(64 << 20, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            big.add_(1.0)  # ~20 x 0.1 ms of work ahead of the fill
+        src.fill_(0x01020304)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    r.waitEvent(ev.cuda_event)
+    r.unpack(R.PT_BUF_FRAME, src.data_ptr())
+    got = r.downloadPixels()
+    assert (got == 0x01020304).all()
+    s = r.stats()
+    assert s["frames"] == 1
+    r.close()
+
+
+def test_sized_stats_getter(ptlib):
+    import ctypes as C
+
+    from optixpathtracer_amd import _lib
+    from optixpathtracer_amd import renderer as R
+
+    r = R.SampleRenderer(scenes.cornell_box())
+    L = _lib.load_library()
+    full = _lib.Stats()
+    assert L.pt_get_stats(r._ctx, C.byref(full)) == 0
+    n = L.pt_stats_size()
+    assert n == C.sizeof(_lib.Stats)
+    small = (C.c_ubyte * 24)()          # a caller built against a header that ended after `paths`
+    big = (C.c_ubyte * (n + 32))(*([0xEE] * (n + 32)))
+    assert L.pt_get_stats_n(r._ctx, small, 24) == 0 and L.pt_get_stats_n(r._ctx, big, n + 32) == 0
+    assert bytes(small) == bytes(full)[:24] and bytes(big)[:n] == bytes(full) and set(bytes(big)[n:]) == {0}
+    r.close()

@@ -720,22 +720,27 @@ static bool async_shadows(const pt_ctx* ctx) {
 // in creation order, back and forth (tools/micro/queue_map.hip on MI355X / ROCm 7.2: streams 0..7 -> queues 0 1 2 3 3 2 1 0), counting
 // every stream of the process — torch's included — so which of a context's streams collide depends on what was created before it.
 // Measured consequences: a synchronous frame 10.1 instead of 9.0 ms, three frames in flight 9.1 instead of 8.2 ms.  So the context asks:
-// a ~150 us spin kernel on `a`, an empty kernel on `b`; if the empty one finishes while the spin is still running, they are concurrent.
-__global__ void k_spin(long long ticks) {
+// a ~200 us spin kernel on `a`, a kernel on `b` that stamps the device clock: if `b` was stamped before the spin ended, the two ran
+// concurrently.  Both times are read on the device, so a host thread that is preempted between the launches (or the rank threads of a
+// pt_multi contending for cores) cannot turn a concurrent pair into a serial one or vice versa.
+__global__ void k_spin(long long ticks, long long* end_out) {
     const long long t0 = wall_clock64(); // constant 100 MHz counter
     while (wall_clock64() - t0 < ticks) {}
+    if (threadIdx.x == 0) *end_out = wall_clock64();
 }
-__global__ void k_empty() {}
-static bool streams_concurrent(hipStream_t a, hipStream_t b, hipEvent_t ea, hipEvent_t eb) {
-    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, 15000LL);
-    if (hipEventRecord(ea, a) != hipSuccess) return true;
-    hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, b);
-    if (hipEventRecord(eb, b) != hipSuccess) return true;
-    hipEventSynchronize(eb);
-    const bool concurrent = hipEventQuery(ea) == hipErrorNotReady;
-    (void)hipGetLastError();
-    hipEventSynchronize(ea);
-    return concurrent;
+__global__ void k_stamp(long long* out) {
+    if (threadIdx.x == 0) *out = wall_clock64();
+}
+static bool streams_concurrent(hipStream_t a, hipStream_t b, long long* d_stamps) {
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, 20000LL, d_stamps);
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, b, d_stamps + 1);
+    long long h[2] = {0, 0};
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess ||
+        hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return true; // inconclusive: keep creation order
+    }
+    return h[1] < h[0];
 }
 // The context's stream and the streams of the first three batch sets — the four that carry a frame — are picked so that no two share a
 // hardware queue: streams are created until enough mutually concurrent ones are found (at most 12; among any eight consecutive
@@ -744,27 +749,33 @@ static bool streams_concurrent(hipStream_t a, hipStream_t b, hipEvent_t ea, hipE
 static int pick_streams(pt_ctx* ctx, int nsets) {
     const char* pe = getenv("PT_STREAM_PROBE");
     if (pe && atoi(pe) == 0) return PT_OK;
-    hipEvent_t ea = nullptr, eb = nullptr;
-    CK(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
-    CK(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+    long long* d_stamps = nullptr;
+    CK(hipMalloc(&d_stamps, 2 * sizeof(long long)));
     CK(hipStreamSynchronize(ctx->stream));
+    // the streams that already carry frames stay; new ones must be concurrent with all of them (re-probed when the number of sets grows)
     std::vector<hipStream_t> chosen{ctx->stream}, spare;
+    for (int i = 0; i < nsets && i < 3; ++i)
+        if (ctx->set_streams[i]) chosen.push_back(ctx->set_streams[i]);
     const int want = 1 + std::min(nsets, 3);
-    for (int attempt = 0; attempt < 12 && (int)chosen.size() < want; ++attempt) {
+    int attempts = 0;
+    for (; attempts < 12 && (int)chosen.size() < want; ++attempts) {
         hipStream_t st = nullptr;
         if (stream_create(&st) != hipSuccess) break;
         bool ok = true;
         for (hipStream_t c : chosen)
-            if (!streams_concurrent(c, st, ea, eb)) { ok = false; break; }
+            if (!streams_concurrent(c, st, d_stamps)) { ok = false; break; }
         (ok ? chosen : spare).push_back(st);
     }
-    hipEventDestroy(ea);
-    hipEventDestroy(eb);
+    hipFree(d_stamps);
     (void)hipGetLastError();
-    size_t next_spare = 0;
+    if (getenv("PT_DEBUG"))
+        fprintf(stderr, "[ptamd] pick_streams: %d sets, %d streams created, %zu mutually concurrent (want %d), %zu to the side\n", nsets, attempts, chosen.size(), want, spare.size());
+    size_t next_chosen = 1, next_spare = 0;
+    for (int i = 0; i < nsets && i < 3; ++i)
+        if (ctx->set_streams[i]) ++next_chosen; // those were put at the front of `chosen`
     for (int i = 0; i < nsets && i < 3; ++i) {
         if (ctx->set_streams[i]) continue;
-        if ((size_t)(1 + i) < chosen.size()) ctx->set_streams[i] = chosen[1 + i];
+        if (next_chosen < chosen.size()) ctx->set_streams[i] = chosen[next_chosen++];
         else if (next_spare < spare.size()) ctx->set_streams[i] = spare[next_spare++]; // probing was inconclusive: any stream will do
     }
     for (size_t k = 0; k < ctx->side_streams.size() && next_spare < spare.size(); ++k)
@@ -779,7 +790,9 @@ static int assign_streams(pt_ctx* ctx, int nsets) {
     const bool async = async_shadows(ctx);
     if ((int)ctx->set_streams.size() < nsets) ctx->set_streams.resize(nsets, nullptr);
     if ((int)ctx->side_streams.size() < 2 * nsets) ctx->side_streams.resize((size_t)2 * nsets, nullptr);
-    if (!ctx->streams_probed) {
+    bool missing = false;
+    for (int i = 0; i < nsets && i < 3; ++i) missing |= !ctx->set_streams[i];
+    if (!ctx->streams_probed || missing) { // first use, or more sets than were probed for
         int rc = pick_streams(ctx, nsets);
         if (rc) return rc;
     }

@@ -702,16 +702,24 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
 
 // PLOC hierarchy over the sorted leaves (leaf boxes at box[n-1+i] come from the refit pass); overwrites the
 // internal-node arrays left/right/box/cnt (ids 0..n-2, root = the last one created)
+// frees its device allocations on every exit path of the function that owns it
+struct DevFrees {
+    std::vector<void*> p;
+    template <typename T> hipError_t alloc(T** q, size_t bytes) { hipError_t e = hipMalloc((void**)q, bytes ? bytes : 16); if (e == hipSuccess) p.push_back((void*)*q); return e; }
+    ~DevFrees() { for (void* q : p) hipFree(q); }
+};
+
 static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt, hipStream_t stream, int* root_out) {
+    DevFrees mem;
     int *cl_a = nullptr, *cl_b = nullptr, *nn = nullptr;
     uint32_t *merge = nullptr, *valid = nullptr, *merge_rank = nullptr, *valid_rank = nullptr;
-    HIPCHK(hipMalloc(&cl_a, sizeof(int) * (size_t)n)); HIPCHK(hipMalloc(&cl_b, sizeof(int) * (size_t)n)); HIPCHK(hipMalloc(&nn, sizeof(int) * (size_t)n));
-    HIPCHK(hipMalloc(&merge, 4 * (size_t)n)); HIPCHK(hipMalloc(&valid, 4 * (size_t)n));
-    HIPCHK(hipMalloc(&merge_rank, 4 * (size_t)n)); HIPCHK(hipMalloc(&valid_rank, 4 * (size_t)n));
+    HIPCHK(mem.alloc(&cl_a, sizeof(int) * (size_t)n)); HIPCHK(mem.alloc(&cl_b, sizeof(int) * (size_t)n)); HIPCHK(mem.alloc(&nn, sizeof(int) * (size_t)n));
+    HIPCHK(mem.alloc(&merge, 4 * (size_t)n)); HIPCHK(mem.alloc(&valid, 4 * (size_t)n));
+    HIPCHK(mem.alloc(&merge_rank, 4 * (size_t)n)); HIPCHK(mem.alloc(&valid_rank, 4 * (size_t)n));
     size_t tmp_bytes = 0;
     HIPCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, merge, merge_rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
     void* tmp = nullptr;
-    HIPCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    HIPCHK(mem.alloc(&tmp, tmp_bytes));
     const int B = 256;
     hipLaunchKernelGGL(k_ploc_init, dim3((n + B - 1) / B), dim3(B), 0, stream, n, cl_a);
     int N = n, next_id = 0, iters = 0;
@@ -729,7 +737,7 @@ static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt,
             HIPCHK(hipMemcpyAsync(&lv[1], valid_rank + (N - 1), 4, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
             merged = (int)(lm[0] + lm[1]);
-            if (merged * 64 >= N || N <= 64) break; // a healthy round merges a good part of the clusters; a starved one is repeated with the partner rule
+            if ((int64_t)merged * 64 >= N || N <= 64) break; // a healthy round merges a good part of the clusters; a starved one is repeated with the partner rule
         }
         hipLaunchKernelGGL(k_ploc_merge, dim3((N + B - 1) / B), dim3(B), 0, stream, cl_a, nn, N, merge, merge_rank, valid, valid_rank, next_id, left, right, box, cnt, cl_b);
         if (merged == 0 || ++iters > 4096) return hipErrorUnknown; // cannot happen: the global closest pair is always mutual
@@ -739,7 +747,6 @@ static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt,
     }
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipMemcpy(root_out, cl_a, sizeof(int), hipMemcpyDeviceToHost));
-    hipFree(cl_a); hipFree(cl_b); hipFree(nn); hipFree(merge); hipFree(valid); hipFree(merge_rank); hipFree(valid_rank); hipFree(tmp);
     return hipSuccess;
 }
 
@@ -759,7 +766,12 @@ static hipError_t import_hierarchy(const char* path, int n, const uint64_t* keys
     HIPCHK(hipMemcpy(keys.data(), keys_sorted, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(hbox.data(), box, sizeof(float) * 12 * (size_t)n, hipMemcpyDeviceToHost));
     std::vector<int> pos((size_t)n), hl((size_t)n), hr((size_t)n), hc((size_t)2 * n, 1);
-    for (int i = 0; i < n; ++i) pos[(uint32_t)keys[i]] = i;
+    for (int i = 0; i < n; ++i) {
+        if ((uint32_t)keys[i] >= (uint32_t)n) return hipErrorInvalidValue;
+        pos[(uint32_t)keys[i]] = i;
+    }
+    for (int c : lr) // the file is untrusted: an internal child must be a node id, a leaf child a primitive
+        if (c >= 0 ? c >= n - 1 : ~c >= n) return hipErrorInvalidValue;
     auto tr = [&](int c) { return c >= 0 ? c : n - 1 + pos[~c]; };
     for (int j = 0; j < n - 1; ++j) { hl[j] = tr(lr[2 * j]); hr[j] = tr(lr[2 * j + 1]); }
     // children have larger ids than their parent (preorder): one backward sweep computes boxes and counts

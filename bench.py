@@ -49,6 +49,10 @@ WORKLOADS = {
     "c4_terrain1M_4k_16spp_d8": ("terrain", "TERRAIN_CAMERA", 3840, 2160, 16, 8),
     # second 1 M-triangle workload (scenes.stadium_scene): rotated, displaced, long thin triangles over six decades of edge length, camera inside
     "stadium1M_1080p_4spp_d8": ("stadium", "STADIUM_CAMERA", 1920, 1080, 4, 8),
+    # the shape of the reference's real inputs (main.cpp:171-194: OBJ scenes with diffuse textures): the C3 terrain with texcoords and one
+    # 1024^2 RGBA8 texture per height band, written as OBJ + MTL + PNG and read back through objloader (= loadOBJ, Model.cpp:137-212), so
+    # every closest hit takes the tex2D branch (deviceProgram.cu:512-523) and the materials are what an MTL file can carry (Kd, Ke)
+    "terrain1M_textured_1080p_4spp_d8": ("terrain_textured_obj", "TERRAIN_CAMERA", 1920, 1080, 4, 8),
     # the reference's only published runs (HelloPathtracing_sv4_vmv23, 3840x2160, depth cutoff 4):
     # uniform 8 spp without accumulation, and the 3-region foveated schedule (radii 157/515, 1/2/8 spp)
     "sv4_uniform_terrain1M_4k_8spp_d4": ("terrain", "TERRAIN_CAMERA", 3840, 2160, 8, 4),
@@ -167,7 +171,7 @@ def main():
         # per-GPU work fixed: the image grows to N x the pixels (same aspect, multiples of 8) and is tile-partitioned
         f = world ** 0.5
         w, h = int(round(w * f / 8)) * 8, int(round(h * f / 8)) * 8
-    model = {"terrain": scenes.voxel_terrain, "stadium": scenes.stadium_scene, "cornell": scenes.cornell_box}[scene_name]()
+    model = {"terrain": scenes.voxel_terrain, "stadium": scenes.stadium_scene, "cornell": scenes.cornell_box, "terrain_textured_obj": textured_terrain_through_obj}[scene_name]()
     probe = scenes.sky_probe(2048, 1024).BuildCDF()
     cam = getattr(scenes, cam_name)
 
@@ -402,6 +406,9 @@ def main():
         # scene bytes read at least once per frame: the wide tree with its leaf triangles (which the shade kernel re-reads — there is no second
         # triangle array any more) and the probe's texels, pdf and cdf rows
         scene_bytes = st["bvh_bytes"] + probe.data.shape[0] * probe.data.shape[1] * (16 + 4 + 4)
+        textured = any(mm.diffuseTextureID >= 0 and mm.texcoord is not None for mm in model.meshes)
+        if textured:  # the texels and the per-primitive texcoords (24 B) the closest-hit program reads
+            scene_bytes += sum(int(t.pixel.nbytes) for t in model.textures) + 24 * model.num_triangles
         rays_frame = rays_all / args.steps
         px_frame = float(w * h) if world > 1 else float(owned_px)
         alg_frame = rays_frame * BYTES_PER_RAY_FRAME + px_frame * BYTES_PER_PIXEL_FRAME + scene_bytes * (world if world > 1 else 1)
@@ -459,7 +466,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": args.workload + (f"_weak_x{world}_area" if (world > 1 and not strong) else ""), "triangles": model.num_triangles, "width": w, "height": h, "spp": spp,
-                "max_depth": depth, "bsdf": "disney", "probe": "sky2048x1024+sun", "partition": f"tiles{args.tile[0]}x{args.tile[1]}/{part_world}",
+                "max_depth": depth, "bsdf": "disney", "probe": "sky2048x1024+sun", "textures": [list(t.resolution) for t in model.textures] or None, "partition": f"tiles{args.tile[0]}x{args.tile[1]}/{part_world}",
             },
             "rays_per_frame": int(rays_frame),
             "fps": round(args.steps / dt_max, 2),
@@ -505,6 +512,27 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def textured_terrain_through_obj():
+    """scenes.textured_terrain() -> OBJ + MTL + PNG in a scratch directory -> objloader.load_obj: the reference's own route for its
+    scenes (≈50 s of host time for 1 M triangles: 150 MB of text through a restatement of tinyobjloader's parser; untimed)."""
+    import shutil
+    import tempfile
+
+    from optixpathtracer_amd import objloader, scenes
+
+    d = tempfile.mkdtemp(prefix="ptamd_obj_")
+    try:
+        t0 = time.perf_counter()
+        path = scenes.write_obj(scenes.textured_terrain(), os.path.join(d, "terrain.obj"))
+        t1 = time.perf_counter()
+        model = objloader.load_obj(path)
+        print(f"[bench] textured terrain: wrote {os.path.getsize(path) >> 20} MiB of OBJ in {t1 - t0:.1f} s, loadOBJ semantics in {time.perf_counter() - t1:.1f} s: "
+              f"{len(model.meshes)} meshes, {model.num_triangles} triangles, {len(model.textures)} textures", file=sys.stderr)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return model
 
 
 def launch_ranks(n):

@@ -118,6 +118,43 @@ def _try_parse_double(s: str):
     return sign * mant
 
 
+_TOKENS = re.compile(r"[^ \t]+").findall  # fields as parseReal / parseTriple delimit them (blank or tab; a line holds no \r or \n)
+_REAL_CACHE: dict = {}
+
+
+def _reals(text: str, n: int, default=0.0):
+    """n consecutive parseReal calls (tiny_obj_loader.h:962-970) on `text`: a missing or malformed field takes the default."""
+    toks = _TOKENS(text)
+    out = []
+    for k in range(n):
+        if k < len(toks):
+            t = toks[k]
+            v = _REAL_CACHE.get(t)
+            if v is None:
+                d = _try_parse_double(t)
+                with np.errstate(over="ignore"):
+                    v = _F(default if d is None else d)
+                if d is not None and len(_REAL_CACHE) < 4_000_000:
+                    _REAL_CACHE[t] = v
+            out.append(v)
+        else:
+            out.append(_F(default))
+    return out
+
+
+def _fix_group(g, n):
+    """fixIndex (:770-790) on a matched index field: -1 = field absent, None = the reference's `return false` (index 0)."""
+    if g is None:
+        return -1
+    k = int(g)
+    if k > 0:
+        return k - 1
+    return None if k == 0 else n + k
+
+
+_FACE_TOKEN = re.compile(r"([+-]?\d+)(?:/([+-]?\d+)?(?:/([+-]?\d+))?)?").fullmatch
+
+
 class _Cursor:
     """The `const char** token` the parser walks along a line."""
 
@@ -373,6 +410,54 @@ def _triangulate(face, V):
     return out
 
 
+def _quads_clip_to_fan(Q: np.ndarray, V: np.ndarray) -> np.ndarray:
+    """For many 4-gons at once: does the ear clipping of _triangulate take its FIRST candidate ear (corners 0,1,2), so that the result is
+    the fan (0,1,2),(0,2,3)?  The same float operations in the same order as the scalar code, on arrays.  False = run the scalar code."""
+    nv = len(V)
+    ok = ((Q >= 0) & (Q < nv)).all(axis=1)
+    Qs = np.where(ok[:, None], Q, 0)
+    P = V[Qs]  # (m, 4, 3)
+    m = len(Q)
+    eps = _F(np.finfo(np.float32).eps)
+    a0 = np.full(m, 1, np.int64)
+    a1 = np.full(m, 2, np.int64)
+    found = np.zeros(m, bool)
+    with np.errstate(all="ignore"):
+        for k in range(4):
+            v0, v1, v2 = P[:, k], P[:, (k + 1) % 4], P[:, (k + 2) % 4]
+            e0, e1 = v1 - v0, v2 - v1
+            cx = np.abs(e0[:, 1] * e1[:, 2] - e0[:, 2] * e1[:, 1])
+            cy = np.abs(e0[:, 2] * e1[:, 0] - e0[:, 0] * e1[:, 2])
+            cz = np.abs(e0[:, 0] * e1[:, 1] - e0[:, 1] * e1[:, 0])
+            corner = ((cx > eps) | (cy > eps) | (cz > eps)) & ~found
+            keep = (cx > cy) & (cx > cz)
+            a0 = np.where(corner & ~keep, 0, a0)
+            a1 = np.where(corner & ~keep & (cz > cx) & (cz > cy), 1, a1)
+            found |= corner
+        rows = np.arange(m)
+        X = np.stack([P[rows, k, a0] for k in range(4)], 1)  # (m, 4) first working axis
+        Y = np.stack([P[rows, k, a1] for k in range(4)], 1)
+        half = _F(0.5)
+        area = np.zeros(m, np.float32)
+        for k in range(4):
+            j = (k + 1) % 4
+            area = area + (X[:, k] * Y[:, j] - Y[:, k] * X[:, j]) * half
+        e0x, e0y = X[:, 1] - X[:, 0], Y[:, 1] - Y[:, 0]
+        e1x, e1y = X[:, 2] - X[:, 1], Y[:, 2] - Y[:, 1]
+        cross = e0x * e1y - e0y * e1x
+        ok &= ~(cross * area < _F(0))
+        tx, ty = X[:, 3], Y[:, 3]
+        inside = np.zeros(m, bool)
+        j = 2
+        for i in range(3):
+            c1 = (Y[:, i] > ty) != (Y[:, j] > ty)
+            c2 = tx < (X[:, j] - X[:, i]) * (ty - Y[:, i]) / (Y[:, j] - Y[:, i]) + X[:, i]
+            inside ^= c1 & c2
+            j = i
+        ok &= ~inside
+    return ok
+
+
 def _parse_obj(obj_file: str, mtl_basedir: str):
     """tinyobj::LoadObj(..., triangulate=true) (:2158-2745) -> V, VN, VT, shapes, materials.
     A shape = (indices [(v, vt, vn) x 3 per triangle], material id per triangle)."""
@@ -393,10 +478,21 @@ def _parse_obj(obj_file: str, mtl_basedir: str):
         if not faces:
             return False
         Vf = Varr()
-        for face in faces:
+        quads = [i for i, face in enumerate(faces) if len(face) == 4]
+        fan = {}
+        if len(quads) >= 32:  # many 4-gons: decide for all of them at once which ones the ear clipping turns into the plain fan
+            okq = _quads_clip_to_fan(np.array([[c[0] for c in faces[i]] for i in quads], np.int64), Vf)
+            fan = dict(zip(quads, okq.tolist()))
+        for i, face in enumerate(faces):
             if len(face) < 3:
                 continue
-            for tri in ([tuple(face)] if len(face) == 3 else _triangulate(face, Vf)):
+            if len(face) == 3:
+                tris = (tuple(face),)
+            elif fan.get(i, False):
+                tris = ((face[0], face[1], face[2]), (face[0], face[2], face[3]))
+            else:
+                tris = _triangulate(face, Vf)
+            for tri in tris:
                 shape[0].extend(tri)
                 shape[1].append(material)
         return True
@@ -413,28 +509,39 @@ def _parse_obj(obj_file: str, mtl_basedir: str):
         c1 = tok[1] if len(tok) > 1 else "\0"
         c2 = tok[2] if len(tok) > 2 else "\0"
         if tok[0] == "v" and c1 in " \t":
-            cur = _Cursor(tok, 2)
-            V.append((cur.real(), cur.real(), cur.real()))
+            V.append(_reals(tok[2:], 3))
             continue
         if tok[0] == "v" and c1 == "n" and c2 in " \t":
-            cur = _Cursor(tok, 3)
-            VN.append((cur.real(), cur.real(), cur.real()))
+            VN.append(_reals(tok[3:], 3))
             continue
         if tok[0] == "v" and c1 == "t" and c2 in " \t":
-            cur = _Cursor(tok, 3)
-            VT.append((cur.real(), cur.real()))
+            VT.append(_reals(tok[3:], 2))
             continue
         if tok[0] == "f" and c1 in " \t":
-            cur = _Cursor(tok, 2)
-            cur.skip_blank()
             face = []
-            while not cur.at_end():
-                t = _parse_triple(cur, len(V), len(VN), len(VT))
-                if t is None:
-                    raise RuntimeError(f"Could not read OBJ model from {obj_file} : Failed parse `f' line(e.g. zero value for face index. line {ln}.)")
-                face.append(t)
-                while cur.p < len(cur.s) and cur.s[cur.p] in " \t\r":
-                    cur.p += 1
+            nv, nvn, nvt = len(V), len(VN), len(VT)
+            for ft in _TOKENS(tok[2:]):  # the common spellings i, i/j, i//k, i/j/k without going through the cursor
+                mt = _FACE_TOKEN(ft)
+                if mt is None or ft[-1] == "/":
+                    face = None
+                    break
+                a, b, c = mt.groups()
+                a, b, c = _fix_group(a, nv), _fix_group(b, nvt), _fix_group(c, nvn)
+                if a is None or b is None or c is None:
+                    face = None
+                    break
+                face.append((a, b, c))
+            if face is None:  # anything else: the reference's parser, character by character
+                cur = _Cursor(tok, 2)
+                cur.skip_blank()
+                face = []
+                while not cur.at_end():
+                    t = _parse_triple(cur, len(V), len(VN), len(VT))
+                    if t is None:
+                        raise RuntimeError(f"Could not read OBJ model from {obj_file} : Failed parse `f' line(e.g. zero value for face index. line {ln}.)")
+                    face.append(t)
+                    while cur.p < len(cur.s) and cur.s[cur.p] in " \t\r":
+                        cur.p += 1
             faces.append(face)
             continue
         if tok.startswith("usemtl"):

@@ -376,6 +376,107 @@ def voxel_terrain(n: int = 360, seed: int = 1234, extent: float = 100.0, target_
     return model
 
 
+def band_texture(band: int, size: int = 1024) -> Texture:
+    """Deterministic RGBA8 texture of one height band: three octaves of value noise in the band's hue plus a brick-like grid, so that
+    neighbouring texels differ (a filter or layout error shows) and the texture tiles without a seam only approximately (wrap shows)."""
+    rng = np.random.default_rng(9000 + band)
+    base = np.array([(0.55, 0.45, 0.30), (0.35, 0.55, 0.25), (0.50, 0.50, 0.50), (0.70, 0.65, 0.45), (0.30, 0.40, 0.60), (0.60, 0.35, 0.30),
+                     (0.80, 0.80, 0.85), (0.25, 0.30, 0.25)][band % 8])
+    n = _value_noise(size, 500 + band, octaves=6)
+    ys, xs = np.mgrid[0:size, 0:size]
+    grid = ((xs % 64 < 3) | (ys % 32 < 3)).astype(np.float64)
+    speck = rng.random((size, size))
+    rgb = np.clip((0.55 + 0.9 * (n[..., None] - 0.5)) * base[None, None, :] * (1.0 - 0.45 * grid[..., None]) + 0.08 * (speck[..., None] - 0.5), 0.0, 1.0)
+    px = (rgb * 255.0 + 0.5).astype(np.uint32)
+    return Texture(np.ascontiguousarray(px[..., 0] | (px[..., 1] << 8) | (px[..., 2] << 16) | np.uint32(0xFF000000)))
+
+
+def textured_terrain(n: int = 360, seed: int = 1234, extent: float = 100.0, target_tris: int = 1_000_000, tex_size: int = 1024, tile: float = 12.5) -> Model:
+    """The C3 terrain with what the reference's real inputs have (main.cpp:171-194: sponza, lost_empire, San Miguel through loadOBJ):
+    every mesh carries texcoords and a diffuse texture, so every closest hit takes the tex2D branch (deviceProgram.cu:512-523).
+    One tex_size^2 RGBA8 texture per height band; texcoords = world position / tile (top faces: x,z; side faces: x+z, y), i.e. they run
+    over roughly [-8, 8] and exercise the wrap on both sides of 0."""
+    m = voxel_terrain(n, seed, extent, target_tris)
+    for b, mesh in enumerate(m.meshes):
+        v = mesh.vertex.reshape(-1, 4, 3)
+        e1, e2 = v[:, 1] - v[:, 0], v[:, 3] - v[:, 0]
+        nrm = np.cross(e1, e2)
+        top = np.abs(nrm[:, 1]) > 0
+        uv = np.empty((len(v), 4, 2), np.float32)
+        t = np.float32(tile)
+        uv[top, :, 0] = v[top, :, 0] / t
+        uv[top, :, 1] = v[top, :, 2] / t
+        uv[~top, :, 0] = (v[~top, :, 0] + v[~top, :, 2]) / t
+        uv[~top, :, 1] = v[~top, :, 1] / t
+        mesh.texcoord = np.ascontiguousarray(uv.reshape(-1, 2))
+        mesh.diffuseTextureID = b
+        m.textures.append(band_texture(b, tex_size))
+    return m
+
+
+def _fmt9(a: np.ndarray):
+    """float32 -> decimal with 9 significant digits: within 5e-10 relative of the value, far inside the half-ulp (>= 3e-8) any
+    decimal -> double -> float reader needs to land on the same float again (tinyobjloader's digit-by-digit parser included)."""
+    return np.char.mod("%.9g", a.astype(np.float64))
+
+
+def write_obj(model: Model, obj_path: str) -> str:
+    """Writes `model` as OBJ + MTL + PNG textures the way a DCC tool would: one `o` per mesh with its `usemtl`, `v` / `vt` per vertex,
+    faces as QUADS when consecutive triangle pairs form (a,b,c),(a,c,d) (the loader's triangulation gives the pair back), triangles
+    otherwise.  objloader.load_obj(obj_path) reproduces the model's triangles in order, with bit-identical corner positions and texcoords
+    (vertex numbering inside a mesh changes: addVertex numbers corners in the order loadOBJ meets them)."""
+    import os
+
+    from PIL import Image
+
+    d = os.path.dirname(os.path.abspath(obj_path))
+    os.makedirs(d, exist_ok=True)
+    stem = os.path.splitext(os.path.basename(obj_path))[0]
+    with open(os.path.join(d, stem + ".mtl"), "w") as f:
+        for i, mesh in enumerate(model.meshes):
+            c, e = mesh.material["color"], mesh.material["emission"]
+            f.write(f"newmtl m{i}\nKd {float(c[0]):.9g} {float(c[1]):.9g} {float(c[2]):.9g}\nKe {float(e[0]):.9g} {float(e[1]):.9g} {float(e[2]):.9g}\n")
+            if mesh.diffuseTextureID >= 0:
+                f.write(f"map_Kd {stem}_tex{mesh.diffuseTextureID}.png\n")
+    for t, tex in enumerate(model.textures):
+        px = tex.pixel[::-1]  # the file holds the top row first; loadTexture mirrors it back (Model.cpp:112-121)
+        rgba = np.stack([(px >> s) & 0xFF for s in (0, 8, 16, 24)], -1).astype(np.uint8)
+        Image.fromarray(rgba, "RGBA").save(os.path.join(d, f"{stem}_tex{t}.png"))
+    with open(obj_path, "w") as f:
+        f.write(f"mtllib {stem}.mtl\n")
+        vbase = tbase = 0
+        for i, mesh in enumerate(model.meshes):
+            f.write(f"o mesh{i}\nusemtl m{i}\n")
+            V = _fmt9(mesh.vertex)
+            f.write("\n".join("v " + " ".join(r) for r in V) + "\n")
+            has_tc = mesh.texcoord is not None and len(mesh.texcoord)
+            if has_tc:
+                T = _fmt9(mesh.texcoord)
+                f.write("\n".join("vt " + " ".join(r) for r in T) + "\n")
+            idx = mesh.index.astype(np.int64)
+            nt = len(idx)
+            quad = np.zeros(nt, bool)
+            if nt >= 2:
+                a, b = idx[:-1], idx[1:]
+                quad[:-1] = (a[:, 0] == b[:, 0]) & (a[:, 2] == b[:, 1])
+                quad[1:] &= ~quad[:-1]  # pairs do not overlap
+                quad[-1] = False
+            k = 0
+            out = []
+            while k < nt:
+                ids = [idx[k, 0], idx[k, 1], idx[k, 2]]
+                if quad[k]:
+                    ids.append(idx[k + 1, 2])
+                    k += 2
+                else:
+                    k += 1
+                out.append("f " + " ".join(f"{vbase + j + 1}/{tbase + j + 1}" if has_tc else f"{vbase + j + 1}" for j in ids))
+            f.write("\n".join(out) + "\n")
+            vbase += len(mesh.vertex)
+            tbase += len(mesh.texcoord) if has_tc else 0
+    return obj_path
+
+
 # ------------------------------------------------------------------ second 1 M-triangle workload: "teapots in a stadium"
 STADIUM_CAMERA = dict(eye=(-62.0, 9.0, 21.0), lookat=(0.0, 4.0, 0.0), up=(0.0, 1.0, 0.0), fovY=50.0)
 

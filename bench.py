@@ -407,8 +407,8 @@ def main():
         # triangle array any more) and the probe's texels, pdf and cdf rows
         scene_bytes = st["bvh_bytes"] + probe.data.shape[0] * probe.data.shape[1] * (16 + 4 + 4)
         textured = any(mm.diffuseTextureID >= 0 and mm.texcoord is not None for mm in model.meshes)
-        if textured:  # the texels and the per-primitive texcoords (24 B) the closest-hit program reads
-            scene_bytes += sum(int(t.pixel.nbytes) for t in model.textures) + 24 * model.num_triangles
+        if textured:  # the texels and the 64-byte per-triangle records (vertices + texcoords) a textured closest hit reads
+            scene_bytes += sum(int(t.pixel.nbytes) for t in model.textures) + 64 * model.num_triangles
         rays_frame = rays_all / args.steps
         px_frame = float(w * h) if world > 1 else float(owned_px)
         alg_frame = rays_frame * BYTES_PER_RAY_FRAME + px_frame * BYTES_PER_PIXEL_FRAME + scene_bytes * (world if world > 1 else 1)

@@ -36,7 +36,8 @@ struct pt_ctx {
     bool has_catcher = false;
     // textures
     int32_t* d_mesh_tex = nullptr;
-    PrimUV* d_uvs = nullptr;
+    PrimUV* d_uvs = nullptr;   // per primitive, only until the leaf-ordered records are emitted
+    TexTri* d_textris = nullptr;
     DevTex* d_textures = nullptr;
     std::vector<uint32_t*> d_tex_pixels;
     DevTex tex0{};
@@ -343,10 +344,14 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
         for (uint32_t t = 0; t < scene->num_textures; ++t) {
             const pt_texture_desc& td = scene->textures[t];
             uint32_t* px = nullptr;
-            CKC(dalloc(&px, (size_t)td.width * td.height));
+            const int tiles_x = (td.width + 7) / 8, tiles_y = (td.height + 3) / 4; // 8 x 4-texel tiles of 128 bytes (pt_device.h DevTex)
+            std::vector<uint32_t> tiled((size_t)tiles_x * tiles_y * 32, 0u);
+            for (int y = 0; y < td.height; ++y)
+                for (int x = 0; x < td.width; ++x) tiled[tex_tiled_index(x, y, tiles_x)] = td.pixel[(size_t)y * td.width + x];
+            CKC(dalloc(&px, tiled.size()));
             ctx->d_tex_pixels.push_back(px);
-            CKC(hipMemcpy(px, td.pixel, sizeof(uint32_t) * (size_t)td.width * td.height, hipMemcpyHostToDevice));
-            tex[t] = DevTex{px, td.width, td.height};
+            CKC(hipMemcpy(px, tiled.data(), sizeof(uint32_t) * tiled.size(), hipMemcpyHostToDevice));
+            tex[t] = DevTex{px, td.width, td.height, tiles_x};
         }
         if (!tex.empty()) {
             CKC(dalloc(&ctx->d_textures, tex.size()));
@@ -361,11 +366,16 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     CKC(pt_bvh_build(ctx->d_verts, ctx->d_idx, ctx->d_tri_mesh, (uint32_t)nt, ctx->stream, &ctx->bvh));
     CKC(dalloc(&ctx->d_tri_nrm, (size_t)ctx->bvh.num_tris8));
     hipLaunchKernelGGL(k_shade_normals, dim3((ctx->bvh.num_tris8 + 255) / 256), dim3(256), 0, ctx->stream, ctx->bvh.tris8, ctx->bvh.num_tris8, ctx->d_tri_nrm);
+    if (ctx->d_uvs) { // textured scene: the 64-byte records a textured hit reads, in leaf order
+        CKC(dalloc(&ctx->d_textris, (size_t)ctx->bvh.num_tris8));
+        hipLaunchKernelGGL(k_emit_textris, dim3((ctx->bvh.num_tris8 + 255) / 256), dim3(256), 0, ctx->stream, ctx->bvh.tris8, ctx->d_uvs, ctx->bvh.num_tris8, ctx->d_textris);
+    }
     CKC(hipEventRecord(e1, ctx->stream));
     CKC(hipStreamSynchronize(ctx->stream));
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     ctx->bvh_build_ms = ms;
+    dfree(ctx->d_uvs);
     CKC(dalloc(&ctx->d_totals, (size_t)PT_MAX_FRAMES * PT_MAX_SETS * 4));
     CKC(dclear(ctx->stream, ctx->d_totals, sizeof(unsigned long long) * PT_MAX_FRAMES * PT_MAX_SETS * 4));
     CKC(hipHostMalloc((void**)&ctx->h_totals, sizeof(unsigned long long) * PT_MAX_FRAMES * PT_MAX_SETS * 4));
@@ -438,7 +448,7 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     for (hipStream_t st : ctx->side_streams) if (st) hipStreamDestroy(st);
     free_frame(ctx);
     dfree(ctx->d_verts); dfree(ctx->d_idx); dfree(ctx->d_tri_mesh); dfree(ctx->d_mats);
-    dfree(ctx->d_mesh_tex); dfree(ctx->d_uvs); dfree(ctx->d_textures);
+    dfree(ctx->d_mesh_tex); dfree(ctx->d_uvs); dfree(ctx->d_textris); dfree(ctx->d_textures);
     for (uint32_t*& px : ctx->d_tex_pixels) dfree(px);
     pt_bvh_free(&ctx->bvh);
     dfree(ctx->d_tri_nrm);
@@ -980,7 +990,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeueB + (size_t)b * qsize, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1, (b == 0) ? 1 : 0};
+                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_textris, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1, (b == 0) ? 1 : 0};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, stream_view(bs, sin), sp);
@@ -1026,7 +1036,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             for (int b = 0; b <= last_bounce; ++b) {
                 QView qnext{qnext_base, cntA + (size_t)(b + 1) * CS, ctx->sub_cap};
                 QView qshadow{bs.squeue, cntS + (size_t)b * CS, ctx->sub_cap};
-                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1, (b == 0) ? 1 : 0};
+                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_textris, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1, (b == 0) ? 1 : 0};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, stream_view(bs, sin), sp);
@@ -1058,7 +1068,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                 ++lc.trace;
             }
-            ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1, (b == 0) ? 1 : 0};
+            ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_textris, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1, (b == 0) ? 1 : 0};
             if (ev_shadow_done) hipStreamWaitEvent(bs.stream, ev_shadow_done, 0); // shade overwrites what shadow(b-1) reads
             {
                 SpanGuard g(ctx, CLS_SHADE, bs.stream);
@@ -1111,7 +1121,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                     hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
                     ++lc.trace;
                 }
-                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_uvs, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, 1, 0};
+                ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_textris, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, 1, 0};
                 {
                     SpanGuard g(ctx, CLS_SHADE, bs.stream);
                     if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) launch_shade<PT_BSDF_LAMBERT>(ctx, bs, stream_view(bs, sin), sp);

@@ -9,6 +9,8 @@
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include <cstring>
@@ -156,6 +158,73 @@ __global__ void k_refit(const float* __restrict__ verts, const uint32_t* __restr
     }
 }
 
+// ---- level-synchronous bottom-up passes.  The climb above pays an agent-scope fence (buffer_wbl2 + buffer_inv, microseconds each) per
+// thread and level: 6.3 ms for a million leaves, twice that for the collapse costs.  Instead: the depth of every internal node by pointer
+// jumping over the parent array (log2(depth) rounds), nodes bucketed by depth, then one small launch per level from the deepest up — a
+// kernel boundary is the only ordering needed, nothing fences.  Same values as the climb (min/max and the DP are order-independent).
+__global__ void k_leaf_boxes(const float* __restrict__ verts, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ keys, int n, float* __restrict__ box) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = (uint32_t)(keys[i] & 0xffffffffu);
+    float b[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int k = 0; k < 3; ++k) {
+        const float* v = &verts[3 * (size_t)idx[3 * (size_t)p + k]];
+        for (int a = 0; a < 3; ++a) {
+            b[a] = fminf(b[a], v[a]);
+            b[3 + a] = fmaxf(b[3 + a], v[a]);
+        }
+    }
+    for (int a = 0; a < 6; ++a) box[(size_t)(n - 1 + i) * 6 + a] = b[a];
+}
+__global__ void k_depth_init(int ni, const int* __restrict__ parent, int root, int* __restrict__ anc, int* __restrict__ depth) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ni) return;
+    const int p = i == root ? -1 : parent[i];
+    anc[i] = p;
+    depth[i] = p >= 0 ? 1 : 0;
+}
+__global__ void k_depth_jump(int ni, const int* __restrict__ anc_in, const int* __restrict__ d_in, int* __restrict__ anc_out, int* __restrict__ d_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ni) return;
+    const int a = anc_in[i];
+    if (a >= 0) {
+        d_out[i] = d_in[i] + d_in[a];
+        anc_out[i] = anc_in[a];
+    } else {
+        d_out[i] = d_in[i];
+        anc_out[i] = -1;
+    }
+}
+#define PT_MAX_TREE_LEVELS 512
+// hist[0..PT_MAX_TREE_LEVELS): nodes per depth; hist[PT_MAX_TREE_LEVELS]: nodes whose depth is not final or does not fit
+__global__ void k_depth_hist(int ni, const int* __restrict__ anc, const int* __restrict__ depth, int* __restrict__ hist) {
+    __shared__ int h[PT_MAX_TREE_LEVELS + 1];
+    for (int k = threadIdx.x; k <= PT_MAX_TREE_LEVELS; k += blockDim.x) h[k] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ni; i += gridDim.x * blockDim.x) {
+        const int d = depth[i];
+        atomicAdd(&h[(anc[i] >= 0 || d >= PT_MAX_TREE_LEVELS) ? PT_MAX_TREE_LEVELS : d], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k <= PT_MAX_TREE_LEVELS; k += blockDim.x)
+        if (h[k]) atomicAdd(&hist[k], h[k]);
+}
+__global__ void k_depth_scatter(int ni, const int* __restrict__ depth, int* __restrict__ cursor, int* __restrict__ order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ni) return;
+    order[atomicAdd(&cursor[depth[i]], 1)] = i;
+}
+__global__ void k_refit_level(const int* __restrict__ order, int count, const int* __restrict__ left, const int* __restrict__ right, float* __restrict__ box) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int cur = order[t];
+    const int l = left[cur], r = right[cur];
+    for (int a = 0; a < 3; ++a) {
+        box[(size_t)cur * 6 + a] = fminf(box[(size_t)l * 6 + a], box[(size_t)r * 6 + a]);
+        box[(size_t)cur * 6 + 3 + a] = fmaxf(box[(size_t)l * 6 + 3 + a], box[(size_t)r * 6 + 3 + a]);
+    }
+}
+
 __global__ void k_emit_tris(const float* __restrict__ verts, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ tri_mesh,
                             const uint64_t* __restrict__ keys, int n, LeafTri* __restrict__ tris) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -221,6 +290,44 @@ __device__ __forceinline__ float padded_area(const float* b, float pad) {
     const float dx = b[3] - b[0] + 2.f * pad, dy = b[4] - b[1] + 2.f * pad, dz = b[5] - b[2] + 2.f * pad;
     return dx * dy + dy * dz + dz * dx;
 }
+__device__ __forceinline__ void collapse_cost_node(int cur, int n, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ cnt_of,
+                                                   const float* __restrict__ box, float pad, float cp, float* __restrict__ cost, uint8_t* __restrict__ dec, bool coherent) {
+    const int l = left[cur], r = right[cur];
+    float Cl[8], Cr[8];
+    const float al = padded_area(&box[(size_t)l * 6], pad) * cp, ar = padded_area(&box[(size_t)r * 6], pad) * cp;
+    for (int k = 1; k <= 7; ++k) {
+        Cl[k] = l >= n - 1 ? al : (coherent ? cost[(size_t)l * 7 + (k - 1)] : __builtin_nontemporal_load(&cost[(size_t)l * 7 + (k - 1)]));
+        Cr[k] = r >= n - 1 ? ar : (coherent ? cost[(size_t)r * 7 + (k - 1)] : __builtin_nontemporal_load(&cost[(size_t)r * 7 + (k - 1)]));
+    }
+    float dist[9];
+    int ks[9];
+    for (int j = 2; j <= 8; ++j) {
+        float best = INFINITY;
+        int bk = 1;
+        for (int k = 1; k < j; ++k) {
+            if (k > 7 || j - k > 7) continue;
+            const float c = Cl[k] + Cr[j - k];
+            if (c < best) { best = c; bk = k; }
+        }
+        dist[j] = best;
+        ks[j] = bk;
+    }
+    const float A = padded_area(&box[(size_t)cur * 6], pad);
+    const int cnt = cnt_of[cur];
+    const float c_leaf = cnt <= PT8_LEAF_MAX ? A * (float)cnt * cp : INFINITY;
+    const float c_int = A + dist[8];
+    float prev = fminf(c_leaf, c_int);
+    uint8_t* d = &dec[(size_t)cur * 8];
+    d[0] = c_leaf <= c_int ? 0 : 1;
+    cost[(size_t)cur * 7 + 0] = prev;
+    for (int b = 2; b <= 7; ++b) {
+        if (dist[b] < prev) { prev = dist[b]; d[b - 1] = (uint8_t)ks[b]; }
+        else d[b - 1] = 0;
+        cost[(size_t)cur * 7 + (b - 1)] = prev;
+    }
+    d[7] = (uint8_t)ks[8];
+}
+// fallback for hierarchies deeper than PT_MAX_TREE_LEVELS: the atomic climb (one agent-scope fence per thread and level)
 __global__ void k_collapse_cost(int n, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ parent,
                                 const int* __restrict__ cnt_of, const float* __restrict__ box, float pad, float cp,
                                 float* __restrict__ cost, uint8_t* __restrict__ dec, int* __restrict__ visits) {
@@ -230,43 +337,17 @@ __global__ void k_collapse_cost(int n, const int* __restrict__ left, const int* 
     while (cur >= 0) {
         if (atomicAdd(&visits[cur], 1) == 0) return; // the sibling subtree's thread finishes this node
         __threadfence();
-        const int l = left[cur], r = right[cur];
-        float Cl[8], Cr[8];
-        const float al = padded_area(&box[(size_t)l * 6], pad) * cp, ar = padded_area(&box[(size_t)r * 6], pad) * cp;
-        for (int k = 1; k <= 7; ++k) {
-            Cl[k] = l >= n - 1 ? al : __builtin_nontemporal_load(&cost[(size_t)l * 7 + (k - 1)]);
-            Cr[k] = r >= n - 1 ? ar : __builtin_nontemporal_load(&cost[(size_t)r * 7 + (k - 1)]);
-        }
-        float dist[9];
-        int ks[9];
-        for (int j = 2; j <= 8; ++j) {
-            float best = INFINITY;
-            int bk = 1;
-            for (int k = 1; k < j; ++k) {
-                if (k > 7 || j - k > 7) continue;
-                const float c = Cl[k] + Cr[j - k];
-                if (c < best) { best = c; bk = k; }
-            }
-            dist[j] = best;
-            ks[j] = bk;
-        }
-        const float A = padded_area(&box[(size_t)cur * 6], pad);
-        const int cnt = cnt_of[cur];
-        const float c_leaf = cnt <= PT8_LEAF_MAX ? A * (float)cnt * cp : INFINITY;
-        const float c_int = A + dist[8];
-        float prev = fminf(c_leaf, c_int);
-        uint8_t* d = &dec[(size_t)cur * 8];
-        d[0] = c_leaf <= c_int ? 0 : 1;
-        cost[(size_t)cur * 7 + 0] = prev;
-        for (int b = 2; b <= 7; ++b) {
-            if (dist[b] < prev) { prev = dist[b]; d[b - 1] = (uint8_t)ks[b]; }
-            else d[b - 1] = 0;
-            cost[(size_t)cur * 7 + (b - 1)] = prev;
-        }
-        d[7] = (uint8_t)ks[8];
+        collapse_cost_node(cur, n, left, right, cnt_of, box, pad, cp, cost, dec, false);
         __threadfence();
         cur = parent[cur];
     }
+}
+__global__ void k_collapse_cost_level(const int* __restrict__ order, int count, int n, const int* __restrict__ left, const int* __restrict__ right,
+                                      const int* __restrict__ cnt_of, const float* __restrict__ box, float pad, float cp,
+                                      float* __restrict__ cost, uint8_t* __restrict__ dec) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    collapse_cost_node(order[t], n, left, right, cnt_of, box, pad, cp, cost, dec, true);
 }
 
 __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* __restrict__ tout, uint32_t* __restrict__ counters /*0 next tasks,1 nodes,2 tris*/,
@@ -607,9 +688,60 @@ __global__ void __launch_bounds__(64) k_calibrate8(const Node8* __restrict__ nod
         if (e_ != hipSuccess) return e_;  \
     } while (0)
 
+// frees its device allocations on every exit path of the function that owns it
+struct DevFrees {
+    std::vector<void*> p;
+    template <typename T> hipError_t alloc(T** q, size_t bytes) { hipError_t e = hipMalloc((void**)q, bytes ? bytes : 16); if (e == hipSuccess) p.push_back((void*)*q); return e; }
+    ~DevFrees() { for (void* q : p) hipFree(q); }
+};
+
+// internal nodes of a binary hierarchy bucketed by depth (k_depth_* above): order[off[d] .. off[d+1]) are the nodes at depth d
+struct LevelOrder {
+    int* order = nullptr; // device, n-1 entries
+    std::vector<int> off; // host, levels + 1 entries; empty = the hierarchy is deeper than PT_MAX_TREE_LEVELS (callers fall back to the climb)
+    void release() { if (order) hipFree(order); order = nullptr; off.clear(); }
+};
+static hipError_t build_levels(int n, const int* parent, int root, hipStream_t stream, LevelOrder* lv) {
+    const int ni = n - 1, B = 256;
+    lv->release();
+    if (getenv("PT_BVH_CLIMB")) return hipSuccess; // test hook: the atomic climb instead (the trees must come out byte-identical)
+    DevFrees mem;
+    int *anc[2] = {nullptr, nullptr}, *dep[2] = {nullptr, nullptr}, *hist = nullptr;
+    for (int k = 0; k < 2; ++k) { HIPCHK(mem.alloc(&anc[k], sizeof(int) * (size_t)ni)); HIPCHK(mem.alloc(&dep[k], sizeof(int) * (size_t)ni)); }
+    HIPCHK(mem.alloc(&hist, sizeof(int) * (PT_MAX_TREE_LEVELS + 1)));
+    hipLaunchKernelGGL(k_depth_init, dim3((ni + B - 1) / B), dim3(B), 0, stream, ni, parent, root, anc[0], dep[0]);
+    int cur = 0;
+    std::vector<int> h(PT_MAX_TREE_LEVELS + 1);
+    for (int rounds = 6;; rounds = 3) { // 2^6 = 64 levels cover a Morton hierarchy; deeper ones take more rounds
+        for (int r = 0; r < rounds; ++r) {
+            hipLaunchKernelGGL(k_depth_jump, dim3((ni + B - 1) / B), dim3(B), 0, stream, ni, anc[cur], dep[cur], anc[cur ^ 1], dep[cur ^ 1]);
+            cur ^= 1;
+        }
+        HIPCHK(hipMemsetAsync(hist, 0, sizeof(int) * (PT_MAX_TREE_LEVELS + 1), stream));
+        hipLaunchKernelGGL(k_depth_hist, dim3(std::min((ni + B - 1) / B, 1024)), dim3(B), 0, stream, ni, anc[cur], dep[cur], hist);
+        HIPCHK(hipMemcpyAsync(h.data(), hist, sizeof(int) * (PT_MAX_TREE_LEVELS + 1), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (h[PT_MAX_TREE_LEVELS] == 0) break;
+        int deepest = 0;
+        for (int d = 0; d < PT_MAX_TREE_LEVELS; ++d) if (h[d]) deepest = d;
+        if (deepest >= PT_MAX_TREE_LEVELS - 1) return hipSuccess; // too deep: lv->off stays empty
+    }
+    int levels = 0;
+    for (int d = 0; d < PT_MAX_TREE_LEVELS; ++d) if (h[d]) levels = d + 1;
+    std::vector<int> off(levels + 1, 0);
+    for (int d = 0; d < levels; ++d) off[d + 1] = off[d] + h[d];
+    if (off[levels] != ni) return hipErrorUnknown;
+    HIPCHK(hipMalloc(&lv->order, sizeof(int) * (size_t)std::max(ni, 1)));
+    HIPCHK(hipMemcpyAsync(hist, off.data(), sizeof(int) * (size_t)levels, hipMemcpyHostToDevice, stream)); // cursors
+    hipLaunchKernelGGL(k_depth_scatter, dim3((ni + B - 1) / B), dim3(B), 0, stream, ni, dep[cur], hist, lv->order);
+    HIPCHK(hipStreamSynchronize(stream)); // off.data() was read by the copy; mem is freed on return
+    lv->off = off;
+    return hipSuccess;
+}
+
 // wide BVH from the LBVH temporaries; nodes/tris are sized for the worst case and trimmed logically
 static hipError_t build_bvh8(int n, int root, const int* left, const int* right, const int* cnt, const float* box, float pad,
-                             const LeafTri* tris_sorted, hipStream_t stream, PtBvh* out) {
+                             const LeafTri* tris_sorted, hipStream_t stream, PtBvh* out, const LevelOrder* levels_in = nullptr) {
     Node8* nodes = nullptr;
     LeafTri* tris8 = nullptr;
     Task8 *ta = nullptr, *tb = nullptr;
@@ -635,10 +767,24 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
         HIPCHK(hipMalloc(&visits, sizeof(int) * (size_t)n));
         HIPCHK(hipMalloc(&cost, sizeof(float) * 7 * (size_t)n));
         HIPCHK(hipMalloc(&dec, 8 * (size_t)n));
-        HIPCHK(hipMemsetAsync(visits, 0, sizeof(int) * (size_t)n, stream));
         hipLaunchKernelGGL(k_parents, dim3((n + 255) / 256), dim3(256), 0, stream, n, left, right, root, parent);
-        hipLaunchKernelGGL(k_collapse_cost, dim3((n + 255) / 256), dim3(256), 0, stream, n, left, right, parent, cnt, box, pad, cp, cost, dec, visits);
+        LevelOrder own;
+        const LevelOrder* lv = levels_in;
+        if (!lv) {
+            HIPCHK(build_levels(n, parent, root, stream, &own));
+            lv = &own;
+        }
+        if (!lv->off.empty()) { // one launch per level, deepest first
+            for (int d = (int)lv->off.size() - 2; d >= 0; --d) {
+                const int count = lv->off[d + 1] - lv->off[d];
+                hipLaunchKernelGGL(k_collapse_cost_level, dim3((count + 127) / 128), dim3(128), 0, stream, lv->order + lv->off[d], count, n, left, right, cnt, box, pad, cp, cost, dec);
+            }
+        } else {
+            HIPCHK(hipMemsetAsync(visits, 0, sizeof(int) * (size_t)n, stream));
+            hipLaunchKernelGGL(k_collapse_cost, dim3((n + 255) / 256), dim3(256), 0, stream, n, left, right, parent, cnt, box, pad, cp, cost, dec, visits);
+        }
         HIPCHK(hipStreamSynchronize(stream));
+        own.release();
         if (getenv("PT_DEBUG_BVH")) {
             float rc = 0, rb[6];
             HIPCHK(hipMemcpy(&rc, cost + (size_t)root * 7, 4, hipMemcpyDeviceToHost));
@@ -702,13 +848,6 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
 
 // PLOC hierarchy over the sorted leaves (leaf boxes at box[n-1+i] come from the refit pass); overwrites the
 // internal-node arrays left/right/box/cnt (ids 0..n-2, root = the last one created)
-// frees its device allocations on every exit path of the function that owns it
-struct DevFrees {
-    std::vector<void*> p;
-    template <typename T> hipError_t alloc(T** q, size_t bytes) { hipError_t e = hipMalloc((void**)q, bytes ? bytes : 16); if (e == hipSuccess) p.push_back((void*)*q); return e; }
-    ~DevFrees() { for (void* q : p) hipFree(q); }
-};
-
 static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt, hipStream_t stream, int* root_out) {
     DevFrees mem;
     int *cl_a = nullptr, *cl_b = nullptr, *nn = nullptr;
@@ -793,9 +932,25 @@ static hipError_t import_hierarchy(const char* path, int n, const uint64_t* keys
 }
 
 // Builds the traversal structure for (verts, idx) already resident on the device.
+// PT_DEBUG_BVH: host time of every phase of the build (each closed by a stream synchronisation, so the sum is above the unprofiled total)
+struct PhaseClock {
+    hipStream_t stream;
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    PhaseClock(hipStream_t s) : stream(s), on(getenv("PT_DEBUG_BVH") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pt_bvh] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint32_t* d_tri_mesh, uint32_t ntri, hipStream_t stream, PtBvh* out) {
     const int n = (int)ntri;
     const int B = 256;
+    PhaseClock pc(stream);
     // leaf triangles + keys
     uint64_t *keys = nullptr, *keys_sorted = nullptr;
     uint32_t* bounds = nullptr;
@@ -825,6 +980,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
     }
     const float pad = maxabs * (1.0f / 65536.0f);
     out->pad = pad;
+    pc.mark("bounds, morton, sort");
 
     LeafTri* tris = nullptr;
     HIPCHK(hipMalloc(&tris, sizeof(LeafTri) * (size_t)n));
@@ -857,9 +1013,21 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
     HIPCHK(hipMalloc(&rlast, sizeof(int) * (size_t)n));
     HIPCHK(hipMalloc(&visits, sizeof(int) * (size_t)n));
     HIPCHK(hipMalloc(&box, sizeof(float) * 6 * (size_t)(2 * n)));
-    HIPCHK(hipMemsetAsync(visits, 0, sizeof(int) * (size_t)n, stream));
     hipLaunchKernelGGL(k_karras, dim3((n + B - 1) / B), dim3(B), 0, stream, keys_sorted, n, left, right, parent, rfirst, rlast);
-    hipLaunchKernelGGL(k_refit, dim3((n + B - 1) / B), dim3(B), 0, stream, d_verts, d_idx, keys_sorted, n, left, right, parent, box, visits);
+    pc.mark("emit tris, allocs");
+    LevelOrder lbvh_levels; // of the Karras hierarchy: the refit and the LBVH's collapse costs both run level by level over it
+    HIPCHK(build_levels(n, parent, 0, stream, &lbvh_levels));
+    if (!lbvh_levels.off.empty()) {
+        hipLaunchKernelGGL(k_leaf_boxes, dim3((n + B - 1) / B), dim3(B), 0, stream, d_verts, d_idx, keys_sorted, n, box);
+        for (int d = (int)lbvh_levels.off.size() - 2; d >= 0; --d) {
+            const int count = lbvh_levels.off[d + 1] - lbvh_levels.off[d];
+            hipLaunchKernelGGL(k_refit_level, dim3((count + B - 1) / B), dim3(B), 0, stream, lbvh_levels.order + lbvh_levels.off[d], count, left, right, box);
+        }
+    } else {
+        HIPCHK(hipMemsetAsync(visits, 0, sizeof(int) * (size_t)n, stream));
+        hipLaunchKernelGGL(k_refit, dim3((n + B - 1) / B), dim3(B), 0, stream, d_verts, d_idx, keys_sorted, n, left, right, parent, box, visits);
+    }
+    pc.mark("karras, levels, refit");
     {
         // hierarchy for the wide tree: the LBVH itself (default) or PLOC (PT_BVH_BUILDER=ploc).  Measured on the C3 voxel
         // terrain: PLOC gives MORE node visits per ray (13.3 vs 12.5 primary, 15.9 vs 13.6 diffuse bounce) and 5 % lower
@@ -874,14 +1042,18 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
         if (force_ploc) HIPCHK(build_ploc(n, left, right, box, cnt, stream, &root));
         const char* import = getenv("PT_BVH_IMPORT");
         if (import) HIPCHK(import_hierarchy(import, n, keys_sorted, left, right, box, cnt, stream, &root));
-        HIPCHK(build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, out));
+        HIPCHK(build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, out, (force_ploc || import) ? nullptr : &lbvh_levels));
+        lbvh_levels.release();
+        pc.mark("wide tree 1");
         out->builder = import ? 2 : force_ploc ? 1 : 0;
         if (import) { hipFree(cnt); goto done; }
         if (!force_lbvh && !force_ploc && n >= 4096) {
             // both hierarchies, the one that costs the calibration rays less (see k_calibrate8); small scenes keep the LBVH
             PtBvh alt;
             hipError_t pe = build_ploc(n, left, right, box, cnt, stream, &root); // overwrites the LBVH's internal nodes: the first wide tree is already emitted
+            pc.mark("ploc hierarchy");
             if (pe == hipSuccess) pe = build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, &alt);
+            pc.mark("wide tree 2");
             if (pe != hipSuccess) { // the alternative is optional: the LBVH tree stands
                 (void)hipGetLastError();
                 pt_bvh_free(&alt);
@@ -898,6 +1070,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
             HIPCHK(hipMemcpyAsync(hcnt, counts, sizeof(hcnt), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
             hipFree(counts);
+            pc.mark("calibration");
             // a triangle step costs the traversal kernel about 0.6 node steps (≈110 against ≈185 instructions)
             const double cost_lbvh = (double)hcnt[0] + 0.6 * (double)hcnt[1], cost_ploc = (double)hcnt[2] + 0.6 * (double)hcnt[3];
             if (getenv("PT_DEBUG_BVH"))
@@ -918,6 +1091,7 @@ done:
     hipFree(left); hipFree(right); hipFree(parent); hipFree(rfirst); hipFree(rlast); hipFree(visits);
     hipFree(box);
     hipFree(tris); // the Morton-ordered triangles only fed the wide tree's leaf arrays
+    pc.mark("frees");
     return hipSuccess;
 }
 

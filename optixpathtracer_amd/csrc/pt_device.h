@@ -549,10 +549,16 @@ PT_DEV void probe_sample(const DevProbe& p, const ProbeMarg& pm, v3& dir, v3& co
 // ------------------------------------------------------------------ software tex2D (SimplePathtracer.cpp:603-654 settings)
 // uchar4 array, wrap addressing, bilinear filter, normalised float read, normalised coordinates, no sRGB — the formula of
 // the CUDA C Programming Guide appendix "Texture Fetching" (weights in 1.8 fixed point; rounding to nearest assumed).
+// Texel layout: 8 x 4-texel tiles, one tile = 128 contiguous bytes = one L2 line, tiles row-major (tiles_x per row, the last column / row
+// of tiles padded).  A bilinear footprint (2 x 2 texels) then lies in one line with probability 7/8 * 3/4 and in two otherwise (four at a
+// tile corner: 3 %); in a row-major image it always spans two rows = two lines.  Which texels are read, and every operation on them, is
+// unchanged: same bits as the row-major restatement in the checker.
 struct DevTex {
-    const uint32_t* pixel;
+    const uint32_t* pixel; // tiled (tex_tiled_index)
     int w, h;
+    int tiles_x;
 };
+PT_HD size_t tex_tiled_index(int x, int y, int tiles_x) { return ((size_t)(y >> 2) * (size_t)tiles_x + (size_t)(x >> 3)) * 32u + (size_t)(((y & 3) << 3) | (x & 7)); }
 PT_DEV float texel_ch(uint32_t p, int k) { return (float)((p >> (8 * k)) & 0xffu) / 255.0f; }
 PT_DEV float4 tex2d_wrap_linear(const DevTex& tx, float s, float t) {
     const int W = tx.w, H = tx.h;
@@ -561,12 +567,17 @@ PT_DEV float4 tex2d_wrap_linear(const DevTex& tx, float s, float t) {
     const float fi = floorf(xB), fj = floorf(yB);
     const float alpha = floorf((xB - fi) * 256.0f + 0.5f) * (1.0f / 256.0f);
     const float beta = floorf((yB - fj) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    // wrap: x lies in [0, W] (W itself when s - floor(s) rounds to 1), so i0 = floor(x - 0.5) lies in [-1, W - 1] and i1 in [0, W]: one
+    // conditional step each instead of the four integer remainders of ((i % W) + W) % W — the same index for every finite coordinate.
+    // The unsigned minimum keeps a non-finite coordinate (NaN converts to 0) inside the image.
     int i0 = (int)fi, j0 = (int)fj;
     int i1 = i0 + 1, j1 = j0 + 1;
-    i0 = ((i0 % W) + W) % W; i1 = ((i1 % W) + W) % W;
-    j0 = ((j0 % H) + H) % H; j1 = ((j1 % H) + H) % H;
-    const uint32_t t00 = tx.pixel[(size_t)j0 * W + i0], t10 = tx.pixel[(size_t)j0 * W + i1], t01 = tx.pixel[(size_t)j1 * W + i0],
-                   t11 = tx.pixel[(size_t)j1 * W + i1];
+    i0 = i0 < 0 ? i0 + W : i0; i1 = i1 >= W ? i1 - W : i1;
+    j0 = j0 < 0 ? j0 + H : j0; j1 = j1 >= H ? j1 - H : j1;
+    i0 = (int)min((uint32_t)i0, (uint32_t)(W - 1)); i1 = (int)min((uint32_t)i1, (uint32_t)(W - 1));
+    j0 = (int)min((uint32_t)j0, (uint32_t)(H - 1)); j1 = (int)min((uint32_t)j1, (uint32_t)(H - 1));
+    const uint32_t t00 = tx.pixel[tex_tiled_index(i0, j0, tx.tiles_x)], t10 = tx.pixel[tex_tiled_index(i1, j0, tx.tiles_x)],
+                   t01 = tx.pixel[tex_tiled_index(i0, j1, tx.tiles_x)], t11 = tx.pixel[tex_tiled_index(i1, j1, tx.tiles_x)];
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)

@@ -198,12 +198,20 @@ __global__ void __launch_bounds__(256) k_generate(PathState st, FrameParams fp, 
 struct PrimUV { // texcoords of the three vertices of a primitive (sbtData.texcoord[index.*])
     float2 c0, c1, c2;
 };
+// What a TEXTURED hit reads, as one aligned 64-byte record per leaf triangle (in leaf order, like tri_nrm): the vertices for the
+// barycentrics and the three texcoords.  Before: 48 bytes of LeafTri (1.4 lines) + 24 bytes of PrimUV indexed by primitive (a random line).
+struct TexTri {
+    float4 a; // v0.xyz, v1.x
+    float4 b; // v1.yz, v2.xy
+    float4 c; // v2.z, uv0.xy, uv1.x
+    float4 d; // uv1.y, uv2.xy, -
+};
 struct ShadeParams {
     const LeafTri* tris; // the traversal structure's leaf triangles: vertices, primitive and mesh of a hit (what sbtData.vertex[index[prim]] and the SBT record gave, :481-489)
     const float4* tri_nrm; // per leaf triangle: (normalize(cross(v1 - v0, v2 - v0)), mesh) — all the closest-hit program needs of an untextured hit, in ONE 16-byte load (k_shade_normals)
     const pt_material* mats;
     const int32_t* mesh_tex; // per mesh: texture id when the mesh has a texture AND texcoords, else -1 (null: no textures)
-    const PrimUV* uvs;
+    const TexTri* textris; // scenes with textures only (k_emit_textris)
     const DevTex* textures;
     DevProbe probe;
     int max_depth;
@@ -315,18 +323,17 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             if (sp.mesh_tex) { // deviceProgram.cu:512-523: a textured mesh's albedo is REPLACED by tex2D at the hit's texcoord
                 const int tid = sp.mesh_tex[mesh];
                 if (tid >= 0) {
-                    const LeafTri tri = sp.tris[leaf];
-                    const v3 v0 = mk3(tri.t0.x, tri.t0.y, tri.t0.z), v1 = mk3(tri.t0.w, tri.t1.x, tri.t1.y), v2 = mk3(tri.t1.z, tri.t1.w, tri.t2.x);
+                    const TexTri tt = sp.textris[leaf];
+                    const v3 v0 = mk3(tt.a.x, tt.a.y, tt.a.z), v1 = mk3(tt.a.w, tt.b.x, tt.b.y), v2 = mk3(tt.b.z, tt.b.w, tt.c.x);
                     // optixGetTriangleBarycentrics = (weight of vertex 1, weight of vertex 2): the hit test's own weights
                     const v3 A = sub3(v0, ray_o), B = sub3(v1, ray_o), C = sub3(v2, ray_o);
                     const v3 CxB = cross3(C, B), AxC = cross3(A, C), BxA = cross3(B, A);
                     const float Uw = dot3(ray_dir, CxB), Vw = dot3(ray_dir, AxC), Ww = dot3(ray_dir, BxA);
                     const float det = Uw + Vw + Ww;
                     const float bu = Vw / det, bv = Ww / det;
-                    const PrimUV uv = sp.uvs[__float_as_int(tri.t2.y)]; // optixGetPrimitiveIndex
-                    const float w0 = 1.f - bu - bv;
-                    const float tcx = w0 * uv.c0.x + bu * uv.c1.x + bv * uv.c2.x;
-                    const float tcy = w0 * uv.c0.y + bu * uv.c1.y + bv * uv.c2.y;
+                    const float w0 = 1.f - bu - bv; // texcoords of optixGetPrimitiveIndex()'s vertices, (1 - u - v, u, v) weighted (:515-518)
+                    const float tcx = w0 * tt.c.y + bu * tt.c.w + bv * tt.d.y;
+                    const float tcy = w0 * tt.c.z + bu * tt.d.x + bv * tt.d.z;
                     const float4 tx = tex2d_wrap_linear(sp.textures[tid], tcx, tcy);
                     albedo = mk3(tx.x, tx.y, tx.z);
                 }
@@ -1077,6 +1084,18 @@ __global__ void k_emit_uvs(const float* __restrict__ texcoord, const uint32_t* _
     u.c1 = make_float2(texcoord[2 * (size_t)b], texcoord[2 * (size_t)b + 1]);
     u.c2 = make_float2(texcoord[2 * (size_t)c], texcoord[2 * (size_t)c + 1]);
     uvs[p] = u;
+}
+__global__ void k_emit_textris(const LeafTri* __restrict__ tris, const PrimUV* __restrict__ uvs, uint32_t n, TexTri* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const LeafTri t = tris[i];
+    const PrimUV u = uvs[__float_as_int(t.t2.y)];
+    TexTri o;
+    o.a = t.t0;
+    o.b = t.t1;
+    o.c = make_float4(t.t2.x, u.c0.x, u.c0.y, u.c1.x);
+    o.d = make_float4(u.c1.y, u.c2.x, u.c2.y, 0.f);
+    out[i] = o;
 }
 __global__ void k_table_rng(const float* __restrict__ in, uint32_t n, float* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,65 @@
+"""The on-GPU builder (row a16, replaces optixAccelBuild + optixAccelCompact, SimplePathtracer.cpp:561-591): the level-synchronous
+refit / collapse-cost passes must produce the very tree the atomic climb produced, and the build has a time budget."""
+import os
+
+import numpy as np
+import pytest
+
+from optixpathtracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _export(model, monkeypatch, **env):
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    for k in ("PT_BVH_CLIMB", "PT_BVH_BUILDER"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = SampleRenderer(model)
+    nodes, tris = r.exportBVH()[:2]
+    st = r.stats()
+    r.close()
+    return np.asarray(nodes).tobytes(), np.asarray(tris).tobytes(), st
+
+
+@pytest.mark.parametrize("scene", ["terrain1M", "stadium200k", "copies", "small"])
+def test_level_passes_reproduce_the_climb(ptlib, monkeypatch, scene):
+    """PT_BVH_CLIMB=1 runs the bottom-up passes the way rounds 1-3 did (one thread per leaf climbing with atomic counters and agent-scope
+    fences); the default runs them level by level.  Nodes and leaf triangles of the wide tree must be byte-identical, for both
+    hierarchies (the calibration then picks the same one)."""
+    if scene == "terrain1M":
+        m = scenes.voxel_terrain()
+    elif scene == "stadium200k":
+        m = scenes.stadium_scene(target_tris=200_000)
+    elif scene == "copies":  # thousands of copies of one triangle: the deepest hierarchies the builder meets (Morton ties broken by primitive id)
+        base = np.array([[0, 0, 0], [4, 0, 0], [0, 3, 0]], np.float32)
+        tri = np.repeat(base[None], 6000, 0)
+        m = scenes.Model(meshes=[scenes.TriangleMesh(vertex=tri.reshape(-1, 3).copy(), index=np.arange(18000, dtype=np.uint32).reshape(-1, 3), material=scenes.Material())])
+    else:
+        m = scenes.cornell_box()
+    for builder in ("lbvh", "ploc", None):
+        env = {} if builder is None else {"PT_BVH_BUILDER": builder}
+        a = _export(m, monkeypatch, **env)
+        b = _export(m, monkeypatch, PT_BVH_CLIMB="1", **env)
+        assert a[0] == b[0] and a[1] == b[1], f"{scene}/{builder}: the level-synchronous build differs from the climb"
+        assert a[2]["bvh_builder"] == b[2]["bvh_builder"] and a[2]["bvh_levels"] == b[2]["bvh_levels"]
+
+
+def test_build_time_budget(ptlib, monkeypatch):
+    """pt_stats.bvh_build_ms for a million triangles (both hierarchies, both wide trees, calibration): rounds 1-3 took 43-60 ms."""
+    for k in ("PT_BVH_CLIMB", "PT_BVH_BUILDER"):
+        monkeypatch.delenv(k, raising=False)
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    out = {}
+    for name, m in (("terrain", scenes.voxel_terrain()), ("stadium", scenes.stadium_scene())):
+        best = 1e9
+        for _ in range(3):
+            r = SampleRenderer(m)
+            best = min(best, r.stats()["bvh_build_ms"])
+            r.close()
+        out[name] = best
+    print(f"\n[bvh build, 1 M triangles] terrain {out['terrain']:.1f} ms, stadium {out['stadium']:.1f} ms")
+    assert out["terrain"] < 25 and out["stadium"] < 25, out

@@ -209,10 +209,25 @@ __global__ void k_depth_hist(int ni, const int* __restrict__ anc, const int* __r
     for (int k = threadIdx.x; k <= PT_MAX_TREE_LEVELS; k += blockDim.x)
         if (h[k]) atomicAdd(&hist[k], h[k]);
 }
-__global__ void k_depth_scatter(int ni, const int* __restrict__ depth, int* __restrict__ cursor, int* __restrict__ order) {
+// one global atomic per (workgroup, depth present in it): the workgroup counts its nodes per depth in LDS, reserves a range per depth and
+// places its nodes inside (a global atomic per NODE on ~40 cursors serialised: 5.3 ms for a million nodes)
+__global__ void __launch_bounds__(1024) k_depth_scatter(int ni, const int* __restrict__ depth, int* __restrict__ cursor, int* __restrict__ order) {
+    __shared__ int h[PT_MAX_TREE_LEVELS];
+    for (int k = threadIdx.x; k < PT_MAX_TREE_LEVELS; k += blockDim.x) h[k] = 0;
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ni) return;
-    order[atomicAdd(&cursor[depth[i]], 1)] = i;
+    int d = 0, local = 0;
+    if (i < ni) {
+        d = depth[i];
+        local = atomicAdd(&h[d], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < PT_MAX_TREE_LEVELS; k += blockDim.x) {
+        const int c = h[k];
+        if (c) h[k] = atomicAdd(&cursor[k], c); // count -> base of this workgroup's range
+    }
+    __syncthreads();
+    if (i < ni) order[h[d] + local] = i;
 }
 __global__ void k_refit_level(const int* __restrict__ order, int count, const int* __restrict__ left, const int* __restrict__ right, float* __restrict__ box) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -507,9 +522,7 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
 // right for the partner that minimises the surface area of the merged box; mutual nearest neighbours merge; repeat.
 // Much closer to a SAH tree than the LBVH split-at-Morton-bit hierarchy, still fully parallel.
 #define PLOC_R 25
-__global__ void k_ploc_nn(const int* __restrict__ cl, int N, const float* __restrict__ box, int tie_partner, int* __restrict__ nn) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+__device__ __forceinline__ int ploc_search(const int* cl, int N, const float* __restrict__ box, int tie_partner, int i) {
     const float* bi = &box[(size_t)cl[i] * 6];
     const float l0 = bi[0], l1 = bi[1], l2 = bi[2], h0 = bi[3], h1 = bi[4], h2 = bi[5];
     float best = INFINITY;
@@ -538,7 +551,12 @@ __global__ void k_ploc_nn(const int* __restrict__ cl, int N, const float* __rest
             bj = j;
         }
     }
-    nn[i] = bj;
+    return bj;
+}
+__global__ void k_ploc_nn(const int* __restrict__ cl, int N, const float* __restrict__ box, int tie_partner, int* __restrict__ nn) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    nn[i] = ploc_search(cl, N, box, tie_partner, i);
 }
 // flags: merge[i] = 1 if i starts a merged pair (i < nn[i], mutual); valid[i] = 0 if i is the absorbed partner
 __global__ void k_ploc_flags(const int* __restrict__ nn, int N, uint32_t* __restrict__ merge, uint32_t* __restrict__ valid) {
@@ -574,6 +592,104 @@ __global__ void k_ploc_merge(const int* __restrict__ cl, const int* __restrict__
 __global__ void k_ploc_init(int n, int* __restrict__ cl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) cl[i] = n - 1 + i; // leaf node ids, Morton order
+}
+
+// the two numbers the host needs of a round, in one 8-byte read-back: pairs merged, clusters left
+__global__ void k_ploc_totals(const uint32_t* __restrict__ merge, const uint32_t* __restrict__ merge_rank, const uint32_t* __restrict__ valid,
+                              const uint32_t* __restrict__ valid_rank, int N, uint32_t* __restrict__ out2) {
+    if (threadIdx.x || blockIdx.x) return;
+    out2[0] = merge[N - 1] + merge_rank[N - 1];
+    out2[1] = valid[N - 1] + valid_rank[N - 1];
+}
+// The last rounds of the clustering (N <= PLOC_TAIL clusters: about a dozen rounds, each five launches, a read-back and a host wait when run
+// from the host — 3-4 ms of a 7-11 ms hierarchy) in ONE workgroup: the same search, the same acceptance rule for a round, the same
+// numbering of the merged nodes, hence the same tree.  result[0] = root, result[1] = 0 ok / 1 a round merged nothing.
+#define PLOC_TAIL 2048
+__global__ void __launch_bounds__(1024) k_ploc_tail(const int* __restrict__ cl_in, int N, int next_id, int* __restrict__ left, int* __restrict__ right,
+                                                    float* box, int* cnt, int* __restrict__ result) {
+    __shared__ int cl[2][PLOC_TAIL];
+    __shared__ int nn[PLOC_TAIL];
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t totals;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < N; e += 1024) cl[0][e] = cl_in[e];
+    __syncthreads();
+    int cur = 0, status = 0;
+    while (N > 1) {
+        int tp = 0;
+        uint32_t m[2], v[2], excl = 0, merged = 0, nleft = 0;
+        for (;;) {
+            for (int k = 0; k < 2; ++k) {
+                const int e = 2 * tid + k;
+                if (e < N) nn[e] = ploc_search(cl[cur], N, box, tp, e);
+            }
+            __syncthreads();
+            for (int k = 0; k < 2; ++k) {
+                const int e = 2 * tid + k;
+                m[k] = 0; v[k] = 0;
+                if (e < N) {
+                    const int j = nn[e];
+                    const bool mutual = j >= 0 && nn[j] == e;
+                    m[k] = (mutual && e < j) ? 1u : 0u;
+                    v[k] = (mutual && e > j) ? 0u : 1u;
+                }
+            }
+            // exclusive scan of (m, v) packed as m | v << 16 (N <= 2048 < 65536): two elements per thread, then 1024 partial sums
+            const uint32_t mine = (m[0] + m[1]) | ((v[0] + v[1]) << 16);
+            part[tid] = mine;
+            __syncthreads();
+            for (int off = 1; off < 1024; off <<= 1) {
+                const uint32_t add = tid >= off ? part[tid - off] : 0u;
+                __syncthreads();
+                part[tid] += add;
+                __syncthreads();
+            }
+            excl = part[tid] - mine;
+            if (tid == 1023) totals = part[1023];
+            __syncthreads();
+            merged = totals & 0xffffu;
+            nleft = totals >> 16;
+            if (tp == 0 && !((long long)merged * 64 >= N || N <= 64)) { // a starved round: again with the partner rule (build_ploc)
+                tp = 1;
+                __syncthreads();
+                continue;
+            }
+            break;
+        }
+        if (merged == 0) { status = 1; break; }
+        uint32_t mr = excl & 0xffffu, vr = excl >> 16;
+        for (int k = 0; k < 2; ++k) {
+            const int e = 2 * tid + k;
+            if (e < N && v[k]) {
+                int node = cl[cur][e];
+                if (m[k]) {
+                    const int a = cl[cur][e], b = cl[cur][nn[e]];
+                    node = next_id + (int)mr;
+                    left[node] = a;
+                    right[node] = b;
+                    const float *ba = &box[(size_t)a * 6], *bb = &box[(size_t)b * 6];
+                    float* bo = &box[(size_t)node * 6];
+                    for (int q = 0; q < 3; ++q) {
+                        bo[q] = fminf(ba[q], bb[q]);
+                        bo[3 + q] = fmaxf(ba[3 + q], bb[3 + q]);
+                    }
+                    cnt[node] = cnt[a] + cnt[b];
+                }
+                cl[cur ^ 1][vr] = node;
+            }
+            mr += m[k];
+            vr += v[k];
+        }
+        __threadfence_block(); // the merged nodes' boxes and counts are read by other waves of this workgroup in the next round
+        __syncthreads();
+        next_id += (int)merged;
+        N = (int)nleft;
+        cur ^= 1;
+    }
+    if (tid == 0) {
+        result[0] = cl[cur][0];
+        result[1] = status;
+    }
 }
 
 // scenes with <= PT8_LEAF_MAX triangles: one node, one leaf child
@@ -688,23 +804,60 @@ __global__ void __launch_bounds__(64) k_calibrate8(const Node8* __restrict__ nod
         if (e_ != hipSuccess) return e_;  \
     } while (0)
 
+// The build's temporaries (≈270 bytes per triangle over ~40 arrays) come out of ONE device allocation: hipMalloc / hipFree cost tens to
+// hundreds of microseconds each and a free synchronises the device (3 ms of "frees" at the end of a 1 M-triangle build, measured).
+// Phases release what they took by resetting the mark (ArenaMark).  A request that does not fit falls back to hipMalloc.
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    hipError_t init(size_t bytes) {
+        cap = bytes;
+        used = 0;
+        return hipMalloc((void**)&base, bytes);
+    }
+    void* take(size_t bytes) {
+        const size_t a = (used + 255) & ~(size_t)255;
+        if (!base || a + bytes > cap) return nullptr;
+        used = a + bytes;
+        return base + a;
+    }
+    bool owns(const void* q) const { return base && (const char*)q >= base && (const char*)q < base + cap; }
+    ~Arena() { if (base) hipFree(base); }
+};
+thread_local Arena* t_arena = nullptr; // pt_multi builds one tree per rank thread
+template <typename T> static hipError_t tmalloc(T** q, size_t bytes) {
+    if (t_arena) {
+        if (void* r = t_arena->take(bytes ? bytes : 16)) { *q = (T*)r; return hipSuccess; }
+    }
+    return hipMalloc((void**)q, bytes ? bytes : 16);
+}
+static void tfree(const void* q) {
+    if (q && !(t_arena && t_arena->owns(q))) hipFree(const_cast<void*>(q));
+}
+struct ArenaMark { // arena memory taken after the mark is handed back when the mark goes out of scope
+    size_t used;
+    ArenaMark() : used(t_arena ? t_arena->used : 0) {}
+    ~ArenaMark() { if (t_arena) t_arena->used = used; }
+};
 // frees its device allocations on every exit path of the function that owns it
 struct DevFrees {
     std::vector<void*> p;
-    template <typename T> hipError_t alloc(T** q, size_t bytes) { hipError_t e = hipMalloc((void**)q, bytes ? bytes : 16); if (e == hipSuccess) p.push_back((void*)*q); return e; }
-    ~DevFrees() { for (void* q : p) hipFree(q); }
+    template <typename T> hipError_t alloc(T** q, size_t bytes) { hipError_t e = tmalloc(q, bytes); if (e == hipSuccess) p.push_back((void*)*q); return e; }
+    ~DevFrees() { for (void* q : p) tfree(q); }
 };
 
 // internal nodes of a binary hierarchy bucketed by depth (k_depth_* above): order[off[d] .. off[d+1]) are the nodes at depth d
 struct LevelOrder {
     int* order = nullptr; // device, n-1 entries
     std::vector<int> off; // host, levels + 1 entries; empty = the hierarchy is deeper than PT_MAX_TREE_LEVELS (callers fall back to the climb)
-    void release() { if (order) hipFree(order); order = nullptr; off.clear(); }
+    void release() { tfree(order); order = nullptr; off.clear(); }
 };
 static hipError_t build_levels(int n, const int* parent, int root, hipStream_t stream, LevelOrder* lv) {
     const int ni = n - 1, B = 256;
     lv->release();
-    if (getenv("PT_BVH_CLIMB")) return hipSuccess; // test hook: the atomic climb instead (the trees must come out byte-identical)
+    if (getenv("PT_BVH_CLIMB")) return hipSuccess; // test hook: the atomic climb instead (the trees must come out the same)
+    HIPCHK(tmalloc(&lv->order, sizeof(int) * (size_t)std::max(ni, 1))); // outlives this function's mark
+    ArenaMark mark;
     DevFrees mem;
     int *anc[2] = {nullptr, nullptr}, *dep[2] = {nullptr, nullptr}, *hist = nullptr;
     for (int k = 0; k < 2; ++k) { HIPCHK(mem.alloc(&anc[k], sizeof(int) * (size_t)ni)); HIPCHK(mem.alloc(&dep[k], sizeof(int) * (size_t)ni)); }
@@ -731,9 +884,8 @@ static hipError_t build_levels(int n, const int* parent, int root, hipStream_t s
     std::vector<int> off(levels + 1, 0);
     for (int d = 0; d < levels; ++d) off[d + 1] = off[d] + h[d];
     if (off[levels] != ni) return hipErrorUnknown;
-    HIPCHK(hipMalloc(&lv->order, sizeof(int) * (size_t)std::max(ni, 1)));
     HIPCHK(hipMemcpyAsync(hist, off.data(), sizeof(int) * (size_t)levels, hipMemcpyHostToDevice, stream)); // cursors
-    hipLaunchKernelGGL(k_depth_scatter, dim3((ni + B - 1) / B), dim3(B), 0, stream, ni, dep[cur], hist, lv->order);
+    hipLaunchKernelGGL(k_depth_scatter, dim3((ni + 1023) / 1024), dim3(1024), 0, stream, ni, dep[cur], hist, lv->order);
     HIPCHK(hipStreamSynchronize(stream)); // off.data() was read by the copy; mem is freed on return
     lv->off = off;
     return hipSuccess;
@@ -746,12 +898,13 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
     LeafTri* tris8 = nullptr;
     Task8 *ta = nullptr, *tb = nullptr;
     uint32_t* counters = nullptr;
+    ArenaMark mark;
     const size_t max_nodes = (size_t)n + 1; // every wide node has >= 2 children, so < n nodes
-    HIPCHK(hipMalloc(&nodes, sizeof(Node8) * max_nodes));
+    HIPCHK(tmalloc(&nodes, sizeof(Node8) * max_nodes)); // worst-case size while the tree is emitted; the context keeps an exact-size copy
     HIPCHK(hipMalloc(&tris8, sizeof(LeafTri) * (size_t)n));
-    HIPCHK(hipMalloc(&ta, sizeof(Task8) * max_nodes));
-    HIPCHK(hipMalloc(&tb, sizeof(Task8) * max_nodes));
-    HIPCHK(hipMalloc(&counters, sizeof(uint32_t) * 4));
+    HIPCHK(tmalloc(&ta, sizeof(Task8) * max_nodes));
+    HIPCHK(tmalloc(&tb, sizeof(Task8) * max_nodes));
+    HIPCHK(tmalloc(&counters, sizeof(uint32_t) * 4));
     uint32_t hc[4] = {0u, 1u, 0u, 0u}; // node 0 = root is taken
     HIPCHK(hipMemcpyAsync(counters, hc, sizeof(hc), hipMemcpyHostToDevice, stream));
     // which binary nodes become wide nodes / leaf slots: SAH-optimal collapse (default) or greedy opening of the
@@ -763,10 +916,10 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
         if (const char* e = getenv("PT_BVH_CP")) cp = (float)atof(e);
         int *parent = nullptr, *visits = nullptr;
         float* cost = nullptr;
-        HIPCHK(hipMalloc(&parent, sizeof(int) * (size_t)(2 * n)));
-        HIPCHK(hipMalloc(&visits, sizeof(int) * (size_t)n));
-        HIPCHK(hipMalloc(&cost, sizeof(float) * 7 * (size_t)n));
-        HIPCHK(hipMalloc(&dec, 8 * (size_t)n));
+        HIPCHK(tmalloc(&parent, sizeof(int) * (size_t)(2 * n)));
+        HIPCHK(tmalloc(&visits, sizeof(int) * (size_t)n));
+        HIPCHK(tmalloc(&cost, sizeof(float) * 7 * (size_t)n));
+        HIPCHK(tmalloc(&dec, 8 * (size_t)n));
         hipLaunchKernelGGL(k_parents, dim3((n + 255) / 256), dim3(256), 0, stream, n, left, right, root, parent);
         LevelOrder own;
         const LevelOrder* lv = levels_in;
@@ -792,7 +945,7 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
             const float dx = rb[3] - rb[0] + 2 * pad, dy = rb[4] - rb[1] + 2 * pad, dz = rb[5] - rb[2] + 2 * pad;
             fprintf(stderr, "[pt_bvh] SAH cost of the wide tree (node steps + %.2f x triangle tests per random ray through the root box): %.3f\n", cp, rc / (dx * dy + dy * dz + dz * dx));
         }
-        hipFree(parent); hipFree(visits); hipFree(cost);
+        tfree(parent); tfree(visits); tfree(cost);
     }
     Task8 root_task{root, 0u};
     HIPCHK(hipMemcpyAsync(ta, &root_task, sizeof(root_task), hipMemcpyHostToDevice, stream));
@@ -836,19 +989,27 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
         for (int k = 1; k <= 8; ++k) if (leafsz[k]) fprintf(stderr, " %d:%llu", k, leafsz[k]);
         fprintf(stderr, "\n");
     }
+    {
+        Node8* exact = nullptr;
+        HIPCHK(hipMalloc(&exact, sizeof(Node8) * (size_t)std::max(hc[1], 1u)));
+        HIPCHK(hipMemcpyAsync(exact, nodes, sizeof(Node8) * (size_t)hc[1], hipMemcpyDeviceToDevice, stream));
+        tfree(nodes);
+        nodes = exact;
+    }
     out->nodes8 = nodes;
     out->tris8 = tris8;
     out->num_nodes8 = hc[1];
     out->num_tris8 = hc[2];
     out->levels8 = levels;
-    hipFree(ta); hipFree(tb); hipFree(counters);
-    if (dec) hipFree(dec);
+    tfree(ta); tfree(tb); tfree(counters);
+    if (dec) tfree(dec);
     return hipSuccess;
 }
 
 // PLOC hierarchy over the sorted leaves (leaf boxes at box[n-1+i] come from the refit pass); overwrites the
 // internal-node arrays left/right/box/cnt (ids 0..n-2, root = the last one created)
 static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt, hipStream_t stream, int* root_out) {
+    ArenaMark mark;
     DevFrees mem;
     int *cl_a = nullptr, *cl_b = nullptr, *nn = nullptr;
     uint32_t *merge = nullptr, *valid = nullptr, *merge_rank = nullptr, *valid_rank = nullptr;
@@ -860,28 +1021,38 @@ static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt,
     void* tmp = nullptr;
     HIPCHK(mem.alloc(&tmp, tmp_bytes));
     const int B = 256;
+    uint32_t* d2 = nullptr;
+    HIPCHK(mem.alloc(&d2, 16));
     hipLaunchKernelGGL(k_ploc_init, dim3((n + B - 1) / B), dim3(B), 0, stream, n, cl_a);
     int N = n, next_id = 0, iters = 0;
+    const bool tail = getenv("PT_PLOC_TAIL") == nullptr || atoi(getenv("PT_PLOC_TAIL")) != 0;
     while (N > 1) {
-        uint32_t lm[2], lv[2];
+        if (tail && N <= PLOC_TAIL) { // the rest in one workgroup
+            hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(1024), 0, stream, cl_a, N, next_id, left, right, box, cnt, (int*)d2);
+            int res[2] = {0, 1};
+            HIPCHK(hipMemcpyAsync(res, d2, sizeof(res), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            if (res[1] != 0) return hipErrorUnknown;
+            *root_out = res[0];
+            return hipSuccess;
+        }
+        uint32_t tot[2] = {0, 0};
         int merged = 0;
         for (int tie_partner = 0; tie_partner < 2; ++tie_partner) {
             hipLaunchKernelGGL(k_ploc_nn, dim3((N + B - 1) / B), dim3(B), 0, stream, cl_a, N, box, tie_partner, nn);
             hipLaunchKernelGGL(k_ploc_flags, dim3((N + B - 1) / B), dim3(B), 0, stream, nn, N, merge, valid);
             HIPCHK(rocprim::exclusive_scan(tmp, tmp_bytes, merge, merge_rank, 0u, (size_t)N, rocprim::plus<uint32_t>(), stream));
             HIPCHK(rocprim::exclusive_scan(tmp, tmp_bytes, valid, valid_rank, 0u, (size_t)N, rocprim::plus<uint32_t>(), stream));
-            HIPCHK(hipMemcpyAsync(&lm[0], merge + (N - 1), 4, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(&lm[1], merge_rank + (N - 1), 4, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(&lv[0], valid + (N - 1), 4, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(&lv[1], valid_rank + (N - 1), 4, hipMemcpyDeviceToHost, stream));
+            hipLaunchKernelGGL(k_ploc_totals, dim3(1), dim3(64), 0, stream, merge, merge_rank, valid, valid_rank, N, d2);
+            HIPCHK(hipMemcpyAsync(tot, d2, sizeof(tot), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
-            merged = (int)(lm[0] + lm[1]);
+            merged = (int)tot[0];
             if ((int64_t)merged * 64 >= N || N <= 64) break; // a healthy round merges a good part of the clusters; a starved one is repeated with the partner rule
         }
         hipLaunchKernelGGL(k_ploc_merge, dim3((N + B - 1) / B), dim3(B), 0, stream, cl_a, nn, N, merge, merge_rank, valid, valid_rank, next_id, left, right, box, cnt, cl_b);
         if (merged == 0 || ++iters > 4096) return hipErrorUnknown; // cannot happen: the global closest pair is always mutual
         next_id += merged;
-        N = (int)(lv[0] + lv[1]);
+        N = (int)tot[1];
         int* t = cl_a; cl_a = cl_b; cl_b = t;
     }
     HIPCHK(hipStreamSynchronize(stream));
@@ -951,12 +1122,17 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
     const int n = (int)ntri;
     const int B = 256;
     PhaseClock pc(stream);
+    Arena arena;
+    struct ArenaScope { ~ArenaScope() { t_arena = nullptr; } } arena_scope;
+    if (n >= 4096 && arena.init((size_t)n * 300 + (8u << 20)) == hipSuccess) t_arena = &arena; // else every temporary is its own allocation
+    else (void)hipGetLastError();
+    pc.mark("arena");
     // leaf triangles + keys
     uint64_t *keys = nullptr, *keys_sorted = nullptr;
     uint32_t* bounds = nullptr;
-    HIPCHK(hipMalloc(&keys, sizeof(uint64_t) * (size_t)n));
-    HIPCHK(hipMalloc(&keys_sorted, sizeof(uint64_t) * (size_t)n));
-    HIPCHK(hipMalloc(&bounds, sizeof(uint32_t) * 6));
+    HIPCHK(tmalloc(&keys, sizeof(uint64_t) * (size_t)n));
+    HIPCHK(tmalloc(&keys_sorted, sizeof(uint64_t) * (size_t)n));
+    HIPCHK(tmalloc(&bounds, sizeof(uint32_t) * 6));
     uint32_t binit[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIPCHK(hipMemcpyAsync(bounds, binit, sizeof(binit), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_bounds, dim3(min((n + B - 1) / B, 2048)), dim3(B), 0, stream, d_verts, d_idx, ntri, bounds);
@@ -964,7 +1140,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
     size_t tmp_bytes = 0;
     HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, keys_sorted, (size_t)n, 0, 64, stream));
     void* tmp = nullptr;
-    HIPCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    HIPCHK(tmalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
     HIPCHK(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, keys_sorted, (size_t)n, 0, 64, stream));
     uint32_t hb[6];
     HIPCHK(hipMemcpyAsync(hb, bounds, sizeof(hb), hipMemcpyDeviceToHost, stream));
@@ -983,7 +1159,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
     pc.mark("bounds, morton, sort");
 
     LeafTri* tris = nullptr;
-    HIPCHK(hipMalloc(&tris, sizeof(LeafTri) * (size_t)n));
+    HIPCHK(tmalloc(&tris, sizeof(LeafTri) * (size_t)n));
     hipLaunchKernelGGL(k_emit_tris, dim3((n + B - 1) / B), dim3(B), 0, stream, d_verts, d_idx, d_tri_mesh, keys_sorted, n, tris);
 
     if (n <= PT8_LEAF_MAX) { // the whole scene is one leaf child of one node
@@ -992,27 +1168,27 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
         float* dbounds = nullptr;
         HIPCHK(hipMalloc(&nodes8, sizeof(Node8)));
         HIPCHK(hipMalloc(&tris8, sizeof(LeafTri) * (size_t)n));
-        HIPCHK(hipMalloc(&dbounds, sizeof(float) * 6));
+        HIPCHK(tmalloc(&dbounds, sizeof(float) * 6));
         HIPCHK(hipMemcpyAsync(dbounds, out->bounds, sizeof(float) * 6, hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(tris8, tris, sizeof(LeafTri) * (size_t)n, hipMemcpyDeviceToDevice, stream));
         hipLaunchKernelGGL(k_single_node8, dim3(1), dim3(64), 0, stream, n, dbounds, pad, nodes8);
         out->nodes8 = nodes8; out->tris8 = tris8; out->num_nodes8 = 1; out->num_tris8 = (uint32_t)n; out->levels8 = 1;
         HIPCHK(hipStreamSynchronize(stream));
-        hipFree(dbounds);
-        hipFree(tris);
-        hipFree(keys); hipFree(keys_sorted); hipFree(bounds); hipFree(tmp);
+        tfree(dbounds);
+        tfree(tris);
+        tfree(keys); tfree(keys_sorted); tfree(bounds); tfree(tmp);
         return hipSuccess;
     }
 
     int *left, *right, *parent, *rfirst, *rlast, *visits;
     float* box;
-    HIPCHK(hipMalloc(&left, sizeof(int) * (size_t)n));
-    HIPCHK(hipMalloc(&right, sizeof(int) * (size_t)n));
-    HIPCHK(hipMalloc(&parent, sizeof(int) * (size_t)(2 * n)));
-    HIPCHK(hipMalloc(&rfirst, sizeof(int) * (size_t)n));
-    HIPCHK(hipMalloc(&rlast, sizeof(int) * (size_t)n));
-    HIPCHK(hipMalloc(&visits, sizeof(int) * (size_t)n));
-    HIPCHK(hipMalloc(&box, sizeof(float) * 6 * (size_t)(2 * n)));
+    HIPCHK(tmalloc(&left, sizeof(int) * (size_t)n));
+    HIPCHK(tmalloc(&right, sizeof(int) * (size_t)n));
+    HIPCHK(tmalloc(&parent, sizeof(int) * (size_t)(2 * n)));
+    HIPCHK(tmalloc(&rfirst, sizeof(int) * (size_t)n));
+    HIPCHK(tmalloc(&rlast, sizeof(int) * (size_t)n));
+    HIPCHK(tmalloc(&visits, sizeof(int) * (size_t)n));
+    HIPCHK(tmalloc(&box, sizeof(float) * 6 * (size_t)(2 * n)));
     hipLaunchKernelGGL(k_karras, dim3((n + B - 1) / B), dim3(B), 0, stream, keys_sorted, n, left, right, parent, rfirst, rlast);
     pc.mark("emit tris, allocs");
     LevelOrder lbvh_levels; // of the Karras hierarchy: the refit and the LBVH's collapse costs both run level by level over it
@@ -1034,7 +1210,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
         // Mrays/s — on a scene of uniform, evenly spread quads the Morton split is already near the SAH optimum and
         // balances the 8-wide collapse better; PLOC stays selectable for irregular scenes.
         int* cnt = nullptr;
-        HIPCHK(hipMalloc(&cnt, sizeof(int) * (size_t)(2 * n)));
+        HIPCHK(tmalloc(&cnt, sizeof(int) * (size_t)(2 * n)));
         hipLaunchKernelGGL(k_counts_from_ranges, dim3((2 * n + B - 1) / B), dim3(B), 0, stream, n, rfirst, rlast, cnt);
         int root = 0;
         const char* builder = getenv("PT_BVH_BUILDER");
@@ -1046,7 +1222,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
         lbvh_levels.release();
         pc.mark("wide tree 1");
         out->builder = import ? 2 : force_ploc ? 1 : 0;
-        if (import) { hipFree(cnt); goto done; }
+        if (import) { tfree(cnt); goto done; }
         if (!force_lbvh && !force_ploc && n >= 4096) {
             // both hierarchies, the one that costs the calibration rays less (see k_calibrate8); small scenes keep the LBVH
             PtBvh alt;
@@ -1057,19 +1233,19 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
             if (pe != hipSuccess) { // the alternative is optional: the LBVH tree stands
                 (void)hipGetLastError();
                 pt_bvh_free(&alt);
-                hipFree(cnt);
+                tfree(cnt);
                 goto done;
             }
             unsigned long long* counts = nullptr;
             unsigned long long hcnt[4] = {0, 0, 0, 0};
-            HIPCHK(hipMalloc(&counts, sizeof(hcnt)));
+            HIPCHK(tmalloc(&counts, sizeof(hcnt)));
             HIPCHK(hipMemsetAsync(counts, 0, sizeof(hcnt), stream));
             const uint32_t nrays = 1u << 16;
             hipLaunchKernelGGL(k_calibrate8, dim3(nrays / 64), dim3(64), 0, stream, out->nodes8, out->tris8, tris, (uint32_t)n, nrays, 0.5f * pad, counts);
             hipLaunchKernelGGL(k_calibrate8, dim3(nrays / 64), dim3(64), 0, stream, alt.nodes8, alt.tris8, tris, (uint32_t)n, nrays, 0.5f * pad, counts + 2);
             HIPCHK(hipMemcpyAsync(hcnt, counts, sizeof(hcnt), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
-            hipFree(counts);
+            tfree(counts);
             pc.mark("calibration");
             // a triangle step costs the traversal kernel about 0.6 node steps (≈110 against ≈185 instructions)
             const double cost_lbvh = (double)hcnt[0] + 0.6 * (double)hcnt[1], cost_ploc = (double)hcnt[2] + 0.6 * (double)hcnt[3];
@@ -1084,13 +1260,13 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
                 hipFree((void*)alt.nodes8); hipFree((void*)alt.tris8);
             }
         }
-        hipFree(cnt);
+        tfree(cnt);
     }
 done:
-    hipFree(keys); hipFree(keys_sorted); hipFree(bounds); hipFree(tmp);
-    hipFree(left); hipFree(right); hipFree(parent); hipFree(rfirst); hipFree(rlast); hipFree(visits);
-    hipFree(box);
-    hipFree(tris); // the Morton-ordered triangles only fed the wide tree's leaf arrays
+    tfree(keys); tfree(keys_sorted); tfree(bounds); tfree(tmp);
+    tfree(left); tfree(right); tfree(parent); tfree(rfirst); tfree(rlast); tfree(visits);
+    tfree(box);
+    tfree(tris); // the Morton-ordered triangles only fed the wide tree's leaf arrays
     pc.mark("frees");
     return hipSuccess;
 }

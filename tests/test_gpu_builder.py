@@ -10,10 +10,30 @@ from optixpathtracer_amd import scenes
 pytestmark = pytest.mark.gpu
 
 
+def _canonical(nodes_bytes, tris_bytes):
+    """The exported tree without its node numbering: k_collapse8 hands out child and triangle ranges with atomic counters, so the order
+    of the nodes inside a level (and of the leaf-triangle groups) differs from build to build.  Walk from the root in slot order and
+    emit every node's content (grid, masks, planes) and its leaf triangles: equal trees give equal bytes."""
+    N = np.frombuffer(nodes_bytes, np.uint32).reshape(-1, 20)
+    T = np.frombuffer(tris_bytes, np.uint32).reshape(-1, 12)
+    out_nodes, out_tris = [], []
+    stack = [0]
+    while stack:
+        i = stack.pop()
+        nd = N[i]
+        child_base, tri_base, leafbits, imask = int(nd[4]), int(nd[5]), int(nd[6]), int(nd[7]) >> 16
+        out_nodes.append(np.concatenate([nd[:4], nd[6:]]))
+        ntri = bin(leafbits).count("1")
+        out_tris.append(T[tri_base:tri_base + ntri])
+        kids = [child_base + k for k in range(bin(imask).count("1"))]
+        stack.extend(reversed(kids))
+    return np.concatenate(out_nodes).tobytes(), np.concatenate(out_tris).tobytes(), len(out_nodes)
+
+
 def _export(model, monkeypatch, **env):
     from optixpathtracer_amd.renderer import SampleRenderer
 
-    for k in ("PT_BVH_CLIMB", "PT_BVH_BUILDER"):
+    for k in ("PT_BVH_CLIMB", "PT_BVH_BUILDER", "PT_PLOC_TAIL"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -27,7 +47,7 @@ def _export(model, monkeypatch, **env):
 @pytest.mark.parametrize("scene", ["terrain1M", "stadium200k", "copies", "small"])
 def test_level_passes_reproduce_the_climb(ptlib, monkeypatch, scene):
     """PT_BVH_CLIMB=1 runs the bottom-up passes the way rounds 1-3 did (one thread per leaf climbing with atomic counters and agent-scope
-    fences); the default runs them level by level.  Nodes and leaf triangles of the wide tree must be byte-identical, for both
+    fences); the default runs them level by level.  Nodes and leaf triangles of the wide tree must be identical up to the numbering of the nodes, for both
     hierarchies (the calibration then picks the same one)."""
     if scene == "terrain1M":
         m = scenes.voxel_terrain()
@@ -43,8 +63,29 @@ def test_level_passes_reproduce_the_climb(ptlib, monkeypatch, scene):
         env = {} if builder is None else {"PT_BVH_BUILDER": builder}
         a = _export(m, monkeypatch, **env)
         b = _export(m, monkeypatch, PT_BVH_CLIMB="1", **env)
-        assert a[0] == b[0] and a[1] == b[1], f"{scene}/{builder}: the level-synchronous build differs from the climb"
+        ca, cb = _canonical(a[0], a[1]), _canonical(b[0], b[1])
+        assert len(a[0]) == len(b[0]) and len(a[1]) == len(b[1]) and ca[2] * 80 == len(a[0])
+        assert ca[0] == cb[0] and ca[1] == cb[1], f"{scene}/{builder}: the level-synchronous build differs from the climb"
         assert a[2]["bvh_builder"] == b[2]["bvh_builder"] and a[2]["bvh_levels"] == b[2]["bvh_levels"]
+
+
+@pytest.mark.parametrize("scene", ["terrain70k", "stadium200k", "copies"])
+def test_ploc_tail_in_one_workgroup_builds_the_same_hierarchy(ptlib, monkeypatch, scene):
+    """The last rounds of the PLOC clustering run in one workgroup (k_ploc_tail) instead of five launches and a host wait per round:
+    same search, same acceptance rule, same node numbering — the wide tree over it must be the same as with PT_PLOC_TAIL=0."""
+    if scene == "terrain70k":
+        m = scenes.voxel_terrain(n=96, target_tris=70000)
+    elif scene == "stadium200k":
+        m = scenes.stadium_scene(target_tris=200_000)
+    else:
+        base = np.array([[0, 0, 0], [4, 0, 0], [0, 3, 0]], np.float32)
+        tri = np.repeat(base[None], 6000, 0)
+        m = scenes.Model(meshes=[scenes.TriangleMesh(vertex=tri.reshape(-1, 3).copy(), index=np.arange(18000, dtype=np.uint32).reshape(-1, 3), material=scenes.Material())])
+    a = _export(m, monkeypatch, PT_BVH_BUILDER="ploc")
+    b = _export(m, monkeypatch, PT_BVH_BUILDER="ploc", PT_PLOC_TAIL="0")
+    ca, cb = _canonical(a[0], a[1]), _canonical(b[0], b[1])
+    assert ca[0] == cb[0] and ca[1] == cb[1]
+    assert a[2]["bvh_builder"] == 1
 
 
 def test_build_time_budget(ptlib, monkeypatch):

@@ -84,13 +84,6 @@ struct Bvh8Dev {
 #define PT8_STEAL_PERIOD 3 // traversal iterations between two steal rounds while lanes are idle
 #endif
 
-// Experiment (round 4): operands only the triangle step, the write-back and the steal round read — ray direction d, dn = d / (d.d),
-// the queue position, tmax, the pending triangle group's base and bits, the best hit's leaf index — parked in LDS ([word][lane], conflict-free
-// like the stack) instead of 11 VGPRs, to reach 6 waves per SIMD.  Off by default; numbers in DESIGN.md §5.
-#ifndef PT8_PARK
-#define PT8_PARK 0
-#endif
-
 #ifdef PT_DEBUG_STATS
 #define PT_STAT(x) x
 #else
@@ -118,11 +111,6 @@ template <int MODE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT8_WAVES_PER_EU, PT8_WAVES_PER_EU)))
 k_trace8(Trace8Args a) {
     __shared__ uint32_t s_stack[PT8_LDS_DEPTH * 2 * 64];
-#if PT8_PARK
-    __shared__ uint32_t s_park[11 * 64];
-#define PK(k) s_park[(k) * 64 + lane]
-#define PKF(k) __uint_as_float(s_park[(k) * 64 + lane])
-#endif
     __shared__ uint32_t s_prefix[PT_NSUB + 1];
     __shared__ uint32_t s_prefix2[PT_NSUB + 1];
 #ifdef PT8_TOP_NODES
@@ -159,21 +147,12 @@ k_trace8(Trace8Args a) {
     bool active = false, exhausted = false;
     RaySetup r;
     r.o = r.d = r.idir = r.dn = mk3(0.f);
-#if PT8_PARK
-    float tmin = 0.f, best = 0.f;
-#define tmax PKF(7)
-#define bleaf (*(int32_t*)&s_park[10 * 64 + lane])
-#define t_base PK(8)
-#define t_bits PK(9)
-    uint32_t t_mask = 0;
-#else
     float tmin = 0.f, tmax = 0.f, best = 0.f;
-    int32_t bleaf = -1;                        // closest-hit lanes: leaf triangle of the best hit (before the stealing phase; then s_leaf)
-    uint32_t t_base = 0, t_mask = 0, t_bits = 0; // current triangle group: pending bits of the node's leafbits
-#endif
     int32_t bprim = -1;                        // closest-hit lanes: primitive of the best hit; shadow lanes: 1 = occluded
+    int32_t bleaf = -1;                        // closest-hit lanes: leaf triangle of the best hit (before the stealing phase; then s_leaf)
     uint32_t pm = 0;                           // near-side slot masks of the ray's octant: z half | y quarters << 8 | x slots << 16
     uint32_t g_base = 0, g_imask = 0, g_hits = 0; // current node group: children still to visit (slot positions)
+    uint32_t t_base = 0, t_mask = 0, t_bits = 0; // current triangle group: pending bits of the node's leafbits
     int sp = 0;
     bool stealing = false;   // wave-uniform: the queue is exhausted and the shared records are in use
     // four small per-lane fields share one register (the kernel sits exactly at the 96 VGPRs of 5 waves per SIMD):
@@ -184,16 +163,7 @@ k_trace8(Trace8Args a) {
 #define SB ((int)(misc >> 24))
 #define SET_OWNER(v) (misc = (misc & ~0xffu) | (uint32_t)(v))
 #define SET_SB(v) (misc = (misc & 0x00ffffffu) | ((uint32_t)(v) << 24))
-#if PT8_PARK
-#define SET_TMAX(v) (s_park[7 * 64 + lane] = __float_as_uint(v))
-#else
-#define SET_TMAX(v) (tmax = (v))
-#endif
-#if PT8_PARK
-#define slot PK(6)
-#else
     uint32_t slot = 0; // position of the lane's ray in its queue's arrays (PathState)
-#endif
 #if PT8_DEFER_WRITE
     bool unwritten = false; // this lane holds a finished ray whose result is not written yet
 #endif
@@ -338,12 +308,12 @@ k_trace8(Trace8Args a) {
                         d4 = st_ld<PT_NT_TRACE_LD>(&a.st.shD[slot]);
                     }
                     tmin = 0.01f;
-                    SET_TMAX(1e16f);
+                    tmax = 1e16f;
                 } else {
                     o4 = st_ld<PT_NT_TRACE_LD>(&a.st.rayO[slot]);
                     d4 = st_ld<PT_NT_TRACE_LD>(&a.st.rayD[slot]);
                     tmin = o4.w;
-                    SET_TMAX(d4.w);
+                    tmax = d4.w;
                 }
                 // Refilling a lane runs with few lanes active, so it is kept short: the reciprocal direction only feeds the
                 // conservative box tests and uses v_rcp_f32 (1 ulp); dn = d / dot(d,d) feeds t and keeps the IEEE division.
@@ -359,10 +329,6 @@ k_trace8(Trace8Args a) {
                 r.idir = mk3(__builtin_amdgcn_rcpf(d4.x), __builtin_amdgcn_rcpf(d4.y), __builtin_amdgcn_rcpf(d4.z));
 #endif
                 r.dn = scl3(r.d, 1.0f / dot3(r.d, r.d));
-#if PT8_PARK
-                PK(0) = __float_as_uint(r.d.x); PK(1) = __float_as_uint(r.d.y); PK(2) = __float_as_uint(r.d.z);
-                PK(3) = __float_as_uint(r.dn.x); PK(4) = __float_as_uint(r.dn.y); PK(5) = __float_as_uint(r.dn.z);
-#endif
                 if (!(fabsf(d4.x) > 1e-30f)) r.idir.x = copysignf(1e30f, d4.x);
                 if (!(fabsf(d4.y) > 1e-30f)) r.idir.y = copysignf(1e30f, d4.y);
                 if (!(fabsf(d4.z) > 1e-30f)) r.idir.z = copysignf(1e30f, d4.z);
@@ -407,32 +373,23 @@ k_trace8(Trace8Args a) {
                 __syncthreads();
                 const uint32_t v = take ? s_vlane[irank] : lane; // every lane runs the shuffles; only takers keep what they read
                 const float ox = __shfl(r.o.x, (int)v), oy = __shfl(r.o.y, (int)v), oz = __shfl(r.o.z, (int)v);
-#if !PT8_PARK
                 const float dx = __shfl(r.d.x, (int)v), dy = __shfl(r.d.y, (int)v), dz = __shfl(r.d.z, (int)v);
-                const float nx_ = __shfl(r.dn.x, (int)v), ny_ = __shfl(r.dn.y, (int)v), nz_ = __shfl(r.dn.z, (int)v);
-                const float vtmax = __shfl(tmax, (int)v);
-                const uint32_t vslot = __shfl(slot, (int)v);
-#endif
                 const float ix = __shfl(r.idir.x, (int)v), iy = __shfl(r.idir.y, (int)v), iz = __shfl(r.idir.z, (int)v);
-                const float vtmin = __shfl(tmin, (int)v);
-                const uint32_t vpm = __shfl(pm, (int)v), vmisc = __shfl(misc, (int)v);
+                const float nx_ = __shfl(r.dn.x, (int)v), ny_ = __shfl(r.dn.y, (int)v), nz_ = __shfl(r.dn.z, (int)v);
+                const float vtmin = __shfl(tmin, (int)v), vtmax = __shfl(tmax, (int)v);
+                const uint32_t vpm = __shfl(pm, (int)v), vslot = __shfl(slot, (int)v), vmisc = __shfl(misc, (int)v);
                 const uint32_t vowner = vmisc & 0xffu;
                 const int vsb = (int)(vmisc >> 24);
                 const int vshadow = __shfl((int)shadow_lane, (int)v);
                 if (take) {
                     r.o = mk3(ox, oy, oz);
-                    r.idir = mk3(ix, iy, iz);
-                    tmin = vtmin;
-#if PT8_PARK
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) s_park[k * 64 + lane] = s_park[k * 64 + v]; // d, dn, queue position, tmax: constants of the victim's ray
-#else
                     r.d = mk3(dx, dy, dz);
+                    r.idir = mk3(ix, iy, iz);
                     r.dn = mk3(nx_, ny_, nz_);
+                    tmin = vtmin;
                     tmax = vtmax;
-                    slot = vslot;
-#endif
                     pm = vpm;
+                    slot = vslot;
                     SET_OWNER(vowner);
                     shadow_lane = vshadow != 0;
                     const uint32_t e0 = s_stack[(vsb * 2) * 64 + v], e1 = s_stack[(vsb * 2 + 1) * 64 + v];
@@ -585,10 +542,6 @@ k_trace8(Trace8Args a) {
                 const float4 ta = r0, tb = r1, tc = r2;
                 float t, det;
                 const v3 v0 = mk3(ta.x, ta.y, ta.z), v1 = mk3(ta.w, tb.x, tb.y), v2 = mk3(tb.z, tb.w, tc.x);
-#if PT8_PARK
-                r.d = mk3(PKF(0), PKF(1), PKF(2));
-                r.dn = mk3(PKF(3), PKF(4), PKF(5));
-#endif
                 if (tri_test_det(r, v0, v1, v2, t, det)) {
                     const int32_t prim = __float_as_int(tc.y);
                     if (MODE == TR_SHADOW_APPLY || MODE == TR_ANY_QUERY || (MODE == TR_UNIFIED && shadow_lane)) {
@@ -641,16 +594,6 @@ k_trace8(Trace8Args a) {
         }
     })
 }
-#if PT8_PARK
-#undef PK
-#undef PKF
-#undef tmax
-#undef bleaf
-#undef t_base
-#undef t_bits
-#undef slot
-#endif
-#undef SET_TMAX
 #undef OWNER
 #undef SB
 #undef SET_OWNER

@@ -723,9 +723,17 @@ __global__ void k_single_node8(int n, const float* __restrict__ bounds6, float p
 // tracer's camera, bounce and shadow rays travel — is traced through each by this plain per-thread traversal, which visits what
 // k_trace8 visits (a node step per internal child hit when its parent was tested, the leaf triangles of a node before its children,
 // children in slot ^ octant order, everything culled by the closest hit so far) and only counts.
-__global__ void __launch_bounds__(64) k_calibrate8(const Node8* __restrict__ nodes, const LeafTri* __restrict__ tris, const LeafTri* __restrict__ src,
+// One launch traces the batch through BOTH trees (the second half of the grid takes nodes_b / tris_b and adds to counts + 2): a single ray per
+// lane and 1024 waves leave the chip latency-bound, so two launches cost twice one.
+__global__ void __launch_bounds__(64) k_calibrate8(const Node8* __restrict__ nodes_a, const LeafTri* __restrict__ tris_a, const Node8* __restrict__ nodes_b,
+                                                   const LeafTri* __restrict__ tris_b, const LeafTri* __restrict__ src,
                                                    uint32_t ntri, uint32_t nrays, float hp, unsigned long long* __restrict__ counts) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t half = (nrays + 63u) / 64u;
+    const bool second = blockIdx.x >= half;
+    const Node8* __restrict__ nodes = second ? nodes_b : nodes_a;
+    const LeafTri* __restrict__ tris = second ? tris_b : tris_a;
+    if (second) counts += 2;
+    const uint32_t i = (blockIdx.x - (second ? half : 0u)) * blockDim.x + threadIdx.x;
     unsigned long long nsteps = 0, ntests = 0;
     if (i < nrays) {
         uint32_t h = i * 2654435761u + 12345u;
@@ -1241,8 +1249,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
             HIPCHK(tmalloc(&counts, sizeof(hcnt)));
             HIPCHK(hipMemsetAsync(counts, 0, sizeof(hcnt), stream));
             const uint32_t nrays = 1u << 16;
-            hipLaunchKernelGGL(k_calibrate8, dim3(nrays / 64), dim3(64), 0, stream, out->nodes8, out->tris8, tris, (uint32_t)n, nrays, 0.5f * pad, counts);
-            hipLaunchKernelGGL(k_calibrate8, dim3(nrays / 64), dim3(64), 0, stream, alt.nodes8, alt.tris8, tris, (uint32_t)n, nrays, 0.5f * pad, counts + 2);
+            hipLaunchKernelGGL(k_calibrate8, dim3(2 * (nrays / 64)), dim3(64), 0, stream, out->nodes8, out->tris8, alt.nodes8, alt.tris8, tris, (uint32_t)n, nrays, 0.5f * pad, counts);
             HIPCHK(hipMemcpyAsync(hcnt, counts, sizeof(hcnt), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
             tfree(counts);

@@ -106,6 +106,7 @@ struct pt_ctx {
     uint32_t* ovf = nullptr; // spill stacks for pt_trace queries
     unsigned long long* dbg = nullptr; // PT_DEBUG_COUNTS: traversal step counters of the last frame
     int trace_grid = 0;
+    bool cam_packets = true; // camera rays as packets (PT_CAM_PACKETS=0 turns it off)
     bool adapt_grid = false; // set around the enqueue of a whole frame (frames_in_flight = 3)
     int trace_grid_min = 2048, grid_chunks = 6; // PT_GRID_MIN / PT_GRID_CHUNKS (tuning hooks): smallest persistent grid, chunks of 64 paths per wave aimed at
     int lds_skip = 0; // PT_STACK_LDS_SKIP (test hook, pt_bvh8.h)
@@ -388,6 +389,7 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
         if (const char* e = getenv("PT_GRID_CHUNKS")) ctx->grid_chunks = std::max(1, atoi(e));
         if (const char* e = getenv("PT_STACK_LDS_SKIP")) ctx->lds_skip = std::max(0, std::min(PT8_LDS_DEPTH, atoi(e)));
         ctx->trace_grid = prop.multiProcessorCount * 4 * wpe;
+        if (const char* e = getenv("PT_CAM_PACKETS")) ctx->cam_packets = atoi(e) != 0;
         CKC(dalloc(&ctx->ovf, ovf_words(ctx)));
         ctx->ovf_depth = PT8_OVF_DEPTH;
         if (const char* e = getenv("PT_STACK_CAP")) ctx->ovf_depth = std::max(0, std::min(PT8_OVF_DEPTH, atoi(e) - (PT8_LDS_DEPTH - ctx->lds_skip)));
@@ -925,6 +927,18 @@ static void launch_shade(pt_ctx* ctx, pt_ctx::BatchSet& bs, const PathState& st,
         hipLaunchKernelGGL((k_shade<MODE, false>), dim3(GRID), dim3(256), lds, bs.stream, st, sp);
 }
 
+// Closest-hit launch of a bounce chain.  The identity queue of bounce 0 holds camera rays in pixel-block order: they are traversed as
+// packets, one wave per 64 consecutive rays (k_trace8_cam, pt_bvh8.h: 55 VGPRs, so eight waves per SIMD instead of five); every other queue
+// (later bounces, foveated launches, whose paths arrive through the sub-queues) takes the per-ray kernel.  PT_CAM_PACKETS=0: per-ray always.
+static void launch_closest(pt_ctx* ctx, hipStream_t stream, const Trace8Args& ta, unsigned tgrid) {
+    if (ta.queue.base == nullptr && ctx->cam_packets) {
+        const unsigned g = std::max(1u, tgrid * 8u / (unsigned)PT8_WAVES_PER_EU);
+        hipLaunchKernelGGL(k_trace8_cam, dim3(g), dim3(64), 0, stream, ta);
+    } else {
+        hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, stream, ta);
+    }
+}
+
 // enqueue every kernel of one pixel chunk (all its samples) on the streams of one batch set
 struct RegionJob { // non-null: one launch-index range of a foveated launch instead of a pixel chunk
     RegionParams rg;
@@ -984,7 +998,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
                 Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
+                launch_closest(ctx, bs.stream, ta, tgrid);
                 ++lc.trace;
             }
             for (int b = 0; b <= last_bounce; ++b) {
@@ -1015,7 +1029,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
                     Trace8Args ta{stream_view(bs, sin ^ 1), bvh8, qnext, QView{}, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                    hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
+                    launch_closest(ctx, bs.stream, ta, tgrid);
                     ++lc.trace;
                 }
                 qcur = qnext;
@@ -1030,7 +1044,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
                 Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
+                launch_closest(ctx, bs.stream, ta, tgrid);
                 ++lc.trace;
             }
             for (int b = 0; b <= last_bounce; ++b) {
@@ -1065,7 +1079,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
                 Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
+                launch_closest(ctx, bs.stream, ta, tgrid);
                 ++lc.trace;
             }
             ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_textris, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1, (b == 0) ? 1 : 0};
@@ -1118,7 +1132,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
                     Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                    hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, bs.stream, ta);
+                    launch_closest(ctx, bs.stream, ta, tgrid);
                     ++lc.trace;
                 }
                 ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_textris, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, 1, 0};

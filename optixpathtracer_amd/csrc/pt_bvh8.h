@@ -598,4 +598,156 @@ k_trace8(Trace8Args a) {
 #undef SB
 #undef SET_OWNER
 #undef SET_SB
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Camera rays as PACKETS: k_generate writes the paths of a pass sample-major in the order of the pixel list, which is made of 8 x 8-pixel
+// blocks — 64 consecutive queue entries are the same sample of one 8 x 8 block, a frustum a few triangles wide.  One wave traverses the
+// tree ONCE for its 64 rays: a single stack of node groups per wave (LDS, 512 bytes), node and leaf-triangle records fetched by scalar
+// loads (one request per wave instead of five 16-byte loads per lane from up to 64 different lines: the traversal kernels are bound by
+// that address rate), every lane testing its own ray against the eight child boxes with its own interval (tmin, best), a child visited
+// when ANY lane hits it, a leaf's triangles tested by the lanes that hit the leaf's box.  Control flow is wave-uniform: no votes, no
+// per-lane stacks, no idle lanes waiting for the other step type.
+// Same answer as k_trace8<TR_CLOSEST>, bit for bit: a ray's result is the minimum (t, then primitive) over the triangles its lane tested,
+// every triangle whose padded box the ray enters within (tmin, best] is tested (box tests conservative as in k_trace8, same arithmetic),
+// and a triangle tested "too often" cannot add a hit brute force would not find (hit_in_box confines accepted hits to the triangle's box).
+// Used for the identity queue of bounce 0 only (pt_api.hip); foveated launches queue their paths through sub-queues and keep k_trace8.
+#ifndef PT8_CAM_STACK
+#define PT8_CAM_STACK 64 // groups with children still to visit: at most one per level (pt_create refuses trees deeper than 62 levels)
+#endif
+#if __HIP_DEVICE_COMPILE__
+typedef const __attribute__((address_space(4))) Node8* ConstNode8;     // constant address space: s_load
+typedef const __attribute__((address_space(4))) LeafTri* ConstLeafTri;
+#endif
+__global__ void __launch_bounds__(64) k_trace8_cam(Trace8Args a) {
+#if __HIP_DEVICE_COMPILE__
+    __shared__ uint2 s_grp[PT8_CAM_STACK];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = a.queue.counts[0]; // identity queue: entries [0, n), state in launch order
+    const uint32_t npk = (n + 63u) >> 6;
+    // packets per grab: the first grab is static (blockIdx), later ones come from the work counter (same-address atomics cost ~10 ns each)
+    uint32_t per = npk / (gridDim.x * 4u);
+    per = per < 1u ? 1u : (per > 8u ? 8u : per);
+    uint32_t pk = blockIdx.x * per, pk_end = pk + per;
+    const ConstNode8 nodes = (ConstNode8)(uintptr_t)a.bvh.nodes;
+    const ConstLeafTri tris = (ConstLeafTri)(uintptr_t)a.bvh.tris;
+    for (;;) {
+        if (pk == pk_end) {
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(a.work, 1u);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c) + gridDim.x;
+            pk = c * per;
+            pk_end = pk + per;
+        }
+        if (pk >= npk) break;
+        const uint32_t pos = (pk << 6) + lane;
+        ++pk;
+        const bool valid = pos < n;
+        float4 o4 = make_float4(0.f, 0.f, 0.f, 1.f), d4 = make_float4(0.f, 0.f, 1.f, -1.f);
+        if (valid) {
+            o4 = st_ld<PT_NT_TRACE_LD>(&a.st.rayO[pos]);
+            d4 = st_ld<PT_NT_TRACE_LD>(&a.st.rayD[pos]);
+        }
+        RaySetup r;
+        r.o = mk3(o4.x, o4.y, o4.z);
+        r.d = mk3(d4.x, d4.y, d4.z);
+        r.idir = mk3(__builtin_amdgcn_rcpf(d4.x), __builtin_amdgcn_rcpf(d4.y), __builtin_amdgcn_rcpf(d4.z)); // as the refill of k_trace8
+        r.dn = scl3(r.d, 1.0f / dot3(r.d, r.d));
+        if (!(fabsf(d4.x) > 1e-30f)) r.idir.x = copysignf(1e30f, d4.x);
+        if (!(fabsf(d4.y) > 1e-30f)) r.idir.y = copysignf(1e30f, d4.y);
+        if (!(fabsf(d4.z) > 1e-30f)) r.idir.z = copysignf(1e30f, d4.z);
+        const float tmin = o4.w;
+        float best = d4.w; // tmax; a lane past the end holds -1: every box test fails (tf <= -1 < tmin <= tn)
+        int32_t bprim = -1, bleaf = -1;
+        // visiting order of a group's children: the octant of the packet's first ray (any order gives the same answer)
+        const uint32_t pm_lane = ((__float_as_uint(d4.z) >> 31) ? 0xF0u : 0x0Fu) | (((__float_as_uint(d4.y) >> 31) ? 0xCCu : 0x33u) << 8) |
+                                 (((__float_as_uint(d4.x) >> 31) ? 0xAAu : 0x55u) << 16);
+        const uint32_t pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)pm_lane);
+        const bool nx = r.idir.x < 0.0f, ny = r.idir.y < 0.0f, nz = r.idir.z < 0.0f;
+        uint32_t g_base = 0u, g_imask = 1u, g_hits = 1u; // the root is slot 0 of a virtual parent
+        int sp = 0;
+        for (;;) {
+            if (g_hits == 0u) {
+                if (sp == 0) break;
+                --sp;
+                const uint2 e = s_grp[sp];
+                g_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
+                const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+                g_imask = e1 & 0xffu;
+                g_hits = e1 >> 8;
+            }
+            uint32_t h = g_hits, t = h & pm;
+            h = t ? t : h;
+            t = h & (pm >> 8);
+            h = t ? t : h;
+            t = h & (pm >> 16);
+            h = t ? t : h; // a single bit
+            g_hits ^= h;
+            const uint32_t idx = g_base + (uint32_t)__popc(g_imask & (h - 1u));
+            if (g_hits != 0u) {
+                if (sp < PT8_CAM_STACK) s_grp[sp] = make_uint2(g_base, g_imask | (g_hits << 8)); // every lane writes the same value
+                else atomicOr(a.fault, 1u);
+                sp = sp < PT8_CAM_STACK ? sp + 1 : sp;
+            }
+            const float4 n0 = nodes[idx].n0, n1 = nodes[idx].n1, n2 = nodes[idx].n2, n3 = nodes[idx].n3, n4 = nodes[idx].n4;
+            const uint32_t e01 = __float_as_uint(n0.w), e2m = __float_as_uint(n1.w);
+            const float sx = __uint_as_float(e01 << 16), sy = __uint_as_float(e01 & 0xffff0000u), sz = __uint_as_float(e2m << 16);
+            const uint32_t imask = e2m >> 16;
+            const float ax = sx * r.idir.x, ay = sy * r.idir.y, az = sz * r.idir.z;
+            const float bx = (n0.x - r.o.x) * r.idir.x, by = (n0.y - r.o.y) * r.idir.y, bz = (n0.z - r.o.z) * r.idir.z;
+            const uint32_t lox0 = __float_as_uint(n2.x), lox1 = __float_as_uint(n2.y), loy0 = __float_as_uint(n2.z), loy1 = __float_as_uint(n2.w);
+            const uint32_t loz0 = __float_as_uint(n3.x), loz1 = __float_as_uint(n3.y), hix0 = __float_as_uint(n3.z), hix1 = __float_as_uint(n3.w);
+            const uint32_t hiy0 = __float_as_uint(n4.x), hiy1 = __float_as_uint(n4.y), hiz0 = __float_as_uint(n4.z), hiz1 = __float_as_uint(n4.w);
+            const uint32_t nearx[2] = {nx ? hix0 : lox0, nx ? hix1 : lox1}, farx[2] = {nx ? lox0 : hix0, nx ? lox1 : hix1};
+            const uint32_t neary[2] = {ny ? hiy0 : loy0, ny ? hiy1 : loy1}, fary[2] = {ny ? loy0 : hiy0, ny ? loy1 : hiy1};
+            const uint32_t nearz[2] = {nz ? hiz0 : loz0, nz ? hiz1 : loz1}, farz[2] = {nz ? loz0 : hiz0, nz ? loz1 : hiz1};
+            uint32_t miss = 0u;
+#pragma unroll
+            for (int s = 7; s >= 0; --s) {
+                const int w = s >> 2, k = s & 3;
+                const float tnx = __builtin_fmaf(u8f(nearx[w], k), ax, bx), tfx = __builtin_fmaf(u8f(farx[w], k), ax, bx);
+                const float tny = __builtin_fmaf(u8f(neary[w], k), ay, by), tfy = __builtin_fmaf(u8f(fary[w], k), ay, by);
+                const float tnz = __builtin_fmaf(u8f(nearz[w], k), az, bz), tfz = __builtin_fmaf(u8f(farz[w], k), az, bz);
+                const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+                const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best));
+                miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31u);
+            }
+            const uint32_t hm = miss ^ 0xffu; // this lane's hit mask in slot positions
+            uint32_t whm = 0u;                // slots hit by any lane of the packet
+#pragma unroll
+            for (int s = 0; s < 8; ++s) whm |= __ballot((hm >> s) & 1u) != 0ull ? (1u << s) : 0u;
+            // the node's leaf triangles first (they shrink the lanes' intervals before the packet descends) ...
+            const uint32_t leafbits = __float_as_uint(n1.z), tri_base = __float_as_uint(n1.y);
+            uint32_t lm = whm & ~imask;
+            while (lm != 0u) {
+                const uint32_t s = (uint32_t)__ffs((int)lm) - 1u;
+                lm &= lm - 1u;
+                const bool mine = (hm >> s) & 1u;
+                for (uint32_t k = 0; k < 3u; ++k) {
+                    const uint32_t bit = 3u * s + k;
+                    if (!(leafbits & (1u << bit))) break;
+                    const uint32_t leaf = tri_base + (uint32_t)__popc(leafbits & ((1u << bit) - 1u));
+                    const float4 ta = tris[leaf].t0, tb = tris[leaf].t1, tc = tris[leaf].t2;
+                    if (mine) {
+                        float tt, det;
+                        const v3 v0 = mk3(ta.x, ta.y, ta.z), v1 = mk3(ta.w, tb.x, tb.y), v2 = mk3(tb.z, tb.w, tc.x);
+                        if (tri_test_det(r, v0, v1, v2, tt, det)) {
+                            const int32_t prim = __float_as_int(tc.y);
+                            if (tt > tmin && (tt < best || (tt == best && bprim >= 0 && prim < bprim)) && hit_in_box(r, v0, v1, v2, a.bvh.hit_pad, tt)) {
+                                best = tt;
+                                bprim = prim;
+                                bleaf = (int32_t)leaf;
+                            }
+                        }
+                    }
+                }
+            }
+            // ... then its internal children
+            g_base = __float_as_uint(n1.x);
+            g_imask = imask;
+            g_hits = whm & imask;
+        }
+        if (valid) st_st<PT_NT_TRACE_ST>(&a.st.hit[pos], make_float2(best, __int_as_float(bleaf)));
+    }
+#endif
+}
 #endif // PT_BVH8_NODE_ONLY

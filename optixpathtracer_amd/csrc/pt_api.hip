@@ -932,7 +932,10 @@ static void launch_shade(pt_ctx* ctx, pt_ctx::BatchSet& bs, const PathState& st,
 // (later bounces, foveated launches, whose paths arrive through the sub-queues) takes the per-ray kernel.  PT_CAM_PACKETS=0: per-ray always.
 static void launch_closest(pt_ctx* ctx, hipStream_t stream, const Trace8Args& ta, unsigned tgrid) {
     if (ta.queue.base == nullptr && ctx->cam_packets) {
-        const unsigned g = std::max(1u, tgrid * 8u / (unsigned)PT8_WAVES_PER_EU);
+        static const int env_grid = getenv("PT_CAM_GRID") ? atoi(getenv("PT_CAM_GRID")) : 0;
+        // as many waves as the per-ray kernel gets (five per SIMD), two per SIMD for a tree of a few nodes whose packets cost next to nothing
+        // (measured: C3 8.00 / stadium 12.51 ms at 5120 waves, 8.20 / 12.81 at 2048; Cornell 2.98 ms at 2048, 3.14 at 5120 = the per-ray kernel's)
+        const unsigned g = env_grid > 0 ? (unsigned)env_grid : std::max(1u, ctx->bvh.num_nodes8 < 256u ? tgrid * 2u / (unsigned)PT8_WAVES_PER_EU : tgrid);
         hipLaunchKernelGGL(k_trace8_cam, dim3(g), dim3(64), 0, stream, ta);
     } else {
         hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(tgrid), dim3(64), 0, stream, ta);
@@ -1322,6 +1325,9 @@ static int render_finish(pt_ctx* ctx, int slot = 0) {
         fprintf(stderr, "[pt_render] traversal: node steps %llu, tri tests %llu, max steps of one ray %llu, max wave loop iterations %llu, mean %.1f\n", h[0], h[1], h[4], h[5], h[7] ? (double)h[6] / h[7] : 0.0);
         fprintf(stderr, "[pt_render] per loop iteration: lanes holding a ray %.1f / 64, lanes executing the chosen step %.1f / 64, node-step iterations %.1f %%\n",
                 h[6] ? (double)h[8] / h[6] : 0.0, h[6] ? (double)h[9] / h[6] : 0.0, h[6] ? 100.0 * h[10] / h[6] : 0.0);
+        if (h[48])
+            fprintf(stderr, "[pt_render] camera packets %llu: node steps %.1f per packet (%.1f lanes hit something), triangle tests %.1f per packet (%.1f lanes inside the leaf's box)\n",
+                    h[48], (double)h[49] / h[48], h[49] ? (double)h[52] / h[49] : 0.0, (double)h[50] / h[48], h[50] ? (double)h[51] / h[50] : 0.0);
     }
     if (getenv("PT_DEBUG_COUNTS") && owned) { // per-bounce queue sizes of the last chunk of set 0
         const size_t CS = (size_t)PT_NSUB * PT_CSTRIDE;

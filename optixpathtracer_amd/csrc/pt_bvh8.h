@@ -624,9 +624,12 @@ __global__ void __launch_bounds__(64) k_trace8_cam(Trace8Args a) {
     const uint32_t lane = threadIdx.x;
     const uint32_t n = a.queue.counts[0]; // identity queue: entries [0, n), state in launch order
     const uint32_t npk = (n + 63u) >> 6;
-    // packets per grab: the first grab is static (blockIdx), later ones come from the work counter (same-address atomics cost ~10 ns each)
+    // Work distribution: the first grab of a wave is static (blockIdx), later ones come from ONE work counter, `per` packets at a time, in
+    // image order — the waves in flight then work on one band of the image and share the tree's lines in L2.  (Measured and rejected: 64
+    // sub-range counters to spread the atomic traffic — the waves spread over 64 bands of the image: C3 8.17 instead of 8.00 ms; eight
+    // waves per SIMD (the kernel needs 55 VGPRs) — they crowd out the other chunk streams' kernels: C3 8.6 ms, Cornell 4.1 instead of 3.1.)
     uint32_t per = npk / (gridDim.x * 4u);
-    per = per < 1u ? 1u : (per > 8u ? 8u : per);
+    per = per < 4u ? 4u : (per > 16u ? 16u : per);
     uint32_t pk = blockIdx.x * per, pk_end = pk + per;
     const ConstNode8 nodes = (ConstNode8)(uintptr_t)a.bvh.nodes;
     const ConstLeafTri tris = (ConstLeafTri)(uintptr_t)a.bvh.tris;
@@ -665,6 +668,7 @@ __global__ void __launch_bounds__(64) k_trace8_cam(Trace8Args a) {
         const bool nx = r.idir.x < 0.0f, ny = r.idir.y < 0.0f, nz = r.idir.z < 0.0f;
         uint32_t g_base = 0u, g_imask = 1u, g_hits = 1u; // the root is slot 0 of a virtual parent
         int sp = 0;
+        PT_STAT(uint32_t c_nodes = 0; uint32_t c_tris = 0; uint32_t c_mine = 0; uint32_t c_hitl = 0;)
         for (;;) {
             if (g_hits == 0u) {
                 if (sp == 0) break;
@@ -712,6 +716,7 @@ __global__ void __launch_bounds__(64) k_trace8_cam(Trace8Args a) {
                 miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31u);
             }
             const uint32_t hm = miss ^ 0xffu; // this lane's hit mask in slot positions
+            PT_STAT(++c_nodes; c_hitl += (uint32_t)__popcll(__ballot(hm != 0u));)
             uint32_t whm = 0u;                // slots hit by any lane of the packet
 #pragma unroll
             for (int s = 0; s < 8; ++s) whm |= __ballot((hm >> s) & 1u) != 0ull ? (1u << s) : 0u;
@@ -727,6 +732,7 @@ __global__ void __launch_bounds__(64) k_trace8_cam(Trace8Args a) {
                     if (!(leafbits & (1u << bit))) break;
                     const uint32_t leaf = tri_base + (uint32_t)__popc(leafbits & ((1u << bit) - 1u));
                     const float4 ta = tris[leaf].t0, tb = tris[leaf].t1, tc = tris[leaf].t2;
+                    PT_STAT(++c_tris; c_mine += (uint32_t)__popcll(__ballot(mine));)
                     if (mine) {
                         float tt, det;
                         const v3 v0 = mk3(ta.x, ta.y, ta.z), v1 = mk3(ta.w, tb.x, tb.y), v2 = mk3(tb.z, tb.w, tc.x);
@@ -747,6 +753,13 @@ __global__ void __launch_bounds__(64) k_trace8_cam(Trace8Args a) {
             g_hits = whm & imask;
         }
         if (valid) st_st<PT_NT_TRACE_ST>(&a.st.hit[pos], make_float2(best, __int_as_float(bleaf)));
+        PT_STAT(if (a.dbg && lane == 0) {
+            atomicAdd(&a.dbg[48], 1ull);
+            atomicAdd(&a.dbg[49], (unsigned long long)c_nodes);
+            atomicAdd(&a.dbg[50], (unsigned long long)c_tris);
+            atomicAdd(&a.dbg[51], (unsigned long long)c_mine);
+            atomicAdd(&a.dbg[52], (unsigned long long)c_hitl);
+        })
     }
 #endif
 }

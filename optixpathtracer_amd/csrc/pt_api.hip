@@ -107,6 +107,8 @@ struct pt_ctx {
     unsigned long long* dbg = nullptr; // PT_DEBUG_COUNTS: traversal step counters of the last frame
     int trace_grid = 0;
     bool cam_packets = true; // camera rays as packets (PT_CAM_PACKETS=0 turns it off)
+    uint64_t cam_min_paths = 1u << 19; // ... for launches of at least this many camera rays (PT_CAM_MIN_PATHS): a packet is one wave's work from start to end,
+                                       // so a launch of a few thousand packets is as long as its longest packet (chunks of a 1/8 share of C3, 345 k rays: 1.93 against 1.84 ms per frame; 1/4 share, 690 k: 2.88 against 2.92)
     bool adapt_grid = false; // set around the enqueue of a whole frame (frames_in_flight = 3)
     int trace_grid_min = 2048, grid_chunks = 6; // PT_GRID_MIN / PT_GRID_CHUNKS (tuning hooks): smallest persistent grid, chunks of 64 paths per wave aimed at
     int lds_skip = 0; // PT_STACK_LDS_SKIP (test hook, pt_bvh8.h)
@@ -390,6 +392,7 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
         if (const char* e = getenv("PT_STACK_LDS_SKIP")) ctx->lds_skip = std::max(0, std::min(PT8_LDS_DEPTH, atoi(e)));
         ctx->trace_grid = prop.multiProcessorCount * 4 * wpe;
         if (const char* e = getenv("PT_CAM_PACKETS")) ctx->cam_packets = atoi(e) != 0;
+        if (const char* e = getenv("PT_CAM_MIN_PATHS")) ctx->cam_min_paths = (uint64_t)atoll(e);
         CKC(dalloc(&ctx->ovf, ovf_words(ctx)));
         ctx->ovf_depth = PT8_OVF_DEPTH;
         if (const char* e = getenv("PT_STACK_CAP")) ctx->ovf_depth = std::max(0, std::min(PT8_OVF_DEPTH, atoi(e) - (PT8_LDS_DEPTH - ctx->lds_skip)));
@@ -930,8 +933,8 @@ static void launch_shade(pt_ctx* ctx, pt_ctx::BatchSet& bs, const PathState& st,
 // Closest-hit launch of a bounce chain.  The identity queue of bounce 0 holds camera rays in pixel-block order: they are traversed as
 // packets, one wave per 64 consecutive rays (k_trace8_cam, pt_bvh8.h: 55 VGPRs, so eight waves per SIMD instead of five); every other queue
 // (later bounces, foveated launches, whose paths arrive through the sub-queues) takes the per-ray kernel.  PT_CAM_PACKETS=0: per-ray always.
-static void launch_closest(pt_ctx* ctx, hipStream_t stream, const Trace8Args& ta, unsigned tgrid) {
-    if (ta.queue.base == nullptr && ctx->cam_packets) {
+static void launch_closest(pt_ctx* ctx, hipStream_t stream, const Trace8Args& ta, unsigned tgrid, uint64_t paths) {
+    if (ta.queue.base == nullptr && ctx->cam_packets && paths >= ctx->cam_min_paths) {
         static const int env_grid = getenv("PT_CAM_GRID") ? atoi(getenv("PT_CAM_GRID")) : 0;
         // as many waves as the per-ray kernel gets (five per SIMD), two per SIMD for a tree of a few nodes whose packets cost next to nothing
         // (measured: C3 8.00 / stadium 12.51 ms at 5120 waves, 8.20 / 12.81 at 2048; Cornell 2.98 ms at 2048, 3.14 at 5120 = the per-ray kernel's)
@@ -1001,7 +1004,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
                 Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                launch_closest(ctx, bs.stream, ta, tgrid);
+                launch_closest(ctx, bs.stream, ta, tgrid, pass_paths);
                 ++lc.trace;
             }
             for (int b = 0; b <= last_bounce; ++b) {
@@ -1032,7 +1035,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
                     Trace8Args ta{stream_view(bs, sin ^ 1), bvh8, qnext, QView{}, work + b + 1, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                    launch_closest(ctx, bs.stream, ta, tgrid);
+                    launch_closest(ctx, bs.stream, ta, tgrid, pass_paths);
                     ++lc.trace;
                 }
                 qcur = qnext;
@@ -1047,7 +1050,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
                 Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work + 0, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                launch_closest(ctx, bs.stream, ta, tgrid);
+                launch_closest(ctx, bs.stream, ta, tgrid, pass_paths);
                 ++lc.trace;
             }
             for (int b = 0; b <= last_bounce; ++b) {
@@ -1082,7 +1085,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
                 Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work + b, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                launch_closest(ctx, bs.stream, ta, tgrid);
+                launch_closest(ctx, bs.stream, ta, tgrid, pass_paths);
                 ++lc.trace;
             }
             ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_textris, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, job ? (job->var.write_aov && job->var.initial_depth == 0 ? 1 : 0) : 1, (b == 0) ? 1 : 0};
@@ -1135,7 +1138,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
                     Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work + cur, bs.ovf, cull, nullptr, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
-                    launch_closest(ctx, bs.stream, ta, tgrid);
+                    launch_closest(ctx, bs.stream, ta, tgrid, pass_paths);
                     ++lc.trace;
                 }
                 ShadeParams sp{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_textris, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, qcur, qnext, qshadow, bs.X[sin ^ 1].rayO, bs.X[sin ^ 1].rayD, bs.X[sin ^ 1].thr, bs.X[sin ^ 1].rf, 1, 0};

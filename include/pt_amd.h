@@ -418,7 +418,8 @@ int pt_export_bvh(pt_ctx* ctx, void* nodes, size_t nodes_bytes, void* tris, size
  *  which = 5: detmath in: n x {fn, x, y} (3) out: n x 1   fn: 0 sin 1 cos 2 acos 3 atan2(x,y) 4 log 5 pow(x,y) 6 x/y 7 sqrt(x)
  *  which = 6: tea4/lcg/Random in: n x {a bits, b bits} out: n x {tea4(a,b), lcg state, rnd, Randf bits...} (8)
  *  which = 7: tex2D of scene texture 0 in: n x {s,t} (2) out: n x rgba (4)
- * material applies to which 0,1; the context's probe to 2,3. All arrays are host memory. */
+ *  which = 8: ProbePdf (Probe.cuh:69-93; unused by the reference's device code) in: n x dir[3] out: n x pdf (1)
+ * material applies to which 0,1; the context's probe to 2,3,8. All arrays are host memory. */
 int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material, int bsdf_mode, const float* in, uint32_t n,
                   float* out);
 

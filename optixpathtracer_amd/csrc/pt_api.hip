@@ -1961,10 +1961,10 @@ extern "C" int pt_export_bvh(pt_ctx* ctx, void* nodes, size_t nodes_bytes, void*
 extern "C" int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material, int bsdf_mode, const float* in, uint32_t n, float* out) {
     if (!ctx || !in || !out) return PT_ERR_INVALID;
     if (n == 0) return PT_OK;
-    static const int in_w[8] = {11, 9, 1, 3, 3, 3, 2, 2}, out_w[8] = {4, 6, 9, 6, 1, 1, 8, 4};
-    if (which < 0 || which > 7) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: unknown table");
+    static const int in_w[9] = {11, 9, 1, 3, 3, 3, 2, 2, 3}, out_w[9] = {4, 6, 9, 6, 1, 1, 8, 4, 1};
+    if (which < 0 || which > 8) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: unknown table");
     if (which <= 1 && !material) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: material required");
-    if ((which == 2 || which == 3) && !ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: no probe set");
+    if ((which == 2 || which == 3 || which == 8) && !ctx->probe.data) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: no probe set");
     if (which == 7 && !ctx->tex0.pixel) return fail(ctx, PT_ERR_INVALID, "pt_eval_table: the scene has no texture");
     CK(hipSetDevice(ctx->device));
     DevScope tmp;
@@ -1990,6 +1990,7 @@ extern "C" int pt_eval_table(pt_ctx* ctx, int which, const pt_material* material
         case 5: hipLaunchKernelGGL(k_table_math, g, b, 0, ctx->stream, dIn, n, dOut); break;
         case 6: hipLaunchKernelGGL(k_table_rng, g, b, 0, ctx->stream, dIn, n, dOut); break;
         case 7: hipLaunchKernelGGL(k_table_tex, g, b, 0, ctx->stream, ctx->tex0, dIn, n, dOut); break;
+        case 8: hipLaunchKernelGGL(k_table_probe_pdf, g, b, 0, ctx->stream, ctx->probe, dIn, n, dOut); break;
     }
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipGetLastError());

@@ -432,6 +432,21 @@ PT_DEV float4 probe_eval(const DevProbe& p, float u, float v) {
     int py = clampi((int)(v * p.height), 0, p.height - 1);
     return p.data[(size_t)py * p.width + px];
 }
+// :69-93 ProbePdf: the solid-angle pdf of ProbeSample for a direction.  The reference's device code never calls it (its caller, the MIS term of
+// the miss program, is commented out: deviceProgram.cu:214-224); here for the function table (pt_eval_table 8) and a future MIS miss program.
+PT_DEV float probe_pdf(const DevProbe& p, v3 d) {
+    float u, v;
+    probe_dir_to_uv(d, u, v);
+    const int col = clampi((int)(u * p.width), 0, p.width - 1);
+    const int row = clampi((int)(v * p.height), 0, p.height - 1);
+    float pdf = p.pdfX[(size_t)row * p.width + col] * p.pdfY[row];
+    const float sinTheta = pt_sinf(v * kPi);
+    if (fabsf(sinTheta) < 0.0001f)
+        pdf = 0.0f;
+    else
+        pdf *= (float)p.width * (float)p.height / (2.0f * kPi * kPi * sinTheta);
+    return pdf;
+}
 // :119-136
 PT_DEV int lower_bound(const float* __restrict__ array, int lower, int upper, float value) {
     while (lower < upper) {

@@ -1046,6 +1046,11 @@ __global__ void k_table_probe_eval(DevProbe probe, const float* __restrict__ in,
     float* o = &out[6 * (size_t)i];
     o[0] = u; o[1] = v; o[2] = c.x; o[3] = c.y; o[4] = c.z; o[5] = c.w;
 }
+__global__ void k_table_probe_pdf(DevProbe probe, const float* __restrict__ in, uint32_t n, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = probe_pdf(probe, mk3(in[3 * (size_t)i], in[3 * (size_t)i + 1], in[3 * (size_t)i + 2]));
+}
 __global__ void k_table_color(const float* __restrict__ in, uint32_t n, float* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -84,6 +84,8 @@ class Oracle:
         L.orc_probe_uv_to_dir.argtypes = [f32p, f32p]
         L.orc_probe_eval.argtypes = [C.POINTER(Probe), f32p, f32p]
         L.orc_probe_sample.argtypes = [C.POINTER(Probe), C.c_uint32, f32p, f32p, C.POINTER(C.c_float), u32p]
+        L.orc_probe_pdf.restype = C.c_float
+        L.orc_probe_pdf.argtypes = [C.POINTER(Probe), f32p]
         L.orc_make_color.restype = C.c_uint32
         L.orc_make_color.argtypes = [f32p]
         L.orc_tonemap_sqrt.argtypes = [f32p, u32p, C.c_int]
@@ -282,6 +284,9 @@ def load_ref():
         R.ref_lerp3.argtypes = [f32p, f32p, C.c_float, f32p]
         R.ref_clamp3.argtypes = [f32p, C.c_float, C.c_float, f32p]
         R.ref_to_srgb.argtypes = [f32p, f32p]
+    if hasattr(R, "ref_probe_pdf"):
+        R.ref_probe_pdf.restype = C.c_float
+        R.ref_probe_pdf.argtypes = [C.c_int, C.c_int, f32p, f32p, f32p, f32p]
     if hasattr(R, "refm_load_obj"):  # oracle/ref_build/ref_model.cpp: the reference's Model.cpp
         R.refm_load_obj.restype = C.c_void_p
         R.refm_load_obj.argtypes = [C.c_char_p]

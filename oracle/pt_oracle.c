@@ -450,6 +450,21 @@ void orc_probe_eval(const orc_probe* p, const float uv[2], float rgba[4]) {
     int py = clampi((int)(uv[1] * p->height), 0, p->height - 1);
     memcpy(rgba, &p->data[4 * ((size_t)py * p->width + px)], 16);
 }
+/* Probe.cuh:69-93: pdf (solid angle) with which ProbeSample draws direction d.  Unused by the reference's device code (the MIS term of
+ * __miss__radiance that called it is commented out, deviceProgram.cu:214-224); restated and pinned for completeness. */
+float orc_probe_pdf(const orc_probe* p, const float d[3]) {
+    float uv[2];
+    orc_probe_dir_to_uv(d, uv);
+    int col = clampi((int)(uv[0] * p->width), 0, p->width - 1);
+    int row = clampi((int)(uv[1] * p->height), 0, p->height - 1);
+    float pdf = p->pdfX[(size_t)row * p->width + col] * p->pdfY[row];
+    float sinTheta = M_SIN(uv[1] * kPi);
+    if (fabsf(sinTheta) < 0.0001f)
+        pdf = 0.0f;
+    else
+        pdf *= (float)p->width * (float)p->height / (2.0f * kPi * kPi * sinTheta);
+    return pdf;
+}
 /* Probe.cuh:119-136 */
 static inline int lower_bound(const float* array, int lower, int upper, float value) {
     while (lower < upper) {

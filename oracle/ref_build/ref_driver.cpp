@@ -57,6 +57,10 @@ void ref_probe_sample(int w, int h, const float* data, const float* pdfX, const 
     Probe p = mk_probe(w, h, data, pdfX, cdfX, pdfY, cdfY); Random r(seed); float3 d, c;
     ProbeSample(p, d, c, *pdf, r); dir[0] = d.x; dir[1] = d.y; dir[2] = d.z; color[0] = c.x; color[1] = c.y; color[2] = c.z; st[0] = r.seed1; st[1] = r.seed2;
 }
+// Probe.cuh:69-93 (not called by the reference's device code: its only caller, the MIS term of the miss program, is commented out, deviceProgram.cu:214-224)
+float ref_probe_pdf(int w, int h, const float* data, const float* pdfX, const float* pdfY, const float d[3]) {
+    Probe p = mk_probe(w, h, data, pdfX, 0, pdfY, 0); return ProbePdf(p, make_float3(d[0], d[1], d[2]));
+}
 float ref_luminance(const float c[4]) { return Luminance(make_float4(c[0], c[1], c[2], c[3])); }
 uint32_t ref_make_color(const float c[3]) { uchar4 q = make_color(make_float3(c[0], c[1], c[2])); return q.x | (q.y << 8) | (q.z << 16) | ((uint32_t)q.w << 24); }
 size_t ref_sizeof_material() { return sizeof(Material); }

@@ -131,6 +131,13 @@ def main():
         R.ref_clamp3(cv[i].copy(), 0.0, 10.0, cl[i])
         R.ref_to_srgb(sc[i].copy(), so[i])
     G.update(safe_in=sa, safe_out=sn, lerp_a=la, lerp_b=lb, lerp_t=lt, lerp_out=lo, clamp_in=cv, clamp_out=cl, srgb_in=sc, srgb_out=so)
+    # --- round 4: ProbePdf (Probe.cuh:69-93) on the disc probe above: the 2000 unit directions of vec_dir plus directions at and next to the poles
+    # (|sin(theta)| < 1e-4 gives pdf 0) — appended with its own generator so that every earlier table stays byte-identical
+    rng4 = np.random.default_rng(404)
+    pdirs = np.concatenate([d, np.array([[0, 1, 0], [0, -1, 0], [1e-5, 1, 0], [0, -1, 1e-5], [3e-4, 1, 0], [1, 0, 0], [0, 0, -1]], np.float32),
+                            (rng4.standard_normal((500, 3)) * np.array([1e-3, 1, 1e-3])).astype(np.float32)])
+    ppdf = np.array([R.ref_probe_pdf(pd.width, pd.height, pd.data.reshape(-1), pd.pdfValuesX.reshape(-1), pd.pdfValuesY, pdirs[i].copy()) for i in range(len(pdirs))], np.float32)
+    G.update(probe_pdf_dirs=pdirs, probe_pdf=ppdf)
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_tables.npz")
     np.savez_compressed(out, **G)
     print("wrote", out, os.path.getsize(out), "bytes")

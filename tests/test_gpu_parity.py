@@ -198,6 +198,11 @@ def test_probe_tables(ptlib, orc_det):
             orc_det.lib.orc_probe_eval(C.byref(pr), uv, px)
             ref[i, :2] = uv; ref[i, 2:] = px
         assert_bits_equal(g, ref, "ProbeEval(ProbeDirToUV)")
+        # ProbePdf (Probe.cuh:69-93; pinned to the reference in tests/test_oracle_golden.py::test_probe_pdf): poles and their neighbourhood included
+        pd2 = np.concatenate([dirs[:2000], (rng.standard_normal((300, 3)) * np.array([1e-3, 1, 1e-3])).astype(np.float32)])
+        g = r.evalTable(8, pd2, 1)[:, 0]
+        ref = np.array([orc_det.lib.orc_probe_pdf(C.byref(pr), pd2[i].copy()) for i in range(len(pd2))], np.float32)
+        assert_bits_equal(g, ref, "ProbePdf")
 
 
 def test_make_color_table(ptlib, orc_det):

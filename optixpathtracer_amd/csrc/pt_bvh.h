@@ -42,11 +42,18 @@ PT_DEV bool tri_test_det(const RaySetup& r, v3 v0, v3 v1, v3 v2, float& t, float
 // which a hierarchy finds or not depending on which other boxes it happens to enter (stadium scene: 5 of 3 M camera rays differed
 // between the LBVH- and the PLOC-built tree).  With the criterion every accepted hit lies inside every structure's box of that
 // triangle, so brute force and all trees agree again.  (o + t d as one fused multiply-add per axis: the checker calls fmaf.)
+// The tolerance grows with the distance travelled: t carries a relative error of a few 2^-24, so the computed hit point is off by up to
+// ~2^-22 of |t d| along the ray — for a camera tens of scene sizes away more than hp, and a flat, axis-aligned triangle (a floor quad: a box
+// of zero thickness) then lost genuine hits at random.  hpe = hp + 2^-21 * t * (|dx| + |dy| + |dz|): for origins within ~16 scene sizes the
+// band stays inside the builder's padding (2 hp) and every structure agrees with brute force, as before; beyond, genuine hits are kept and
+// only rounding-noise hits may depend on the structure.  Three multiplications and additions, each rounded, the checker's in the same order.
 PT_DEV bool hit_in_box(const RaySetup& r, v3 v0, v3 v1, v3 v2, float hp, float t) {
     const float px = __builtin_fmaf(r.d.x, t, r.o.x), py = __builtin_fmaf(r.d.y, t, r.o.y), pz = __builtin_fmaf(r.d.z, t, r.o.z);
-    return !(px < fminf(fminf(v0.x, v1.x), v2.x) - hp || px > fmaxf(fmaxf(v0.x, v1.x), v2.x) + hp ||
-             py < fminf(fminf(v0.y, v1.y), v2.y) - hp || py > fmaxf(fmaxf(v0.y, v1.y), v2.y) + hp ||
-             pz < fminf(fminf(v0.z, v1.z), v2.z) - hp || pz > fmaxf(fmaxf(v0.z, v1.z), v2.z) + hp);
+    const float l1 = (fabsf(r.d.x) + fabsf(r.d.y)) + fabsf(r.d.z);
+    const float hpe = hp + (t * l1) * 4.76837158203125e-07f;
+    return !(px < fminf(fminf(v0.x, v1.x), v2.x) - hpe || px > fmaxf(fmaxf(v0.x, v1.x), v2.x) + hpe ||
+             py < fminf(fminf(v0.y, v1.y), v2.y) - hpe || py > fmaxf(fmaxf(v0.y, v1.y), v2.y) + hpe ||
+             pz < fminf(fminf(v0.z, v1.z), v2.z) - hpe || pz > fmaxf(fmaxf(v0.z, v1.z), v2.z) + hpe);
 }
 // det > 0: the ray meets the triangle's front (counter-clockwise) side — what OPTIX_RAY_FLAG_CULL_BACK_FACING keeps
 PT_DEV bool tri_test_det(const RaySetup& r, v3 v0, v3 v1, v3 v2, float& t, float& det_out) {

@@ -638,11 +638,15 @@ static inline int wtri2(const wray* r, const float* p0, const float* p1, const f
     return 1;
 }
 /* the hit point o + t d (one fused multiply-add per axis, like the kernel) inside the triangle's box widened by r->hp */
+/* the tolerance grows with the distance travelled (the computed hit point is off by ~2^-22 of |t d|): hp + 2^-21 t (|dx| + |dy| + |dz|),
+ * the same three rounded operations as pt_bvh.h */
 static inline int hit_in_box(const wray* r, const float* p0, const float* p1, const float* p2, float t) {
     const float o[3] = {r->o.x, r->o.y, r->o.z}, d[3] = {r->d.x, r->d.y, r->d.z};
+    const float l1 = (fabsf(d[0]) + fabsf(d[1])) + fabsf(d[2]);
+    const float hpe = r->hp + (t * l1) * 4.76837158203125e-07f;
     for (int a = 0; a < 3; ++a) {
         const float pa = fmaf(d[a], t, o[a]);
-        const float lo = fminf(fminf(p0[a], p1[a]), p2[a]) - r->hp, hi = fmaxf(fmaxf(p0[a], p1[a]), p2[a]) + r->hp;
+        const float lo = fminf(fminf(p0[a], p1[a]), p2[a]) - hpe, hi = fmaxf(fmaxf(p0[a], p1[a]), p2[a]) + hpe;
         if (pa < lo || pa > hi) return 0;
     }
     return 1;

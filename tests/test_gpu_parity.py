@@ -249,6 +249,43 @@ def test_trace_cornell_vs_bruteforce(ptlib, orc_det):
     assert np.array_equal(occ, orc_det.trace_any(sc, rays))
 
 
+def test_far_camera_keeps_hits_on_flat_triangles(ptlib, orc_det):
+    """A floor quad in the plane y = 0 (a bounding box of zero thickness) seen from 5 to 60 scene sizes away along oblique directions: the
+    computed hit point o + t d is off the plane by up to ~2^-22 of the distance travelled, more than the fixed half padding hp from about
+    16 scene sizes on — hit_in_box's tolerance grows with t d for that reason (pt_bvh.h).  Every ray aimed at the interior of the quad
+    must hit it; kernel and brute-force checker agree bit for bit."""
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    S = 100.0
+    m = scenes.Model()
+    m.meshes.append(scenes._quads_to_mesh([[(-S, 0, -S), (S, 0, -S), (S, 0, S), (-S, 0, S)]], scenes.Material()))
+    scenes.add_box(m, scenes.Material(), (0.0, 5.0, 0.0), (5.0, 5.0, 5.0))
+    r = SampleRenderer(m)
+    sc = orc_det.make_scene(m, use_bvh=False)
+    rng = np.random.default_rng(77)
+    n = 40000
+    targets = np.zeros((n, 3), np.float32)
+    targets[:, 0] = rng.uniform(-0.95 * S, 0.95 * S, n)
+    targets[:, 2] = rng.uniform(-0.95 * S, 0.95 * S, n)
+    keep = (np.abs(targets[:, 0]) > 6.0) | (np.abs(targets[:, 2]) > 6.0)  # not under the box
+    dist = rng.choice([5.0, 16.0, 32.0, 60.0], n) * S
+    elev = rng.uniform(0.05, 1.2, n)  # radians above the floor: grazing to steep
+    azim = rng.uniform(0, 2 * np.pi, n)
+    back = np.stack([np.cos(elev) * np.cos(azim), np.sin(elev), np.cos(elev) * np.sin(azim)], 1)
+    o = (targets + back * dist[:, None]).astype(np.float32)
+    d = (targets - o).astype(np.float64)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays = np.concatenate([o, np.full((n, 1), 1e-3, np.float32), d, np.full((n, 1), 1e16, np.float32)], 1).astype(np.float32)
+    (t, prim), _ = r.trace(rays)
+    to, po = orc_det.trace_closest(sc, rays)
+    assert np.array_equal(prim, po)
+    assert_bits_equal(t, to, "closest-hit t from far away")
+    # box shadows aside, every such ray reaches the floor (primitives 0 and 1) unless the box is in the way
+    floor_or_box = prim >= 0
+    assert floor_or_box[keep].all(), f"{(~floor_or_box[keep]).sum()} of {keep.sum()} far rays fell through the floor"
+    assert (prim[keep] <= 1).mean() > 0.9
+
+
 def test_trace_terrain_vs_oracle(ptlib, orc_det):
     from optixpathtracer_amd.renderer import SampleRenderer
 

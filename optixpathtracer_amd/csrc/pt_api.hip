@@ -1328,12 +1328,16 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
         std::vector<hipEvent_t> before;
         if (pipelined && ctx->ev_resolved && ctx->resolved_kind != 0) before.push_back(ctx->ev_resolved);
         if (pipelined && ctx->ev_pack_guard) before.push_back(ctx->ev_pack_guard); // (a synchronous frame starts behind the context's stream, which carries the pack)
-        // A synchronous frame in the default schedule: chunk c's chain is enqueued by thread c, so that all chains start together instead of
-        // one third / two thirds of the enqueue time apart (a 1/8 share of C3: the third chain started 1.4 ms into a 2.5 ms frame under the
-        // profiler).  Each chunk runs on its own batch set and stream; nothing the threads touch is shared but the error string (locked).
+        // A SMALL synchronous frame in the default schedule (a share of a partitioned image): chunk c's chain is enqueued by thread c, so that
+        // all chains start together instead of one third / two thirds of the enqueue time apart.  Measured: a 1/8 share of C3 1.84 -> 1.78 ms;
+        // 1/4 and 1/2 shares unchanged; the full frame 8.03 -> 8.16 ms (its chains are long, and the staggered start is what makes one chunk's
+        // shade launches overlap another's traversal) — hence the size limit.  Each chunk runs on its own batch set and stream; nothing the
+        // threads touch is shared but the error string (locked).  PT_ENQUEUE_THREADS=0 keeps one thread, =2 uses threads at every size.
         const uint32_t nchunks = (owned + Np - 1) / Np;
-        static const bool threads_on = !(getenv("PT_ENQUEUE_THREADS") && atoi(getenv("PT_ENQUEUE_THREADS")) == 0);
-        const bool parallel = threads_on && !pipelined && nchunks > 1 && nchunks <= (uint32_t)nsets && !ctx->span_timing() && ctx->opt.split_shadow == 0 && before.empty();
+        static const int threads_env = getenv("PT_ENQUEUE_THREADS") ? atoi(getenv("PT_ENQUEUE_THREADS")) : 1;
+        const bool small_frame = (uint64_t)owned * vspp <= (3u << 19); // 1.5 M paths
+        const bool parallel = threads_env != 0 && (small_frame || threads_env == 2) && !pipelined && nchunks > 1 && nchunks <= (uint32_t)nsets && !ctx->span_timing() &&
+                              ctx->opt.split_shadow == 0 && before.empty();
         if (parallel) {
             while (ctx->chunk_workers.size() + 1 < nchunks) {
                 ctx->chunk_workers.emplace_back(new EnqueueWorker());

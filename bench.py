@@ -399,7 +399,7 @@ def main():
         frame_s = dt_max / args.steps
         owned_px = r.ownedPixels()[0]
         # --- roofline.  (1) The frame against HBM with SURVEY.md §8(d)'s formula: (rays x 160 B + pixels x 84 B + scene bytes)
-        # per frame / frame time.  (2) The dominant kernel class, the BVH traversal launches (k_trace8<0> for the camera rays, one
+        # per frame / frame time.  (2) The dominant kernel class, the BVH traversal launches (k_trace8_cam for the camera rays — packets of 64 —, one
         # k_trace8<3> per bounce tracing that bounce's closest-hit rays with the previous bounce's shadow rays): §8(d)'s traversal-
         # stage bytes (48 B per closest-hit ray, 36 B per shadow ray) per launch / mean ISOLATED launch time (single-stream frames,
         # HIP events on the launch's own stream, pt_stats).
@@ -449,7 +449,7 @@ def main():
         if ws:
             limiter = (f"dependent-load latency at 5 waves/SIMD, not HBM: k_trace8<3> waves wait on memory {100 * ws['wait_mem']:.0f} % of their time, "
                        f"VALU pipe {100 * ws['valu_pipe']:.0f} % used, TA {100 * ws['ta_busy']:.0f} % busy, mean L1->L2 round trip {ws['l2_round_trip_cycles']:.0f} cycles")
-        kname = "k_trace8<3>/<0>"
+        kname = "k_trace8<3> + k_trace8_cam"
         strong = world > 1 and args.scaling == "strong"
         out = {
             "metric": "Mrays/s (and ms/frame) at 1080p 4spp depth8; 1/2/4/8 MI355X scaling",

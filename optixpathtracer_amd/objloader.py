@@ -134,7 +134,7 @@ def _reals(text: str, n: int, default=0.0):
                 d = _try_parse_double(t)
                 with np.errstate(over="ignore"):
                     v = _F(default if d is None else d)
-                if d is not None and len(_REAL_CACHE) < 4_000_000:
+                if d is not None and len(_REAL_CACHE) < 1_000_000:  # grid-aligned scenes repeat a few thousand spellings; the memo is dropped after the file
                     _REAL_CACHE[t] = v
             out.append(v)
         else:
@@ -570,6 +570,7 @@ def _parse_obj(obj_file: str, mtl_basedir: str):
     ret = export()
     if ret or shape[0]:
         shapes.append(shape)
+    _REAL_CACHE.clear()
     return Varr(), np.array(VN, _F).reshape(-1, 3), np.array(VT, _F).reshape(-1, 2), shapes, materials
 
 

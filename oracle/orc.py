@@ -300,7 +300,20 @@ def load_ref():
         R.refm_mesh_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         R.refm_texture_size.argtypes = [C.c_void_p, C.c_int, i32p]
         R.refm_texture_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    if hasattr(R, "refm_loadf"):
+        R.refm_loadf.restype = C.c_int
+        R.refm_loadf.argtypes = [C.c_char_p, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), C.c_void_p, C.c_size_t]
     return R
+
+
+def ref_loadf(R, path):
+    """stbi_loadf(path, ..., 4) of the reference's vendored stb_image (main.cpp:146-156 loadProbe): (h, w, 4) float32 or None."""
+    res = np.zeros(2, np.int32)
+    if not R.refm_loadf(os.fsencode(path), res, None, 0):
+        return None
+    out = np.zeros((int(res[1]), int(res[0]), 4), np.float32)
+    R.refm_loadf(os.fsencode(path), res, out.ctypes.data, out.size)
+    return out
 
 
 def ref_model_arrays(R, handle):

@@ -38,6 +38,17 @@ void refm_mesh_copy(void* m, int i, float* v, float* n, float* tc, uint32_t* idx
     if (!t->index.empty()) memcpy(idx, t->index.data(), t->index.size() * sizeof(uint3));
     memcpy(material, &t->material, sizeof(Material));
 }
+// main.cpp:146-156 loadProbe: stbi_loadf(file, &w, &h, &n, 4) of a Radiance .hdr.  Returns 1 and the size; the pixels (w*h float4) are copied into
+// `out` when it is non-null and `cap_floats` suffices (call twice: size, then data).
+int refm_loadf(const char* path, int res[2], float* out, size_t cap_floats) {
+    int w = 0, h = 0, n = 0;
+    float* data = stbi_loadf(path, &w, &h, &n, 4);
+    if (!data) return 0;
+    res[0] = w; res[1] = h;
+    if (out && cap_floats >= (size_t)w * h * 4) memcpy(out, data, sizeof(float) * (size_t)w * h * 4);
+    stbi_image_free(data);
+    return 1;
+}
 void refm_texture_size(void* m, int i, int res[2]) { Texture* t = ((Model*)m)->textures[i]; res[0] = t->resolution.x; res[1] = t->resolution.y; }
 void refm_texture_copy(void* m, int i, uint32_t* px) { Texture* t = ((Model*)m)->textures[i]; memcpy(px, t->pixel, (size_t)t->resolution.x * t->resolution.y * 4); }
 }

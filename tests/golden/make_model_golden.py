@@ -80,6 +80,58 @@ def write_inputs(d=FIX):
     return ["basic.obj", "concave.obj", "numbers.obj", "quirks.obj"]
 
 
+def write_rle_hdr(path, rgbe, header=b"#?RADIANCE\n# comment\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1\n\n"):
+    """Radiance .hdr with the per-scanline run-length encoding (runs of 4+ equal bytes as runs, the rest as literals)"""
+    h, w, _ = rgbe.shape
+    with open(path, "wb") as f:
+        f.write(header + b"-Y %d +X %d\n" % (h, w))
+        for y in range(h):
+            f.write(bytes([2, 2, w >> 8, w & 255]))
+            for ch in range(4):
+                row = rgbe[y, :, ch]
+                x = 0
+                while x < w:
+                    run = 1
+                    while x + run < w and run < 127 and row[x + run] == row[x]:
+                        run += 1
+                    if run >= 4:
+                        f.write(bytes([128 + run, int(row[x])]))
+                        x += run
+                    else:
+                        lit = 1
+                        while x + lit < w and lit < 128 and not (x + lit + 3 < w and row[x + lit] == row[x + lit + 1] == row[x + lit + 2] == row[x + lit + 3]):
+                            lit += 1
+                        f.write(bytes([lit]) + row[x: x + lit].tobytes())
+                        x += lit
+
+
+def write_flat_hdr(path, rgbe, header=b"#?RGBE\nFORMAT=32-bit_rle_rgbe\n\n"):
+    h, w, _ = rgbe.shape
+    with open(path, "wb") as f:
+        f.write(header + b"-Y %d +X %d\n" % (h, w))
+        f.write(np.ascontiguousarray(rgbe, np.uint8).tobytes())
+
+
+def write_hdr_inputs(d):
+    """Radiance .hdr inputs of loadProbe (main.cpp:146-156): flat and run-length encoded scanlines, widths on both sides of stb_image's RLE limits
+    (8 and 32768), zero exponents, the full exponent range, long runs."""
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(99)
+    out = []
+    a = rng.integers(0, 256, (6, 40, 4), dtype=np.uint8)
+    a[2, 5:30] = (10, 20, 30, 130)
+    a[3, :, 3] = 0
+    a[4, :, 3] = np.arange(40) * 6 + 8  # exponents 8 .. 242
+    write_rle_hdr(os.path.join(d, "rle40.hdr"), a); out.append("rle40.hdr")
+    write_flat_hdr(os.path.join(d, "flat40.hdr"), a); out.append("flat40.hdr")
+    b = rng.integers(0, 256, (3, 7, 4), dtype=np.uint8)  # width < 8: never run-length encoded
+    write_flat_hdr(os.path.join(d, "flat7.hdr"), b); out.append("flat7.hdr")
+    c = rng.integers(100, 140, (5, 300, 4), dtype=np.uint8)
+    c[:, 100:260, :3] = 200  # runs longer than 127: several run records
+    write_rle_hdr(os.path.join(d, "rle300.hdr"), c, b"#?RADIANCE\nGAMMA=2.2\nPRIMARIES=0 0 0 0 0 0 0 0\nFORMAT=32-bit_rle_rgbe\n\n"); out.append("rle300.hdr")
+    return out
+
+
 BOXES = [
     (dict(), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)),
     (dict(color=(0.2, 0.4, 0.8), roughness=0.3, flags=scenes.MATERIAL_FLAG_SHADOW_CATCHER), (0.1, -2.7, 3.3), (0.7, 0.05, 12.9)),
@@ -110,6 +162,11 @@ def main():
         print(name, len(out[0]), "meshes", len(out[1]), "textures")
     boxes = orc.ref_add_boxes(R, [(scenes.Material(**kw), p, e) for kw, p, e in BOXES])
     pack("boxes_", boxes, [], G)
+    for name in write_hdr_inputs(os.path.join(HERE, "hdr_fixture")):
+        img = orc.ref_loadf(R, os.path.join(HERE, "hdr_fixture", name))
+        assert img is not None, name
+        G["hdr_" + name[:-4]] = img
+        print(name, img.shape)
     out = os.path.join(HERE, "ref_model.npz")
     np.savez_compressed(out, **G)
     print("wrote", out, os.path.getsize(out), "bytes")

@@ -46,3 +46,50 @@ def test_flat_and_rle_roundtrip(tmp_path):
     assert np.array_equal(b, ref)
     pd = hdrloader.load_probe(f2).BuildCDF()
     assert pd.valid and pd.width == 40 and pd.height == 8
+
+
+# ---- pinned to the reference's own loader: stbi_loadf of the stb_image it vendors (main.cpp:146-156 loadProbe), compiled into oracle/_ref/libptref.so
+import os
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("name", ["rle40", "flat40", "flat7", "rle300"])
+def test_load_hdr_golden(name):
+    """Committed .hdr inputs (tests/golden/hdr_fixture, written by tests/golden/make_model_golden.py) against the float4 pixels the reference's
+    stbi_loadf returned for them (tests/golden/ref_model.npz): bit for bit, alpha 1, zero exponent = black."""
+    G = np.load(os.path.join(HERE, "golden", "ref_model.npz"))
+    a = hdrloader.load_hdr(os.path.join(HERE, "golden", "hdr_fixture", name + ".hdr"))
+    ref = G["hdr_" + name]
+    assert a.shape == ref.shape and a.dtype == np.float32 and a.tobytes() == ref.tobytes()
+    assert (a[..., 3] == 1).all()
+
+
+def test_load_hdr_live_random(tmp_path):
+    """Random RGBE images, flat and run-length encoded, through stbi_loadf itself and through hdrloader.load_hdr."""
+    import importlib.util
+
+    from oracle import orc
+
+    R = orc.load_ref()
+    if R is None or not hasattr(R, "refm_loadf"):
+        pytest.skip("oracle/_ref/libptref.so with the stb_image shim is not built here")
+    spec = importlib.util.spec_from_file_location("make_model_golden", os.path.join(HERE, "golden", "make_model_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(5)
+    for it in range(40):
+        h, w = int(rng.integers(1, 12)), int(rng.choice([1, 7, 8, 9, 33, 128, 129, 500]))
+        rgbe = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        if it % 3 == 0:
+            rgbe[:, : w // 2] = rgbe[:, :1]  # long runs
+        if it % 4 == 0:
+            rgbe[..., 3] = rng.choice([0, 1, 127, 128, 129, 255], (h, w))
+        path = str(tmp_path / f"r{it}.hdr")
+        (mod.write_rle_hdr if (it % 2 == 0 and w >= 8) else mod.write_flat_hdr)(path, rgbe)
+        ref = orc.ref_loadf(R, path)
+        assert ref is not None
+        got = hdrloader.load_hdr(path)
+        assert got.shape == ref.shape and got.tobytes() == ref.tobytes(), (it, h, w)

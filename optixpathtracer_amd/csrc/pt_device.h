@@ -575,7 +575,9 @@ struct DevTex {
 };
 PT_HD size_t tex_tiled_index(int x, int y, int tiles_x) { return ((size_t)(y >> 2) * (size_t)tiles_x + (size_t)(x >> 3)) * 32u + (size_t)(((y & 3) << 3) | (x & 7)); }
 PT_DEV float texel_ch(uint32_t p, int k) { return (float)((p >> (8 * k)) & 0xffu) / 255.0f; }
-PT_DEV float4 tex2d_wrap_linear(const DevTex& tx, float s, float t) {
+// u8lut (may be null): the 256 values (float)b / 255.0f, one IEEE division each, computed once per workgroup (k_shade keeps them in LDS) instead of
+// sixteen divisions (~10 instructions each) per lookup; the same bits.
+PT_DEV float4 tex2d_wrap_linear(const DevTex& tx, float s, float t, const float* u8lut = nullptr) {
     const int W = tx.w, H = tx.h;
     const float x = (s - floorf(s)) * (float)W, y = (t - floorf(t)) * (float)H;
     const float xB = x - 0.5f, yB = y - 0.5f;
@@ -594,10 +596,17 @@ PT_DEV float4 tex2d_wrap_linear(const DevTex& tx, float s, float t) {
     const uint32_t t00 = tx.pixel[tex_tiled_index(i0, j0, tx.tiles_x)], t10 = tx.pixel[tex_tiled_index(i1, j0, tx.tiles_x)],
                    t01 = tx.pixel[tex_tiled_index(i0, j1, tx.tiles_x)], t11 = tx.pixel[tex_tiled_index(i1, j1, tx.tiles_x)];
     float o[4];
+    if (u8lut) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        o[k] = (1.0f - alpha) * (1.0f - beta) * texel_ch(t00, k) + alpha * (1.0f - beta) * texel_ch(t10, k) +
-               (1.0f - alpha) * beta * texel_ch(t01, k) + alpha * beta * texel_ch(t11, k);
+        for (int k = 0; k < 4; ++k)
+            o[k] = (1.0f - alpha) * (1.0f - beta) * u8lut[(t00 >> (8 * k)) & 0xffu] + alpha * (1.0f - beta) * u8lut[(t10 >> (8 * k)) & 0xffu] +
+                   (1.0f - alpha) * beta * u8lut[(t01 >> (8 * k)) & 0xffu] + alpha * beta * u8lut[(t11 >> (8 * k)) & 0xffu];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = (1.0f - alpha) * (1.0f - beta) * texel_ch(t00, k) + alpha * (1.0f - beta) * texel_ch(t10, k) +
+                   (1.0f - alpha) * beta * texel_ch(t01, k) + alpha * beta * texel_ch(t11, k);
+    }
     return make_float4(o[0], o[1], o[2], o[3]);
 }
 

@@ -260,7 +260,7 @@ PT_DEV void shade_miss(const PathState& st, const ShadeParams& sp, uint32_t pos,
 // position of that entry; a pending shadow ray is pushed into shadow_queue with its record (or, with asynchronous shadow rays, written
 // to the per-bounce record of the slot).
 template <int MODE, bool CATCHER>
-PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMarg& pm, uint32_t pos, uint32_t p, float2 h) {
+PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMarg& pm, const float* u8lut, uint32_t pos, uint32_t p, float2 h) {
     const int32_t leaf = __float_as_int(h.y);
     if (leaf < 0) {
         shade_miss<CATCHER>(st, sp, pos, p);
@@ -334,7 +334,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                     const float w0 = 1.f - bu - bv; // texcoords of optixGetPrimitiveIndex()'s vertices, (1 - u - v, u, v) weighted (:515-518)
                     const float tcx = w0 * tt.c.y + bu * tt.c.w + bv * tt.d.y;
                     const float tcy = w0 * tt.c.z + bu * tt.d.x + bv * tt.d.z;
-                    const float4 tx = tex2d_wrap_linear(sp.textures[tid], tcx, tcy);
+                    const float4 tx = tex2d_wrap_linear(sp.textures[tid], tcx, tcy, u8lut);
                     albedo = mk3(tx.x, tx.y, tx.z);
                 }
             }
@@ -468,7 +468,13 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
 template <int MODE, bool CATCHER>
 __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, ShadeParams sp) {
     __shared__ uint32_t s_prefix[PT_NSUB + 1];
+    __shared__ float s_u8[256]; // textured scenes: (float)b / 255.0f for the 256 byte values (tex2d_wrap_linear)
     extern __shared__ __attribute__((aligned(16))) float s_marg[]; // sized at launch for the probe in use (shade_lds_bytes): 8.8 KB for 1024 rows
+    const float* u8lut = nullptr;
+    if (sp.mesh_tex) { // ordered before its readers by the barrier of qreader_init below
+        s_u8[threadIdx.x & 255u] = (float)(threadIdx.x & 255u) / 255.0f;
+        u8lut = s_u8;
+    }
     ProbeMarg pm = probe_marg_global(sp.probe);
     if (sp.probe.c64Y && sp.probe.height <= PT_LDS_PROBE_ROWS) {
         // ProbeSample's row search (cdfY through its 64- and 8-entry count tables) and pdfY from LDS: 3 of the 6 dependent
@@ -495,7 +501,7 @@ __global__ void __launch_bounds__(256) PT_SHADE_ATTR k_shade(PathState st, Shade
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += gridDim.x * blockDim.x) {
         if (i < n) {
             const uint32_t pos = qreader_pos(sp.queue, s_prefix, i);
-            shade_path<MODE, CATCHER>(st, sp, pm, pos, qslot(sp.queue, pos), st_ld<PT_NT_SHADE_LD>(&st.hit[pos]));
+            shade_path<MODE, CATCHER>(st, sp, pm, u8lut, pos, qslot(sp.queue, pos), st_ld<PT_NT_SHADE_LD>(&st.hit[pos]));
         }
     }
 }

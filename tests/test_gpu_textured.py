@@ -94,11 +94,17 @@ def test_fullsize_textured_terrain_rows(ptlib, orc_det):
 
 
 def test_reference_fixture_obj_renders_like_the_checker(ptlib, orc_det):
-    """tests/golden/obj_fixture/basic.obj through objloader (arrays pinned to the reference's loadOBJ: shared vertex map, back-filled texcoords, a texture
-    loaded twice, a missing one) and through the whole pipeline: five small textures of odd sizes (8x5, 6x4, 3x6, 8x5 again, 2x2 — tiles mostly padding),
-    meshes with and without texcoords.  All five buffers equal the checker's."""
+    """tests/golden/obj_fixture/basic.obj through objloader and through the whole pipeline: five small textures of odd sizes (8x5, 6x4, 3x6, 8x5
+    again, 2x2 — tiles mostly padding), back-filled texcoords, a texture loaded twice, a missing one, meshes with and without texcoords.  All five
+    buffers equal the checker's.  With the reference's own arrays (one vertex map per SHAPE, Model.cpp:176) a mesh of this file indexes a vertex
+    it does not have — the reference would read past its vertex buffer; pt_create refuses the scene — so the render uses the loader's
+    per-mesh map."""
+    from optixpathtracer_amd.renderer import SampleRenderer
+
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "obj_fixture", "basic.obj")
-    m = objloader.load_obj(path)
+    with pytest.raises(RuntimeError, match="vertex index out of range"):
+        SampleRenderer(objloader.load_obj(path))
+    m = objloader.load_obj(path, per_mesh_vertex_map=True)
     assert len(m.meshes) == 8 and len(m.textures) == 5
     probe = scenes.sky_probe(128, 64).BuildCDF()
     cam = dict(eye=(2.6, 2.2, 3.4), lookat=(0.5, 0.5, 0.5), up=(0.0, 1.0, 0.0), fovY=40.0)

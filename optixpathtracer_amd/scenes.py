@@ -105,6 +105,8 @@ class Model:  # Model.h:31-42
         """Global arrays the C-ABI takes: verts (nv,3), idx (nt,3) global, tri_mesh (nt,), mats (nmesh,)."""
         verts, idx, tri_mesh, base = [], [], [], 0
         for mi, m in enumerate(self.meshes):
+            if len(m.index) and int(np.max(m.index)) >= len(m.vertex):  # pt_create refuses such a scene too (the reference would read past the mesh's vertex buffer)
+                raise ValueError(f"mesh {mi}: vertex index {int(np.max(m.index))} out of range ({len(m.vertex)} vertices)")
             verts.append(np.ascontiguousarray(m.vertex, dtype=np.float32))
             idx.append(np.ascontiguousarray(m.index, dtype=np.uint32) + np.uint32(base))
             tri_mesh.append(np.full(len(m.index), mi, dtype=np.uint32))

@@ -244,7 +244,7 @@ def main():
     # rays are counted on the device for every frame; pt_stats also keeps the totals since pt_create, so that a loop with frames in
     # flight does not have to read (= wait for) each frame's statistics
     pipelined = opts["frames_in_flight"] >= 2
-    per_frame_stats = not pipelined and args.batch == 1
+    per_frame_stats = not pipelined and args.batch == 1 and bool(args.kernel_timing)  # (a pt_get_stats + dict per step is host time inside the timed region: only when its per-launch figures are wanted)
     s0 = r.stats()
     t0 = time.perf_counter()
     n_chains = 0

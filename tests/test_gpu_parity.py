@@ -911,6 +911,61 @@ def test_gpu_cdf_build_bit_exact(ptlib, orc_det, small_probe):
     _compare(g, o)
 
 
+def test_probe_8k_by_4k_maximum_size(ptlib, orc_det):
+    """the largest probe the reference's scenes load is 8192 x 4096 (537 MB of texels, 2 x 134 MB of tables).  At that size:
+    BuildCDF on the GPU == the host BuildCDF (Probe.h:29-77) bit for bit, and ProbeSample / ProbeEval / ProbePdf through the device's guide and
+    line tables == the checker, with a sun of a few thousand texels, per-texel noise, and black rows (NaN row CDFs) in it."""
+    import ctypes as C
+
+    from optixpathtracer_amd.renderer import SampleRenderer
+
+    W, H = 8192, 4096
+    rng = np.random.default_rng(11)
+    v = np.linspace(0, 1, H, dtype=np.float32)[:, None]
+    lum = ((np.float32(0.1) + (np.float32(1) - v) * np.float32(0.9)) * (np.float32(0.75) + np.float32(0.5) * rng.random((H, W), dtype=np.float32))).astype(np.float32)
+    lum[1000:1040, 3000:3060] = 5000.0
+    lum[H - 64:] = 0.0
+    lum[2000] = 0.0
+    data = np.empty((H, W, 4), np.float32)
+    data[..., 0] = lum; data[..., 1] = lum * np.float32(0.9); data[..., 2] = lum * np.float32(1.1); data[..., 3] = 1.0
+    del lum
+    ref = orc_det.build_cdf(data, W, H)
+    r = SampleRenderer(scenes.cornell_box())
+    r.setProbeImage(data)
+    got = r.probeCDF()
+    for a, b, name in zip(got, ref, ("pdfX", "cdfX", "pdfY", "cdfY")):
+        assert_bits_equal(a, b, "GPU BuildCDF 8k " + name)
+    del got
+    probe = scenes.ProbeData(W, H, data)
+    probe.pdfValuesX, probe.cdfValuesX, probe.pdfValuesY, probe.cdfValuesY = ref
+    pr = orc_det.make_probe(probe)
+    n = 4000
+    seeds = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    g = r.evalTable(2, seeds.view(np.float32)[:, None], 9)
+    want = np.zeros((n, 9), np.float32)
+    d = np.zeros(3, np.float32); c = np.zeros(3, np.float32); pdf = C.c_float(); st = np.zeros(2, np.uint32)
+    for i in range(n):
+        orc_det.lib.orc_probe_sample(C.byref(pr), int(seeds[i]), d, c, C.byref(pdf), st)
+        want[i, :3] = d; want[i, 3:6] = c; want[i, 6] = pdf.value; want[i, 7:] = st.view(np.float32)
+    assert_bits_equal(g, want, "ProbeSample 8k")
+    assert (want[:, 3] == 5000.0).sum() > n // 4  # the sun is found: importance sampling really goes through the tables
+    dirs = rng.standard_normal((n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    dirs = np.ascontiguousarray(dirs, np.float32)
+    g = r.evalTable(3, dirs, 6)
+    want = np.zeros((n, 6), np.float32)
+    uv = np.zeros(2, np.float32); px = np.zeros(4, np.float32)
+    for i in range(n):
+        orc_det.lib.orc_probe_dir_to_uv(dirs[i].copy(), uv)
+        orc_det.lib.orc_probe_eval(C.byref(pr), uv, px)
+        want[i, :2] = uv; want[i, 2:] = px
+    assert_bits_equal(g, want, "ProbeEval 8k")
+    g = r.evalTable(8, dirs, 1)[:, 0]
+    want = np.array([orc_det.lib.orc_probe_pdf(C.byref(pr), dirs[i].copy()) for i in range(n)], np.float32)
+    assert_bits_equal(g, want, "ProbePdf 8k")
+    r.close()
+
+
 @pytest.mark.parametrize("variant_name", ["SV4_VARIANT", "SV3_VARIANT"])
 def test_foveated_sv4_three_launches(ptlib, orc_det, variant_name):
     """SURVEY §8f row 1 — the foveated variants' render() (HelloPathtracing_sv4_vmv23/SimplePathtracer.cpp:132-216):

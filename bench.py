@@ -53,6 +53,8 @@ WORKLOADS = {
     # 1024^2 RGBA8 texture per height band, written as OBJ + MTL + PNG and read back through objloader (= loadOBJ, Model.cpp:137-212), so
     # every closest hit takes the tex2D branch (deviceProgram.cu:512-523) and the materials are what an MTL file can carry (Kd, Ke)
     "terrain1M_textured_1080p_4spp_d8": ("terrain_textured_obj", "TERRAIN_CAMERA", 1920, 1080, 4, 8),
+    # the order of the reference's largest assets (San Miguel, ~10 M triangles): the same terrain generator on a 1500 x 1500 column grid, 9.5 M triangles
+    "terrain10M_1080p_4spp_d8": ("terrain10M", "TERRAIN_CAMERA", 1920, 1080, 4, 8),
     # the reference's only published runs (HelloPathtracing_sv4_vmv23, 3840x2160, depth cutoff 4):
     # uniform 8 spp without accumulation, and the 3-region foveated schedule (radii 157/515, 1/2/8 spp)
     "sv4_uniform_terrain1M_4k_8spp_d4": ("terrain", "TERRAIN_CAMERA", 3840, 2160, 8, 4),
@@ -171,7 +173,7 @@ def main():
         # per-GPU work fixed: the image grows to N x the pixels (same aspect, multiples of 8) and is tile-partitioned
         f = world ** 0.5
         w, h = int(round(w * f / 8)) * 8, int(round(h * f / 8)) * 8
-    model = {"terrain": scenes.voxel_terrain, "stadium": scenes.stadium_scene, "cornell": scenes.cornell_box, "terrain_textured_obj": textured_terrain_through_obj}[scene_name]()
+    model = {"terrain": scenes.voxel_terrain, "terrain10M": lambda: scenes.voxel_terrain(n=1500, target_tris=10_000_000), "stadium": scenes.stadium_scene, "cornell": scenes.cornell_box, "terrain_textured_obj": textured_terrain_through_obj}[scene_name]()
     probe = scenes.sky_probe(2048, 1024).BuildCDF()
     cam = getattr(scenes, cam_name)
 

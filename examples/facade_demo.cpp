@@ -64,11 +64,11 @@ int main(int argc, char** argv) {
             multi.setCamera(cam);
             multi.launchParams.samples_per_launch = spp;
             std::vector<uint32_t> pixels((size_t)w * h);
-            const int mfif = argc > 4 ? atoi(argv[4]) : 0;  // 2 or 3: render(pixels) shows frame k-1 while frame k renders (overlapped hand-over)
+            const int mfif = argc > 4 ? atoi(argv[4]) : 0;  // 2 or 3: renderToHost(pixels) shows frame k-1 while frame k renders (overlapped hand-over)
             if (mfif >= 2) multi.setFramesInFlight(mfif);
             for (uint32_t s = 0; s < subframes; ++s) {
                 multi.launchParams.frame.subframe_index = s;
-                multi.render(pixels.data());
+                multi.renderToHost(pixels.data());
             }
             if (mfif >= 2) multi.flush(pixels.data());      // the last frame goes on display
             multi.gather(PT_BUF_ACCUM);

@@ -222,7 +222,8 @@ int pt_render(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, uint32_t* host
 int pt_render_batch(pt_ctx* ctx, uint32_t spp, uint32_t first_subframe, uint32_t count, uint32_t* host_rgba8);
 /* SampleRenderer::render(sutil::CUDAOutputBuffer<uint32_t>&) (SimplePathtracer.cpp:99-107): the rgba8 frame lands in a caller-owned
  * DEVICE buffer (width*height*4 bytes on the context's device; the reference aliases the caller's mapped buffer as frame_buffer for
- * the launch).  Synchronous like render(): the buffer is complete when the call returns (also with frames in flight). */
+ * the launch).  Synchronous like render(): the buffer is complete when the call returns (also with frames in flight).
+ * A pointer HIP does not know (plain malloc'ed host memory) is refused with PT_ERR_INVALID before anything is rendered. */
 int pt_render_device(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, void* dev_rgba8);
 /* SampleRenderer::stream (SimplePathtracer.h:107, handed to the display path at main.cpp:245): the hipStream_t (as void*) on which the
  * context's packs, unpacks, epilogues and device copies run — see STREAM CONTRACT at the top. */

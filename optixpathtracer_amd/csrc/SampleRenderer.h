@@ -145,8 +145,11 @@ class SampleRenderer {
         renderTarget.unmap();
         ck(rc);
     }
-    // the same with the mapped device pointer itself
-    void render(uint32_t* d_pixels) { ck(pt_render_device(ctx, launchParams.samples_per_launch, launchParams.frame.subframe_index, d_pixels)); }
+    // the same with the mapped DEVICE pointer itself (pt_render_device refuses plain host memory with PT_ERR_INVALID)
+    void renderToDevice(uint32_t* d_pixels) { ck(pt_render_device(ctx, launchParams.samples_per_launch, launchParams.frame.subframe_index, d_pixels)); }
+    // No render(uint32_t*): rounds 1-3 had one that took HOST memory, round 4 one that took DEVICE memory under the same signature; a caller
+    // written against either must not compile silently against the other — say renderToDevice(d_pixels) or renderToHost(h_pixels).
+    void render(uint32_t*) = delete;
     // render() + downloadPixels() in one call: the frame in HOST memory
     void renderToHost(uint32_t* h_pixels) { ck(pt_render(ctx, launchParams.samples_per_launch, launchParams.frame.subframe_index, h_pixels)); }
     // `count` iterations of the application's progressive loop (render(); launchParams.frame.subframe_index++ — main.cpp:273-278) as one
@@ -180,7 +183,7 @@ class SampleRenderer {
     }
     // Beyond the reference: render() normally returns when its frame is complete (SimplePathtracer.cpp:96); with 2 or 3 frames in flight
     // (pt_options.frames_in_flight) it returns while its own frame is still running, so a progressive loop overlaps consecutive frames.
-    // downloadPixels / render(h_pixels) / resize / sync() wait for the frames in flight; the images are the same bit for bit.
+    // downloadPixels / renderToHost(h_pixels) / renderToDevice(d_pixels) / resize / sync() wait for the frames in flight; the images are the same bit for bit.
     void setFramesInFlight(int n) {
         pt_options o;
         ck(pt_get_options(ctx, &o));
@@ -221,7 +224,9 @@ class MultiSampleRenderer {
     MultiSampleRenderer& operator=(const MultiSampleRenderer&) = delete;
 
     void render() { ck(pt_multi_render(multi, launchParams.samples_per_launch, launchParams.frame.subframe_index, 1u << PT_BUF_FRAME, nullptr)); }
-    void render(uint32_t* h_pixels) { ck(pt_multi_render(multi, launchParams.samples_per_launch, launchParams.frame.subframe_index, 1u << PT_BUF_FRAME, h_pixels)); }
+    // render() + the assembled frame in HOST memory (same name and meaning as SampleRenderer::renderToHost)
+    void renderToHost(uint32_t* h_pixels) { ck(pt_multi_render(multi, launchParams.samples_per_launch, launchParams.frame.subframe_index, 1u << PT_BUF_FRAME, h_pixels)); }
+    void render(uint32_t*) = delete; // see SampleRenderer: the memory kind is part of the name
     void renderBatch(uint32_t count, uint32_t* h_pixels = nullptr) {
         ck(pt_multi_render_batch(multi, launchParams.samples_per_launch, launchParams.frame.subframe_index, count, 1u << PT_BUF_FRAME, h_pixels));
         launchParams.frame.subframe_index += count;
@@ -244,7 +249,7 @@ class MultiSampleRenderer {
         ck(pt_multi_set_probe(multi, &probe.data[0].x, probe.pdfValuesX.data(), probe.cdfValuesX.data(), probe.pdfValuesY.data(), probe.cdfValuesY.data(), probe.width, probe.height));
     }
     void gather(int which) { ck(pt_multi_gather(multi, which)); } // assemble another buffer (e.g. PT_BUF_ACCUM) on every rank
-    // Frames in flight (2 or 3): render(h_pixels) then shows frame k-1 while frame k renders — the exchange of the strips overlaps the
+    // Frames in flight (2 or 3): renderToHost(h_pixels) then shows frame k-1 while frame k renders — the exchange of the strips overlaps the
     // rendering and lands in the ranks' display buffers — and flush(h_pixels) hands over the last frame.
     void setFramesInFlight(int n) {
         pt_options o;

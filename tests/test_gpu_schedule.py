@@ -227,6 +227,25 @@ def test_bench_starts_its_own_ranks():
     assert len(d["ms_per_step_per_rank"]) == 2
 
 
+def test_render_device_refuses_plain_host_memory(ptlib):
+    """a caller written against the old render(uint32_t* h_pixels) must not reach a device-to-device copy with a
+    pageable host destination: pt_render_device answers PT_ERR_INVALID for a pointer HIP does not know, before rendering anything."""
+    import ctypes as C
+
+    from optixpathtracer_amd import renderer as R
+
+    r = R.SampleRenderer(scenes.cornell_box())
+    r.setProbe(scenes.sky_probe(64, 32).BuildCDF())
+    r.resize((64, 48))
+    r.setCamera(R.make_camera(scenes.CORNELL_CAMERA, 64 / 48))
+    host = np.zeros((48, 64), np.uint32)
+    before = r.stats()["frames"]
+    with pytest.raises(RuntimeError, match="not device memory"):
+        r.renderDevice(host.ctypes.data_as(C.c_void_p))
+    assert r.stats()["frames"] == before and not host.any()
+    r.render()  # the context is still usable
+
+
 @pytest.mark.parametrize("fif", [0, 3])
 def test_render_into_a_caller_owned_device_buffer(ptlib, fif):
     """pt_render_device = render(sutil::CUDAOutputBuffer<uint32_t>&) (SimplePathtracer.cpp:99-107): the rgba8 frame lands in the caller's

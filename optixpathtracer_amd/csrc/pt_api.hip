@@ -173,6 +173,8 @@ struct pt_ctx {
     bool cam_packets = true; // camera rays as packets (PT_CAM_PACKETS=0 turns it off)
     uint64_t cam_min_paths = 1u << 19; // ... for launches of at least this many camera rays (PT_CAM_MIN_PATHS): a packet is one wave's work from start to end,
                                        // so a launch of a few thousand packets is as long as its longest packet (chunks of a 1/8 share of C3, 345 k rays: 1.93 against 1.84 ms per frame; 1/4 share, 690 k: 2.88 against 2.92)
+    int cam_grid = 0;        // PT_CAM_GRID (tuning hook): waves of a packet launch, 0 = the policy of launch_closest
+    int enqueue_threads = 1; // PT_ENQUEUE_THREADS: 0 one enqueue thread, 1 one thread per pixel chunk for small synchronous frames (default), 2 at every size
     bool adapt_grid = false; // set around the enqueue of a whole frame (frames_in_flight = 3)
     int trace_grid_min = 2048, grid_chunks = 6; // PT_GRID_MIN / PT_GRID_CHUNKS (tuning hooks): smallest persistent grid, chunks of 64 paths per wave aimed at
     int lds_skip = 0; // PT_STACK_LDS_SKIP (test hook, pt_bvh8.h)
@@ -467,6 +469,8 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
         ctx->trace_grid = prop.multiProcessorCount * 4 * wpe;
         if (const char* e = getenv("PT_CAM_PACKETS")) ctx->cam_packets = atoi(e) != 0;
         if (const char* e = getenv("PT_CAM_MIN_PATHS")) ctx->cam_min_paths = (uint64_t)atoll(e);
+        if (const char* e = getenv("PT_CAM_GRID")) ctx->cam_grid = atoi(e);
+        if (const char* e = getenv("PT_ENQUEUE_THREADS")) ctx->enqueue_threads = atoi(e);
         CKC(dalloc(&ctx->ovf, ovf_words(ctx)));
         ctx->ovf_depth = PT8_OVF_DEPTH;
         if (const char* e = getenv("PT_STACK_CAP")) ctx->ovf_depth = std::max(0, std::min(PT8_OVF_DEPTH, atoi(e) - (PT8_LDS_DEPTH - ctx->lds_skip)));
@@ -1028,7 +1032,7 @@ static void launch_trace8(hipStream_t stream, unsigned tgrid, const Trace8Args& 
 }
 static void launch_closest(pt_ctx* ctx, hipStream_t stream, const Trace8Args& ta, unsigned tgrid, uint64_t paths) {
     if (ta.queue.base == nullptr && ctx->cam_packets && paths >= ctx->cam_min_paths) {
-        static const int env_grid = getenv("PT_CAM_GRID") ? atoi(getenv("PT_CAM_GRID")) : 0;
+        const int env_grid = ctx->cam_grid; // (read at pt_create like every other switch, so a context keeps what it was created with)
         // as many waves as the per-ray kernel gets (five per SIMD), two per SIMD for a tree of a few nodes whose packets cost next to nothing
         // (measured: C3 8.00 / stadium 12.51 ms at 5120 waves, 8.20 / 12.81 at 2048; Cornell 2.98 ms at 2048, 3.14 at 5120 = the per-ray kernel's)
         const unsigned g = env_grid > 0 ? (unsigned)env_grid : std::max(1u, ctx->bvh.num_nodes8 < 256u ? tgrid * 2u / (unsigned)PT8_WAVES_PER_EU : tgrid);
@@ -1366,7 +1370,7 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
         // shade launches overlap another's traversal) — hence the size limit.  Each chunk runs on its own batch set and stream; nothing the
         // threads touch is shared but the error string (locked).  PT_ENQUEUE_THREADS=0 keeps one thread, =2 uses threads at every size.
         const uint32_t nchunks = (owned + Np - 1) / Np;
-        static const int threads_env = getenv("PT_ENQUEUE_THREADS") ? atoi(getenv("PT_ENQUEUE_THREADS")) : 1;
+        const int threads_env = ctx->enqueue_threads;
         const bool small_frame = (uint64_t)owned * vspp <= (3u << 19); // 1.5 M paths
         const bool parallel = threads_env != 0 && (small_frame || threads_env == 2) && !pipelined && nchunks > 1 && nchunks <= (uint32_t)nsets && !ctx->span_timing() &&
                               ctx->opt.split_shadow == 0 && before.empty();
@@ -1385,7 +1389,9 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
                 });
             }
             enqueue_chunk(ctx, ctx->sets[0], fp, 0, std::min(Np, owned), vspp, S, lcs[0]);
-            for (uint32_t c = 1; c < nchunks; ++c) enqueue_worker_wait(ctx->chunk_workers[c - 1].get());
+            int wrc = 0;
+            for (uint32_t c = 1; c < nchunks; ++c) wrc |= enqueue_worker_wait(ctx->chunk_workers[c - 1].get());
+            if (wrc != 0) return fail(ctx, PT_ERR_HIP, "pt_render: a chunk's enqueue thread failed");
             for (const LaunchCounts& l : lcs) { lc.trace += l.trace; lc.shadow += l.shadow; lc.shade += l.shade; }
         } else {
             uint32_t k = 0;

@@ -60,6 +60,12 @@ struct Bvh8Dev {
 #ifndef PT8_MIN_CHUNK
 #define PT8_MIN_CHUNK 64
 #endif
+#ifndef PT8_INTERLEAVE
+#define PT8_INTERLEAVE 0 // > 0: launches of one static chunk per wave and at least this many rays deal their rays to the waves round robin
+#endif
+#ifndef PT8_WIDE_MIN
+#define PT8_WIDE_MIN 64 // rays per wave at least in a launch smaller than the grid (64: one full chunk per wave, as before)
+#endif
 #define PT8_CHUNK 512
 #ifndef PT8_WAVES_PER_EU
 #define PT8_WAVES_PER_EU 5
@@ -129,18 +135,19 @@ struct Bvh8Dev {
 // launch's epoch: seq == (epoch, pos): free for the donor of position pos — as is any cell of an older epoch for pos < CELLS —,
 // (epoch, pos + 1): published, (epoch, pos + CELLS) after the taker has read it.
 #ifndef PT8_XW_GROUPS
-#define PT8_XW_GROUPS 8u
+#define PT8_XW_GROUPS 16u
 #endif
-#define PT8_XW_CELLS 512u  // per group
-#define PT8_XW_RECS 8192u  // per group
+#define PT8_XW_CELLS 256u  // per group
+#define PT8_XW_RECS 4096u  // per group
+#ifndef PT8_XW_MAXHUNGRY
+#define PT8_XW_MAXHUNGRY 4u // hungry waves per group at a time: every poll is a same-address access at the memory side (about 10 ns each, serialised —
+                            // a thousand pollers slow the whole chip: 1/8 share 1.8 -> 3.4 ms before a single cell is donated)
+#endif
 #ifndef PT8_XW_TIMEOUT
 #define PT8_XW_TIMEOUT 20000000ll // wall-clock ticks (100 MHz), 0.2 s: a spin on a cell that never ends fails the launch instead of hanging the device
 #endif
 #ifndef PT8_XW_LINGER
 #define PT8_XW_LINGER 5000ll // ticks a hungry wave stays without work: 50 us
-#endif
-#ifndef PT8_XW_HELPERS
-#define PT8_XW_HELPERS 512u // waves without a share of their own that stay as helpers
 #endif
 #ifndef PT8_XW_DONATE
 #define PT8_XW_DONATE 32 // cells a wave donates per steal round at most
@@ -148,8 +155,12 @@ struct Bvh8Dev {
 #ifndef PT8_XW_TAKE
 #define PT8_XW_TAKE 16 // cells a hungry wave takes per claim at most (its other lanes then steal from those in LDS)
 #endif
+#ifndef PT8_XW_EXPERIMENT
+#define PT8_XW_EXPERIMENT 0
+#endif
 #ifndef PT8_XW_POLL
-#define PT8_XW_POLL 1 // a wave in its stealing phase reads its group's `hungry` every this many iterations (0: never — lingering only; < 0: assumes hungry waves)
+#define PT8_XW_POLL 2 // a wave in its stealing phase reads its group's `hungry` every this many iterations at least (more for large groups, see
+                      // poll_period; 0: never — lingering only; < 0: assumes hungry waves)
 #endif
 #ifndef PT8_XW_WAVES_PER_EU
 #define PT8_XW_WAVES_PER_EU 4 // the XW variants need ~125 VGPRs; their launches are small, occupancy is not what limits them
@@ -163,11 +174,12 @@ struct XwRec {
     unsigned long long key;
     uint32_t cnt, pad;
 };
+#define PT8_XW_CLOSED 0x80000000u
 struct XwCtr { // per launch and group, zeroed with the pass's counters; every word that is hammered has a line of its own
-    uint32_t tail, head; // one 8-byte load reads both
+    uint32_t tail, head; // one 8-byte load reads both; tail's top bit: the group is closed (set when nothing can be donated any more)
     uint32_t pad0[14];
-    uint32_t hungry, closed;
-    uint32_t pad1[14];
+    uint32_t hungry;
+    uint32_t pad1[15];
     unsigned long long state; // finished units | donated cells << 32
     uint32_t pad2[14];
     uint32_t nrec; // global records allocated
@@ -240,6 +252,16 @@ k_trace8(Trace8Args a) {
     const uint32_t n = n1 + n2;
     uint32_t chunk = (n / (gridDim.x * 2u)) & ~(uint32_t)(PT8_MIN_CHUNK < 64 ? PT8_MIN_CHUNK - 1 : 63);
     chunk = chunk < (uint32_t)PT8_MIN_CHUNK ? (uint32_t)PT8_MIN_CHUNK : (chunk > (uint32_t)PT8_CHUNK ? (uint32_t)PT8_CHUNK : chunk);
+#if PT8_WIDE_MIN < 64
+    // Wide start (round 5): a launch with fewer rays than the grid has lanes is not throughput-bound but as long as its slowest ray's chain of
+    // dependent steps (1.5 us each with a lone wave on a SIMD).  Such a launch is spread over more waves — ceil(n / waves) rays each, at least
+    // PT8_WIDE_MIN — whose spare lanes take stack entries of the wave's rays from the first iteration on (the stealing phase below), so a
+    // ray's subtrees are traversed side by side.  The split is static: no chunk counter is touched.
+    if (n < gridDim.x * 64u) {
+        chunk = ((n + gridDim.x - 1u) / gridDim.x + 15u) & ~15u;
+        chunk = chunk < (uint32_t)PT8_WIDE_MIN ? (uint32_t)PT8_WIDE_MIN : chunk;
+    }
+#endif
     const bool no_share = (unsigned long long)blockIdx.x * chunk >= n; // this wave has no chunk of its own
     const uint32_t nchunks = (n + chunk - 1u) / chunk;
     const uint32_t nshare = nchunks < gridDim.x ? nchunks : gridDim.x; // waves that start with a chunk of their own (chunk blockIdx.x)
@@ -251,9 +273,11 @@ k_trace8(Trace8Args a) {
     XwRec* const recs = XW ? a.xw->recs[grp] : nullptr;
     if (no_share) {
         // XW: some waves without a share stay as helpers of their group (a group without shares never closes: its helpers leave at once)
-        if (!XW || nshare_g == 0u || blockIdx.x >= nshare + PT8_XW_HELPERS) return;
+        if (!XW || PT8_XW_EXPERIMENT != 0 || nshare_g == 0u || blockIdx.x >= nshare + PT8_XW_GROUPS * PT8_XW_MAXHUNGRY) return;
     }
     uint32_t units = no_share ? 0u : 1u; // XW, wave-uniform: work units this wave will report finished when it next runs dry
+    // XW: a busy wave reads `hungry` every poll_period iterations of its stealing phase, so that a group's polls stay near ten per microsecond
+    const uint32_t poll_period = PT8_XW_POLL > 0 ? ((uint32_t)PT8_XW_POLL > nshare_g / 16u ? (uint32_t)PT8_XW_POLL : nshare_g / 16u) : 1u;
     uint32_t chunk_next = no_share ? n : blockIdx.x * chunk;
     uint32_t chunk_end = (chunk_next + chunk < n) ? chunk_next + chunk : n;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -409,6 +433,7 @@ k_trace8(Trace8Args a) {
         t_mask = 0;
     };
     uint32_t hs = 0u; // XW, wave-uniform: hungry waves seen by the last poll
+    uint32_t since_poll = 0u;
 
     for (;;) {
 #if PT8_DEFER_WRITE
@@ -422,20 +447,35 @@ k_trace8(Trace8Args a) {
         if (idle != 0ull && !exhausted) {
             const uint32_t cnt = (uint32_t)__popcll(idle);
             if (chunk_next == chunk_end) {
-                uint32_t c = 0;
-                if (lane == 0) c = atomicAdd(a.work, 1u);
-                c = __shfl(c, 0) + gridDim.x;
-                const unsigned long long b0 = (unsigned long long)c * chunk;
-                chunk_next = b0 < n ? (uint32_t)b0 : n;
-                chunk_end = (b0 + chunk < n) ? (uint32_t)(b0 + chunk) : n;
-                if (chunk_next >= chunk_end) exhausted = true;
+                if (nchunks <= gridDim.x) { // every chunk belongs to a wave by its block index: nothing to fetch (and no same-address atomic: 10 ns each, serialised)
+                    exhausted = true;
+                } else {
+                    uint32_t c = 0;
+                    if (lane == 0) c = atomicAdd(a.work, 1u);
+                    c = __shfl(c, 0) + gridDim.x;
+                    const unsigned long long b0 = (unsigned long long)c * chunk;
+                    chunk_next = b0 < n ? (uint32_t)b0 : n;
+                    chunk_end = (b0 + chunk < n) ? (uint32_t)(b0 + chunk) : n;
+                    if (chunk_next >= chunk_end) exhausted = true;
+                }
             }
             const uint32_t take = (chunk_end - chunk_next) < cnt ? (chunk_end - chunk_next) : cnt;
             const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
             const uint32_t first = chunk_next;
             chunk_next += take;
+            if (chunk_next == chunk_end && nchunks <= gridDim.x) exhausted = true; // the wave's only chunk is taken: its spare lanes start stealing at once
+#if PT8_INTERLEAVE
+            // A launch of one static chunk per wave: wave w's lane l takes ray l * (waves with a share) + w instead of ray 64 w + l, so every wave
+            // holds rays from all over the queue — which is in image order: a wave of 64 neighbouring camera rays that all graze the terrain has
+            // no idle lane to help (max / mean wave time 2.7-3.4 in camera launches of a 1/8 share, profiles/r5_01_wavelog_w8.txt).
+            const bool spread = nchunks <= gridDim.x && chunk == 64u && n >= (uint32_t)PT8_INTERLEAVE;
+            const uint32_t gi_spread = lane * nshare + blockIdx.x;
+            if (!active && (spread ? gi_spread < n : rank < take)) {
+                const uint32_t gi = spread ? gi_spread : first + rank;
+#else
             if (!active && rank < take) {
                 const uint32_t gi = first + rank;
+#endif
                 if (MODE == TR_UNIFIED) {
                     // shadow rays first: the longest rays of a launch are probe shadow rays that graze the terrain and hit nothing;
                     // started early, their tails overlap the closest-hit bulk instead of trailing it
@@ -637,6 +677,9 @@ k_trace8(Trace8Args a) {
 #endif
         unsigned long long act = __ballot(active);
 #if PT8_STEAL
+#if PT8_XW_EXPERIMENT == 1
+        if (XW && act == 0ull) break; // experiment: the XW kernel variant without any of its protocol
+#endif
         if (XW && act == 0ull) {
             // ---------------- XW: this wave is dry (so the queue is exhausted and `stealing` is set): report the work units it finished,
             // announce itself and poll its group's mailbox until cells arrive, the group closes, or PT8_XW_LINGER has passed without work
@@ -645,21 +688,36 @@ k_trace8(Trace8Args a) {
                 if (units != 0u) {
                     const unsigned long long old = atomicAdd(&ctr->state, (unsigned long long)units);
                     if ((uint32_t)old + units == nshare_g + (uint32_t)(old >> 32)) { // every share and every donated cell of the group is finished
-                        xw_st(&ctr->closed, 1u);
+                        atomicOr(&ctr->tail, PT8_XW_CLOSED);
                         cl = 1u;
                     }
                 }
-                if (cl == 0u) atomicAdd(&ctr->hungry, 1u);
+#if PT8_XW_EXPERIMENT == 2
+                cl = 1u; // experiment: report, never linger
+#endif
+                // at most PT8_XW_MAXHUNGRY waves of a group linger; a wave that has just seen that many leaves without touching the counter
+                if (cl == 0u) {
+                    if (hs >= PT8_XW_MAXHUNGRY) cl = 1u;
+                    else if (atomicAdd(&ctr->hungry, 1u) >= PT8_XW_MAXHUNGRY) {
+                        atomicSub(&ctr->hungry, 1u);
+                        cl = 1u;
+                    }
+                }
             }
             units = 0u;
             cl = (uint32_t)__builtin_amdgcn_readfirstlane((int)cl);
-            if (cl != 0u) break; // this wave closed the group: nothing is left
+            if (cl != 0u) { // closed, or enough hungry waves: but never leave cells behind (they were published while this wave was busy)
+                const unsigned long long th0 = xw_ld64(reinterpret_cast<const unsigned long long*>(&ctr->tail));
+                if ((int32_t)(((uint32_t)th0 & ~PT8_XW_CLOSED) - (uint32_t)(th0 >> 32)) <= 0) break;
+                if (lane == 0) atomicAdd(&ctr->hungry, 1u); // there are cells: take them as a hungry wave like any other
+            }
             bool got = false;
             const long long t_h = wall_clock64();
             uint32_t nap = 4u;
             for (;;) {
                 const unsigned long long th = xw_ld64(reinterpret_cast<const unsigned long long*>(&ctr->tail));
-                const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)th), h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(th >> 32));
+                const uint32_t tw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)th), h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(th >> 32));
+                const uint32_t t = tw & ~PT8_XW_CLOSED;
                 const int32_t avail = (int32_t)(t - h);
                 if (avail > 0) {
                     const uint32_t m = avail > PT8_XW_TAKE ? (uint32_t)PT8_XW_TAKE : (uint32_t)avail;
@@ -714,13 +772,11 @@ k_trace8(Trace8Args a) {
                     }
                     continue; // another taker was faster: look again at once
                 }
-                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)xw_ld(&ctr->closed)) != 0u) break;
+                if ((tw & PT8_XW_CLOSED) != 0u) break;
                 if (wall_clock64() - t_h > (long long)PT8_XW_LINGER) break;
-                __builtin_amdgcn_s_sleep(4); // (the s_sleep operand is an immediate)
+                __builtin_amdgcn_s_sleep(8); // (the s_sleep operand is an immediate) 0.25 us, then 0.5 us between polls
                 if (nap >= 8u) __builtin_amdgcn_s_sleep(8);
-                if (nap >= 16u) __builtin_amdgcn_s_sleep(16);
-                if (nap >= 32u) __builtin_amdgcn_s_sleep(32);
-                nap = nap < 32u ? nap * 2u : nap; // 0.1 us, then up to 1.7 us between polls
+                nap = 8u;
             }
             if (lane == 0) atomicSub(&ctr->hungry, 1u);
             PT_WLOG(w_linger += (unsigned long long)(wall_clock64() - t_h); w_taken += units;)
@@ -737,7 +793,8 @@ k_trace8(Trace8Args a) {
 #if PT8_STEAL
             uint32_t hs_v = 0u;
 #if PT8_XW_POLL > 0
-            const bool polled = XW && stealing && (it % (uint32_t)PT8_XW_POLL) == 0u;
+            const bool polled = XW && stealing && (++since_poll >= poll_period);
+            if (polled) since_poll = 0u;
             if (polled) hs_v = xw_ld(&ctr->hungry); // waited for at the end of the iteration, behind the node loads
 #endif
             if (stealing && active) { // pick up what the ray's other workers found

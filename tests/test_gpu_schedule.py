@@ -227,6 +227,57 @@ def test_bench_starts_its_own_ranks():
     assert len(d["ms_per_step_per_rank"]) == 2
 
 
+def _partition_frame(monkeypatch, env):
+    """a small frame on rank 1 of a 3-way partition (three pixel chunks, launches far below the grid size) under the given environment"""
+    from optixpathtracer_amd import renderer as R
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = R.SampleRenderer(scenes.voxel_terrain(n=96, target_tris=70000))
+    r.setProbe(scenes.sky_probe(256, 128).BuildCDF())
+    r.setPartition(1, 3, 64, 16)
+    w, h = 320, 192
+    r.resize((w, h))
+    r.setCamera(R.make_camera(scenes.TERRAIN_CAMERA, w / h))
+    r.launchParams.samples_per_launch = 3
+    out = []
+    for k in range(2):
+        r.launchParams.frame.subframe_index = k
+        r.render()
+        out.append({b: r.download(b).copy() for b in (R.PT_BUF_ACCUM, R.PT_BUF_COLOR, R.PT_BUF_NORMAL, R.PT_BUF_ALBEDO)} | {"frame": r.downloadPixels().copy()})
+    st = r.stats()
+    r.close()
+    for k in env:
+        monkeypatch.delenv(k)
+    return out, {k: st[k] for k in ("radiance_rays", "shadow_rays", "shaded_hits", "paths")}
+
+
+def test_enqueue_threads_do_not_change_a_bit(ptlib, monkeypatch):
+    """small synchronous frames enqueue each pixel chunk's chain from its own thread (PT_ENQUEUE_THREADS, read per context at
+    pt_create since round 5); the single-thread path and the threaded path must leave the same five buffers and the same ray counts."""
+    a, sa = _partition_frame(monkeypatch, {"PT_ENQUEUE_THREADS": "0"})
+    b, sb = _partition_frame(monkeypatch, {"PT_ENQUEUE_THREADS": "2"})
+    assert sa == sb
+    for fa, fb in zip(a, b):
+        for k in fa:
+            assert np.array_equal(fa[k].view(np.uint8), fb[k].view(np.uint8)), k
+
+
+def test_cross_wave_stealing_is_bit_identical(ptlib, monkeypatch):
+    """Cross-wave work stealing (PT_XW, opt-in: profiles/r5_02_cross_wave_stealing.md measured it slower) splits a ray over several waves and
+    merges through a global record; the result is the minimum over the same accepted triangles, so every buffer and every ray count must
+    equal the default schedule's — in every launch (PT_XW=2) of a frame whose launches are far smaller than the grid (helpers, lingering,
+    donations all happen) and with the stack's LDS levels cut down so that donated entries come from shallow stacks too."""
+    a, sa = _partition_frame(monkeypatch, {"PT_XW": "0"})
+    b, sb = _partition_frame(monkeypatch, {"PT_XW": "2"})
+    c, sc = _partition_frame(monkeypatch, {"PT_XW": "2", "PT_STACK_LDS_SKIP": "7"})
+    assert sa == sb == sc
+    for fa, fb, fc in zip(a, b, c):
+        for k in fa:
+            assert np.array_equal(fa[k].view(np.uint8), fb[k].view(np.uint8)), k
+            assert np.array_equal(fa[k].view(np.uint8), fc[k].view(np.uint8)), k
+
+
 def test_render_device_refuses_plain_host_memory(ptlib):
     """a caller written against the old render(uint32_t* h_pixels) must not reach a device-to-device copy with a
     pageable host destination: pt_render_device answers PT_ERR_INVALID for a pointer HIP does not know, before rendering anything."""

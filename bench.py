@@ -431,6 +431,7 @@ def main():
         # PMC-derived figures (HBM traffic, VALU issue / lane utilisation) cannot be collected inside an unprofiled run: they are
         # read from the committed rocprofv3 passes of this same command and quoted only for the sources they were measured on
         traffic = valu = trav_traffic_frame = None
+        replayed = None  # the committed file the PMC-derived fields below were read from (they are REPLAYED, not measured by this run)
         shash = source_hash()
         default_cfg = args.workload == "c3_terrain1M_1080p_4spp_d8" and world == 1 and args.simulate_world == 0 and args.batch == 1 and not pipelined
         pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
@@ -442,10 +443,12 @@ def main():
                     traffic = T.get("traffic_bytes_per_frame")  # per frame, like `achieved` / alg_bytes_per_frame
                     trav_traffic_frame = T.get("traversal_traffic_bytes_per_frame")
                     valu = T.get("valu")
+                    replayed = os.path.relpath(tj, ROOT)
                     if shade is not None and "shade" in T:
                         shade["pmc"] = T["shade"]
+                        shade["pmc_replayed_from"] = replayed
             except Exception:
-                traffic = valu = None
+                traffic = valu = replayed = None
         limiter = None
         ws = ((valu or {}).get("wave_state") or {}).get("k_trace8<3>")
         if ws:
@@ -495,17 +498,21 @@ def main():
             "roofline": {
                 "kernel": "whole frame, all wavefront stages (SURVEY.md 8d: rays x 160 B + pixels x 84 B + scene bytes)", "bound": "hbm",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                # every PMC-derived field of this line (traffic, dominant_kernel.traffic, valu, measured_limiter, shade.pmc) is replayed from this committed
+                # rocprofv3 pass of the same command — quoted only while its src_hash equals the hash of the kernel sources — never measured in this run
+                "traffic_replayed_from": replayed if traffic is not None else None,
                 "alg_bytes_per_frame": int(alg_frame), "scene_bytes": int(scene_bytes),
                 # what the counters say limits the dominant kernel — quoted, like every PMC-derived figure, only for the profiled sources
-                "measured_limiter": limiter,
+                "measured_limiter": limiter, "measured_limiter_replayed_from": replayed if limiter is not None else None,
                 "dominant_kernel": None if trav_ms <= 0 else {
                     "kernel": kname + " (BVH traversal: closest-hit + shadow rays per launch)", "bytes_per_ray": [BYTES_PER_RADIANCE_RAY_TRACE, BYTES_PER_SHADOW_RAY_TRACE],
                     "alg_bytes_per_launch": int(trav_bytes), "avg_launch_ms": round(trav_ms, 4), "isolated": iso is not None,
                     "achieved": round(trav_gbs, 2), "unit": "GB/s", "frac": round(trav_gbs / HBM_PEAK_GBS, 5),
                     # measured fabric traffic of the traversal kernels per frame / launches per frame of THIS (single-stream) schedule
                     "traffic": None if trav_traffic_frame is None else int(trav_traffic_frame / n_launch),
+                    "traffic_replayed_from": replayed if trav_traffic_frame is not None else None,
                 },
-                "shade": shade, "valu": valu, "src_hash": shash,
+                "shade": shade, "valu": valu, "valu_replayed_from": replayed if valu is not None else None, "src_hash": shash,
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -1092,6 +1092,17 @@ static hipError_t import_hierarchy(const char* path, int n, const uint64_t* keys
         if (c >= 0 ? c >= n - 1 : ~c >= n) return hipErrorInvalidValue;
     auto tr = [&](int c) { return c >= 0 ? c : n - 1 + pos[~c]; };
     for (int j = 0; j < n - 1; ++j) { hl[j] = tr(lr[2 * j]); hr[j] = tr(lr[2 * j + 1]); }
+    // ... and it must be a TREE over exactly these nodes: every internal node but the root and every leaf referenced once, the root never.
+    // (The level-synchronous passes read parent[] of every internal node: a node no parent names would leave uninitialised arena memory
+    // there, and one named twice would be climbed twice.)
+    {
+        std::vector<uint8_t> refs((size_t)2 * n - 1, 0);
+        for (int j = 0; j < n - 1; ++j)
+            for (int c : {hl[j], hr[j]})
+                if (c == 0 || refs[(size_t)c]++ != 0) return hipErrorInvalidValue;
+        for (size_t c = 1; c < refs.size(); ++c)
+            if (refs[c] != 1) return hipErrorInvalidValue;
+    }
     // children have larger ids than their parent (preorder): one backward sweep computes boxes and counts
     for (int j = n - 2; j >= 0; --j) {
         const int a = hl[j], b = hr[j];

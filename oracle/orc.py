@@ -64,7 +64,8 @@ class Oracle:
     def __init__(self, mode: str = "det"):
         build()
         self.mode = mode
-        self.lib = L = C.CDLL(os.path.join(HERE, f"liborc_{mode}.so"))
+        # ORC_LIB_DIR: the sanitizer builds (make -C oracle asan -> oracle/asan/, tools/sanitize.sh)
+        self.lib = L = C.CDLL(os.path.join(os.environ.get("ORC_LIB_DIR") or HERE, f"liborc_{mode}.so"))
         L.orc_tea4.restype = C.c_uint32
         L.orc_tea4.argtypes = [C.c_uint32, C.c_uint32]
         L.orc_lcg.restype = C.c_uint32

@@ -104,3 +104,54 @@ def test_build_time_budget(ptlib, monkeypatch):
         out[name] = best
     print(f"\n[bvh build, 1 M triangles] terrain {out['terrain']:.1f} ms, stadium {out['stadium']:.1f} ms")
     assert out["terrain"] < 25 and out["stadium"] < 25, out
+
+
+def test_imported_hierarchy_is_validated(ptlib, monkeypatch, tmp_path):
+    """PT_BVH_IMPORT (experiment hook: a binary hierarchy built elsewhere) reads an untrusted file.  A well-formed tree — here a right comb,
+    the worst shape there is — must give the image the GPU builders give (ray search is defined by geometry); a file
+    that names a node twice, leaves one unreferenced, refers to the root or to an id out of range must be refused by pt_create
+    (the level-synchronous passes read parent[] of every internal node)."""
+    from optixpathtracer_amd import renderer as R
+
+    m = scenes.cornell_box()
+    n = sum(len(mesh.index) for mesh in m.meshes)
+    probe = scenes.sky_probe(64, 32).BuildCDF()
+
+    def render():
+        r = R.SampleRenderer(m)
+        r.setProbe(probe)
+        r.resize((96, 64))
+        r.setCamera(R.make_camera(scenes.CORNELL_CAMERA, 96 / 64))
+        r.launchParams.samples_per_launch = 2
+        r.render()
+        a = r.download(R.PT_BUF_ACCUM).copy()
+        r.close()
+        return a
+
+    monkeypatch.delenv("PT_BVH_IMPORT", raising=False)
+    ref = render()
+    comb = np.empty((n - 1, 2), np.int32)  # node j = (primitive j, node j + 1); the last node holds the last two primitives
+    for j in range(n - 1):
+        comb[j] = (~j, j + 1)
+    comb[n - 2] = (~(n - 2), ~(n - 1))
+
+    def write(tree, name):
+        p = tmp_path / name
+        with open(p, "wb") as f:
+            f.write(np.int32(n).tobytes())
+            f.write(np.ascontiguousarray(tree, np.int32).tobytes())
+        return str(p)
+
+    monkeypatch.setenv("PT_BVH_IMPORT", write(comb, "comb.tree"))
+    assert np.array_equal(render().view(np.uint32), ref.view(np.uint32))
+    bad = {}
+    t = comb.copy(); t[3, 1] = 5; bad["node 5 named twice, node 4 never"] = t
+    t = comb.copy(); t[2, 0] = ~0; bad["primitive 0 named twice, primitive 2 never"] = t
+    t = comb.copy(); t[n - 2, 1] = 0; bad["the root as a child"] = t
+    t = comb.copy(); t[1, 1] = n - 1; bad["node id out of range"] = t
+    t = comb.copy(); t[1, 0] = ~n; bad["primitive out of range"] = t
+    t = comb.copy(); t[4, 1] = 2; bad["a child with a smaller id than its parent"] = t
+    for what, tree in bad.items():
+        monkeypatch.setenv("PT_BVH_IMPORT", write(tree, "bad.tree"))
+        with pytest.raises(RuntimeError):
+            R.SampleRenderer(m)

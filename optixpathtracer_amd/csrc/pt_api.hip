@@ -134,6 +134,7 @@ struct pt_ctx {
     // set runs on its own pair of streams, so one chunk's kernel tails overlap with the other chunks' bulk work
     struct BatchSet {
         hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
+        hipStream_t shade_stream = nullptr; // PT_SHADE_CUS experiment: k_shade runs here (every CU) while `stream` is confined to the other CUs
         PathState st{}; // the arrays indexed by path slot; the stream pointers are filled per launch (stream_view)
         // what a path carries from bounce to bounce, in queue order (pt_kernels.h PathState): X[0] travels with queueA, X[1] with queueB
         // (the generate kernels write X[1]); the shadow records travel with squeue
@@ -170,9 +171,12 @@ struct pt_ctx {
     uint32_t* ovf = nullptr; // spill stacks for pt_trace queries
     unsigned long long* dbg = nullptr; // PT_DEBUG_COUNTS: traversal step counters of the last frame
     int trace_grid = 0;
+    int num_cus = 0;
     bool cam_packets = true; // camera rays as packets (PT_CAM_PACKETS=0 turns it off)
     uint64_t cam_min_paths = 1u << 19; // ... for launches of at least this many camera rays (PT_CAM_MIN_PATHS): a packet is one wave's work from start to end,
                                        // so a launch of a few thousand packets is as long as its longest packet (chunks of a 1/8 share of C3, 345 k rays: 1.93 against 1.84 ms per frame; 1/4 share, 690 k: 2.88 against 2.92)
+    int shade_cus = 0;       // PT_SHADE_CUS (experiment): CUs the chunk chains' streams may NOT use; k_shade launches go to unmasked streams
+    std::vector<hipStream_t> masked_streams; // [set]: the set's stream when shade_cus > 0 (set_streams[set] then carries its k_shade launches)
     int cam_grid = 0;        // PT_CAM_GRID (tuning hook): waves of a packet launch, 0 = the policy of launch_closest
     int enqueue_threads = 1; // PT_ENQUEUE_THREADS: 0 one enqueue thread, 1 one thread per pixel chunk for small synchronous frames (default), 2 at every size
     bool adapt_grid = false; // set around the enqueue of a whole frame (frames_in_flight = 3)
@@ -470,6 +474,8 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
         if (const char* e = getenv("PT_CAM_PACKETS")) ctx->cam_packets = atoi(e) != 0;
         if (const char* e = getenv("PT_CAM_MIN_PATHS")) ctx->cam_min_paths = (uint64_t)atoll(e);
         if (const char* e = getenv("PT_CAM_GRID")) ctx->cam_grid = atoi(e);
+        if (const char* e = getenv("PT_SHADE_CUS")) ctx->shade_cus = std::max(0, std::min(prop.multiProcessorCount - 8, atoi(e)));
+        ctx->num_cus = prop.multiProcessorCount;
         if (const char* e = getenv("PT_ENQUEUE_THREADS")) ctx->enqueue_threads = atoi(e);
         CKC(dalloc(&ctx->ovf, ovf_words(ctx)));
         ctx->ovf_depth = PT8_OVF_DEPTH;
@@ -531,6 +537,7 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     free_path_state(ctx);
     for (hipStream_t st : ctx->set_streams) if (st) hipStreamDestroy(st);
     for (hipStream_t st : ctx->side_streams) if (st) hipStreamDestroy(st);
+    for (hipStream_t st : ctx->masked_streams) if (st) hipStreamDestroy(st);
     free_frame(ctx);
     dfree(ctx->d_verts); dfree(ctx->d_idx); dfree(ctx->d_tri_mesh); dfree(ctx->d_mats);
     dfree(ctx->d_mesh_tex); dfree(ctx->d_uvs); dfree(ctx->d_textris); dfree(ctx->d_textures);
@@ -896,8 +903,20 @@ static int assign_streams(pt_ctx* ctx, int nsets) {
         if (!ctx->set_streams[i]) CK(stream_create(&ctx->set_streams[i]));
         if (!ctx->side_streams[2 * i]) CK(stream_create(&ctx->side_streams[2 * i]));
         if (async && !ctx->side_streams[2 * i + 1]) CK(stream_create(&ctx->side_streams[2 * i + 1]));
+        if (ctx->shade_cus > 0) { // experiment: the chain's stream is a queue of its own with a CU mask, the probed stream carries k_shade
+            if ((int)ctx->masked_streams.size() <= i) ctx->masked_streams.resize(i + 1, nullptr);
+            if (!ctx->masked_streams[i]) {
+                std::vector<uint32_t> mask((size_t)(ctx->num_cus + 31) / 32, 0u);
+                for (int c = 0; c < ctx->num_cus - ctx->shade_cus; ++c) mask[c / 32] |= 1u << (c % 32);
+                CK(hipExtStreamCreateWithCUMask(&ctx->masked_streams[i], (uint32_t)mask.size(), mask.data()));
+            }
+        }
         if (i < (int)ctx->sets.size()) {
             ctx->sets[i].stream = ctx->set_streams[i];
+            if (ctx->shade_cus > 0) {
+                ctx->sets[i].stream = ctx->masked_streams[i];
+                ctx->sets[i].shade_stream = ctx->set_streams[i];
+            }
             ctx->sets[i].stream2 = ctx->side_streams[2 * i];
             ctx->sets[i].stream3 = ctx->side_streams[2 * i + 1];
         }
@@ -1015,10 +1034,22 @@ static PathState stream_view(const pt_ctx::BatchSet& bs, int k) {
 template <int MODE>
 static void launch_shade(pt_ctx* ctx, pt_ctx::BatchSet& bs, const PathState& st, const ShadeParams& sp) {
     const unsigned lds = (unsigned)shade_lds_bytes(sp.probe);
+    hipStream_t s = bs.stream;
+    if (bs.shade_stream) { // PT_SHADE_CUS experiment: behind the chain's last launch, on the stream that may use every CU
+        hipEvent_t e = next_event(ctx);
+        hipEventRecord(e, bs.stream);
+        s = bs.shade_stream;
+        hipStreamWaitEvent(s, e, 0);
+    }
     if (ctx->has_catcher)
-        hipLaunchKernelGGL((k_shade<MODE, true>), dim3(GRID), dim3(256), lds, bs.stream, st, sp);
+        hipLaunchKernelGGL((k_shade<MODE, true>), dim3(GRID), dim3(256), lds, s, st, sp);
     else
-        hipLaunchKernelGGL((k_shade<MODE, false>), dim3(GRID), dim3(256), lds, bs.stream, st, sp);
+        hipLaunchKernelGGL((k_shade<MODE, false>), dim3(GRID), dim3(256), lds, s, st, sp);
+    if (bs.shade_stream) {
+        hipEvent_t e = next_event(ctx);
+        hipEventRecord(e, s);
+        hipStreamWaitEvent(bs.stream, e, 0);
+    }
 }
 
 // Closest-hit launch of a bounce chain.  The identity queue of bounce 0 holds camera rays in pixel-block order: they are traversed as
@@ -1372,7 +1403,7 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
         const uint32_t nchunks = (owned + Np - 1) / Np;
         const int threads_env = ctx->enqueue_threads;
         const bool small_frame = (uint64_t)owned * vspp <= (3u << 19); // 1.5 M paths
-        const bool parallel = threads_env != 0 && (small_frame || threads_env == 2) && !pipelined && nchunks > 1 && nchunks <= (uint32_t)nsets && !ctx->span_timing() &&
+        const bool parallel = ctx->shade_cus == 0 && threads_env != 0 && (small_frame || threads_env == 2) && !pipelined && nchunks > 1 && nchunks <= (uint32_t)nsets && !ctx->span_timing() &&
                               ctx->opt.split_shadow == 0 && before.empty();
         if (parallel) {
             while (ctx->chunk_workers.size() + 1 < nchunks) {

@@ -409,6 +409,36 @@ int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit, float* t_o
  * record: k_shade reads these very triangles through the leaf index a closest-hit record holds), 1 unused. */
 int pt_export_bvh(pt_ctx* ctx, void* nodes, size_t nodes_bytes, void* tris, size_t tris_bytes, uint32_t* num_nodes, uint32_t* num_tris);
 
+/* Scene ingestion, host only (no GPU needed): loadOBJ (HelloPathtracing_original/Model.cpp:137-212 — tinyobjloader 2.0.0's LoadObj with
+ * triangulation, then one TriangleMesh per (shape, material id)) as native code.  The arrays are the reference's bit for bit
+ * (tests/test_objloader.py: the reference's own Model.cpp, compiled from where it lies, on committed fixtures and random files):
+ * vertices, normals (null when the mesh has none), texcoords (null when none), indices, the Material bytes (Kd -> color, Ke ->
+ * emission, defaults otherwise), mesh order.
+ * per_mesh_vertex_map = 0 reproduces the reference's ONE knownVertices map per shape shared by its materials (Model.cpp:176): a
+ * second material's mesh then indexes vertices it does not own — out of bounds for the renderer (pt_create refuses such a mesh);
+ * per_mesh_vertex_map = 1 gives every mesh its own map: what a renderer needs, and the default of the Python facade's
+ * load_obj.  Images are not decoded here (the reference uses stb_image): texture_ref numbers a mesh's texture REFERENCE
+ * — (shape, file name) pairs in loadTexture's order of first use (Model.cpp:88-135, :177), path = model directory + "/" + name with
+ * '\\' -> '/' — or is -1; the caller decodes pt_obj_texture_path(i) (RGBA8, rows mirrored in y), gives unreadable files the id -1
+ * and numbers the others in order, as loadTexture does.  Errors: PT_ERR_INVALID, text in pt_obj_last_error() (thread-local). */
+typedef struct pt_obj pt_obj;
+typedef struct pt_obj_mesh {
+    const float* vertex;   /* num_vertices * 3 */
+    const float* normal;   /* num_vertices * 3 or NULL */
+    const float* texcoord; /* num_vertices * 2 or NULL */
+    const uint32_t* index; /* num_triangles * 3 */
+    uint32_t num_vertices, num_triangles;
+    pt_material material;
+    int32_t texture_ref; /* index for pt_obj_texture_path, or -1 */
+} pt_obj_mesh;
+int pt_load_obj(const char* obj_path, int per_mesh_vertex_map, pt_obj** out);
+void pt_obj_free(pt_obj* obj);
+uint32_t pt_obj_num_meshes(const pt_obj* obj);
+int pt_obj_get_mesh(const pt_obj* obj, uint32_t i, pt_obj_mesh* out); /* the pointers live until pt_obj_free */
+uint32_t pt_obj_num_textures(const pt_obj* obj);
+const char* pt_obj_texture_path(const pt_obj* obj, uint32_t i);
+const char* pt_obj_last_error(void);
+
 /* Device-function tables for function-level parity tests (the reference's commented-out BSDFTest /
  * ProbeCreateTest, Disney.cuh:430-503, Probe.cuh:207-269, turned into entry points).
  *  which = 0: BSDFEval+BSDFPdf  in: n x {N[3],V[3],L[3],etaI,etaO} (11 floats)  out: n x {f[3],pdf}

@@ -21,6 +21,7 @@ EXPORTS = [
     "pt_multi_get_stats", "pt_export_bvh", "pt_render_batch", "pt_multi_render_batch",
     "pt_pack_async", "pt_pack_wait", "pt_unpack_display", "pt_display_sync", "pt_display_buffer", "pt_download_display", "pt_multi_flush",
     "pt_render_device", "pt_stream", "pt_wait_event", "pt_get_stats_n", "pt_stats_size",
+    "pt_load_obj", "pt_obj_free", "pt_obj_num_meshes", "pt_obj_get_mesh", "pt_obj_num_textures", "pt_obj_texture_path", "pt_obj_last_error",
 ]
 
 
@@ -36,6 +37,13 @@ class Material(C.Structure):  # pt_material == Material.h:47-68
         ("roughness", C.c_float), ("specularTint", C.c_float), ("anisotropic", C.c_float), ("sheen", C.c_float),
         ("sheenTint", C.c_float), ("clearcoat", C.c_float), ("clearcoatGloss", C.c_float), ("transmission", C.c_float),
         ("bump", C.c_float), ("bumpTile", C.c_float * 3), ("flags", C.c_int32),
+    ]
+
+
+class ObjMesh(C.Structure):  # pt_obj_mesh
+    _fields_ = [
+        ("vertex", C.POINTER(C.c_float)), ("normal", C.POINTER(C.c_float)), ("texcoord", C.POINTER(C.c_float)), ("index", C.POINTER(C.c_uint32)),
+        ("num_vertices", C.c_uint32), ("num_triangles", C.c_uint32), ("material", Material), ("texture_ref", C.c_int32),
     ]
 
 
@@ -148,6 +156,17 @@ def load_library() -> C.CDLL:
     L.pt_render_batch.argtypes = [vp, u32, u32, u32, vp]
     L.pt_sync.argtypes = [vp]
     L.pt_render_device.argtypes = [vp, u32, u32, vp]
+    L.pt_load_obj.argtypes = [C.c_char_p, i, C.POINTER(vp)]
+    L.pt_obj_free.argtypes = [vp]
+    L.pt_obj_free.restype = None
+    L.pt_obj_num_meshes.argtypes = [vp]
+    L.pt_obj_num_meshes.restype = u32
+    L.pt_obj_get_mesh.argtypes = [vp, u32, C.POINTER(ObjMesh)]
+    L.pt_obj_num_textures.argtypes = [vp]
+    L.pt_obj_num_textures.restype = u32
+    L.pt_obj_texture_path.argtypes = [vp, u32]
+    L.pt_obj_texture_path.restype = C.c_char_p
+    L.pt_obj_last_error.restype = C.c_char_p
     L.pt_stream.restype = vp
     L.pt_stream.argtypes = [vp]
     L.pt_wait_event.argtypes = [vp, vp]

@@ -1061,6 +1061,13 @@ static void launch_trace8(hipStream_t stream, unsigned tgrid, const Trace8Args& 
     if (ta.xw) hipLaunchKernelGGL((k_trace8<MODE, true>), dim3(tgrid), dim3(64), 0, stream, ta);
     else hipLaunchKernelGGL((k_trace8<MODE, false>), dim3(tgrid), dim3(64), 0, stream, ta);
 }
+static Bvh8Dev bvh_dev(const pt_ctx* ctx) {
+#if PT8_NODE64
+    return Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8, 0.5f * ctx->bvh.pad, ctx->bvh.grid};
+#else
+    return Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8, 0.5f * ctx->bvh.pad};
+#endif
+}
 static void launch_closest(pt_ctx* ctx, hipStream_t stream, const Trace8Args& ta, unsigned tgrid, uint64_t paths) {
     if (ta.queue.base == nullptr && ctx->cam_packets && paths >= ctx->cam_min_paths) {
         const int env_grid = ctx->cam_grid; // (read at pt_create like every other switch, so a context keeps what it was created with)
@@ -1087,7 +1094,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
     const int nq = ctx->nq;
     const float tmin_rad = job ? job->var.radiance_tmin : 0.001f;
     const int cull = job ? job->var.cull_back_occlusion : 0;
-    Bvh8Dev bvh8{ctx->bvh.nodes8, ctx->bvh.tris8, 0.5f * ctx->bvh.pad};
+    const Bvh8Dev bvh8 = bvh_dev(ctx);
     const LeafTri* shade_tris = ctx->bvh.tris8; // the hit records index the leaf triangles of the structure that was traversed
     const size_t CS = (size_t)PT_NSUB * PT_CSTRIDE;
     for (uint32_t s0 = 0; s0 < spp; s0 += S) {
@@ -2094,7 +2101,7 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
     CK(hipEventRecord(e0, ctx->stream));
     for (int it = 0; it < iters; ++it) {
         {
-            Trace8Args ta{st, Bvh8Dev{ctx->bvh.nodes8, ctx->bvh.tris8, 0.5f * ctx->bvh.pad}, QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, 0, dDbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
+            Trace8Args ta{st, bvh_dev(ctx), QView{nullptr, dCount, 0}, QView{}, dWork + it, ctx->ovf, 0, dDbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(ctx), ctx->bvh.num_nodes8};
             if (any_hit) hipLaunchKernelGGL((k_trace8<TR_ANY_QUERY>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
             else hipLaunchKernelGGL((k_trace8<TR_CLOSEST>), dim3(ctx->trace_grid), dim3(64), 0, ctx->stream, ta);
         }
@@ -2137,14 +2144,29 @@ extern "C" int pt_trace(pt_ctx* ctx, const float* rays, uint32_t n, int any_hit,
 
 extern "C" int pt_export_bvh(pt_ctx* ctx, void* nodes, size_t nodes_bytes, void* tris, size_t tris_bytes, uint32_t* num_nodes, uint32_t* num_tris) {
     if (!ctx) return PT_ERR_INVALID;
-    static_assert(sizeof(Node8) == 80 && sizeof(LeafTri) == 48, "exported layout");
+    // the exported layout is the documented 80-byte node whatever the kernels traverse (PT8_NODE64: converted on the device, box for box)
+    static_assert(sizeof(Node80) == 80 && sizeof(LeafTri) == 48, "exported layout");
     if (num_nodes) *num_nodes = ctx->bvh.num_nodes8;
     if (num_tris) *num_tris = ctx->bvh.num_tris8;
     if (!nodes && !tris) return PT_OK;
-    if (!nodes || !tris || nodes_bytes != sizeof(Node8) * (size_t)ctx->bvh.num_nodes8 || tris_bytes != sizeof(LeafTri) * (size_t)ctx->bvh.num_tris8)
+    if (!nodes || !tris || nodes_bytes != sizeof(Node80) * (size_t)ctx->bvh.num_nodes8 || tris_bytes != sizeof(LeafTri) * (size_t)ctx->bvh.num_tris8)
         return fail(ctx, PT_ERR_INVALID, "pt_export_bvh: buffer sizes must be num_nodes * 80 and num_tris * 48 bytes");
     CK(hipSetDevice(ctx->device));
+#if PT8_NODE64
+    {
+        int rc = drain(ctx);
+        if (rc) return rc;
+        Node80* tmp80 = nullptr;
+        CK(hipMalloc((void**)&tmp80, nodes_bytes));
+        hipLaunchKernelGGL(k_nodes_to80, dim3((ctx->bvh.num_nodes8 + 255) / 256), dim3(256), 0, ctx->stream, ctx->bvh.nodes8, ctx->bvh.num_nodes8, ctx->bvh.grid, tmp80);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(nodes, tmp80, nodes_bytes, hipMemcpyDeviceToHost);
+        hipFree(tmp80);
+        CK(e);
+    }
+#else
     CK(hipMemcpy(nodes, ctx->bvh.nodes8, nodes_bytes, hipMemcpyDeviceToHost));
+#endif
     CK(hipMemcpy(tris, ctx->bvh.tris8, tris_bytes, hipMemcpyDeviceToHost));
     return PT_OK;
 }

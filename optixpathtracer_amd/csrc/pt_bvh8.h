@@ -29,10 +29,38 @@
 #else
 #include "pt_kernels.h"
 #endif
+#include "pt_host.h" // Grid8
 
-struct Node8 {
+// The documented 80-byte node (above): what pt_export_bvh hands out whatever the kernels traverse
+struct Node80 {
     float4 n0, n1, n2, n3, n4;
 };
+// One-line node (PT8_NODE64, round 5): the same eight quantised child boxes in 64 bytes, 64-byte aligned — four
+// 16-byte loads from ONE line instead of five from a record that straddles two 128-byte lines four times in eight; the node array
+// shrinks by 20 %.  What pays for it: the grid origin is no longer three floats but three integers on a grid over the scene's (padded)
+// bounds (14 / 13 / 14 bits, rounded DOWN so the box only grows, by less than 1 / 8192 of the scene per axis), the grid steps are powers
+// of two (a 5-bit exponent per axis above the tree's base exponent: up to twice as coarse as the 80-byte node's 8-significant-bit
+// steps), child and triangle bases have 24 bits (16.7 M nodes / leaf triangles), and the triangle counts of the leaf slots are two bit
+// planes (count = b0 + 2 b1) instead of three unary bits per slot.
+//   h.x: child_base | imask << 24
+//   h.y: tri_base | ex << 24 | oy[0:3] << 29
+//   h.z: b0 | b1 << 8 | ey << 16 | ez << 21 | oy[3:9] << 26
+//   h.w: ox | oz << 14 | oy[9:13] << 28
+//   q0, q1, q2: qlo.x[8] qlo.y[8] | qlo.z[8] qhi.x[8] | qhi.y[8] qhi.z[8] — the 80-byte node's n2, n3, n4
+// origin.a = fma(o.a, gstep.a, glo.a), step.a = 2^(ebase + e.a - 127): Bvh8Dev carries glo, gstep, ebase.
+struct Node64 {
+    uint4 h, q0, q1, q2;
+};
+#ifndef PT8_NODE64
+#define PT8_NODE64 0
+#endif
+#if PT8_NODE64
+struct Node8 : Node64 {};
+#else
+struct Node8 : Node80 {};
+#endif
+#define PT8_GRID_BITS_XZ 14
+#define PT8_GRID_BITS_Y 13
 #ifndef PT8_LEAF_MAX
 #define PT8_LEAF_MAX 3
 #endif
@@ -44,7 +72,87 @@ struct Bvh8Dev {
     const Node8* nodes;
     const LeafTri* tris;
     float hit_pad; // half the builder's box padding (pt_bvh.h tri_test_det)
+#if PT8_NODE64
+    Grid8 grid;
+#endif
 };
+
+// What a traversal step needs of a node's first 16 / 32 bytes, in either layout
+struct NodeHdr {
+    float ox, oy, oz, sx, sy, sz;
+    uint32_t imask, child_base, tri_base;
+    uint32_t lbits; // triangle counts of the leaf slots: 80-byte node: bit 3 s + k = slot s holds more than k; one-line node: b0 | b1 << 8
+};
+#if PT8_NODE64
+PT_DEV NodeHdr node_hdr(const uint4 h, const Grid8& b) {
+    NodeHdr n;
+    n.child_base = h.x & 0xffffffu;
+    n.imask = h.x >> 24;
+    n.tri_base = h.y & 0xffffffu;
+    n.lbits = h.z & 0xffffu;
+    n.sx = __uint_as_float((b.ebase + ((h.y >> 24) & 31u)) << 23);
+    n.sy = __uint_as_float((b.ebase + ((h.z >> 16) & 31u)) << 23);
+    n.sz = __uint_as_float((b.ebase + ((h.z >> 21) & 31u)) << 23);
+    const uint32_t oyq = (h.y >> 29) | ((h.z >> 26) << 3) | ((h.w >> 28) << 9);
+    n.ox = __builtin_fmaf((float)(h.w & 0x3fffu), b.gstep[0], b.glo[0]);
+    n.oy = __builtin_fmaf((float)oyq, b.gstep[1], b.glo[1]);
+    n.oz = __builtin_fmaf((float)((h.w >> 14) & 0x3fffu), b.gstep[2], b.glo[2]);
+    return n;
+}
+// pending (slot, k) pairs of the leaf slots in `hm`: bit 8 k + s
+PT_DEV uint32_t leaf_pending(uint32_t hm, uint32_t lbits) {
+    const uint32_t b0 = lbits & 0xffu, b1 = lbits >> 8;
+    return ((b0 | b1) & hm) | ((b1 & hm) << 8) | ((b0 & b1 & hm) << 16);
+}
+PT_DEV uint32_t leaf_first(uint32_t tri_base, uint32_t lbits, uint32_t s) { // index of the first triangle of leaf slot s
+    const uint32_t low = (1u << s) - 1u;
+    return tri_base + (uint32_t)__popc(lbits & low) + 2u * (uint32_t)__popc((lbits >> 8) & low);
+}
+PT_DEV uint32_t leaf_of(uint32_t tri_base, uint32_t lbits, uint32_t bit) { return leaf_first(tri_base, lbits, bit & 7u) + (bit >> 3); }
+PT_DEV uint32_t leaf_count(uint32_t lbits, uint32_t s) { return ((lbits >> s) & 1u) + 2u * ((lbits >> (8u + s)) & 1u); }
+#else
+PT_DEV NodeHdr node_hdr(const float4 n0, const float4 n1) {
+    NodeHdr n;
+    const uint32_t e01 = __float_as_uint(n0.w), e2m = __float_as_uint(n1.w);
+    n.ox = n0.x; n.oy = n0.y; n.oz = n0.z;
+    n.sx = __uint_as_float(e01 << 16); n.sy = __uint_as_float(e01 & 0xffff0000u); n.sz = __uint_as_float(e2m << 16);
+    n.imask = e2m >> 16;
+    n.child_base = __float_as_uint(n1.x);
+    n.tri_base = __float_as_uint(n1.y);
+    n.lbits = __float_as_uint(n1.z);
+    return n;
+}
+// pending (slot, k) pairs of the leaf slots in `hm`: bit 3 s + k
+PT_DEV uint32_t leaf_pending(uint32_t hm, uint32_t lbits) {
+    uint32_t sp3 = (hm | (hm << 8)) & 0x00F00Fu; // every hit bit s -> bits 3s..3s+2, masked by the node's leafbits
+    sp3 = (sp3 | (sp3 << 4)) & 0x0C30C3u;
+    sp3 = (sp3 | (sp3 << 2)) & 0x249249u;
+    return (sp3 * 7u) & lbits;
+}
+PT_DEV uint32_t leaf_of(uint32_t tri_base, uint32_t lbits, uint32_t bit) { return tri_base + (uint32_t)__popc(lbits & ((1u << bit) - 1u)); }
+PT_DEV uint32_t leaf_first(uint32_t tri_base, uint32_t lbits, uint32_t s) { return leaf_of(tri_base, lbits, 3u * s); }
+PT_DEV uint32_t leaf_count(uint32_t lbits, uint32_t s) { return (uint32_t)__popc((lbits >> (3u * s)) & 7u); }
+#endif
+
+#if PT8_NODE64
+// pt_export_bvh / PT_DEBUG_BVH: one-line nodes as the documented 80-byte records — the same origin and (power-of-two) steps as floats,
+// the same planes, the leaf counts as three unary bits per slot: the tree the kernels traverse, box for box
+static __global__ void k_nodes_to80(const Node64* __restrict__ in, uint32_t n, Grid8 b, Node80* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Node64 nd = in[i];
+    const NodeHdr h = node_hdr(nd.h, b);
+    uint32_t leafbits = 0u;
+    for (uint32_t s = 0; s < 8u; ++s) leafbits |= ((1u << leaf_count(h.lbits, s)) - 1u) << (3u * s);
+    Node80 o;
+    o.n0 = make_float4(h.ox, h.oy, h.oz, __uint_as_float((__float_as_uint(h.sx) >> 16) | (__float_as_uint(h.sy) & 0xffff0000u)));
+    o.n1 = make_float4(__uint_as_float(h.child_base), __uint_as_float(h.tri_base), __uint_as_float(leafbits), __uint_as_float((__float_as_uint(h.sz) >> 16) | (h.imask << 16)));
+    o.n2 = make_float4(__uint_as_float(nd.q0.x), __uint_as_float(nd.q0.y), __uint_as_float(nd.q0.z), __uint_as_float(nd.q0.w));
+    o.n3 = make_float4(__uint_as_float(nd.q1.x), __uint_as_float(nd.q1.y), __uint_as_float(nd.q1.z), __uint_as_float(nd.q1.w));
+    o.n4 = make_float4(__uint_as_float(nd.q2.x), __uint_as_float(nd.q2.y), __uint_as_float(nd.q2.z), __uint_as_float(nd.q2.w));
+    out[i] = o;
+}
+#endif
 
 #ifndef PT_BVH8_NODE_ONLY
 #ifndef PT8_LDS_DEPTH
@@ -225,14 +333,6 @@ k_trace8(Trace8Args a) {
     __shared__ uint32_t s_stack[PT8_LDS_DEPTH * 2 * 64];
     __shared__ uint32_t s_prefix[PT_NSUB + 1];
     __shared__ uint32_t s_prefix2[PT_NSUB + 1];
-#ifdef PT8_TOP_NODES
-    // experiment (north_star: "BVH nodes staged in LDS"): the first PT8_TOP_NODES nodes of the breadth-first node array — the root and
-    // its children (9), or two levels (73) — are copied to LDS by every workgroup and read from there
-    __shared__ Node8 s_top[PT8_TOP_NODES];
-    for (uint32_t k = threadIdx.x; k < (uint32_t)PT8_TOP_NODES * 5u; k += 64u)
-        if (k / 5u < a.num_nodes) reinterpret_cast<float4*>(s_top)[k] = reinterpret_cast<const float4*>(a.bvh.nodes)[k];
-    __syncthreads();
-#endif
 #if PT8_STEAL
     __shared__ unsigned long long s_key[64]; // per owner lane: merged result of the ray that lane loaded
     __shared__ uint32_t s_cnt[64];           // per owner lane: co-workers still traversing that ray
@@ -842,12 +942,13 @@ k_trace8(Trace8Args a) {
                     const uint32_t idx = g_base + (uint32_t)__popc(g_imask & (h - 1u));
                     if (g_hits != 0u) push(g_base, g_imask | (g_hits << 8));
                     PT_STAT(++c_nodes; ++c_ray;)
-#ifdef PT8_TOP_NODES
-                    const Node8* nd = idx < (uint32_t)PT8_TOP_NODES ? &s_top[idx] : &a.bvh.nodes[idx];
+#if PT8_NODE64
+                    const float4* nd = reinterpret_cast<const float4*>(&a.bvh.nodes[idx]); // one 64-byte line: header, then the planes
+                    r0 = nd[0]; r2 = nd[1]; r3 = nd[2]; r4 = nd[3];
 #else
                     const Node8* nd = &a.bvh.nodes[idx];
-#endif
                     r0 = nd->n0; r1 = nd->n1; r2 = nd->n2; r3 = nd->n3; r4 = nd->n4;
+#endif
                     do_node = true;
                 }
             }
@@ -856,19 +957,22 @@ k_trace8(Trace8Args a) {
                 const uint32_t bit = (uint32_t)__ffs((int)t_mask) - 1u;
                 t_mask &= t_mask - 1u;
                 PT_STAT(++c_tris; ++c_ray;)
-                const uint32_t leaf = t_base + (uint32_t)__popc(t_bits & ((1u << bit) - 1u));
+                const uint32_t leaf = leaf_of(t_base, t_bits, bit);
                 const LeafTri* tp = &a.bvh.tris[leaf];
                 r0 = tp->t0; r1 = tp->t1; r2 = tp->t2;
                 r3.x = __uint_as_float(leaf); // rides to phase 2 in a register the node lanes keep live anyway
             }
             // ---- phase 2: the arithmetic
             if (do_node) {
-                const float4 n0 = r0, n1 = r1, n2 = r2, n3 = r3, n4 = r4;
-                const uint32_t e01 = __float_as_uint(n0.w), e2m = __float_as_uint(n1.w);
-                const float sx = __uint_as_float(e01 << 16), sy = __uint_as_float(e01 & 0xffff0000u), sz = __uint_as_float(e2m << 16);
-                const uint32_t imask = e2m >> 16;
-                const float ax = sx * r.idir.x, ay = sy * r.idir.y, az = sz * r.idir.z;
-                const float bx = (n0.x - r.o.x) * r.idir.x, by = (n0.y - r.o.y) * r.idir.y, bz = (n0.z - r.o.z) * r.idir.z;
+                const float4 n2 = r2, n3 = r3, n4 = r4;
+#if PT8_NODE64
+                const NodeHdr nh = node_hdr(make_uint4(__float_as_uint(r0.x), __float_as_uint(r0.y), __float_as_uint(r0.z), __float_as_uint(r0.w)), a.bvh.grid);
+#else
+                const NodeHdr nh = node_hdr(r0, r1);
+#endif
+                const uint32_t imask = nh.imask;
+                const float ax = nh.sx * r.idir.x, ay = nh.sy * r.idir.y, az = nh.sz * r.idir.z;
+                const float bx = (nh.ox - r.o.x) * r.idir.x, by = (nh.oy - r.o.y) * r.idir.y, bz = (nh.oz - r.o.z) * r.idir.z;
                 // near/far planes per axis follow the direction sign
                 const bool nx = r.idir.x < 0.0f, ny = r.idir.y < 0.0f, nz = r.idir.z < 0.0f;
                 const uint32_t lox0 = __float_as_uint(n2.x), lox1 = __float_as_uint(n2.y), loy0 = __float_as_uint(n2.z), loy1 = __float_as_uint(n2.w);
@@ -895,18 +999,13 @@ k_trace8(Trace8Args a) {
                 }
                 const uint32_t hm = miss ^ 0xffu; // hit mask in slot positions
                 const uint32_t hits = hm & imask;
-                // triangles of the leaf children that were hit: every hit bit s → bits 3s..3s+2, masked by the node's leafbits
-                const uint32_t leafbits = __float_as_uint(n1.z);
-                uint32_t sp3 = (hm | (hm << 8)) & 0x00F00Fu;
-                sp3 = (sp3 | (sp3 << 4)) & 0x0C30C3u;
-                sp3 = (sp3 | (sp3 << 2)) & 0x249249u;
-                const uint32_t tm = (sp3 * 7u) & leafbits;
-                g_base = __float_as_uint(n1.x);
+                // triangles of the leaf children that were hit
+                g_base = nh.child_base;
                 g_imask = imask;
                 g_hits = hits;
-                t_base = __float_as_uint(n1.y);
-                t_bits = leafbits;
-                t_mask = tm;
+                t_base = nh.tri_base;
+                t_bits = nh.lbits;
+                t_mask = leaf_pending(hm, nh.lbits);
             }
             if (do_tri) {
                 const float4 ta = r0, tb = r1, tc = r2;
@@ -1009,6 +1108,7 @@ k_trace8(Trace8Args a) {
 #if __HIP_DEVICE_COMPILE__
 typedef const __attribute__((address_space(4))) Node8* ConstNode8;     // constant address space: s_load
 typedef const __attribute__((address_space(4))) LeafTri* ConstLeafTri;
+typedef const __attribute__((address_space(4))) float4* ConstF4;
 #endif
 __global__ void __launch_bounds__(64) k_trace8_cam(Trace8Args a) {
 #if __HIP_DEVICE_COMPILE__
@@ -1023,7 +1123,9 @@ __global__ void __launch_bounds__(64) k_trace8_cam(Trace8Args a) {
     uint32_t per = npk / (gridDim.x * 4u);
     per = per < 4u ? 4u : (per > 16u ? 16u : per);
     uint32_t pk = blockIdx.x * per, pk_end = pk + per;
+#if !PT8_NODE64
     const ConstNode8 nodes = (ConstNode8)(uintptr_t)a.bvh.nodes;
+#endif
     const ConstLeafTri tris = (ConstLeafTri)(uintptr_t)a.bvh.tris;
     for (;;) {
         if (pk == pk_end) {
@@ -1084,12 +1186,17 @@ __global__ void __launch_bounds__(64) k_trace8_cam(Trace8Args a) {
                 else atomicOr(a.fault, 1u);
                 sp = sp < PT8_CAM_STACK ? sp + 1 : sp;
             }
+#if PT8_NODE64
+            const ConstF4 np = (ConstF4)(uintptr_t)(a.bvh.nodes + idx);
+            const float4 hq = np[0], n2 = np[1], n3 = np[2], n4 = np[3];
+            const NodeHdr nh = node_hdr(make_uint4(__float_as_uint(hq.x), __float_as_uint(hq.y), __float_as_uint(hq.z), __float_as_uint(hq.w)), a.bvh.grid);
+#else
             const float4 n0 = nodes[idx].n0, n1 = nodes[idx].n1, n2 = nodes[idx].n2, n3 = nodes[idx].n3, n4 = nodes[idx].n4;
-            const uint32_t e01 = __float_as_uint(n0.w), e2m = __float_as_uint(n1.w);
-            const float sx = __uint_as_float(e01 << 16), sy = __uint_as_float(e01 & 0xffff0000u), sz = __uint_as_float(e2m << 16);
-            const uint32_t imask = e2m >> 16;
-            const float ax = sx * r.idir.x, ay = sy * r.idir.y, az = sz * r.idir.z;
-            const float bx = (n0.x - r.o.x) * r.idir.x, by = (n0.y - r.o.y) * r.idir.y, bz = (n0.z - r.o.z) * r.idir.z;
+            const NodeHdr nh = node_hdr(n0, n1);
+#endif
+            const uint32_t imask = nh.imask;
+            const float ax = nh.sx * r.idir.x, ay = nh.sy * r.idir.y, az = nh.sz * r.idir.z;
+            const float bx = (nh.ox - r.o.x) * r.idir.x, by = (nh.oy - r.o.y) * r.idir.y, bz = (nh.oz - r.o.z) * r.idir.z;
             const uint32_t lox0 = __float_as_uint(n2.x), lox1 = __float_as_uint(n2.y), loy0 = __float_as_uint(n2.z), loy1 = __float_as_uint(n2.w);
             const uint32_t loz0 = __float_as_uint(n3.x), loz1 = __float_as_uint(n3.y), hix0 = __float_as_uint(n3.z), hix1 = __float_as_uint(n3.w);
             const uint32_t hiy0 = __float_as_uint(n4.x), hiy1 = __float_as_uint(n4.y), hiz0 = __float_as_uint(n4.z), hiz1 = __float_as_uint(n4.w);
@@ -1113,16 +1220,14 @@ __global__ void __launch_bounds__(64) k_trace8_cam(Trace8Args a) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) whm |= __ballot((hm >> s) & 1u) != 0ull ? (1u << s) : 0u;
             // the node's leaf triangles first (they shrink the lanes' intervals before the packet descends) ...
-            const uint32_t leafbits = __float_as_uint(n1.z), tri_base = __float_as_uint(n1.y);
             uint32_t lm = whm & ~imask;
             while (lm != 0u) {
                 const uint32_t s = (uint32_t)__ffs((int)lm) - 1u;
                 lm &= lm - 1u;
                 const bool mine = (hm >> s) & 1u;
-                for (uint32_t k = 0; k < 3u; ++k) {
-                    const uint32_t bit = 3u * s + k;
-                    if (!(leafbits & (1u << bit))) break;
-                    const uint32_t leaf = tri_base + (uint32_t)__popc(leafbits & ((1u << bit) - 1u));
+                const uint32_t cnt = leaf_count(nh.lbits, s), first_leaf = leaf_first(nh.tri_base, nh.lbits, s);
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const uint32_t leaf = first_leaf + k;
                     const float4 ta = tris[leaf].t0, tb = tris[leaf].t1, tc = tris[leaf].t2;
                     PT_STAT(++c_tris; c_mine += (uint32_t)__popcll(__ballot(mine));)
                     if (mine) {
@@ -1140,7 +1245,7 @@ __global__ void __launch_bounds__(64) k_trace8_cam(Trace8Args a) {
                 }
             }
             // ... then its internal children
-            g_base = __float_as_uint(n1.x);
+            g_base = nh.child_base;
             g_imask = imask;
             g_hits = whm & imask;
         }

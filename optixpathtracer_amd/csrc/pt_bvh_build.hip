@@ -368,7 +368,7 @@ __global__ void k_collapse_cost_level(const int* __restrict__ order, int count, 
 __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* __restrict__ tout, uint32_t* __restrict__ counters /*0 next tasks,1 nodes,2 tris*/,
                             int n, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ cnt_of,
                             const float* __restrict__ box, float pad, const uint8_t* __restrict__ dec /* null: greedy by area */,
-                            const LeafTri* __restrict__ tris_sorted, Node8* __restrict__ nodes, LeafTri* __restrict__ tris_out) {
+                            const LeafTri* __restrict__ tris_sorted, Node8* __restrict__ nodes, LeafTri* __restrict__ tris_out, Grid8 grid) {
     const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
     if (ti >= nin) return;
     const Task8 task = tin[ti];
@@ -465,6 +465,28 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
     const uint32_t child_base = nint ? atomicAdd(&counters[1], nint) : 0u;
     const uint32_t tri_base = ntri ? atomicAdd(&counters[2], ntri) : 0u;
     const uint32_t task_base = nint ? atomicAdd(&counters[0], nint) : 0u;
+#if PT8_NODE64
+    // one-line node: the origin on the scene grid, rounded down (never above the node's padded lower corner), and the smallest power-of-two
+    // step whose 255 multiples reach the upper corner from there; both exactly as the traversal kernels decode them (node_hdr)
+    uint32_t oq[3], e5[3];
+    float step[3];
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t cells = 1u << (a == 1 ? PT8_GRID_BITS_Y : PT8_GRID_BITS_XZ);
+        float fq = floorf((lo[a] - grid.glo[a]) / grid.gstep[a]);
+        fq = fminf(fmaxf(fq, 0.f), (float)(cells - 1u));
+        uint32_t q0 = (uint32_t)fq;
+        while (q0 > 0u && __builtin_fmaf((float)q0, grid.gstep[a], grid.glo[a]) > lo[a]) --q0;
+        oq[a] = q0;
+        lo[a] = __builtin_fmaf((float)q0, grid.gstep[a], grid.glo[a]); // the grid's origin from here on
+        uint32_t e = 0u;
+        for (; e < 31u; ++e) {
+            const float st = __uint_as_float((grid.ebase + e) << 23);
+            if (lo[a] + 255.0f * st >= hi[a]) break;
+        }
+        e5[a] = e;
+        step[a] = __uint_as_float((grid.ebase + e) << 23);
+    }
+#else
     // grid step per axis: ext/255 rounded UP to a float with an 8-bit significand (the 16 bits the node stores), so the
     // 255 steps cover the extent with < 1 % slack (a power-of-two step wasted up to 2x of the 8-bit resolution)
     uint32_t eb[3]; // upper 16 bits of the step
@@ -477,6 +499,7 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
         eb[a] = (__float_as_uint(st) + 0xffffu) >> 16;
         step[a] = __uint_as_float(eb[a] << 16);
     }
+#endif
     uint32_t q[6][2] = {{0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
     uint32_t leafbits = 0u;
     uint32_t toff = 0, irank = 0;
@@ -509,11 +532,25 @@ __global__ void k_collapse8(const Task8* __restrict__ tin, uint32_t nin, Task8* 
         }
     }
     Node8 nd;
+#if PT8_NODE64
+    uint32_t b0 = 0u, b1 = 0u; // count planes of the leaf slots
+    for (int s = 0; s < 8; ++s) {
+        const uint32_t c = (uint32_t)__popc((leafbits >> (3 * s)) & 7u);
+        b0 |= (c & 1u) << s;
+        b1 |= (c >> 1) << s;
+    }
+    nd.h = make_uint4(child_base | (imask << 24), tri_base | (e5[0] << 24) | ((oq[1] & 7u) << 29),
+                      b0 | (b1 << 8) | (e5[1] << 16) | (e5[2] << 21) | (((oq[1] >> 3) & 63u) << 26), oq[0] | (oq[2] << 14) | ((oq[1] >> 9) << 28));
+    nd.q0 = make_uint4(q[0][0], q[0][1], q[1][0], q[1][1]);
+    nd.q1 = make_uint4(q[2][0], q[2][1], q[3][0], q[3][1]);
+    nd.q2 = make_uint4(q[4][0], q[4][1], q[5][0], q[5][1]);
+#else
     nd.n0 = make_float4(lo[0], lo[1], lo[2], __uint_as_float(eb[0] | (eb[1] << 16)));
     nd.n1 = make_float4(__uint_as_float(child_base), __uint_as_float(tri_base), __uint_as_float(leafbits), __uint_as_float(eb[2] | (imask << 16)));
     nd.n2 = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
     nd.n3 = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
     nd.n4 = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
+#endif
     nodes[task.widx] = nd;
 }
 
@@ -693,9 +730,27 @@ __global__ void __launch_bounds__(1024) k_ploc_tail(const int* __restrict__ cl_i
 }
 
 // scenes with <= PT8_LEAF_MAX triangles: one node, one leaf child
-__global__ void k_single_node8(int n, const float* __restrict__ bounds6, float pad, Node8* __restrict__ nodes) {
+__global__ void k_single_node8(int n, const float* __restrict__ bounds6, float pad, Node8* __restrict__ nodes, Grid8 grid) {
     if (threadIdx.x || blockIdx.x) return;
     float lo[3], hi[3];
+#if PT8_NODE64
+    uint32_t e5[3];
+    for (int a = 0; a < 3; ++a) { // origin = the grid's own origin (cell 0), slot 0 = the whole 255-step range
+        hi[a] = bounds6[3 + a] + pad;
+        uint32_t e = 0u;
+        for (; e < 31u; ++e)
+            if (grid.glo[a] + 255.0f * __uint_as_float((grid.ebase + e) << 23) >= hi[a]) break;
+        e5[a] = e;
+    }
+    const uint32_t c = (uint32_t)n; // 1..3 triangles in slot 0
+    Node8 nd;
+    nd.h = make_uint4(0u, e5[0] << 24, (c & 1u) | ((c >> 1) << 8) | (e5[1] << 16) | (e5[2] << 21), 0u);
+    nd.q0 = make_uint4(0xffffff00u, 0xffffffffu, 0xffffff00u, 0xffffffffu);
+    nd.q1 = make_uint4(0xffffff00u, 0xffffffffu, 0x000000ffu, 0u);
+    nd.q2 = make_uint4(0x000000ffu, 0u, 0x000000ffu, 0u);
+    nodes[0] = nd;
+    (void)lo;
+#else
     uint32_t eb[3];
     for (int a = 0; a < 3; ++a) {
         lo[a] = bounds6[a] - pad;
@@ -714,6 +769,7 @@ __global__ void k_single_node8(int n, const float* __restrict__ bounds6, float p
     nd.n3 = make_float4(__uint_as_float(qlo), __uint_as_float(0xffffffffu), __uint_as_float(qhi), __uint_as_float(0u));
     nd.n4 = make_float4(__uint_as_float(qhi), __uint_as_float(0u), __uint_as_float(qhi), __uint_as_float(0u));
     nodes[0] = nd;
+#endif
 }
 
 // ---- choosing between two hierarchies by measurement (pt_bvh_build, PT_BVH_BUILDER unset).  The SAH cost of the collapsed tree
@@ -727,7 +783,7 @@ __global__ void k_single_node8(int n, const float* __restrict__ bounds6, float p
 // lane and 1024 waves leave the chip latency-bound, so two launches cost twice one.
 __global__ void __launch_bounds__(64) k_calibrate8(const Node8* __restrict__ nodes_a, const LeafTri* __restrict__ tris_a, const Node8* __restrict__ nodes_b,
                                                    const LeafTri* __restrict__ tris_b, const LeafTri* __restrict__ src,
-                                                   uint32_t ntri, uint32_t nrays, float hp, unsigned long long* __restrict__ counts) {
+                                                   uint32_t ntri, uint32_t nrays, float hp, unsigned long long* __restrict__ counts, Grid8 grid) {
     const uint32_t half = (nrays + 63u) / 64u;
     const bool second = blockIdx.x >= half;
     const Node8* __restrict__ nodes = second ? nodes_b : nodes_a;
@@ -760,27 +816,31 @@ __global__ void __launch_bounds__(64) k_calibrate8(const Node8* __restrict__ nod
         while (sp) {
             const Node8 nd = nodes[stack[--sp]];
             ++nsteps;
-            const uint32_t e01 = __float_as_uint(nd.n0.w), e2m = __float_as_uint(nd.n1.w);
-            const float sx = __uint_as_float(e01 << 16), sy = __uint_as_float(e01 & 0xffff0000u), sz = __uint_as_float(e2m << 16);
-            const uint32_t imask = e2m >> 16, leafbits = __float_as_uint(nd.n1.z);
+#if PT8_NODE64
+            const NodeHdr nh = node_hdr(nd.h, grid);
+            const uint32_t q[12] = {nd.q0.x, nd.q0.y, nd.q0.z, nd.q0.w, nd.q1.x, nd.q1.y, nd.q1.z, nd.q1.w, nd.q2.x, nd.q2.y, nd.q2.z, nd.q2.w};
+#else
+            const NodeHdr nh = node_hdr(nd.n0, nd.n1);
             const uint32_t q[12] = {__float_as_uint(nd.n2.x), __float_as_uint(nd.n2.y), __float_as_uint(nd.n2.z), __float_as_uint(nd.n2.w),
                                     __float_as_uint(nd.n3.x), __float_as_uint(nd.n3.y), __float_as_uint(nd.n3.z), __float_as_uint(nd.n3.w),
                                     __float_as_uint(nd.n4.x), __float_as_uint(nd.n4.y), __float_as_uint(nd.n4.z), __float_as_uint(nd.n4.w)};
+#endif
+            const float sx = nh.sx, sy = nh.sy, sz = nh.sz;
+            const uint32_t imask = nh.imask;
             uint32_t hits = 0;
             for (int sl = 0; sl < 8; ++sl) {
                 const int w = sl >> 2, k = sl & 3;
-                const float lx = nd.n0.x + u8f(q[0 + w], k) * sx, ly = nd.n0.y + u8f(q[2 + w], k) * sy, lz = nd.n0.z + u8f(q[4 + w], k) * sz;
-                const float hx = nd.n0.x + u8f(q[6 + w], k) * sx, hy = nd.n0.y + u8f(q[8 + w], k) * sy, hz = nd.n0.z + u8f(q[10 + w], k) * sz;
+                const float lx = nh.ox + u8f(q[0 + w], k) * sx, ly = nh.oy + u8f(q[2 + w], k) * sy, lz = nh.oz + u8f(q[4 + w], k) * sz;
+                const float hx = nh.ox + u8f(q[6 + w], k) * sx, hy = nh.oy + u8f(q[8 + w], k) * sy, hz = nh.oz + u8f(q[10 + w], k) * sz;
                 float tn;
                 if (lx <= hx && box_test(lx, ly, lz, hx, hy, hz, r, tmin, best, tn)) hits |= 1u << sl;
             }
             // the leaf triangles of this node first ...
             for (int sl = 0; sl < 8; ++sl) {
                 if (!(hits & (1u << sl)) || (imask & (1u << sl))) continue;
-                for (int k = 0; k < 3; ++k) {
-                    const int bit = 3 * sl + k;
-                    if (!(leafbits & (1u << bit))) break;
-                    const LeafTri t = tris[__float_as_uint(nd.n1.y) + (uint32_t)__popc(leafbits & ((1u << bit) - 1u))];
+                const uint32_t cnt = leaf_count(nh.lbits, (uint32_t)sl), first_leaf = leaf_first(nh.tri_base, nh.lbits, (uint32_t)sl);
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const LeafTri t = tris[first_leaf + k];
                     ++ntests;
                     float tt, det;
                     const v3 v0 = mk3(t.t0.x, t.t0.y, t.t0.z), v1 = mk3(t.t0.w, t.t1.x, t.t1.y), v2 = mk3(t.t1.z, t.t1.w, t.t2.x);
@@ -790,7 +850,7 @@ __global__ void __launch_bounds__(64) k_calibrate8(const Node8* __restrict__ nod
             // ... then its internal children, the one the ray enters first on top of the stack
             for (int k = 7; k >= 0; --k) {
                 const uint32_t sl = (uint32_t)k ^ oct;
-                if ((hits & imask & (1u << sl)) && sp < 192) stack[sp++] = __float_as_uint(nd.n1.x) + (uint32_t)__popc(imask & ((1u << sl) - 1u));
+                if ((hits & imask & (1u << sl)) && sp < 192) stack[sp++] = nh.child_base + (uint32_t)__popc(imask & ((1u << sl) - 1u));
             }
         }
     }
@@ -961,7 +1021,7 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
     int levels = 0;
     while (nin) {
         hipLaunchKernelGGL(k_collapse8, dim3((nin + 63) / 64), dim3(64), 0, stream, ta, nin, tb, counters, n, left, right, cnt, box, pad, dec,
-                           tris_sorted, nodes, tris8);
+                           tris_sorted, nodes, tris8, out->grid);
         HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         nin = hc[0];
@@ -973,11 +1033,22 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
     HIPCHK(hipGetLastError());
     if (getenv("PT_DEBUG_BVH")) { // slot occupancy of the wide tree
         auto fbits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
-        std::vector<Node8> h(hc[1]);
+        std::vector<Node80> h(hc[1]);
         HIPCHK(hipStreamSynchronize(stream)); // the library's streams do not synchronise with the null stream
+#if PT8_NODE64
+        {
+            Node80* tmp80 = nullptr;
+            HIPCHK(hipMalloc(&tmp80, sizeof(Node80) * h.size()));
+            hipLaunchKernelGGL(k_nodes_to80, dim3((hc[1] + 255) / 256), dim3(256), 0, stream, nodes, hc[1], out->grid, tmp80);
+            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(hipMemcpy(h.data(), tmp80, sizeof(Node80) * h.size(), hipMemcpyDeviceToHost));
+            hipFree(tmp80);
+        }
+#else
         HIPCHK(hipMemcpy(h.data(), nodes, sizeof(Node8) * h.size(), hipMemcpyDeviceToHost));
+#endif
         unsigned long long fill[9] = {0}, leafsz[9] = {0}, nint = 0, nleaf = 0;
-        for (const Node8& nd : h) {
+        for (const Node80& nd : h) {
             const uint32_t imask = fbits(nd.n1.w) >> 16;
             const uint32_t qlo[2] = {fbits(nd.n2.x), fbits(nd.n2.y)}, qhi[2] = {fbits(nd.n3.z), fbits(nd.n3.w)};
             const uint32_t leafbits = fbits(nd.n1.z);
@@ -1138,6 +1209,7 @@ struct PhaseClock {
 };
 
 hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint32_t* d_tri_mesh, uint32_t ntri, hipStream_t stream, PtBvh* out) {
+    if (PT8_NODE64 && ntri > (1u << 24)) return hipErrorInvalidValue; // one-line nodes address 2^24 nodes and leaf triangles
     const int n = (int)ntri;
     const int B = 256;
     PhaseClock pc(stream);
@@ -1175,6 +1247,26 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
     }
     const float pad = maxabs * (1.0f / 65536.0f);
     out->pad = pad;
+#if PT8_NODE64
+    {
+        // the one-line nodes' origin grid: over the scene's bounds widened by twice the padding (every node box lies inside), 2^14 / 2^13 / 2^14
+        // cells; base exponent: 255 steps of 2^(ebase + 31 - 127) span twice the largest extent, so the root always finds its step
+        float maxext = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            const float glo = out->bounds[a] - 2.0f * pad, ghi = out->bounds[3 + a] + 2.0f * pad;
+            const float cells = (float)(1u << (a == 1 ? PT8_GRID_BITS_Y : PT8_GRID_BITS_XZ));
+            float gs = (ghi - glo) / cells * (1.0f + 1.0f / 262144.0f);
+            if (!(gs > 1e-37f)) gs = 1e-37f;
+            out->grid.glo[a] = glo;
+            out->grid.gstep[a] = gs;
+            maxext = fmaxf(maxext, ghi - glo);
+        }
+        int e = 0;
+        if (maxext > 0.f) frexpf(2.0f * maxext / 255.0f, &e); // 2^(e-1) <= x < 2^e
+        int eb = e + 127 - 31;
+        out->grid.ebase = (uint32_t)std::max(1, std::min(223, eb));
+    }
+#endif
     pc.mark("bounds, morton, sort");
 
     LeafTri* tris = nullptr;
@@ -1190,7 +1282,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
         HIPCHK(tmalloc(&dbounds, sizeof(float) * 6));
         HIPCHK(hipMemcpyAsync(dbounds, out->bounds, sizeof(float) * 6, hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(tris8, tris, sizeof(LeafTri) * (size_t)n, hipMemcpyDeviceToDevice, stream));
-        hipLaunchKernelGGL(k_single_node8, dim3(1), dim3(64), 0, stream, n, dbounds, pad, nodes8);
+        hipLaunchKernelGGL(k_single_node8, dim3(1), dim3(64), 0, stream, n, dbounds, pad, nodes8, out->grid);
         out->nodes8 = nodes8; out->tris8 = tris8; out->num_nodes8 = 1; out->num_tris8 = (uint32_t)n; out->levels8 = 1;
         HIPCHK(hipStreamSynchronize(stream));
         tfree(dbounds);
@@ -1245,6 +1337,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
         if (!force_lbvh && !force_ploc && n >= 4096) {
             // both hierarchies, the one that costs the calibration rays less (see k_calibrate8); small scenes keep the LBVH
             PtBvh alt;
+            alt.grid = out->grid; // same scene, same origin grid
             hipError_t pe = build_ploc(n, left, right, box, cnt, stream, &root); // overwrites the LBVH's internal nodes: the first wide tree is already emitted
             pc.mark("ploc hierarchy");
             if (pe == hipSuccess) pe = build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, &alt);
@@ -1260,7 +1353,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
             HIPCHK(tmalloc(&counts, sizeof(hcnt)));
             HIPCHK(hipMemsetAsync(counts, 0, sizeof(hcnt), stream));
             const uint32_t nrays = 1u << 16;
-            hipLaunchKernelGGL(k_calibrate8, dim3(2 * (nrays / 64)), dim3(64), 0, stream, out->nodes8, out->tris8, alt.nodes8, alt.tris8, tris, (uint32_t)n, nrays, 0.5f * pad, counts);
+            hipLaunchKernelGGL(k_calibrate8, dim3(2 * (nrays / 64)), dim3(64), 0, stream, out->nodes8, out->tris8, alt.nodes8, alt.tris8, tris, (uint32_t)n, nrays, 0.5f * pad, counts, out->grid);
             HIPCHK(hipMemcpyAsync(hcnt, counts, sizeof(hcnt), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
             tfree(counts);

@@ -9,6 +9,10 @@
 
 struct Node8;
 struct LeafTri;
+struct Grid8 { // origin grid and base exponent of a tree of one-line nodes (pt_bvh8.h PT8_NODE64; zero for 80-byte nodes)
+    float glo[3], gstep[3];
+    uint32_t ebase; // biased float exponent of the tree's smallest grid step
+};
 
 // the traversal structure on the device: the 8-wide compressed tree (pt_bvh8.h) and what the kernels need to know about it
 struct PtBvh {
@@ -18,6 +22,7 @@ struct PtBvh {
     const LeafTri* tris8 = nullptr;
     uint32_t num_nodes8 = 0, num_tris8 = 0;
     int levels8 = 0; // levels of the wide tree = upper bound of its traversal stack depth (one pushed group per level)
+    Grid8 grid{}; // PT8_NODE64: what the one-line nodes' origins and steps are measured in (pt_bvh8.h)
     int builder = 0; // hierarchy under the wide tree: 0 LBVH (Morton order, Karras 2012), 1 PLOC (Meister & Bittner 2018) — chosen by calibration rays unless PT_BVH_BUILDER=lbvh|ploc
 };
 

@@ -44,7 +44,7 @@ import re
 
 import numpy as np
 
-from .scenes import Material, Model, Texture, TriangleMesh
+from .scenes import MATERIAL_DTYPE, Material, Model, Texture, TriangleMesh
 
 _F = np.float32
 _POW_LUT = (1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001)
@@ -597,10 +597,73 @@ def load_texture(model: Model, known: dict, name: str, model_dir: str) -> int:
     return tid
 
 
-def load_obj(obj_file: str, per_mesh_vertex_map: bool = False) -> Model:
-    """loadOBJ (Model.cpp:137-212).  `per_mesh_vertex_map` undoes the shared knownVertices map (module docstring)."""
+def _decode_texture(fn: str):
+    """what loadTexture (Model.cpp:88-135) keeps of an image file: RGBA8 texels, rows mirrored in y; None when the file cannot be read."""
+    try:
+        from PIL import Image
+
+        with Image.open(fn) as im:
+            img = np.asarray(im.convert("RGBA"), np.uint32)  # top row first, like stbi_load(..., STBI_rgb_alpha)
+        px = img[..., 0] | (img[..., 1] << 8) | (img[..., 2] << 16) | (img[..., 3] << 24)
+        return np.ascontiguousarray(px[::-1], np.uint32)
+    except Exception:
+        print(f"Could not load texture from {fn}!")
+        return None
+
+
+def _load_obj_native(obj_file: str, per_mesh_vertex_map: bool) -> Model:
+    """pt_load_obj (include/pt_amd.h, csrc/pt_objload.cpp): the same arrays from native code — 150 MB of OBJ in seconds instead of a minute."""
+    import ctypes as C
+
+    from . import _lib
+
+    L = _lib.load_library()
+    h = C.c_void_p()
+    # (the path goes through as bytes; latin-1 keeps every byte of an odd file name)
+    if L.pt_load_obj(os.fsencode(obj_file), 1 if per_mesh_vertex_map else 0, C.byref(h)) != 0:
+        msg = L.pt_obj_last_error().decode("latin-1")
+        raise (ValueError if "out of range" in msg else RuntimeError)(msg)
+    try:
+        model = Model()
+        final_id = {}
+        for k in range(L.pt_obj_num_textures(h)):  # loadTexture's order; unreadable files get -1 and no number
+            px = _decode_texture(L.pt_obj_texture_path(h, k).decode("latin-1"))
+            if px is None:
+                final_id[k] = -1
+            else:
+                final_id[k] = len(model.textures)
+                model.textures.append(Texture(px))
+        for i in range(L.pt_obj_num_meshes(h)):
+            m = _lib.ObjMesh()
+            if L.pt_obj_get_mesh(h, i, C.byref(m)) != 0:
+                raise RuntimeError("pt_obj_get_mesh failed")
+            nv, nt = m.num_vertices, m.num_triangles
+            mat = np.frombuffer(bytes(m.material), MATERIAL_DTYPE)[0].copy()  # pt_material == Material, field for field (scenes.MATERIAL_DTYPE)
+            mesh = TriangleMesh(np.ctypeslib.as_array(m.vertex, (nv, 3)).copy(), np.ctypeslib.as_array(m.index, (nt, 3)).copy(), mat)
+            mesh.normal = np.ctypeslib.as_array(m.normal, (nv, 3)).copy() if m.normal else None
+            mesh.texcoord = np.ctypeslib.as_array(m.texcoord, (nv, 2)).copy() if m.texcoord else None
+            mesh.diffuseTextureID = final_id.get(m.texture_ref, -1)
+            model.meshes.append(mesh)
+        return model
+    finally:
+        L.pt_obj_free(h)
+
+
+def load_model(obj_file: str) -> Model:
+    """The product's route for RENDERING an OBJ scene: native parser, every mesh with its own vertex map.  (loadOBJ as the reference
+    wrote it shares one vertex map among the materials of a shape, Model.cpp:176, so a second material's mesh indexes vertices it
+    does not own — out of bounds in the reference's renderer too; `load_obj` reproduces that for the parity tests.)"""
+    return load_obj(obj_file, per_mesh_vertex_map=True, native=True)
+
+
+def load_obj(obj_file: str, per_mesh_vertex_map: bool = False, native: bool = True) -> Model:
+    """loadOBJ (Model.cpp:137-212), the reference's arrays bit for bit.  `per_mesh_vertex_map` undoes the shared knownVertices map
+    (module docstring); `native=False` runs the line-cited Python restatement below instead of pt_load_obj (the two are held equal by
+    tests/test_objloader.py, and both to the reference's own Model.cpp)."""
     if not os.path.isfile(obj_file):
         raise RuntimeError(f"Could not read OBJ model from {obj_file} : Cannot open file [{obj_file}]")
+    if native:
+        return _load_obj_native(obj_file, per_mesh_vertex_map)
     model = Model()
     model_dir = obj_file[: obj_file.rfind("/") + 1]
     V, VN, VT, shapes, materials = _parse_obj(obj_file, model_dir)

@@ -4,7 +4,10 @@ stb_image it vendors, into oracle/_ref/libptref.so — makes of the same files. 
 
   * test_*_golden: the committed inputs (tests/golden/obj_fixture/, written by tests/golden/make_model_golden.py) against the
     reference's stored outputs (tests/golden/ref_model.npz) — runs anywhere;
-  * test_*_live: freshly generated random OBJ / MTL / PNG sets against libptref.so directly — runs where the library was built."""
+  * test_*_live: freshly generated random OBJ / MTL / PNG sets against libptref.so directly — runs where the library was built.
+
+Two implementations are held to the reference: the native parser behind the C ABI (pt_load_obj, csrc/pt_objload.cpp — the product's
+route, `native=True`, the default) and the line-cited Python restatement it was written from (`native=False`)."""
 import os
 
 import numpy as np
@@ -53,11 +56,12 @@ def golden():
     return np.load(os.path.join(HERE, "golden", "ref_model.npz"))
 
 
+@pytest.mark.parametrize("native", [True, False], ids=["native", "python"])
 @pytest.mark.parametrize("name", ["basic", "concave", "numbers", "quirks"])
-def test_load_obj_golden(golden, name):
+def test_load_obj_golden(golden, name, native):
     meshes, textures = _unpack(golden, name + "_")
     assert len(meshes) > 0
-    _check_model(objloader.load_obj(os.path.join(FIX, name + ".obj")), meshes, textures, name)
+    _check_model(objloader.load_obj(os.path.join(FIX, name + ".obj"), native=native), meshes, textures, name)
 
 
 def test_load_obj_golden_covers_the_quirks(golden):
@@ -89,22 +93,61 @@ def test_add_box_golden(golden):
     assert meshes[0]["vertex"].shape == (36, 3) and meshes[0]["index"].shape == (12, 3) and meshes[0]["texcoord"].shape == (36, 2)
 
 
-def test_per_mesh_vertex_map_option(tmp_path):
-    """The opt-in repair of the shared vertex map: every mesh indexes its own vertices."""
-    m = objloader.load_obj(os.path.join(FIX, "basic.obj"), per_mesh_vertex_map=True)
+@pytest.mark.parametrize("native", [True, False], ids=["native", "python"])
+def test_per_mesh_vertex_map_option(tmp_path, native):
+    """The repair of the shared vertex map (what load_model, the product's route for rendering, uses): every mesh indexes its own vertices;
+    the shared-map mode does not on this fixture (the reference's out-of-bounds indices, kept for parity)."""
+    m = objloader.load_obj(os.path.join(FIX, "basic.obj"), per_mesh_vertex_map=True, native=native)
     for mesh in m.meshes:
         assert mesh.index.max() < len(mesh.vertex)
     v, idx, tri_mesh, mats = m.flatten()
     assert idx.max() < len(v)
+    shared = objloader.load_obj(os.path.join(FIX, "basic.obj"), native=native)
+    assert any(mesh.index.max() >= len(mesh.vertex) for mesh in shared.meshes)
 
 
-def test_load_obj_errors(tmp_path):
+def test_load_model_is_the_native_per_mesh_route():
+    a = objloader.load_model(os.path.join(FIX, "basic.obj"))
+    b = objloader.load_obj(os.path.join(FIX, "basic.obj"), per_mesh_vertex_map=True, native=False)
+    assert len(a.meshes) == len(b.meshes) and len(a.textures) == len(b.textures)
+    for x, y in zip(a.meshes, b.meshes):
+        assert _same_bits(x.vertex, y.vertex) and _same_bits(x.index, y.index) and x.diffuseTextureID == y.diffuseTextureID
+        assert np.array(x.material).tobytes() == np.array(y.material).tobytes()
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["native", "python"])
+def test_load_obj_errors(tmp_path, native):
     with pytest.raises(RuntimeError):
-        objloader.load_obj(str(tmp_path / "absent.obj"))
+        objloader.load_obj(str(tmp_path / "absent.obj"), native=native)
     p = tmp_path / "zero.obj"
     p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 0 1 2\n")  # index 0: tinyobj fails the load, loadOBJ throws (Model.cpp:160-162)
     with pytest.raises(RuntimeError):
-        objloader.load_obj(str(p))
+        objloader.load_obj(str(p), native=native)
+    q = tmp_path / "range.obj"
+    q.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 7\n")  # a vertex that does not exist: the reference reads past its array, both loaders refuse
+    with pytest.raises(ValueError):
+        objloader.load_obj(str(q), native=native)
+
+
+def test_native_loader_speed(tmp_path):
+    """the Python restatement needs 26-50 s for the 150 MB OBJ of the textured 1 M-triangle terrain; the native parser
+    must do a comparable file in seconds.  Here: 300 k triangles with normals and texcoords (45 MB of text), bound 5 s, both loaders equal."""
+    import time
+
+    rng = np.random.default_rng(3)
+    n = 100_000
+    V = rng.standard_normal((3 * n, 3)).astype(np.float32)
+    VT = rng.random((3 * n, 2)).astype(np.float32)
+    lines = ["v %.9g %.9g %.9g" % tuple(p) for p in V] + ["vt %.9g %.9g" % tuple(p) for p in VT] + ["vn 0 1 0"]
+    lines += ["f %d/%d/1 %d/%d/1 %d/%d/1" % (a, a, b, b, c, c) for a, b, c in np.arange(1, 3 * n + 1).reshape(n, 3)] * 3
+    path = tmp_path / "big.obj"
+    path.write_text("\n".join(lines) + "\n")
+    t0 = time.perf_counter()
+    a = objloader.load_obj(str(path), native=True)
+    dt = time.perf_counter() - t0
+    assert len(a.meshes) == 1 and len(a.meshes[0].index) == 3 * n and len(a.meshes[0].vertex) == 3 * n
+    assert dt < 5.0, dt
+    print(f"\n[pt_load_obj] {os.path.getsize(path) / 1e6:.0f} MB, {3 * n} triangles in {dt:.2f} s")
 
 
 # ----------------------------------------------------------------------------------------------------------------- live
@@ -187,11 +230,12 @@ def _random_set(rng, d):
     return os.path.join(d, "r.obj")
 
 
-def test_load_obj_live_fixture():
+@pytest.mark.parametrize("native", [True, False], ids=["native", "python"])
+def test_load_obj_live_fixture(native):
     orc, R = _ref()
     for name in ("basic", "concave", "numbers", "quirks"):
         out = orc.ref_load_obj(R, os.path.join(FIX, name + ".obj"))
-        _check_model(objloader.load_obj(os.path.join(FIX, name + ".obj")), out[0], out[1], name)
+        _check_model(objloader.load_obj(os.path.join(FIX, name + ".obj"), native=native), out[0], out[1], name)
 
 
 def test_load_obj_live_random(tmp_path):
@@ -205,7 +249,8 @@ def test_load_obj_live_random(tmp_path):
         path = _random_set(rng, str(d))
         out = orc.ref_load_obj(R, path)
         assert out is not None
-        _check_model(objloader.load_obj(path), out[0], out[1], f"random set {it}")
+        _check_model(objloader.load_obj(path, native=True), out[0], out[1], f"random set {it} (native)")
+        _check_model(objloader.load_obj(path, native=False), out[0], out[1], f"random set {it} (python)")
         total_tris += sum(len(m["index"]) for m in out[0])
     assert total_tris > 1500
 
@@ -248,15 +293,17 @@ def test_batched_quad_triangulation_equals_scalar_ear_clipping():
         lines = ["v %.9g %.9g %.9g" % tuple(p) for p in V[: 4 * 800]] + ["f %d %d %d %d" % tuple(q + 1) for q in Q[:800]]
         path = os.path.join(d, "q.obj")
         open(path, "w").write("\n".join(lines) + "\n")
-        a = objloader.load_obj(path)
+        a = objloader.load_obj(path, native=False)
         saved = objloader._quads_clip_to_fan
         try:
             objloader._quads_clip_to_fan = lambda Q, V: np.zeros(len(Q), bool)
-            b = objloader.load_obj(path)
+            b = objloader.load_obj(path, native=False)
         finally:
             objloader._quads_clip_to_fan = saved
-        assert len(a.meshes) == len(b.meshes) == 1
-        assert a.meshes[0].index.tobytes() == b.meshes[0].index.tobytes() and a.meshes[0].vertex.tobytes() == b.meshes[0].vertex.tobytes()
+        c = objloader.load_obj(path, native=True)  # the native parser only has the scalar ear clipping
+        assert len(a.meshes) == len(b.meshes) == len(c.meshes) == 1
+        assert a.meshes[0].index.tobytes() == b.meshes[0].index.tobytes() == c.meshes[0].index.tobytes()
+        assert a.meshes[0].vertex.tobytes() == b.meshes[0].vertex.tobytes() == c.meshes[0].vertex.tobytes()
 
 
 def test_load_obj_live_many_quads(tmp_path):
@@ -271,5 +318,6 @@ def test_load_obj_live_many_quads(tmp_path):
     lines = ["mtllib q.mtl", "usemtl a"] + ["v %.9g %.9g %.9g" % tuple(p) for p in V] + ["f %d %d %d %d" % tuple(q) for q in np.arange(1, 4 * n + 1).reshape(n, 4)]
     open(tmp_path / "q.obj", "w").write("\n".join(lines) + "\n")
     out = orc.ref_load_obj(R, str(tmp_path / "q.obj"))
-    _check_model(objloader.load_obj(str(tmp_path / "q.obj")), out[0], out[1], "many quads")
+    _check_model(objloader.load_obj(str(tmp_path / "q.obj"), native=True), out[0], out[1], "many quads (native)")
+    _check_model(objloader.load_obj(str(tmp_path / "q.obj"), native=False), out[0], out[1], "many quads (python)")
     assert len(out[0][0]["index"]) > 1.5 * n

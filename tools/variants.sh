@@ -8,5 +8,6 @@ FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize
 /opt/rocm/bin/hipcc $FLAGS -c pt_api.hip -o /tmp/pt_api_$NAME.o &
 /opt/rocm/bin/hipcc $FLAGS -c pt_bvh_build.hip -o /tmp/pt_bvh_build_$NAME.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libptamd_$NAME.so /tmp/pt_api_$NAME.o /tmp/pt_bvh_build_$NAME.o -ldl
+make -s pt_objload.o  # the host-only scene ingestion is the same in every variant
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libptamd_$NAME.so /tmp/pt_api_$NAME.o /tmp/pt_bvh_build_$NAME.o pt_objload.o -ldl
 echo built variants/libptamd_$NAME.so

@@ -524,50 +524,25 @@ def main():
 
 
 def textured_terrain_through_obj():
-    """scenes.textured_terrain() -> OBJ + MTL + PNG in a scratch directory -> objloader.load_obj: the reference's own route for its
-    scenes (≈50 s of host time for 1 M triangles: 150 MB of text through a restatement of tinyobjloader's parser; untimed).  The loaded
-    model is kept as arrays under the temp directory, so that the passes of a profiling script do not parse the same text again."""
+    """scenes.textured_terrain() -> OBJ + MTL + PNG in a scratch directory -> objloader.load_model: the reference's own route for its scenes
+    (loadOBJ semantics through the native parser pt_load_obj, every mesh with its own vertex map; untimed).  No cache: 150 MB of OBJ parse in
+    a few seconds since round 5 (the Python restatement needed 26-50 s and kept a predictable file in the shared temp directory)."""
     import shutil
     import tempfile
 
     from optixpathtracer_amd import objloader, scenes
 
-    cache = os.path.join(tempfile.gettempdir(), f"ptamd_textured_terrain_{source_hash_py()}.npz")
-    if os.path.exists(cache):
-        Z = np.load(cache)
-        model = scenes.Model()
-        for i in range(int(Z["n"][0])):
-            mesh = scenes.TriangleMesh(Z[f"v{i}"], Z[f"i{i}"], np.frombuffer(Z[f"m{i}"].tobytes(), scenes.MATERIAL_DTYPE)[0].copy(), int(Z[f"t{i}"]), Z[f"c{i}"])
-            model.meshes.append(mesh)
-        model.textures = [scenes.Texture(Z[f"x{k}"]) for k in range(int(Z["n"][1]))]
-        return model
     d = tempfile.mkdtemp(prefix="ptamd_obj_")
     try:
         t0 = time.perf_counter()
         path = scenes.write_obj(scenes.textured_terrain(), os.path.join(d, "terrain.obj"))
         t1 = time.perf_counter()
-        model = objloader.load_obj(path)
-        print(f"[bench] textured terrain: wrote {os.path.getsize(path) >> 20} MiB of OBJ in {t1 - t0:.1f} s, loadOBJ semantics in {time.perf_counter() - t1:.1f} s: "
+        model = objloader.load_model(path)
+        print(f"[bench] textured terrain: wrote {os.path.getsize(path) >> 20} MiB of OBJ in {t1 - t0:.1f} s, pt_load_obj + textures in {time.perf_counter() - t1:.1f} s: "
               f"{len(model.meshes)} meshes, {model.num_triangles} triangles, {len(model.textures)} textures", file=sys.stderr)
     finally:
         shutil.rmtree(d, ignore_errors=True)
-    G = {"n": np.array([len(model.meshes), len(model.textures)])}
-    for i, mesh in enumerate(model.meshes):
-        G.update({f"v{i}": mesh.vertex, f"i{i}": mesh.index, f"m{i}": np.frombuffer(np.array(mesh.material).tobytes(), np.uint8), f"t{i}": np.int32(mesh.diffuseTextureID), f"c{i}": mesh.texcoord})
-    for k, t in enumerate(model.textures):
-        G[f"x{k}"] = t.pixel
-    tmp = cache + f".{os.getpid()}.tmp.npz"
-    np.savez(tmp, **G)
-    os.replace(tmp, cache)
     return model
-
-
-def source_hash_py():
-    """hash of the host code that produces the cached scene"""
-    h = hashlib.sha256()
-    for f in ("scenes.py", "objloader.py"):
-        h.update(open(os.path.join(ROOT, "optixpathtracer_amd", f), "rb").read())
-    return h.hexdigest()[:12]
 
 
 def launch_ranks(n):

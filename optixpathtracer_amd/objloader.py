@@ -33,8 +33,13 @@ and Model.cpp itself, quirks included (they decide the arrays a drop-in must han
   * `loadTexture` (:88-135): '\\\\' -> '/', RGBA8, rows mirrored in y, -1 (and a message) when the file cannot be read.
 
 Deliberate differences: a face without material (`materials[-1]`, an out-of-bounds read in the reference) gets the default Material;
-out-of-range v/vn/vt indices raise instead of reading past the arrays.  Images are decoded with PIL: identical to stb_image for
-8-bit PNG/BMP/TGA/PPM; a lossy format (JPEG) may differ in the last bit of a texel, as it does between any two decoders.
+out-of-range v/vn/vt indices raise instead of reading past the arrays.  Images are decoded with PIL: pinned bit for bit to the
+reference's stb_image for PNG, BMP and TGA (true colour, RLE with alpha, grey: tests/test_objloader.py); JPEG differs in the last bits of
+some texels (8 % of the channel values of the committed fixture, by at most 2 of 255), as it does between any two decoders.
+
+Three entry points: `load_model(path)` — what a renderer wants: the native parser (pt_load_obj, include/pt_amd.h) with a vertex map per
+mesh; `load_obj(path)` — loadOBJ's arrays bit for bit, shared vertex map and all (native by default, `native=False` for the Python
+restatement below, from which csrc/pt_objload.cpp was written).
 """
 from __future__ import annotations
 

@@ -77,7 +77,22 @@ def write_inputs(d=FIX):
     W("quirks.mtl", "newmtl first\nmap_Kd tex/gray.png\nnewmtl second\nKd 0.2 0.3 0.4\nnewmtl third\nmap_Kd tex/gray.png\nnewmtl second\nKd 0.9 0.9 0.9\nnewmtl fourth\n")
     W("quirks.obj", "mtllib nothere.mtl quirks.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0 0\nvt 1 0\nvt 0 1\n"
       "usemtl first\nf 1/1 2/2 3/3\nusemtl second\nf 2 4 3\nusemtl third\nf 1/1 2/2 4/3\nusemtl fourth\nf 1 4 3\nusemtlsecond\nf 1 2 4\n")
-    return ["basic.obj", "concave.obj", "numbers.obj", "quirks.obj"]
+    # --- images: the other formats loadTexture's stb_image decodes (Model.cpp:88-135; the reference's assets use TGA and JPEG beside PNG):
+    # TGA true colour, run-length encoded TGA with alpha, grey TGA — lossless, so any decoder must agree bit for bit — and a JPEG, where
+    # two conforming decoders may differ in a texel's last bits (stb_image's IDCT and upsampling are its own)
+    rng2 = np.random.default_rng(78)
+    Image.fromarray(rng2.integers(0, 256, (7, 5, 3), dtype=np.uint8), "RGB").save(os.path.join(d, "tex", "rgb.tga"))
+    flat = np.repeat(rng2.integers(0, 256, (4, 3, 4), dtype=np.uint8), 3, axis=1)  # runs of three equal texels: packets of both kinds
+    Image.fromarray(flat, "RGBA").save(os.path.join(d, "tex", "rgba_rle.tga"), compression="tga_rle")
+    Image.fromarray(rng2.integers(0, 256, (3, 4), dtype=np.uint8), "L").save(os.path.join(d, "tex", "gray.tga"))
+    yy, xx = np.mgrid[0:16, 0:24]
+    photo = np.stack([(xx * 10) % 256, (yy * 15) % 256, ((xx + yy) * 6) % 256], -1).astype(np.uint8)
+    Image.fromarray(photo, "RGB").save(os.path.join(d, "tex", "photo.jpg"), quality=92)
+    W("images.mtl", "newmtl a\nKd 1 1 1\nmap_Kd tex/rgb.tga\nnewmtl b\nKd 1 1 1\nmap_Kd tex/rgba_rle.tga\nnewmtl c\nKd 1 1 1\nmap_Kd tex/gray.tga\n"
+      "newmtl d\nKd 1 1 1\nmap_Kd tex/photo.jpg\n")
+    W("images.obj", "mtllib images.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nvt 1 1\n"
+      "usemtl a\nf 1/1 2/2 3/3\nusemtl b\nf 2/2 4/4 3/3\nusemtl c\nf 1/1 4/4 3/3\nusemtl d\nf 1/1 2/2 4/4\n")
+    return ["basic.obj", "concave.obj", "numbers.obj", "quirks.obj", "images.obj"]
 
 
 def write_rle_hdr(path, rgbe, header=b"#?RADIANCE\n# comment\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1\n\n"):

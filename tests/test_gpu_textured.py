@@ -20,7 +20,7 @@ def test_textured_terrain_through_obj_matches_oracle(ptlib, orc_det, tmp_path):
     model the file was written from (same triangles in the same order; only the vertex numbering inside the meshes differs)."""
     direct = scenes.textured_terrain(n=96, target_tris=70000, tex_size=256)
     path = scenes.write_obj(direct, str(tmp_path / "terrain.obj"))
-    m = objloader.load_obj(path)
+    m = objloader.load_model(path)  # the route for rendering: native parser, a vertex map per mesh
     assert m.num_triangles == direct.num_triangles and len(m.textures) == 8 and all(x.diffuseTextureID >= 0 for x in m.meshes)
     for a, b in zip(direct.meshes, m.meshes):
         assert a.vertex[a.index].tobytes() == b.vertex[b.index].tobytes() and a.texcoord[a.index].tobytes() == b.texcoord[b.index].tobytes()
@@ -104,7 +104,7 @@ def test_reference_fixture_obj_renders_like_the_checker(ptlib, orc_det):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "obj_fixture", "basic.obj")
     with pytest.raises(RuntimeError, match="vertex index out of range"):
         SampleRenderer(objloader.load_obj(path))
-    m = objloader.load_obj(path, per_mesh_vertex_map=True)
+    m = objloader.load_model(path)
     assert len(m.meshes) == 8 and len(m.textures) == 5
     probe = scenes.sky_probe(128, 64).BuildCDF()
     cam = dict(eye=(2.6, 2.2, 3.4), lookat=(0.5, 0.5, 0.5), up=(0.0, 1.0, 0.0), fovY=40.0)

@@ -131,7 +131,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0, help="pt_options.frames_in_flight of the TIMED loop. 0 (default): every frame synchronous like the reference's render(); 3: frame k runs whole on stream k mod 3 and pt_render(k) returns once frame k-2 is complete (three frames overlap, same images); 2: pixel chunks as in the synchronous frame, pt_render(k) waits for frame k-1")
     ap.add_argument("--batch", type=int, default=1, help="timed loop: frames are rendered as wavefront batches of this many subframes (pt_render_batch; the last batch of the loop may be shorter). 1 (default, every N) = every frame its own pt_render, like the reference's loop; the batched schedule (N subframes per launch chain on an N-way partition) is reported beside it under `batched`")
     ap.add_argument("--no-extra-schedules", action="store_true", help="skip the extra frames after the timed region (pipelined / batched figures; profiling runs: keeps the frame count at warmup + steps)")
-    ap.add_argument("--launch-check", action="store_true", help="ranks only join the process group, all-reduce their rank and print {n_ranks_seen}: tests the self-launcher without a GPU")
+    ap.add_argument("--launch-check", action="store_true", help="ranks only join the process group, all-reduce their rank, gather one record per rank and print {n_ranks_seen, ranks}: tests the self-launcher without a GPU")
+    ap.add_argument("--launch-render", action="store_true", help="with --launch-check (implied by --backend nccl): every rank also creates a renderer on its device, renders its share of C1 (Cornell box, 256x256, 1 spp, depth 4) and the checksums of the shares are gathered and compared with rank 0's render of the whole frame — first contact with N devices in seconds")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -143,7 +144,7 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.launch_check:
-        return launch_check(rank, world, args.backend)
+        return launch_check(rank, world, args.backend, args.launch_render or args.backend == "nccl", 0 if args.share_device else local_rank)
 
     import torch
 
@@ -313,9 +314,13 @@ def main():
         per_rank[rank] = dt / args.steps * 1e3
         dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
         per_rank_ms = [round(float(x), 3) for x in per_rank.tolist()]
+        per_rank_b = torch.zeros(world, dtype=torch.float64, device=red_dev)  # every rank builds its own copy of the tree (replicated scene)
+        per_rank_b[rank] = r.stats()["bvh_build_ms"]
+        dist.all_reduce(per_rank_b, op=dist.ReduceOp.SUM)
+        per_rank_build_ms = [round(float(x), 2) for x in per_rank_b.tolist()]
     else:
         dt_max, rays_all = dt, float(rays)
-        per_rank_ms = None
+        per_rank_ms = per_rank_build_ms = None
     extra_out = {}
     for name, tup in extra.items():  # max time over the ranks, rays summed over the ranks
         te = torch.tensor([tup[0]], dtype=torch.float64, device=red_dev)
@@ -488,6 +493,7 @@ def main():
             # device time from a launch chain's first kernel to its last (with frames in flight: one frame's LATENCY, three frames overlap) — of the last chain of the loop
             "frame_latency_ms": round(agg["render_ms"] / n_chains, 3),
             "ms_per_step_per_rank": per_rank_ms,
+            "bvh_build_ms_per_rank": per_rank_build_ms,
             "kernel_ms_per_frame_isolated": None if iso is None else {k: round(iso[k], 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
             "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2), "hierarchy": ["lbvh", "ploc", "imported"][st["bvh_builder"]]},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
@@ -599,23 +605,87 @@ def launch_ranks(n):
     return worst
 
 
-def launch_check(rank, world, backend):
-    """What --launch-check runs in each rank: join the group, all-reduce, rank 0 prints the communicator's size (no GPU unless backend nccl)."""
+def launch_check(rank, world, backend, render=False, device=0):
+    """What --launch-check runs in each rank: join the group, all-reduce, gather one record per rank, rank 0 prints the communicator's size and
+    the records (no GPU unless backend nccl or --launch-render).  With `render`: first contact with the devices before the long run — every
+    rank creates a renderer on its device (scene upload, BVH build, stream probing), renders its share of C1 through pt_set_partition and
+    reports build / render times and a checksum of its own pixels; rank 0 renders the whole frame on its device and checks every share
+    against it (the union of the shares is the single-GPU frame bit for bit)."""
+    import socket
+
     import torch
     import torch.distributed as dist
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    dist.init_process_group(backend)
-    t = torch.tensor([float(rank + 1)], device="cuda" if backend == "nccl" else "cpu")
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend, device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group(backend)
+    cdev = "cuda" if backend == "nccl" else "cpu"
+    t = torch.tensor([float(rank + 1)], device=cdev)
     dist.all_reduce(t)
     ok = float(t[0]) == world * (world + 1) / 2
+    # one record per rank: [rank, pid, device, visible devices, owned pixels, checksum of the owned accum pixels, build us, render us, expected checksums ok]
+    rec = [rank, os.getpid(), device, -1, 0, 0, 0, 0, 1]
+    expected = None
+    if render:
+        from optixpathtracer_amd import multigpu
+        from optixpathtracer_amd import renderer as R
+        from optixpathtracer_amd import scenes
+
+        rec[3] = torch.cuda.device_count()
+        w = h = 256
+        probe = scenes.sky_probe(256, 128).BuildCDF()
+
+        def frame(part):
+            r = R.SampleRenderer(scenes.cornell_box(), device=device)
+            r.setProbe(probe)
+            r.setOptions(max_depth=4)
+            if part:
+                r.setPartition(rank, world, 64, 16)
+            r.resize((w, h))
+            r.setCamera(R.make_camera(scenes.CORNELL_CAMERA, w / h))
+            r.launchParams.samples_per_launch = 1
+            t0 = time.perf_counter()
+            r.render()
+            ms = (time.perf_counter() - t0) * 1e3
+            acc = r.download(R.PT_BUF_ACCUM).copy()
+            build_ms = r.stats()["bvh_build_ms"]
+            r.close()
+            return acc, build_ms, ms
+
+        def checksum(acc, k):
+            px = multigpu.pixel_lists(w, h, world, 64, 16)[k]
+            ys, xs = (px >> 16).astype(np.int64), (px & 0xFFFF).astype(np.int64)
+            own = acc[ys, xs].view(np.uint32).astype(np.uint64)
+            return len(px), int((own * (np.arange(own.size, dtype=np.uint64).reshape(own.shape) % np.uint64(8191) + np.uint64(1))).sum() % np.uint64(1 << 53))
+
+        acc, build_ms, ms = frame(world > 1)
+        rec[4], rec[5] = checksum(acc, rank)
+        rec[6], rec[7] = int(build_ms * 1e3), int(ms * 1e3)
+        if rank == 0:
+            whole = frame(False)[0] if world > 1 else acc
+            expected = [checksum(whole, k) for k in range(world)]
+    mine = torch.tensor(rec, dtype=torch.int64, device=cdev)
+    allr = torch.empty(world * len(rec), dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(allr, mine)
+    recs = allr.cpu().reshape(world, len(rec)).tolist()
+    ok = ok and [x[0] for x in recs] == list(range(world))
     if rank == 0:
-        print(json.dumps({"launch_check": ok, "n_gpus": world, "n_ranks_seen": dist.get_world_size(), "backend": backend}), flush=True)
+        ranks = [{"rank": x[0], "pid": x[1], "device": x[2]} for x in recs]
+        if render:
+            for k, x in enumerate(recs):
+                ranks[k].update(devices_visible=x[3], owned_pixels=x[4], bvh_build_ms=x[6] / 1e3, first_render_ms=x[7] / 1e3,
+                                share_equals_whole_frame=(x[4], x[5]) == expected[k])
+                ok = ok and ranks[k]["share_equals_whole_frame"]
+            ok = ok and sum(x[4] for x in recs) == 256 * 256
+        print(json.dumps({"launch_check": ok, "n_gpus": world, "n_ranks_seen": dist.get_world_size(), "backend": backend, "host": socket.gethostname(), "rendered": bool(render), "ranks": ranks}), flush=True)
+    flag = torch.tensor([1.0 if ok else 0.0], device=cdev)
+    dist.broadcast(flag, 0)
     dist.barrier()
     dist.destroy_process_group()
-    if not ok:
+    if float(flag[0]) != 1.0:
         raise SystemExit(1)
 
 

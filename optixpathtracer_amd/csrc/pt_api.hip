@@ -849,9 +849,12 @@ static bool streams_concurrent(hipStream_t a, hipStream_t b, long long* d_stamps
 // hardware queue: streams are created until enough mutually concurrent ones are found (at most 12; among any eight consecutive
 // creations every queue appears twice), the others become the side streams of the split / asynchronous shadow schedules.
 // PT_STREAM_PROBE=0 keeps plain creation order.
+static std::mutex g_probe_mu; // one probe at a time per process: contexts that share a device (pt_create_multi rehearsals, several renderers of
+                              // one application) would otherwise time each other's spin kernels and misjudge which streams run concurrently
 static int pick_streams(pt_ctx* ctx, int nsets) {
     const char* pe = getenv("PT_STREAM_PROBE");
     if (pe && atoi(pe) == 0) return PT_OK;
+    std::lock_guard<std::mutex> probe_lock(g_probe_mu);
     long long* d_stamps = nullptr;
     CK(hipMalloc(&d_stamps, 2 * sizeof(long long)));
     CK(hipStreamSynchronize(ctx->stream));

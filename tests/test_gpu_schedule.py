@@ -1,5 +1,7 @@
 """Schedules that must not change a bit: frames in flight mixed across entry points, the overlapped display hand-off, parallel
 enqueue of the multi-context renderer.  Self-comparisons against the synchronous schedule (which the parity tests pin to the checker)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -225,6 +227,27 @@ def test_bench_starts_its_own_ranks():
     assert d["ms_per_displayed_frame"] > 0 and d["gather_ms"] >= 0
     assert d["step_ms"]["min"] <= d["step_ms"]["median"] <= d["step_ms"]["max"]
     assert len(d["ms_per_step_per_rank"]) == 2
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_launch_check_renders_every_share(ptlib, n):
+    """`bench.py --gpus N --launch-check --launch-render` (what `--backend nccl --launch-check` does on an N-GPU node, here over gloo with the
+    ranks sharing device 0): every rank creates its renderer, renders its share of C1, and the gathered checksums of the shares equal rank
+    0's render of the whole frame; the line names every rank's device, build time and first-render time."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "gloo", "--share-device", "--launch-check", "--launch-render"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
+    assert d["launch_check"] is True and d["rendered"] is True and d["n_ranks_seen"] == n
+    assert sum(x["owned_pixels"] for x in d["ranks"]) == 256 * 256
+    assert all(x["share_equals_whole_frame"] and x["bvh_build_ms"] > 0 and x["first_render_ms"] > 0 and x["devices_visible"] >= 1 for x in d["ranks"])
 
 
 def _partition_frame(monkeypatch, env):

@@ -157,7 +157,9 @@ def test_bench_self_launcher_cpu(n):
     lines = [l for l in res.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, res.stdout
     d = json.loads(lines[0])
-    assert d == {"launch_check": True, "n_gpus": n, "n_ranks_seen": n, "backend": "gloo"}
+    assert {k: d[k] for k in ("launch_check", "n_gpus", "n_ranks_seen", "backend", "rendered")} == {"launch_check": True, "n_gpus": n, "n_ranks_seen": n, "backend": "gloo", "rendered": False}
+    # one record per rank came through the all-gather (round 5: the same gather carries the per-rank render check of --launch-render on a GPU box)
+    assert [x["rank"] for x in d["ranks"]] == list(range(n)) and len({x["pid"] for x in d["ranks"]}) == n
 
 
 def test_bench_self_launcher_reports_a_failed_rank():

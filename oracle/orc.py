@@ -95,6 +95,8 @@ class Oracle:
         L.orc_scene_create.argtypes = [f32p, C.c_uint32, u32p, C.c_uint32, u32p, C.c_void_p, C.c_uint32, C.c_int]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_scene_set_bvh8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_hit_census.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_hit_census.restype = None
         L.orc_trace_closest.argtypes = [C.c_void_p, f32p, C.c_int, f32p, i32p]
         L.orc_trace_any.argtypes = [C.c_void_p, f32p, C.c_int, u8p]
         L.orc_bsdf_eval.argtypes = [C.c_int, C.c_void_p, f32p, C.c_float, C.c_float, f32p, f32p, f32p, f32p]
@@ -211,6 +213,14 @@ class Oracle:
         t = np.empty(len(rays), np.float32); prim = np.empty(len(rays), np.int32)
         self.lib.orc_trace_closest(scene.h, rays.reshape(-1), len(rays), t, prim)
         return t, prim
+
+    def hit_census(self, scene, rays):
+        """orc_hit_census: the float acceptance rule against double-precision Moller-Trumbore, per ray (needs make_scene(use_bvh=True))."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(8, np.uint64)
+        self.lib.orc_hit_census(scene.h, rays.ctypes.data, len(rays), out.ctypes.data)
+        keys = ("rays", "same_closest_hit", "accepted_but_inexact", "rejected_but_exact", "order_only", "candidates", "candidates_classified_differently", "rays_with_such_a_candidate")
+        return dict(zip(keys, (int(x) for x in out)))
 
     def trace_any(self, scene, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

@@ -999,6 +999,100 @@ void orc_trace_closest(const orc_scene* s, const float* rays, int n, float* t_ou
         prim_out[i] = (int32_t)p;
     }
 }
+/* Census of the float acceptance rule (wtri2 + hit_in_box: this repository's definition of what optixTrace returns) against exact
+ * geometry ("What's weak" 10).  For every ray all triangles whose (padded) boxes the ray enters are tested twice: with the
+ * float rule and with Moller-Trumbore in double precision on the same float vertices (u, v >= 0, u + v <= 1, t in (tmin, tmax): exact up
+ * to ~1e-15, i.e. the mathematical triangle).  Per ray the closest hit of either rule is compared.  out[0] rays, [1] rays whose two
+ * closest hits are the same primitive (or both miss), [2] float rule's closest hit is a triangle the exact test REJECTS ("accepted but
+ * inexact"), [3] the exact closest hit is a triangle the float rule rejected ("rejected but exact"), [4] both accept both triangles but
+ * order them differently (|t| ties within rounding: coplanar / shared-edge neighbours), [5] candidate triangles tested, [6] candidates
+ * the two rules classify differently, [7] rays with any such candidate.  Needs the scene's own BVH (use_bvh). */
+static int mt_double(const double o[3], const double d[3], const float* p0, const float* p1, const float* p2, double tmin, double tmax, double* t_out) {
+    const double e1[3] = {(double)p1[0] - p0[0], (double)p1[1] - p0[1], (double)p1[2] - p0[2]};
+    const double e2[3] = {(double)p2[0] - p0[0], (double)p2[1] - p0[1], (double)p2[2] - p0[2]};
+    const double pv[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+    const double det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+    if (det == 0.0) return 0;
+    const double inv = 1.0 / det;
+    const double tv[3] = {o[0] - p0[0], o[1] - p0[1], o[2] - p0[2]};
+    const double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * inv;
+    if (u < 0.0 || u > 1.0) return 0;
+    const double qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+    const double v = (d[0] * qv[0] + d[1] * qv[1] + d[2] * qv[2]) * inv;
+    if (v < 0.0 || u + v > 1.0) return 0;
+    const double t = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) * inv;
+    if (!(t > tmin && t < tmax)) return 0;
+    *t_out = t;
+    return 1;
+}
+void orc_hit_census(const orc_scene* s, const float* rays, int n, unsigned long long out[8]) {
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    if (!s->use_bvh) return;
+    for (int i = 0; i < n; ++i) {
+        const float* q = rays + 8 * (size_t)i;
+        const f3 o = mk3(q[0], q[1], q[2]), d = mk3(q[4], q[5], q[6]);
+        const float tmin = q[3], tmax = q[7];
+        wray r;
+        wray_init(&r, o, d);
+        r.hp = 0.5f * s->pad;
+        const double od[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+        float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z}, ro[3] = {o.x, o.y, o.z};
+        float fbest = tmax;
+        int64_t fp = -1;
+        double ebest = (double)tmax;
+        int64_t ep = -1;
+        int f_of_exact_best = 0; /* filled below: does the float rule accept the exact rule's closest triangle? */
+        unsigned long long ndiff = 0;
+        uint32_t stack[128];
+        int sp = 0;
+        stack[sp++] = 0;
+        /* first pass: both closest hits, every box the ray enters (no culling by the best hit: the two rules would cull differently) */
+        while (sp) {
+            const onode* nd = &s->nodes[stack[--sp]];
+            if (!slab(nd, ro, inv, tmin, tmax, 4.0f * s->pad)) continue;
+            if (nd->right == 0xffffffffu) {
+                for (uint32_t k = 0; k < nd->count; ++k) {
+                    const uint32_t p = s->order[nd->left + k];
+                    const float *v0, *v1, *v2;
+                    tri_verts(s, p, &v0, &v1, &v2);
+                    float t;
+                    const int fa = wtri(&r, v0, v1, v2, &t) && t > tmin && t < tmax && hit_in_box(&r, v0, v1, v2, t);
+                    double te;
+                    const int ea = mt_double(od, dd, v0, v1, v2, (double)tmin, (double)tmax, &te);
+                    ++out[5];
+                    if (fa != ea) ++ndiff;
+                    if (fa && (t < fbest || (t == fbest && fp >= 0 && (int64_t)p < fp))) { fbest = t; fp = p; }
+                    if (ea && (te < ebest || (te == ebest && ep >= 0 && (int64_t)p < ep))) { ebest = te; ep = p; }
+                }
+            } else {
+                stack[sp++] = nd->left;
+                stack[sp++] = nd->right;
+            }
+        }
+        ++out[0];
+        out[6] += ndiff;
+        if (ndiff) ++out[7];
+        if (fp == ep) { ++out[1]; continue; }
+        /* the closest hits differ: which rule disagrees about which triangle? */
+        int e_of_float_best = 0;
+        if (fp >= 0) {
+            const float *v0, *v1, *v2;
+            double te;
+            tri_verts(s, (uint32_t)fp, &v0, &v1, &v2);
+            e_of_float_best = mt_double(od, dd, v0, v1, v2, (double)tmin, (double)tmax, &te);
+        }
+        if (ep >= 0) {
+            const float *v0, *v1, *v2;
+            float t;
+            tri_verts(s, (uint32_t)ep, &v0, &v1, &v2);
+            f_of_exact_best = wtri(&r, v0, v1, v2, &t) && t > tmin && t < tmax && hit_in_box(&r, v0, v1, v2, t);
+        }
+        if (fp >= 0 && !e_of_float_best) ++out[2];
+        else if (ep >= 0 && !f_of_exact_best) ++out[3];
+        else ++out[4];
+    }
+}
+
 void orc_trace_any(const orc_scene* s, const float* rays, int n, uint8_t* occ_out) {
     for (int i = 0; i < n; ++i) {
         const float* r = &rays[8 * (size_t)i];

@@ -270,3 +270,67 @@ def test_probe_line_search_model_equals_lower_bound():
                     ref = lower_bound_ref(row, np.float32(v))
                 got = model(row, np.float32(v), gk)
                 assert min(got, w) == ref or (got >= w and ref == w), (w, v, got, ref)
+
+
+def _census_rays(orc, sc, cam, n_cam, rng):
+    """camera rays through random points of a 1080p image plane, then — from their hit points — as many bounce rays (uniform directions
+    about the up axis, tmin 1e-3) and as many shadow-like rays (upper hemisphere, tmin 1e-2): the three kinds of rays a frame traces"""
+    U, V, W = scenes.uvw_frame(**cam, aspect=1920 / 1080)
+    x = rng.uniform(-1, 1, n_cam).astype(np.float32)
+    y = rng.uniform(-1, 1, n_cam).astype(np.float32)
+    d = x[:, None] * U[None] + y[:, None] * V[None] + W[None]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    cam_rays = np.zeros((n_cam, 8), np.float32)
+    cam_rays[:, :3] = np.asarray(cam["eye"], np.float32)
+    cam_rays[:, 3] = 1e-3
+    cam_rays[:, 4:7] = d
+    cam_rays[:, 7] = 1e16
+    t, prim = orc.trace_closest(sc, cam_rays)
+    hit = prim >= 0
+    P = (cam_rays[hit, :3] + t[hit, None] * cam_rays[hit, 4:7]).astype(np.float32)
+    out = [cam_rays]
+    for tmin, up_only in ((1e-3, False), (1e-2, True)):
+        dd = rng.standard_normal((len(P), 3)).astype(np.float32)
+        dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+        if up_only:
+            dd[:, 1] = np.abs(dd[:, 1])
+        r = np.zeros((len(P), 8), np.float32)
+        r[:, :3] = P
+        r[:, 3] = tmin
+        r[:, 4:7] = dd
+        r[:, 7] = 1e16
+        out.append(r)
+    return np.concatenate(out)
+
+
+def _census(orc, model, cam, n_cam, seed=7, threads=8):
+    from concurrent.futures import ThreadPoolExecutor
+
+    sc = orc.make_scene(model, use_bvh=True)
+    rays = _census_rays(orc, sc, cam, n_cam, np.random.default_rng(seed))
+    parts = np.array_split(rays, threads)
+    with ThreadPoolExecutor(threads) as ex:  # the C loop runs without the GIL
+        res = list(ex.map(lambda p: orc.hit_census(sc, p), parts))
+    tot = {k: sum(r[k] for r in res) for k in res[0]}
+    return tot
+
+
+def test_hit_in_box_census_against_exact_geometry(orc_det):
+    """VERDICT round 4, "What's weak" 10: how often does the float acceptance rule (sign-consistent triple products + hit_in_box — this
+    repository's definition of optixTrace's answer, the same bits in kernel and checker) return a different closest hit than exact geometry
+    (Moller-Trumbore in double precision on the same vertices)?  Small scenes here; PT_CENSUS_FULL=1 runs the 1 M-triangle terrain and
+    stadium with ~1.5 M rays each and prints the table DESIGN.md section 2 quotes (profiles/r5_07_hit_census.md)."""
+    import os
+
+    full = os.environ.get("PT_CENSUS_FULL") == "1"
+    cases = [("terrain", scenes.voxel_terrain() if full else scenes.voxel_terrain(n=96, target_tris=70000), scenes.TERRAIN_CAMERA),
+             ("stadium", scenes.stadium_scene() if full else scenes.stadium_scene(60000), scenes.STADIUM_CAMERA)]
+    for name, model, cam in cases:
+        c = _census(orc_det, model, cam, 600_000 if full else 40_000)
+        per_m = {k: 1e6 * c[k] / c["rays"] for k in ("accepted_but_inexact", "rejected_but_exact", "order_only")}
+        print(f"\n[census] {name}: {model.num_triangles} triangles, {c['rays']} rays, {c['candidates'] / c['rays']:.1f} candidate triangles per ray; closest hit equal for "
+              f"{100.0 * c['same_closest_hit'] / c['rays']:.5f} %; per million rays: accepted-but-inexact {per_m['accepted_but_inexact']:.1f}, "
+              f"rejected-but-exact {per_m['rejected_but_exact']:.1f}, same two triangles in another order {per_m['order_only']:.1f}; "
+              f"candidates classified differently {c['candidates_classified_differently']} ({1e6 * c['candidates_classified_differently'] / c['candidates']:.2f} per million)")
+        assert c["rays"] > 0 and c["same_closest_hit"] + c["accepted_but_inexact"] + c["rejected_but_exact"] + c["order_only"] == c["rays"]
+        assert c["same_closest_hit"] / c["rays"] > 0.999  # the rule and exact geometry disagree on rays that graze an edge or a needle, nowhere else

@@ -1101,6 +1101,10 @@ k_trace8(Trace8Args a) {
 // Same answer as k_trace8<TR_CLOSEST>, bit for bit: a ray's result is the minimum (t, then primitive) over the triangles its lane tested,
 // every triangle whose padded box the ray enters within (tmin, best] is tested (box tests conservative as in k_trace8, same arithmetic),
 // and a triangle tested "too often" cannot add a hit brute force would not find (hit_in_box confines accepted hits to the triangle's box).
+// Domain: that confinement holds while hit_in_box's tolerance hp + 2^-21 t |d|_1 stays inside the builders' padding 2 hp, i.e.
+// for hits within about 16 scene sizes of the ray's origin; beyond, a rounding-NOISE hit (edge functions that are pure rounding error) accepted
+// by a lane under a node its own ray never entered could differ from the per-ray kernel's answer — genuine hits cannot, they lie inside every
+// box of their triangle.  tests/test_gpu_packets.py renders from 30 scene sizes away with both kernels (equal).
 // Used for the identity queue of bounce 0 only (pt_api.hip); foveated launches queue their paths through sub-queues and keep k_trace8.
 #ifndef PT8_CAM_STACK
 #define PT8_CAM_STACK 64 // groups with children still to visit: at most one per level (pt_create refuses trees deeper than 62 levels)

@@ -495,7 +495,7 @@ def main():
             "ms_per_step_per_rank": per_rank_ms,
             "bvh_build_ms_per_rank": per_rank_build_ms,
             "kernel_ms_per_frame_isolated": None if iso is None else {k: round(iso[k], 3) for k in ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms")},
-            "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2), "hierarchy": ["lbvh", "ploc", "imported"][st["bvh_builder"]]},
+            "bvh": {"nodes": st["bvh_nodes"], "levels": st["bvh_levels"], "bytes": st["bvh_bytes"], "build_ms": round(st["bvh_build_ms"], 2), "hierarchy": ["lbvh", "ploc", "imported", "sah"][st["bvh_builder"]]},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "ms_per_displayed_frame": None if ms_displayed is None else round(ms_displayed, 3),  # loop time / frames handed over, in a loop that hands every launch chain's result over, the exchange overlapping the next chain
             "n_ranks_seen": 1 if dist is None else dist.get_world_size(),  # size of the communicator the collectives ran on (RCCL's for backend nccl)

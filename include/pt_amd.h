@@ -151,8 +151,9 @@ typedef struct pt_stats {
     uint64_t frames;        /* frames completed since pt_create, and the rays they traced: take differences around a */
     uint64_t total_radiance_rays; /* sequence of pt_render calls (pt_get_stats itself waits for the frames in flight) */
     uint64_t total_shadow_rays;
-    uint32_t bvh_builder;   /* hierarchy under the wide tree: 0 = LBVH (Morton order), 1 = PLOC.  pt_create builds both and keeps the one through which
-                             * a fixed batch of calibration rays takes fewer traversal steps; PT_BVH_BUILDER=lbvh|ploc forces one.  Images do not
+    uint32_t bvh_builder;   /* hierarchy under the wide tree: 0 = LBVH (Morton order), 1 = PLOC, 2 = imported (PT_BVH_IMPORT), 3 = binned SAH (round 5).
+                             * pt_create builds the three and keeps the one through which a fixed batch of calibration rays takes fewest traversal
+                             * steps; PT_BVH_BUILDER=lbvh|ploc|sah forces one, PT_BVH_SAH=0 leaves the SAH candidate out.  Images do not
                              * depend on the choice (closest hit, lowest primitive on ties, hits confined to the triangle's padded box). */
     uint32_t reserved_;
 } pt_stats;

@@ -783,7 +783,7 @@ __global__ void k_single_node8(int n, const float* __restrict__ bounds6, float p
 // lane and 1024 waves leave the chip latency-bound, so two launches cost twice one.
 __global__ void __launch_bounds__(64) k_calibrate8(const Node8* __restrict__ nodes_a, const LeafTri* __restrict__ tris_a, const Node8* __restrict__ nodes_b,
                                                    const LeafTri* __restrict__ tris_b, const LeafTri* __restrict__ src,
-                                                   uint32_t ntri, uint32_t nrays, float hp, unsigned long long* __restrict__ counts, Grid8 grid) {
+                                                   uint32_t ntri, uint32_t nrays, float hp, unsigned long long* __restrict__ counts, Grid8 grid, int mode, float4 sphere) {
     const uint32_t half = (nrays + 63u) / 64u;
     const bool second = blockIdx.x >= half;
     const Node8* __restrict__ nodes = second ? nodes_b : nodes_a;
@@ -800,10 +800,38 @@ __global__ void __launch_bounds__(64) k_calibrate8(const Node8* __restrict__ nod
         const LeafTri ta = src[ia], tb = src[ib];
         const v3 ca = mk3((ta.t0.x + ta.t0.w + ta.t1.z) * (1.f / 3.f), (ta.t0.y + ta.t1.x + ta.t1.w) * (1.f / 3.f), (ta.t0.z + ta.t1.y + ta.t2.x) * (1.f / 3.f));
         const v3 cb = mk3((tb.t0.x + tb.t0.w + tb.t1.z) * (1.f / 3.f), (tb.t0.y + tb.t1.x + tb.t1.w) * (1.f / 3.f), (tb.t0.z + tb.t1.y + tb.t2.x) * (1.f / 3.f));
+        v3 org = ca;
         v3 d = sub3(cb, ca);
-        const float dl = sqrtf(dot3(d, d));
-        d = dl > 0.f ? scl3(d, 1.0f / dl) : mk3(0.f, 1.f, 0.f);
-        RaySetup r = ray_setup(ca, d);
+        float dl = sqrtf(dot3(d, d));
+        if (mode == 1) {
+            // the rays of a frame rather than segments between triangles (round 5: the segments preferred the LBVH on the voxel terrain, where the
+            // SAH tree renders 1.5 % faster): odd rays leave a triangle in a uniform direction of the hemisphere about its geometric normal (bounce and
+            // shadow rays), even rays come from a point outside the scene towards a triangle (camera rays); everything by hashes of the ray index
+            h = h * 2891336453u + 1013904223u; h ^= h >> 15;
+            const float u1 = (float)(h & 0xffffu) * (1.0f / 65536.0f), u2 = (float)(h >> 16) * (1.0f / 65536.0f);
+            if (i & 1u) {
+                const v3 v0 = mk3(ta.t0.x, ta.t0.y, ta.t0.z), v1 = mk3(ta.t0.w, ta.t1.x, ta.t1.y), v2 = mk3(ta.t1.z, ta.t1.w, ta.t2.x);
+                v3 nrm = cross3(sub3(v1, v0), sub3(v2, v0));
+                const float nl = sqrtf(dot3(nrm, nrm));
+                nrm = nl > 0.f ? scl3(nrm, ((ib & 1u) ? -1.0f : 1.0f) / nl) : mk3(0.f, 1.f, 0.f);
+                const v3 ax = fabsf(nrm.x) > 0.9f ? mk3(0.f, 1.f, 0.f) : mk3(1.f, 0.f, 0.f);
+                v3 tt = cross3(ax, nrm);
+                tt = scl3(tt, 1.0f / sqrtf(dot3(tt, tt)));
+                const v3 bb = cross3(nrm, tt);
+                const float z = u1, rr = sqrtf(fmaxf(0.f, 1.f - z * z)), phi = 6.2831853f * u2;
+                d = add3(add3(scl3(tt, rr * cosf(phi)), scl3(bb, rr * sinf(phi))), scl3(nrm, z));
+                dl = sphere.w;
+            } else {
+                const float z = 1.f - 2.f * u1, rr = sqrtf(fmaxf(0.f, 1.f - z * z)), phi = 6.2831853f * u2;
+                org = add3(mk3(sphere.x, sphere.y, sphere.z), scl3(mk3(rr * cosf(phi), z, rr * sinf(phi)), 1.5f * sphere.w));
+                d = sub3(ca, org);
+                dl = sqrtf(dot3(d, d));
+                d = dl > 0.f ? scl3(d, 1.0f / dl) : mk3(0.f, 1.f, 0.f);
+            }
+        } else {
+            d = dl > 0.f ? scl3(d, 1.0f / dl) : mk3(0.f, 1.f, 0.f);
+        }
+        RaySetup r = ray_setup(org, d);
         if (!(fabsf(d.x) > 1e-30f)) r.idir.x = copysignf(1e30f, d.x);
         if (!(fabsf(d.y) > 1e-30f)) r.idir.y = copysignf(1e30f, d.y);
         if (!(fabsf(d.z) > 1e-30f)) r.idir.z = copysignf(1e30f, d.z);
@@ -1139,6 +1167,441 @@ static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt,
     return hipSuccess;
 }
 
+// ------------------------------------------------------------------ binned SAH, top-down (round 5: the third hierarchy the calibration chooses from)
+// Wald 2007's binned surface-area heuristic, built breadth-first on the GPU.  The leaves are the Morton-sorted triangles (leaf i = node
+// n - 1 + i, its box in box[]), prim[] holds them partitioned by node: a node owns the positions [first, first + count).
+//   * Nodes with more than SAH_SMALL leaves are split level by level: every leaf drops its box into one of SAH_BINS bins per axis (bins
+//     over the node's box, by centroid) — accumulated in LDS for the node that dominates a workgroup, because a same-address global atomic
+//     costs 10.5 ns on this chip and the top levels have a few nodes and a million leaves (tools/micro/xw_probe.hip) —, one thread per node
+//     sweeps the 3 x 15 candidate planes for the smallest A_L N_L + A_R N_R (no candidate with an empty side: the leaves are halved by
+//     position instead), creates the two children with their exact boxes (unions of bins) and the leaves are partitioned by one
+//     exclusive scan of the "goes left" flags and a scatter.  One 16-byte read-back per level tells the host how many large nodes are left.
+//   * A child with at most SAH_SMALL leaves is finished later by ONE thread: exact sweep SAH (every axis, every position of the sorted
+//     centroids) down to single leaves.
+// Node numbering is handed out by atomic counters (like k_collapse8's): the TREE is deterministic, the numbers are not.
+#define SAH_BINS 16
+#define SAH_SMALL 8
+#define SAH_WG 1024
+#define SAH_BIG 8192 // nodes with more leaves are binned by position windows (k_sah_bin: LDS per window, global atomics to merge), smaller ones by a wave of their own
+struct SahBin { // per node slot, axis, bin: box of the leaves (ordered-uint floats) and their number
+    uint32_t lo[3], hi[3], count;
+};
+struct SahCtl { // device counters of a build
+    uint32_t next_id;     // next internal node id
+    uint32_t nlarge_next; // large nodes created for the next level
+    uint32_t nsmall;      // small subtrees waiting for k_sah_small
+    uint32_t nbig_next;   // of the large nodes of the next level: those with more than SAH_BIG leaves
+};
+__device__ __forceinline__ int sah_bin_of(float c, float lo, float hi) {
+    const float ext = hi - lo;
+    if (!(ext > 0.f)) return 0;
+    int b = (int)((c - lo) * ((float)SAH_BINS / ext));
+    return b < 0 ? 0 : (b > SAH_BINS - 1 ? SAH_BINS - 1 : b);
+}
+__global__ void k_sah_init(int n, int* __restrict__ prim, int* __restrict__ node_of, int large_root) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    prim[i] = i;
+    node_of[i] = large_root ? 0 : -1;
+}
+__global__ void k_sah_clear_bins(SahBin* __restrict__ bins, uint32_t nwords) { // lo = +inf, hi = -inf (ordered), count = 0
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwords) return;
+    const uint32_t w = i % 7u;
+    reinterpret_cast<uint32_t*>(bins)[i] = w < 3u ? 0xffffffffu : 0u;
+}
+// every leaf of a large node into its three bins
+// One wave per node of at most SAH_BIG leaves: the node's leaves binned in LDS that only this wave touches, the bins then stored as they are — no
+// global atomic (the first version binned every leaf of every node with 21 device-scope atomics: 21 M per level, 0.5 ms per level).
+__global__ void __launch_bounds__(256) k_sah_bin_node(const int* __restrict__ active, int nactive, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ first,
+                                                      const int* __restrict__ cnt, const int* __restrict__ slot_of, const float* __restrict__ box, SahBin* __restrict__ bins) {
+    __shared__ uint32_t s_all[4][3 * SAH_BINS * 7];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    uint32_t* s_bins = s_all[wave];
+    for (int k = lane; k < 3 * SAH_BINS * 7; k += 64) s_bins[k] = (k % 7) < 3 ? 0xffffffffu : 0u;
+    __syncthreads();
+    const int node = t < nactive ? active[t] : -1;
+    const int m = node >= 0 ? cnt[node] : 0;
+    if (node >= 0 && m <= SAH_BIG) {
+        const int f = first[node];
+        const float* nb = &box[(size_t)node * 6];
+        const float nlo[3] = {nb[0], nb[1], nb[2]}, nhi[3] = {nb[3], nb[4], nb[5]};
+        for (int i = f + lane; i < f + m; i += 64) {
+            const float* b = &box[(size_t)(nleaf_base + prim[i]) * 6];
+            const float blo[3] = {b[0], b[1], b[2]}, bhi[3] = {b[3], b[4], b[5]};
+            for (int a = 0; a < 3; ++a) {
+                uint32_t* w = &s_bins[(a * SAH_BINS + sah_bin_of(0.5f * (blo[a] + bhi[a]), nlo[a], nhi[a])) * 7];
+                for (int k = 0; k < 3; ++k) {
+                    atomicMin(&w[k], f2ord(blo[k]));
+                    atomicMax(&w[3 + k], f2ord(bhi[k]));
+                }
+                atomicAdd(&w[6], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (node >= 0 && m <= SAH_BIG) {
+        uint32_t* g = reinterpret_cast<uint32_t*>(&bins[(size_t)slot_of[node] * 3 * SAH_BINS]);
+        for (int k = lane; k < 3 * SAH_BINS * 7; k += 64) g[k] = s_bins[k];
+    }
+}
+// (big nodes: the window's LDS bins go to partial[window] with plain stores and k_sah_reduce merges the windows of a node — 1024 workgroups
+// flushing 336 atomics each into the same eleven cache lines serialised at 10.5 ns per atomic: 290 us per level)
+__global__ void __launch_bounds__(SAH_WG) k_sah_bin(int n, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ node_of, const int* __restrict__ slot_of,
+                                                    const int* __restrict__ cnt, const float* __restrict__ box, SahBin* __restrict__ bins,
+                                                    uint32_t* __restrict__ partial, int* __restrict__ partial_node) {
+    // a set of bins per wave (16 x 1344 bytes): a thousand threads on one set spend their time in LDS atomic conflicts (284 us per level)
+    __shared__ uint32_t s_wbins[SAH_WG / 64][3 * SAH_BINS * 7];
+    __shared__ int s_first;
+    const int i = blockIdx.x * SAH_WG + threadIdx.x;
+    uint32_t* const s_bins = s_wbins[threadIdx.x >> 6];
+    for (int k = threadIdx.x; k < (SAH_WG / 64) * 3 * SAH_BINS * 7; k += SAH_WG) (&s_wbins[0][0])[k] = (k % 7) < 3 ? 0xffffffffu : 0u;
+    if (threadIdx.x == 0) s_first = 0x7fffffff;
+    __syncthreads();
+    int node = i < n ? node_of[i] : -1;
+    if (node >= 0 && cnt[node] <= SAH_BIG) node = -1; // a wave of its own bins that node (k_sah_bin_node)
+    if (node >= 0) atomicMin(&s_first, (int)threadIdx.x);
+    __syncthreads();
+    if (s_first == 0x7fffffff) { // no big node in this window
+        if (threadIdx.x == 0) partial_node[blockIdx.x] = -1;
+        return;
+    }
+    const int node0 = node_of[blockIdx.x * SAH_WG + s_first]; // the node of the window's first active position: privatised in LDS
+    if (node >= 0) {
+        const float* b = &box[(size_t)(nleaf_base + prim[i]) * 6];
+        const float* nb = &box[(size_t)node * 6];
+        const uint32_t olo[3] = {f2ord(b[0]), f2ord(b[1]), f2ord(b[2])}, ohi[3] = {f2ord(b[3]), f2ord(b[4]), f2ord(b[5])};
+        for (int a = 0; a < 3; ++a) {
+            const int bi = sah_bin_of(0.5f * (b[a] + b[3 + a]), nb[a], nb[3 + a]);
+            uint32_t* w = node == node0 ? &s_bins[(a * SAH_BINS + bi) * 7] : reinterpret_cast<uint32_t*>(&bins[((size_t)slot_of[node] * 3 + a) * SAH_BINS + bi]);
+            for (int k = 0; k < 3; ++k) {
+                atomicMin(&w[k], olo[k]);
+                atomicMax(&w[3 + k], ohi[k]);
+            }
+            atomicAdd(&w[6], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) partial_node[blockIdx.x] = node0;
+    for (int k = threadIdx.x; k < 3 * SAH_BINS * 7; k += SAH_WG) {
+        const int w = k % 7;
+        uint32_t acc = w < 3 ? 0xffffffffu : 0u;
+        for (int v = 0; v < SAH_WG / 64; ++v) {
+            const uint32_t x = s_wbins[v][k];
+            acc = w < 3 ? min(acc, x) : (w < 6 ? max(acc, x) : acc + x);
+        }
+        partial[(size_t)blockIdx.x * (3 * SAH_BINS * 7) + k] = acc;
+    }
+}
+// one workgroup per big node: merges the partial bins of the windows the node covers into its (cleared) bins, where the few leaves that
+// shared a window with another big node already arrived by atomics
+__global__ void __launch_bounds__(3 * SAH_BINS * 7) k_sah_reduce(const int* __restrict__ active, int nactive, const int* __restrict__ first, const int* __restrict__ cnt,
+                                                                  const int* __restrict__ slot_of, const uint32_t* __restrict__ partial, const int* __restrict__ partial_node,
+                                                                  SahBin* __restrict__ bins) {
+    const int node = active[blockIdx.x];
+    const int m = cnt[node];
+    if (m <= SAH_BIG) return;
+    const int f = first[node], w0 = f / SAH_WG, w1 = (f + m - 1) / SAH_WG;
+    const int k = threadIdx.x, w = k % 7;
+    uint32_t acc = w < 3 ? 0xffffffffu : 0u;
+    for (int win = w0; win <= w1; ++win) {
+        if (partial_node[win] != node) continue;
+        const uint32_t v = partial[(size_t)win * (3 * SAH_BINS * 7) + k];
+        acc = w < 3 ? min(acc, v) : (w < 6 ? max(acc, v) : acc + v);
+    }
+    uint32_t* g = reinterpret_cast<uint32_t*>(&bins[(size_t)slot_of[node] * 3 * SAH_BINS]);
+    if (w < 3) { if (acc != 0xffffffffu) atomicMin(&g[k], acc); }
+    else if (w < 6) { if (acc != 0u) atomicMax(&g[k], acc); }
+    else if (acc != 0u) atomicAdd(&g[k], acc);
+}
+__device__ __forceinline__ float sah_area(const float* lo, const float* hi) {
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+// one thread per large node of this level: the split, the children (ids, ranges, boxes), who is large next
+__global__ void k_sah_split(const int* __restrict__ active, int nactive, int n, const SahBin* __restrict__ bins, const int* __restrict__ slot_of, int* __restrict__ first,
+                            int* __restrict__ cnt, float* __restrict__ box, int* __restrict__ left, int* __restrict__ right, int* __restrict__ split,
+                            int* __restrict__ slot_next, int* __restrict__ active_next, int* __restrict__ small_list, SahCtl* __restrict__ ctl) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nactive) return;
+    const int node = active[t];
+    const SahBin* nb = &bins[(size_t)slot_of[node] * 3 * SAH_BINS];
+    const int m = cnt[node], f = first[node];
+    float best = INFINITY;
+    int best_axis = -1, best_bin = 0, best_nl = 0;
+    float blo[2][3], bhi[2][3]; // boxes of the best split's sides
+    for (int a = 0; a < 3; ++a) {
+        // suffix boxes of the bins (area and count of "bins j+1 .."), then a prefix sweep
+        float ra[SAH_BINS];
+        int rn[SAH_BINS];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        int cn = 0;
+        for (int j = SAH_BINS - 1; j >= 1; --j) {
+            const SahBin& b = nb[a * SAH_BINS + j];
+            if (b.count) {
+                for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], ord2f(b.lo[k])); hi[k] = fmaxf(hi[k], ord2f(b.hi[k])); }
+                cn += (int)b.count;
+            }
+            ra[j - 1] = cn ? sah_area(lo, hi) : 0.f;
+            rn[j - 1] = cn;
+        }
+        for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+        cn = 0;
+        for (int j = 0; j < SAH_BINS - 1; ++j) {
+            const SahBin& b = nb[a * SAH_BINS + j];
+            if (b.count) {
+                for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], ord2f(b.lo[k])); hi[k] = fmaxf(hi[k], ord2f(b.hi[k])); }
+                cn += (int)b.count;
+            }
+            if (cn == 0 || rn[j] == 0) continue;
+            const float c = sah_area(lo, hi) * (float)cn + ra[j] * (float)rn[j];
+            if (c < best) { best = c; best_axis = a; best_bin = j; best_nl = cn; }
+        }
+    }
+    int nl;
+    if (best_axis < 0) { // every centroid in one bin on every axis: halve by position; the children's boxes are the node's (a superset: conservative)
+        nl = m / 2;
+        split[node] = -1 - nl;
+        for (int k = 0; k < 3; ++k) { blo[0][k] = blo[1][k] = box[(size_t)node * 6 + k]; bhi[0][k] = bhi[1][k] = box[(size_t)node * 6 + 3 + k]; }
+    } else {
+        nl = best_nl;
+        split[node] = best_axis | (best_bin << 2);
+        for (int s = 0; s < 2; ++s) {
+            for (int k = 0; k < 3; ++k) { blo[s][k] = INFINITY; bhi[s][k] = -INFINITY; }
+            for (int j = s ? best_bin + 1 : 0; j <= (s ? SAH_BINS - 1 : best_bin); ++j) {
+                const SahBin& b = nb[best_axis * SAH_BINS + j];
+                if (!b.count) continue;
+                for (int k = 0; k < 3; ++k) { blo[s][k] = fminf(blo[s][k], ord2f(b.lo[k])); bhi[s][k] = fmaxf(bhi[s][k], ord2f(b.hi[k])); }
+            }
+        }
+    }
+    for (int s = 0; s < 2; ++s) {
+        const int cf = s ? f + nl : f, cm = s ? m - nl : nl;
+        int child;
+        if (cm == 1) {
+            child = -2 - cf; // a single leaf: the scatter writes n - 1 + (the leaf that lands on position cf)
+        } else {
+            child = (int)atomicAdd(&ctl->next_id, 1u);
+            first[child] = cf;
+            cnt[child] = cm;
+            for (int k = 0; k < 3; ++k) { box[(size_t)child * 6 + k] = blo[s][k]; box[(size_t)child * 6 + 3 + k] = bhi[s][k]; }
+            if (cm > SAH_SMALL) {
+                const int sl = (int)atomicAdd(&ctl->nlarge_next, 1u);
+                slot_next[child] = sl;
+                active_next[sl] = child;
+                if (cm > SAH_BIG) atomicAdd(&ctl->nbig_next, 1u);
+            } else {
+                small_list[atomicAdd(&ctl->nsmall, 1u)] = child;
+            }
+        }
+        (s ? right : left)[node] = child;
+    }
+}
+__global__ void k_sah_flag(int n, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ node_of, const int* __restrict__ first, const int* __restrict__ split,
+                           const float* __restrict__ box, uint32_t* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    uint32_t f = 0u;
+    if (i < n) {
+        const int node = node_of[i];
+        if (node >= 0) {
+            const int sp = split[node];
+            if (sp < 0) {
+                f = (i - first[node]) < (-1 - sp) ? 1u : 0u;
+            } else {
+                const int a = sp & 3;
+                const float* b = &box[(size_t)(nleaf_base + prim[i]) * 6];
+                const float* nb = &box[(size_t)node * 6];
+                f = sah_bin_of(0.5f * (b[a] + b[3 + a]), nb[a], nb[3 + a]) <= (sp >> 2) ? 1u : 0u;
+            }
+        }
+    }
+    flag[i] = f; // flag[n] = 0: the scan's last entry is the total
+}
+__global__ void k_sah_scatter(int n, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ node_of, const int* __restrict__ first, const int* __restrict__ cnt_of,
+                              const uint32_t* __restrict__ flag, const uint32_t* __restrict__ scan, int* __restrict__ left, int* __restrict__ right,
+                              int* __restrict__ prim_out, int* __restrict__ node_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int node = node_of[i];
+    if (node < 0) { // finished or small: stays where it is
+        prim_out[i] = prim[i];
+        node_out[i] = -1;
+        return;
+    }
+    const int f = first[node], m = cnt_of[node];
+    const int nl = (int)(scan[f + m] - scan[f]);
+    const int rl = (int)(scan[i] - scan[f]);
+    const bool goes_left = flag[i] != 0u;
+    const int pos = goes_left ? f + rl : f + nl + ((i - f) - rl);
+    const int p = prim[i];
+    prim_out[pos] = p;
+    const int child = goes_left ? left[node] : right[node];
+    if (child <= -2) { // the child is this single leaf
+        (goes_left ? left : right)[node] = nleaf_base + p;
+        node_out[pos] = -1;
+    } else {
+        node_out[pos] = cnt_of[child] > SAH_SMALL ? child : -1;
+    }
+}
+// one thread per small subtree (2 .. SAH_SMALL leaves): exact sweep SAH down to single leaves
+__global__ void k_sah_small(const int* __restrict__ small_list, int nsmall, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ first, int* __restrict__ cnt,
+                            float* __restrict__ box, int* __restrict__ left, int* __restrict__ right, SahCtl* __restrict__ ctl) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nsmall) return;
+    const int root = small_list[t];
+    const int m0 = cnt[root], f0 = first[root];
+    int id[SAH_SMALL];       // leaves of the subtree, reordered as the splits go
+    float lo[SAH_SMALL][3], hi[SAH_SMALL][3];
+    for (int k = 0; k < m0; ++k) {
+        id[k] = prim[f0 + k];
+        const float* b = &box[(size_t)(nleaf_base + id[k]) * 6];
+        for (int a = 0; a < 3; ++a) { lo[k][a] = b[a]; hi[k][a] = b[3 + a]; }
+    }
+    int next = m0 > 2 ? (int)atomicAdd(&ctl->next_id, (uint32_t)(m0 - 2)) : 0; // the subtree has m0 - 1 internal nodes, `root` is one of them
+    int st_node[SAH_SMALL], st_f[SAH_SMALL], st_m[SAH_SMALL], sp = 0;
+    st_node[0] = root; st_f[0] = 0; st_m[0] = m0; sp = 1;
+    while (sp) {
+        --sp;
+        const int node = st_node[sp], f = st_f[sp], m = st_m[sp];
+        // node box
+        float nlo[3] = {INFINITY, INFINITY, INFINITY}, nhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = f; k < f + m; ++k)
+            for (int a = 0; a < 3; ++a) { nlo[a] = fminf(nlo[a], lo[k][a]); nhi[a] = fmaxf(nhi[a], hi[k][a]); }
+        for (int a = 0; a < 3; ++a) { box[(size_t)node * 6 + a] = nlo[a]; box[(size_t)node * 6 + 3 + a] = nhi[a]; }
+        cnt[node] = m;
+        int nl = m / 2;
+        if (m > 2) {
+            float best = INFINITY;
+            int best_axis = 0;
+            for (int a = 0; a < 3; ++a) {
+                // insertion sort of [f, f+m) by centroid along a (keeps id / lo / hi together)
+                for (int i = f + 1; i < f + m; ++i)
+                    for (int j = i; j > f && (lo[j][a] + hi[j][a]) < (lo[j - 1][a] + hi[j - 1][a]); --j) {
+                        const int ti = id[j]; id[j] = id[j - 1]; id[j - 1] = ti;
+                        for (int k = 0; k < 3; ++k) {
+                            const float tl = lo[j][k]; lo[j][k] = lo[j - 1][k]; lo[j - 1][k] = tl;
+                            const float th = hi[j][k]; hi[j][k] = hi[j - 1][k]; hi[j - 1][k] = th;
+                        }
+                    }
+                float ra[SAH_SMALL];
+                float slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (int k = f + m - 1; k > f; --k) {
+                    for (int c = 0; c < 3; ++c) { slo[c] = fminf(slo[c], lo[k][c]); shi[c] = fmaxf(shi[c], hi[k][c]); }
+                    ra[k - f] = sah_area(slo, shi);
+                }
+                for (int c = 0; c < 3; ++c) { slo[c] = INFINITY; shi[c] = -INFINITY; }
+                for (int k = f; k < f + m - 1; ++k) {
+                    for (int c = 0; c < 3; ++c) { slo[c] = fminf(slo[c], lo[k][c]); shi[c] = fmaxf(shi[c], hi[k][c]); }
+                    const int cl = k - f + 1;
+                    const float c = sah_area(slo, shi) * (float)cl + ra[cl] * (float)(m - cl);
+                    if (c < best) { best = c; best_axis = a; nl = cl; }
+                }
+            }
+            if (best_axis != 2) // the leaves are sorted along axis 2 now: put them back in the best axis' order
+                for (int i = f + 1; i < f + m; ++i)
+                    for (int j = i; j > f && (lo[j][best_axis] + hi[j][best_axis]) < (lo[j - 1][best_axis] + hi[j - 1][best_axis]); --j) {
+                        const int ti = id[j]; id[j] = id[j - 1]; id[j - 1] = ti;
+                        for (int k = 0; k < 3; ++k) {
+                            const float tl = lo[j][k]; lo[j][k] = lo[j - 1][k]; lo[j - 1][k] = tl;
+                            const float th = hi[j][k]; hi[j][k] = hi[j - 1][k]; hi[j - 1][k] = th;
+                        }
+                    }
+        }
+        for (int s = 0; s < 2; ++s) {
+            const int cf = s ? f + nl : f, cm = s ? m - nl : nl;
+            int child;
+            if (cm == 1) {
+                child = nleaf_base + id[cf];
+            } else {
+                child = next++;
+                st_node[sp] = child; st_f[sp] = cf; st_m[sp] = cm; ++sp;
+            }
+            (s ? right : left)[node] = child;
+        }
+    }
+}
+
+static hipError_t build_sah(int n, int* left, int* right, float* box, int* cnt, const float bounds[6], hipStream_t stream, int* root_out) {
+    ArenaMark mark;
+    DevFrees mem;
+    const int nleaf_base = n - 1, B = 256;
+    int *prim[2] = {nullptr, nullptr}, *node_of[2] = {nullptr, nullptr}, *first = nullptr, *split = nullptr, *slot[2] = {nullptr, nullptr}, *active[2] = {nullptr, nullptr}, *small_list = nullptr;
+    uint32_t *flag = nullptr, *scan = nullptr;
+    SahCtl* ctl = nullptr;
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(mem.alloc(&prim[k], sizeof(int) * (size_t)n));
+        HIPCHK(mem.alloc(&node_of[k], sizeof(int) * (size_t)n));
+        HIPCHK(mem.alloc(&slot[k], sizeof(int) * (size_t)n));
+        HIPCHK(mem.alloc(&active[k], sizeof(int) * (size_t)(n / SAH_SMALL + 2)));
+    }
+    HIPCHK(mem.alloc(&first, sizeof(int) * (size_t)n));
+    HIPCHK(mem.alloc(&split, sizeof(int) * (size_t)n));
+    HIPCHK(mem.alloc(&small_list, sizeof(int) * (size_t)(n / 2 + 2)));
+    HIPCHK(mem.alloc(&flag, sizeof(uint32_t) * ((size_t)n + 1)));
+    HIPCHK(mem.alloc(&scan, sizeof(uint32_t) * ((size_t)n + 1)));
+    HIPCHK(mem.alloc(&ctl, sizeof(SahCtl)));
+    uint32_t* partial = nullptr; // per position window: the LDS bins of the window's first big node, and which node that was
+    int* partial_node = nullptr;
+    const size_t nwin = ((size_t)n + SAH_WG - 1) / SAH_WG;
+    HIPCHK(mem.alloc(&partial, sizeof(uint32_t) * 3 * SAH_BINS * 7 * nwin));
+    HIPCHK(mem.alloc(&partial_node, sizeof(int) * nwin));
+    // bins of the large nodes of one level: at most n / (SAH_SMALL + 1) of them
+    const size_t max_large = (size_t)n / (SAH_SMALL + 1) + 2;
+    SahBin* bins = nullptr;
+    HIPCHK(hipMalloc((void**)&bins, sizeof(SahBin) * 3 * SAH_BINS * max_large)); // (not from the arena: 1.3 KB per node)
+    struct BinsFree { SahBin* p; ~BinsFree() { hipFree(p); } } bins_free{bins};
+    size_t tmp_bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, flag, scan, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
+    void* tmp = nullptr;
+    HIPCHK(mem.alloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    // root = internal node 0 over all leaves, its box = the scene's bounds
+    const bool large_root = n > SAH_SMALL;
+    SahCtl h{1u, 0u, large_root ? 0u : 1u, 0u};
+    HIPCHK(hipMemcpyAsync(ctl, &h, sizeof(h), hipMemcpyHostToDevice, stream));
+    const int zero = 0;
+    HIPCHK(hipMemcpyAsync(first, &zero, sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(cnt, &n, sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(box, bounds, sizeof(float) * 6, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(slot[0], &zero, sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(large_root ? active[0] : small_list, &zero, sizeof(int), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_sah_init, dim3((n + B - 1) / B), dim3(B), 0, stream, n, prim[0], node_of[0], large_root ? 1 : 0);
+    int cur = 0, nactive = large_root ? 1 : 0, nbig = n > SAH_BIG ? 1 : 0, levels = 0;
+    while (nactive > 0) {
+        const uint32_t nwords = (uint32_t)((size_t)nactive * 3 * SAH_BINS * 7);
+        hipLaunchKernelGGL(k_sah_clear_bins, dim3((nwords + B - 1) / B), dim3(B), 0, stream, bins, nwords);
+        if (nbig > 0) {
+            hipLaunchKernelGGL(k_sah_bin, dim3((n + SAH_WG - 1) / SAH_WG), dim3(SAH_WG), 0, stream, n, nleaf_base, prim[cur], node_of[cur], slot[cur], cnt, box, bins, partial, partial_node);
+            hipLaunchKernelGGL(k_sah_reduce, dim3(nactive), dim3(3 * SAH_BINS * 7), 0, stream, active[cur], nactive, first, cnt, slot[cur], partial, partial_node, bins);
+        }
+        hipLaunchKernelGGL(k_sah_bin_node, dim3((nactive + 3) / 4), dim3(256), 0, stream, active[cur], nactive, nleaf_base, prim[cur], first, cnt, slot[cur], box, bins);
+        hipLaunchKernelGGL(k_sah_split, dim3((nactive + 63) / 64), dim3(64), 0, stream, active[cur], nactive, n, bins, slot[cur], first, cnt, box, left, right, split,
+                           slot[cur ^ 1], active[cur ^ 1], small_list, ctl);
+        hipLaunchKernelGGL(k_sah_flag, dim3((n + 1 + B - 1) / B), dim3(B), 0, stream, n, nleaf_base, prim[cur], node_of[cur], first, split, box, flag);
+        HIPCHK(rocprim::exclusive_scan(tmp, tmp_bytes, flag, scan, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
+        hipLaunchKernelGGL(k_sah_scatter, dim3((n + B - 1) / B), dim3(B), 0, stream, n, nleaf_base, prim[cur], node_of[cur], first, cnt, flag, scan, left, right,
+                           prim[cur ^ 1], node_of[cur ^ 1]);
+        HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        nactive = (int)h.nlarge_next;
+        nbig = (int)h.nbig_next;
+        if ((size_t)nactive > max_large || h.next_id > (uint32_t)(n - 1) || ++levels > 4096) return hipErrorUnknown;
+        const uint32_t z = 0;
+        HIPCHK(hipMemcpyAsync(&ctl->nlarge_next, &z, sizeof(z), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(&ctl->nbig_next, &z, sizeof(z), hipMemcpyHostToDevice, stream));
+        cur ^= 1;
+    }
+    if (h.nsmall) hipLaunchKernelGGL(k_sah_small, dim3((h.nsmall + 63) / 64), dim3(64), 0, stream, small_list, (int)h.nsmall, nleaf_base, prim[cur], first, cnt, box, left, right, ctl);
+    HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipGetLastError());
+    if (h.next_id != (uint32_t)(n - 1)) return hipErrorUnknown; // a binary tree over n leaves has n - 1 internal nodes
+    if (getenv("PT_DEBUG_BVH")) fprintf(stderr, "[pt_bvh] binned SAH: %d levels of large nodes, %u small subtrees\n", levels, h.nsmall);
+    *root_out = 0;
+    return hipSuccess;
+}
+
 // Experiment hook (PT_BVH_IMPORT=file): a binary hierarchy built elsewhere over the same triangles replaces the internal nodes.  File: int32 n,
 // then n-1 pairs (left, right) of int32, node 0 = root, a child >= 0 is an internal node, a child < 0 is primitive ~child.
 static hipError_t import_hierarchy(const char* path, int n, const uint64_t* keys_sorted, int* left, int* right, float* box, int* cnt, hipStream_t stream, int* root_out) {
@@ -1325,50 +1788,69 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
         hipLaunchKernelGGL(k_counts_from_ranges, dim3((2 * n + B - 1) / B), dim3(B), 0, stream, n, rfirst, rlast, cnt);
         int root = 0;
         const char* builder = getenv("PT_BVH_BUILDER");
-        const bool force_lbvh = builder && strcmp(builder, "lbvh") == 0, force_ploc = builder && strcmp(builder, "ploc") == 0;
+        const bool force_lbvh = builder && strcmp(builder, "lbvh") == 0, force_ploc = builder && strcmp(builder, "ploc") == 0, force_sah = builder && strcmp(builder, "sah") == 0;
         if (force_ploc) HIPCHK(build_ploc(n, left, right, box, cnt, stream, &root));
+        if (force_sah) HIPCHK(build_sah(n, left, right, box, cnt, out->bounds, stream, &root));
         const char* import = getenv("PT_BVH_IMPORT");
         if (import) HIPCHK(import_hierarchy(import, n, keys_sorted, left, right, box, cnt, stream, &root));
-        HIPCHK(build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, out, (force_ploc || import) ? nullptr : &lbvh_levels));
+        HIPCHK(build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, out, (force_ploc || force_sah || import) ? nullptr : &lbvh_levels));
         lbvh_levels.release();
         pc.mark("wide tree 1");
-        out->builder = import ? 2 : force_ploc ? 1 : 0;
+        out->builder = import ? 2 : force_sah ? 3 : force_ploc ? 1 : 0;
         if (import) { tfree(cnt); goto done; }
-        if (!force_lbvh && !force_ploc && n >= 4096) {
-            // both hierarchies, the one that costs the calibration rays less (see k_calibrate8); small scenes keep the LBVH
-            PtBvh alt;
-            alt.grid = out->grid; // same scene, same origin grid
-            hipError_t pe = build_ploc(n, left, right, box, cnt, stream, &root); // overwrites the LBVH's internal nodes: the first wide tree is already emitted
-            pc.mark("ploc hierarchy");
-            if (pe == hipSuccess) pe = build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, &alt);
-            pc.mark("wide tree 2");
-            if (pe != hipSuccess) { // the alternative is optional: the LBVH tree stands
-                (void)hipGetLastError();
-                pt_bvh_free(&alt);
-                tfree(cnt);
-                goto done;
-            }
-            unsigned long long* counts = nullptr;
-            unsigned long long hcnt[4] = {0, 0, 0, 0};
-            HIPCHK(tmalloc(&counts, sizeof(hcnt)));
-            HIPCHK(hipMemsetAsync(counts, 0, sizeof(hcnt), stream));
-            const uint32_t nrays = 1u << 16;
-            hipLaunchKernelGGL(k_calibrate8, dim3(2 * (nrays / 64)), dim3(64), 0, stream, out->nodes8, out->tris8, alt.nodes8, alt.tris8, tris, (uint32_t)n, nrays, 0.5f * pad, counts, out->grid);
-            HIPCHK(hipMemcpyAsync(hcnt, counts, sizeof(hcnt), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            tfree(counts);
-            pc.mark("calibration");
-            // a triangle step costs the traversal kernel about 0.6 node steps (≈110 against ≈185 instructions)
-            const double cost_lbvh = (double)hcnt[0] + 0.6 * (double)hcnt[1], cost_ploc = (double)hcnt[2] + 0.6 * (double)hcnt[3];
-            if (getenv("PT_DEBUG_BVH"))
-                fprintf(stderr, "[pt_bvh] calibration (%u rays): LBVH %.2f node steps + %.2f triangle tests per ray, PLOC %.2f + %.2f -> %s\n", nrays,
-                        (double)hcnt[0] / nrays, (double)hcnt[1] / nrays, (double)hcnt[2] / nrays, (double)hcnt[3] / nrays, cost_ploc < cost_lbvh ? "PLOC" : "LBVH");
-            if (cost_ploc < cost_lbvh) {
-                hipFree((void*)out->nodes8); hipFree((void*)out->tris8);
-                out->nodes8 = alt.nodes8; out->tris8 = alt.tris8; out->num_nodes8 = alt.num_nodes8; out->num_tris8 = alt.num_tris8; out->levels8 = alt.levels8;
-                out->builder = 1;
-            } else {
-                hipFree((void*)alt.nodes8); hipFree((void*)alt.tris8);
+        if (!force_lbvh && !force_ploc && !force_sah && n >= 4096) {
+            // The LBVH (already emitted) against the binned-SAH hierarchy, the one that costs the calibration rays less (see k_calibrate8); small scenes
+            // keep the LBVH.  A challenger overwrites the binary hierarchy's internal nodes (the standing wide tree is already emitted), is collapsed into
+            // a wide tree of its own and traced against the standing tree by one calibration launch.  PLOC — the challenger of rounds 3-4 — never
+            // rendered faster than the SAH tree (stadium 12.40 against 12.09 ms, terrain 8.74 against 7.92) and the calibration cannot tell two
+            // trees 4 % apart, so it is a candidate only on request (PT_BVH_PLOC=1; PT_BVH_SAH=0 gives the round-4 pair LBVH | PLOC).
+            static const char* const names[4] = {"LBVH", "PLOC", "imported", "SAH"};
+            const char* cm = getenv("PT_BVH_CALIB"); // segments: centroid-to-centroid segments (rounds 3-4); default: rays like a frame's (k_calibrate8)
+            const int calib_mode = (cm && strcmp(cm, "segments") == 0) ? 0 : 1;
+            const float* bd = out->bounds;
+            const float4 sphere = make_float4(0.5f * (bd[0] + bd[3]), 0.5f * (bd[1] + bd[4]), 0.5f * (bd[2] + bd[5]),
+                                              0.5f * sqrtf((bd[3] - bd[0]) * (bd[3] - bd[0]) + (bd[4] - bd[1]) * (bd[4] - bd[1]) + (bd[5] - bd[2]) * (bd[5] - bd[2])));
+            const char *sah_env = getenv("PT_BVH_SAH"), *ploc_env = getenv("PT_BVH_PLOC");
+            const bool with_sah = !(sah_env && atoi(sah_env) == 0), with_ploc = !with_sah || (ploc_env && atoi(ploc_env) != 0);
+            int kinds[2], ncand = 0;
+            if (with_ploc) kinds[ncand++] = 1;
+            if (with_sah) kinds[ncand++] = 3;
+            for (int cand = 0; cand < ncand; ++cand) {
+                const int kind = kinds[cand];
+                PtBvh alt;
+                alt.grid = out->grid; // same scene, same origin grid
+                hipError_t pe = kind == 1 ? build_ploc(n, left, right, box, cnt, stream, &root) : build_sah(n, left, right, box, cnt, out->bounds, stream, &root);
+                pc.mark(kind == 1 ? "ploc hierarchy" : "sah hierarchy");
+                if (pe == hipSuccess) pe = build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, &alt);
+                pc.mark(kind == 1 ? "wide tree 2" : "wide tree 3");
+                if (pe != hipSuccess) { // a challenger is optional: the standing tree stays
+                    (void)hipGetLastError();
+                    pt_bvh_free(&alt);
+                    if (getenv("PT_DEBUG_BVH")) fprintf(stderr, "[pt_bvh] the %s hierarchy failed (%s): skipped\n", names[kind], hipGetErrorString(pe));
+                    continue;
+                }
+                unsigned long long* counts = nullptr;
+                unsigned long long hcnt[4] = {0, 0, 0, 0};
+                HIPCHK(tmalloc(&counts, sizeof(hcnt)));
+                HIPCHK(hipMemsetAsync(counts, 0, sizeof(hcnt), stream));
+                const uint32_t nrays = 1u << 16;
+                hipLaunchKernelGGL(k_calibrate8, dim3(2 * (nrays / 64)), dim3(64), 0, stream, out->nodes8, out->tris8, alt.nodes8, alt.tris8, tris, (uint32_t)n, nrays, 0.5f * pad, counts, out->grid, calib_mode, sphere);
+                HIPCHK(hipMemcpyAsync(hcnt, counts, sizeof(hcnt), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                tfree(counts);
+                pc.mark("calibration");
+                // a triangle step costs the traversal kernel about 0.6 node steps (≈110 against ≈185 instructions)
+                const double cost_cur = (double)hcnt[0] + 0.6 * (double)hcnt[1], cost_alt = (double)hcnt[2] + 0.6 * (double)hcnt[3];
+                if (getenv("PT_DEBUG_BVH"))
+                    fprintf(stderr, "[pt_bvh] calibration (%u rays): %s %.2f node steps + %.2f triangle tests per ray, %s %.2f + %.2f -> %s\n", nrays, names[out->builder],
+                            (double)hcnt[0] / nrays, (double)hcnt[1] / nrays, names[kind], (double)hcnt[2] / nrays, (double)hcnt[3] / nrays, cost_alt < cost_cur ? names[kind] : names[out->builder]);
+                if (cost_alt < cost_cur) {
+                    hipFree((void*)out->nodes8); hipFree((void*)out->tris8);
+                    out->nodes8 = alt.nodes8; out->tris8 = alt.tris8; out->num_nodes8 = alt.num_nodes8; out->num_tris8 = alt.num_tris8; out->levels8 = alt.levels8;
+                    out->builder = kind;
+                } else {
+                    hipFree((void*)alt.nodes8); hipFree((void*)alt.tris8);
+                }
             }
         }
         tfree(cnt);

@@ -88,8 +88,58 @@ def test_ploc_tail_in_one_workgroup_builds_the_same_hierarchy(ptlib, monkeypatch
     assert a[2]["bvh_builder"] == 1
 
 
+@pytest.mark.parametrize("scene", ["terrain70k", "stadium200k", "copies", "cornell", "five"])
+def test_sah_hierarchy_holds_every_triangle_once(ptlib, monkeypatch, scene):
+    """The binned-SAH hierarchy (round 5, pt_bvh_build.hip build_sah): level-synchronous splits of the large nodes, one thread per subtree of at most
+    eight leaves; coincident centroids (the `copies` scene: 6000 copies of one triangle) fall back to halving by position.  Whatever the shape, the
+    wide tree over it must hold every primitive exactly once, and a render through it must equal the LBVH's bit for bit."""
+    from optixpathtracer_amd import renderer as R
+
+    cam = scenes.TERRAIN_CAMERA
+    if scene == "terrain70k":
+        m = scenes.voxel_terrain(n=96, target_tris=70000)
+    elif scene == "stadium200k":
+        m, cam = scenes.stadium_scene(target_tris=200_000), scenes.STADIUM_CAMERA
+    elif scene == "copies":
+        base = np.array([[0, 0, 0], [4, 0, 0], [0, 3, 0]], np.float32)
+        tri = np.repeat(base[None], 6000, 0)
+        m = scenes.Model(meshes=[scenes.TriangleMesh(vertex=tri.reshape(-1, 3).copy(), index=np.arange(18000, dtype=np.uint32).reshape(-1, 3), material=scenes.Material())])
+        cam = dict(eye=(1.5, 1.0, 6.0), lookat=(1.5, 1.0, 0.0), up=(0.0, 1.0, 0.0), fovY=50.0)
+    elif scene == "cornell":
+        m, cam = scenes.cornell_box(), scenes.CORNELL_CAMERA  # 32 triangles: one level of large nodes, then small subtrees
+    else:
+        rng = np.random.default_rng(4)  # five triangles: the whole hierarchy is one small subtree
+        v = rng.standard_normal((15, 3)).astype(np.float32)
+        m = scenes.Model(meshes=[scenes.TriangleMesh(vertex=v, index=np.arange(15, dtype=np.uint32).reshape(-1, 3), material=scenes.Material())])
+        cam = dict(eye=(0.0, 0.0, 6.0), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fovY=50.0)
+    n = m.num_triangles
+    probe = scenes.sky_probe(128, 64).BuildCDF()
+    frames = {}
+    for builder in ("sah", "lbvh"):
+        for k in ("PT_BVH_CLIMB", "PT_PLOC_TAIL"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("PT_BVH_BUILDER", builder)
+        r = R.SampleRenderer(m)
+        if builder == "sah":
+            nodes, tris = r.exportBVH()[:2]
+            assert r.stats()["bvh_builder"] == 3
+            prims = np.sort(np.frombuffer(np.asarray(tris).tobytes(), np.uint32).reshape(-1, 12)[:, 9])
+            assert len(prims) == n and np.array_equal(prims, np.arange(n, dtype=np.uint32))
+            walked = _canonical(np.asarray(nodes).tobytes(), np.asarray(tris).tobytes())  # every leaf triangle is reachable from the root
+            assert len(walked[1]) == n * 48
+        r.setProbe(probe)
+        r.resize((160, 96))
+        r.setCamera(R.make_camera(cam, 160 / 96))
+        r.launchParams.samples_per_launch = 2
+        r.render()
+        frames[builder] = r.download(R.PT_BUF_ACCUM).copy()
+        r.close()
+    assert np.array_equal(frames["sah"].view(np.uint32), frames["lbvh"].view(np.uint32))
+
+
 def test_build_time_budget(ptlib, monkeypatch):
-    """pt_stats.bvh_build_ms for a million triangles (both hierarchies, both wide trees, calibration): rounds 1-3 took 43-60 ms."""
+    """pt_stats.bvh_build_ms for a million triangles (the LBVH and the binned-SAH hierarchy, a wide tree over each, calibration): rounds 1-3 took
+    43-60 ms, round 4 (LBVH | PLOC) 13.8 / 16.9 ms."""
     for k in ("PT_BVH_CLIMB", "PT_BVH_BUILDER"):
         monkeypatch.delenv(k, raising=False)
     from optixpathtracer_amd.renderer import SampleRenderer

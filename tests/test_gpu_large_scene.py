@@ -22,7 +22,7 @@ def test_ten_million_triangle_terrain(ptlib, orc_det, monkeypatch):
     w, h, spp = 1920, 1080, 4
     cam = scenes.TERRAIN_CAMERA
     out = {}
-    for builder in ("default", "lbvh", "ploc"):
+    for builder in ("default", "lbvh", "ploc", "sah"):
         if builder != "default":
             monkeypatch.setenv("PT_BVH_BUILDER", builder)
         r = R.SampleRenderer(m)
@@ -44,7 +44,7 @@ def test_ten_million_triangle_terrain(ptlib, orc_det, monkeypatch):
     monkeypatch.delenv("PT_BVH_BUILDER")
     a = out["default"]
     assert np.isfinite(a[0]).all() and (a[0][..., 3] == 1.0).all()
-    for other in ("lbvh", "ploc"):
+    for other in ("lbvh", "ploc", "sah"):
         b = out[other]
         for k in range(3):
             assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), f"{other}: buffer {k} depends on the hierarchy"

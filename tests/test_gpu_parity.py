@@ -368,7 +368,7 @@ def test_trace_triangle_soup_adversarial(ptlib, orc_det, monkeypatch):
     to, po = orc_det.trace_closest(sc, rays)
     occ_o = orc_det.trace_any(sc, rays)
     assert (po >= 0).mean() > 0.3
-    for builder in ("lbvh", "ploc"):  # both hierarchies the builder can put under the 8-wide tree
+    for builder in ("lbvh", "ploc", "sah"):  # every hierarchy the builder can put under the 8-wide tree
         monkeypatch.setenv("PT_BVH_BUILDER", builder)
         r = SampleRenderer(m)
         (t, prim), _ = r.trace(rays)
@@ -426,7 +426,7 @@ def test_builder_degenerate_scenes(ptlib, orc_det, case, monkeypatch):
     to, po = orc_det.trace_closest(sc, rays)
     occ_o = orc_det.trace_any(sc, rays)
     assert (po >= 0).mean() > 0.2
-    for builder in ("lbvh", "ploc"):
+    for builder in ("lbvh", "ploc", "sah"):
         monkeypatch.setenv("PT_BVH_BUILDER", builder)
         r = SampleRenderer(m)
         (t, prim), _ = r.trace(rays)
@@ -496,7 +496,7 @@ def test_both_traversal_kernels_agree(ptlib, orc_det, small_probe, monkeypatch):
     w, h = 128, 72
     o = _oracle_render(orc_det, m, small_probe, scenes.TERRAIN_CAMERA, w, h, 2)
     # unified launches (default), closest-hit and shadow launches apart on 2 streams, 3 concurrent pixel chunks, asynchronous shadow records
-    for builder in ("lbvh", "ploc"):
+    for builder in ("lbvh", "ploc", "sah"):
         monkeypatch.setenv("PT_BVH_BUILDER", builder)
         for opt in (dict(), dict(split_shadow=1), dict(streams=3), dict(split_shadow=2)):
             r = _renderer(m, small_probe, scenes.TERRAIN_CAMERA, w, h, **opt)

@@ -24,7 +24,7 @@ def _camera_rays(cam, w, h, rng, n):
     return rays
 
 
-@pytest.mark.parametrize("builder", ["auto", "lbvh", "ploc"])
+@pytest.mark.parametrize("builder", ["auto", "lbvh", "ploc", "sah"])
 def test_stadium_trace_vs_bruteforce(ptlib, orc_det, builder, monkeypatch):
     """60 k-triangle stadium: camera rays, random rays and rays re-launched from the hit points (closest hit and any hit) against the
     checker's brute force — primitive ids equal, t bit-equal — for both hierarchies the builder can choose from."""
@@ -100,7 +100,7 @@ def test_stadium_fullsize_is_tree_independent(ptlib, monkeypatch):
     rng = np.random.default_rng(5)
     rays = _camera_rays(scenes.STADIUM_CAMERA, w, h, rng, 2_000_000)
     out = {}
-    for builder in ("lbvh", "ploc"):
+    for builder in ("lbvh", "ploc", "sah"):
         monkeypatch.setenv("PT_BVH_BUILDER", builder)
         r = R.SampleRenderer(m)
         (t, prim), _ = r.trace(rays)
@@ -119,13 +119,15 @@ def test_stadium_fullsize_is_tree_independent(ptlib, monkeypatch):
         st = r.stats()
         out[builder] = (t, prim, t2, p2, occ, r.download(R.PT_BUF_ACCUM), r.download(R.PT_BUF_NORMAL), st["radiance_rays"], st["shadow_rays"])
         r.close()
-    a, b = out["lbvh"], out["ploc"]
+    a = out["lbvh"]
     assert (a[1] >= 0).mean() > 0.9
-    for k in range(7):
-        x, y = np.ascontiguousarray(a[k]), np.ascontiguousarray(b[k])
-        nd = int((x.view(np.uint32 if x.dtype.itemsize == 4 else np.uint8) != y.view(np.uint32 if y.dtype.itemsize == 4 else np.uint8)).sum())
-        assert nd == 0, (k, nd)
-    assert a[7:] == b[7:]
+    for other in ("ploc", "sah"):
+        b = out[other]
+        for k in range(7):
+            x, y = np.ascontiguousarray(a[k]), np.ascontiguousarray(b[k])
+            nd = int((x.view(np.uint32 if x.dtype.itemsize == 4 else np.uint8) != y.view(np.uint32 if y.dtype.itemsize == 4 else np.uint8)).sum())
+            assert nd == 0, (other, k, nd)
+        assert a[7:] == b[7:], other
 
 
 def test_stadium_fullsize_rows_vs_checker(ptlib, orc_det):
@@ -153,7 +155,7 @@ def test_stadium_fullsize_rows_vs_checker(ptlib, orc_det):
     r.renderBatch(2)
     g1 = r.download(R.PT_BUF_ACCUM)
     st = r.stats()
-    assert np.isfinite(g0).all() and st["bvh_builder"] in (0, 1)
+    assert np.isfinite(g0).all() and st["bvh_builder"] in (0, 1, 3)
 
     sc = orc_det.make_scene(m, True)
     pr = orc_det.make_probe(probe)

@@ -1179,13 +1179,30 @@ static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt,
 //   * A child with at most SAH_SMALL leaves is finished later by ONE thread: exact sweep SAH (every axis, every position of the sorted
 //     centroids) down to single leaves.
 // Node numbering is handed out by atomic counters (like k_collapse8's): the TREE is deterministic, the numbers are not.
+#ifndef SAH_BINS
 #define SAH_BINS 16
+#endif
 #define SAH_SMALL 8
 #define SAH_WG 1024
 #define SAH_BIG 8192 // nodes with more leaves are binned by position windows (k_sah_bin: LDS per window, global atomics to merge), smaller ones by a wave of their own
-struct SahBin { // per node slot, axis, bin: box of the leaves (ordered-uint floats) and their number
+#ifndef SAH_CENTROID_BINS
+#define SAH_CENTROID_BINS 0 // 1: bins span the node's CENTROID bounds (Wald 2007) instead of its box.  Measured (profiles/r5_08_sah.md): the same frame times at 16
+                            // bins (C3 7.84 / 7.83 ms, stadium 12.04 / 12.07, 9.5 M terrain 7.37 / 7.33), 13 instead of 7 words per bin to accumulate — the box stays
+#endif
+#if SAH_CENTROID_BINS
+#define SAH_W 13
+#else
+#define SAH_W 7
+#endif
+struct SahBin { // per node slot, axis, bin: box of the leaves (ordered-uint floats), their number and (SAH_CENTROID_BINS) the bounds of their centroids
     uint32_t lo[3], hi[3], count;
+#if SAH_CENTROID_BINS
+    uint32_t clo[3], chi[3];
+#endif
 };
+// word w of a bin: 0-2 minima, 3-5 maxima, 6 count, 7-9 minima, 10-12 maxima
+__device__ __forceinline__ int sah_word_kind(int w) { return w < 3 ? 0 : (w < 6 ? 1 : (w == 6 ? 2 : (w < 10 ? 0 : 1))); } // 0 min, 1 max, 2 sum
+__device__ __forceinline__ uint32_t sah_word_init(int w) { return sah_word_kind(w) == 0 ? 0xffffffffu : 0u; }
 struct SahCtl { // device counters of a build
     uint32_t next_id;     // next internal node id
     uint32_t nlarge_next; // large nodes created for the next level
@@ -1207,56 +1224,64 @@ __global__ void k_sah_init(int n, int* __restrict__ prim, int* __restrict__ node
 __global__ void k_sah_clear_bins(SahBin* __restrict__ bins, uint32_t nwords) { // lo = +inf, hi = -inf (ordered), count = 0
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nwords) return;
-    const uint32_t w = i % 7u;
-    reinterpret_cast<uint32_t*>(bins)[i] = w < 3u ? 0xffffffffu : 0u;
+    reinterpret_cast<uint32_t*>(bins)[i] = sah_word_init((int)(i % (uint32_t)SAH_W));
+}
+// a leaf into one bin (LDS or global words): its box, its count, its centroid
+__device__ __forceinline__ void sah_accumulate(uint32_t* w, const float* b) {
+    for (int k = 0; k < 3; ++k) {
+        atomicMin(&w[k], f2ord(b[k]));
+        atomicMax(&w[3 + k], f2ord(b[3 + k]));
+    }
+    atomicAdd(&w[6], 1u);
+#if SAH_CENTROID_BINS
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t c = f2ord(0.5f * (b[k] + b[3 + k]));
+        atomicMin(&w[7 + k], c);
+        atomicMax(&w[10 + k], c);
+    }
+#endif
 }
 // every leaf of a large node into its three bins
 // One wave per node of at most SAH_BIG leaves: the node's leaves binned in LDS that only this wave touches, the bins then stored as they are — no
 // global atomic (the first version binned every leaf of every node with 21 device-scope atomics: 21 M per level, 0.5 ms per level).
 __global__ void __launch_bounds__(256) k_sah_bin_node(const int* __restrict__ active, int nactive, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ first,
-                                                      const int* __restrict__ cnt, const int* __restrict__ slot_of, const float* __restrict__ box, SahBin* __restrict__ bins) {
-    __shared__ uint32_t s_all[4][3 * SAH_BINS * 7];
+                                                      const int* __restrict__ cnt, const int* __restrict__ slot_of, const float* __restrict__ box, const float* __restrict__ cbox,
+                                                      SahBin* __restrict__ bins) {
+    __shared__ uint32_t s_all[4][3 * SAH_BINS * SAH_W];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wave;
     uint32_t* s_bins = s_all[wave];
-    for (int k = lane; k < 3 * SAH_BINS * 7; k += 64) s_bins[k] = (k % 7) < 3 ? 0xffffffffu : 0u;
+    for (int k = lane; k < 3 * SAH_BINS * SAH_W; k += 64) s_bins[k] = sah_word_init(k % SAH_W);
     __syncthreads();
     const int node = t < nactive ? active[t] : -1;
     const int m = node >= 0 ? cnt[node] : 0;
     if (node >= 0 && m <= SAH_BIG) {
         const int f = first[node];
-        const float* nb = &box[(size_t)node * 6];
+        const float* nb = &cbox[(size_t)node * 6]; // what the bins span
         const float nlo[3] = {nb[0], nb[1], nb[2]}, nhi[3] = {nb[3], nb[4], nb[5]};
         for (int i = f + lane; i < f + m; i += 64) {
-            const float* b = &box[(size_t)(nleaf_base + prim[i]) * 6];
-            const float blo[3] = {b[0], b[1], b[2]}, bhi[3] = {b[3], b[4], b[5]};
-            for (int a = 0; a < 3; ++a) {
-                uint32_t* w = &s_bins[(a * SAH_BINS + sah_bin_of(0.5f * (blo[a] + bhi[a]), nlo[a], nhi[a])) * 7];
-                for (int k = 0; k < 3; ++k) {
-                    atomicMin(&w[k], f2ord(blo[k]));
-                    atomicMax(&w[3 + k], f2ord(bhi[k]));
-                }
-                atomicAdd(&w[6], 1u);
-            }
+            const float* bp = &box[(size_t)(nleaf_base + prim[i]) * 6];
+            const float b[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
+            for (int a = 0; a < 3; ++a) sah_accumulate(&s_bins[(a * SAH_BINS + sah_bin_of(0.5f * (b[a] + b[3 + a]), nlo[a], nhi[a])) * SAH_W], b);
         }
     }
     __syncthreads();
     if (node >= 0 && m <= SAH_BIG) {
         uint32_t* g = reinterpret_cast<uint32_t*>(&bins[(size_t)slot_of[node] * 3 * SAH_BINS]);
-        for (int k = lane; k < 3 * SAH_BINS * 7; k += 64) g[k] = s_bins[k];
+        for (int k = lane; k < 3 * SAH_BINS * SAH_W; k += 64) g[k] = s_bins[k];
     }
 }
 // (big nodes: the window's LDS bins go to partial[window] with plain stores and k_sah_reduce merges the windows of a node — 1024 workgroups
 // flushing 336 atomics each into the same eleven cache lines serialised at 10.5 ns per atomic: 290 us per level)
 __global__ void __launch_bounds__(SAH_WG) k_sah_bin(int n, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ node_of, const int* __restrict__ slot_of,
-                                                    const int* __restrict__ cnt, const float* __restrict__ box, SahBin* __restrict__ bins,
+                                                    const int* __restrict__ cnt, const float* __restrict__ box, const float* __restrict__ cbox, SahBin* __restrict__ bins,
                                                     uint32_t* __restrict__ partial, int* __restrict__ partial_node) {
     // a set of bins per wave (16 x 1344 bytes): a thousand threads on one set spend their time in LDS atomic conflicts (284 us per level)
-    __shared__ uint32_t s_wbins[SAH_WG / 64][3 * SAH_BINS * 7];
+    __shared__ uint32_t s_wbins[SAH_WG / 64][3 * SAH_BINS * SAH_W];
     __shared__ int s_first;
     const int i = blockIdx.x * SAH_WG + threadIdx.x;
     uint32_t* const s_bins = s_wbins[threadIdx.x >> 6];
-    for (int k = threadIdx.x; k < (SAH_WG / 64) * 3 * SAH_BINS * 7; k += SAH_WG) (&s_wbins[0][0])[k] = (k % 7) < 3 ? 0xffffffffu : 0u;
+    for (int k = threadIdx.x; k < (SAH_WG / 64) * 3 * SAH_BINS * SAH_W; k += SAH_WG) (&s_wbins[0][0])[k] = sah_word_init(k % SAH_W);
     if (threadIdx.x == 0) s_first = 0x7fffffff;
     __syncthreads();
     int node = i < n ? node_of[i] : -1;
@@ -1269,51 +1294,48 @@ __global__ void __launch_bounds__(SAH_WG) k_sah_bin(int n, int nleaf_base, const
     }
     const int node0 = node_of[blockIdx.x * SAH_WG + s_first]; // the node of the window's first active position: privatised in LDS
     if (node >= 0) {
-        const float* b = &box[(size_t)(nleaf_base + prim[i]) * 6];
-        const float* nb = &box[(size_t)node * 6];
-        const uint32_t olo[3] = {f2ord(b[0]), f2ord(b[1]), f2ord(b[2])}, ohi[3] = {f2ord(b[3]), f2ord(b[4]), f2ord(b[5])};
+        const float* bp = &box[(size_t)(nleaf_base + prim[i]) * 6];
+        const float b[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
+        const float* nb = &cbox[(size_t)node * 6];
         for (int a = 0; a < 3; ++a) {
             const int bi = sah_bin_of(0.5f * (b[a] + b[3 + a]), nb[a], nb[3 + a]);
-            uint32_t* w = node == node0 ? &s_bins[(a * SAH_BINS + bi) * 7] : reinterpret_cast<uint32_t*>(&bins[((size_t)slot_of[node] * 3 + a) * SAH_BINS + bi]);
-            for (int k = 0; k < 3; ++k) {
-                atomicMin(&w[k], olo[k]);
-                atomicMax(&w[3 + k], ohi[k]);
-            }
-            atomicAdd(&w[6], 1u);
+            sah_accumulate(node == node0 ? &s_bins[(a * SAH_BINS + bi) * SAH_W] : reinterpret_cast<uint32_t*>(&bins[((size_t)slot_of[node] * 3 + a) * SAH_BINS + bi]), b);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) partial_node[blockIdx.x] = node0;
-    for (int k = threadIdx.x; k < 3 * SAH_BINS * 7; k += SAH_WG) {
-        const int w = k % 7;
-        uint32_t acc = w < 3 ? 0xffffffffu : 0u;
+    for (int k = threadIdx.x; k < 3 * SAH_BINS * SAH_W; k += SAH_WG) {
+        const int kind = sah_word_kind(k % SAH_W);
+        uint32_t acc = kind == 0 ? 0xffffffffu : 0u;
         for (int v = 0; v < SAH_WG / 64; ++v) {
             const uint32_t x = s_wbins[v][k];
-            acc = w < 3 ? min(acc, x) : (w < 6 ? max(acc, x) : acc + x);
+            acc = kind == 0 ? min(acc, x) : (kind == 1 ? max(acc, x) : acc + x);
         }
-        partial[(size_t)blockIdx.x * (3 * SAH_BINS * 7) + k] = acc;
+        partial[(size_t)blockIdx.x * (3 * SAH_BINS * SAH_W) + k] = acc;
     }
 }
 // one workgroup per big node: merges the partial bins of the windows the node covers into its (cleared) bins, where the few leaves that
 // shared a window with another big node already arrived by atomics
-__global__ void __launch_bounds__(3 * SAH_BINS * 7) k_sah_reduce(const int* __restrict__ active, int nactive, const int* __restrict__ first, const int* __restrict__ cnt,
+__global__ void __launch_bounds__(256) k_sah_reduce(const int* __restrict__ active, int nactive, const int* __restrict__ first, const int* __restrict__ cnt,
                                                                   const int* __restrict__ slot_of, const uint32_t* __restrict__ partial, const int* __restrict__ partial_node,
                                                                   SahBin* __restrict__ bins) {
     const int node = active[blockIdx.x];
     const int m = cnt[node];
     if (m <= SAH_BIG) return;
     const int f = first[node], w0 = f / SAH_WG, w1 = (f + m - 1) / SAH_WG;
-    const int k = threadIdx.x, w = k % 7;
-    uint32_t acc = w < 3 ? 0xffffffffu : 0u;
-    for (int win = w0; win <= w1; ++win) {
-        if (partial_node[win] != node) continue;
-        const uint32_t v = partial[(size_t)win * (3 * SAH_BINS * 7) + k];
-        acc = w < 3 ? min(acc, v) : (w < 6 ? max(acc, v) : acc + v);
-    }
     uint32_t* g = reinterpret_cast<uint32_t*>(&bins[(size_t)slot_of[node] * 3 * SAH_BINS]);
-    if (w < 3) { if (acc != 0xffffffffu) atomicMin(&g[k], acc); }
-    else if (w < 6) { if (acc != 0u) atomicMax(&g[k], acc); }
-    else if (acc != 0u) atomicAdd(&g[k], acc);
+    for (int k = threadIdx.x; k < 3 * SAH_BINS * SAH_W; k += 256) {
+        const int kind = sah_word_kind(k % SAH_W);
+        uint32_t acc = kind == 0 ? 0xffffffffu : 0u;
+        for (int win = w0; win <= w1; ++win) {
+            if (partial_node[win] != node) continue;
+            const uint32_t v = partial[(size_t)win * (3 * SAH_BINS * SAH_W) + k];
+            acc = kind == 0 ? min(acc, v) : (kind == 1 ? max(acc, v) : acc + v);
+        }
+        if (kind == 0) { if (acc != 0xffffffffu) atomicMin(&g[k], acc); }
+        else if (kind == 1) { if (acc != 0u) atomicMax(&g[k], acc); }
+        else if (acc != 0u) atomicAdd(&g[k], acc);
+    }
 }
 __device__ __forceinline__ float sah_area(const float* lo, const float* hi) {
     const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -1322,7 +1344,7 @@ __device__ __forceinline__ float sah_area(const float* lo, const float* hi) {
 // one thread per large node of this level: the split, the children (ids, ranges, boxes), who is large next
 __global__ void k_sah_split(const int* __restrict__ active, int nactive, int n, const SahBin* __restrict__ bins, const int* __restrict__ slot_of, int* __restrict__ first,
                             int* __restrict__ cnt, float* __restrict__ box, int* __restrict__ left, int* __restrict__ right, int* __restrict__ split,
-                            int* __restrict__ slot_next, int* __restrict__ active_next, int* __restrict__ small_list, SahCtl* __restrict__ ctl) {
+                            int* __restrict__ slot_next, int* __restrict__ active_next, int* __restrict__ small_list, SahCtl* __restrict__ ctl, float* __restrict__ cbox) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nactive) return;
     const int node = active[t];
@@ -1360,19 +1382,28 @@ __global__ void k_sah_split(const int* __restrict__ active, int nactive, int n, 
         }
     }
     int nl;
+    float clo[2][3], chi[2][3]; // what the children's bins will span: the bounds of their leaves' centroids (SAH_CENTROID_BINS), else their boxes
     if (best_axis < 0) { // every centroid in one bin on every axis: halve by position; the children's boxes are the node's (a superset: conservative)
         nl = m / 2;
         split[node] = -1 - nl;
-        for (int k = 0; k < 3; ++k) { blo[0][k] = blo[1][k] = box[(size_t)node * 6 + k]; bhi[0][k] = bhi[1][k] = box[(size_t)node * 6 + 3 + k]; }
+        for (int k = 0; k < 3; ++k) {
+            blo[0][k] = blo[1][k] = box[(size_t)node * 6 + k]; bhi[0][k] = bhi[1][k] = box[(size_t)node * 6 + 3 + k];
+            clo[0][k] = clo[1][k] = cbox[(size_t)node * 6 + k]; chi[0][k] = chi[1][k] = cbox[(size_t)node * 6 + 3 + k];
+        }
     } else {
         nl = best_nl;
         split[node] = best_axis | (best_bin << 2);
         for (int s = 0; s < 2; ++s) {
-            for (int k = 0; k < 3; ++k) { blo[s][k] = INFINITY; bhi[s][k] = -INFINITY; }
+            for (int k = 0; k < 3; ++k) { blo[s][k] = clo[s][k] = INFINITY; bhi[s][k] = chi[s][k] = -INFINITY; }
             for (int j = s ? best_bin + 1 : 0; j <= (s ? SAH_BINS - 1 : best_bin); ++j) {
                 const SahBin& b = nb[best_axis * SAH_BINS + j];
                 if (!b.count) continue;
-                for (int k = 0; k < 3; ++k) { blo[s][k] = fminf(blo[s][k], ord2f(b.lo[k])); bhi[s][k] = fmaxf(bhi[s][k], ord2f(b.hi[k])); }
+                for (int k = 0; k < 3; ++k) {
+                    blo[s][k] = fminf(blo[s][k], ord2f(b.lo[k])); bhi[s][k] = fmaxf(bhi[s][k], ord2f(b.hi[k]));
+#if SAH_CENTROID_BINS
+                    clo[s][k] = fminf(clo[s][k], ord2f(b.clo[k])); chi[s][k] = fmaxf(chi[s][k], ord2f(b.chi[k]));
+#endif
+                }
             }
         }
     }
@@ -1386,6 +1417,9 @@ __global__ void k_sah_split(const int* __restrict__ active, int nactive, int n, 
             first[child] = cf;
             cnt[child] = cm;
             for (int k = 0; k < 3; ++k) { box[(size_t)child * 6 + k] = blo[s][k]; box[(size_t)child * 6 + 3 + k] = bhi[s][k]; }
+#if SAH_CENTROID_BINS
+            for (int k = 0; k < 3; ++k) { cbox[(size_t)child * 6 + k] = clo[s][k]; cbox[(size_t)child * 6 + 3 + k] = chi[s][k]; }
+#endif
             if (cm > SAH_SMALL) {
                 const int sl = (int)atomicAdd(&ctl->nlarge_next, 1u);
                 slot_next[child] = sl;
@@ -1399,7 +1433,7 @@ __global__ void k_sah_split(const int* __restrict__ active, int nactive, int n, 
     }
 }
 __global__ void k_sah_flag(int n, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ node_of, const int* __restrict__ first, const int* __restrict__ split,
-                           const float* __restrict__ box, uint32_t* __restrict__ flag) {
+                           const float* __restrict__ box, const float* __restrict__ cbox, uint32_t* __restrict__ flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
     uint32_t f = 0u;
@@ -1412,7 +1446,7 @@ __global__ void k_sah_flag(int n, int nleaf_base, const int* __restrict__ prim, 
             } else {
                 const int a = sp & 3;
                 const float* b = &box[(size_t)(nleaf_base + prim[i]) * 6];
-                const float* nb = &box[(size_t)node * 6];
+                const float* nb = &cbox[(size_t)node * 6];
                 f = sah_bin_of(0.5f * (b[a] + b[3 + a]), nb[a], nb[3 + a]) <= (sp >> 2) ? 1u : 0u;
             }
         }
@@ -1545,7 +1579,7 @@ static hipError_t build_sah(int n, int* left, int* right, float* box, int* cnt, 
     uint32_t* partial = nullptr; // per position window: the LDS bins of the window's first big node, and which node that was
     int* partial_node = nullptr;
     const size_t nwin = ((size_t)n + SAH_WG - 1) / SAH_WG;
-    HIPCHK(mem.alloc(&partial, sizeof(uint32_t) * 3 * SAH_BINS * 7 * nwin));
+    HIPCHK(mem.alloc(&partial, sizeof(uint32_t) * 3 * SAH_BINS * SAH_W * nwin));
     HIPCHK(mem.alloc(&partial_node, sizeof(int) * nwin));
     // bins of the large nodes of one level: at most n / (SAH_SMALL + 1) of them
     const size_t max_large = (size_t)n / (SAH_SMALL + 1) + 2;
@@ -1564,21 +1598,26 @@ static hipError_t build_sah(int n, int* left, int* right, float* box, int* cnt, 
     HIPCHK(hipMemcpyAsync(first, &zero, sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(cnt, &n, sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(box, bounds, sizeof(float) * 6, hipMemcpyHostToDevice, stream));
+    float* cbox = box; // what a node's bins span: its box, or (SAH_CENTROID_BINS) the bounds of its leaves' centroids — the root: the scene's bounds
+#if SAH_CENTROID_BINS
+    HIPCHK(mem.alloc(&cbox, sizeof(float) * 6 * (size_t)n));
+    HIPCHK(hipMemcpyAsync(cbox, bounds, sizeof(float) * 6, hipMemcpyHostToDevice, stream));
+#endif
     HIPCHK(hipMemcpyAsync(slot[0], &zero, sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(large_root ? active[0] : small_list, &zero, sizeof(int), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_sah_init, dim3((n + B - 1) / B), dim3(B), 0, stream, n, prim[0], node_of[0], large_root ? 1 : 0);
     int cur = 0, nactive = large_root ? 1 : 0, nbig = n > SAH_BIG ? 1 : 0, levels = 0;
     while (nactive > 0) {
-        const uint32_t nwords = (uint32_t)((size_t)nactive * 3 * SAH_BINS * 7);
+        const uint32_t nwords = (uint32_t)((size_t)nactive * 3 * SAH_BINS * SAH_W);
         hipLaunchKernelGGL(k_sah_clear_bins, dim3((nwords + B - 1) / B), dim3(B), 0, stream, bins, nwords);
         if (nbig > 0) {
-            hipLaunchKernelGGL(k_sah_bin, dim3((n + SAH_WG - 1) / SAH_WG), dim3(SAH_WG), 0, stream, n, nleaf_base, prim[cur], node_of[cur], slot[cur], cnt, box, bins, partial, partial_node);
-            hipLaunchKernelGGL(k_sah_reduce, dim3(nactive), dim3(3 * SAH_BINS * 7), 0, stream, active[cur], nactive, first, cnt, slot[cur], partial, partial_node, bins);
+            hipLaunchKernelGGL(k_sah_bin, dim3((n + SAH_WG - 1) / SAH_WG), dim3(SAH_WG), 0, stream, n, nleaf_base, prim[cur], node_of[cur], slot[cur], cnt, box, cbox, bins, partial, partial_node);
+            hipLaunchKernelGGL(k_sah_reduce, dim3(nactive), dim3(256), 0, stream, active[cur], nactive, first, cnt, slot[cur], partial, partial_node, bins);
         }
-        hipLaunchKernelGGL(k_sah_bin_node, dim3((nactive + 3) / 4), dim3(256), 0, stream, active[cur], nactive, nleaf_base, prim[cur], first, cnt, slot[cur], box, bins);
+        hipLaunchKernelGGL(k_sah_bin_node, dim3((nactive + 3) / 4), dim3(256), 0, stream, active[cur], nactive, nleaf_base, prim[cur], first, cnt, slot[cur], box, cbox, bins);
         hipLaunchKernelGGL(k_sah_split, dim3((nactive + 63) / 64), dim3(64), 0, stream, active[cur], nactive, n, bins, slot[cur], first, cnt, box, left, right, split,
-                           slot[cur ^ 1], active[cur ^ 1], small_list, ctl);
-        hipLaunchKernelGGL(k_sah_flag, dim3((n + 1 + B - 1) / B), dim3(B), 0, stream, n, nleaf_base, prim[cur], node_of[cur], first, split, box, flag);
+                           slot[cur ^ 1], active[cur ^ 1], small_list, ctl, cbox);
+        hipLaunchKernelGGL(k_sah_flag, dim3((n + 1 + B - 1) / B), dim3(B), 0, stream, n, nleaf_base, prim[cur], node_of[cur], first, split, box, cbox, flag);
         HIPCHK(rocprim::exclusive_scan(tmp, tmp_bytes, flag, scan, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
         hipLaunchKernelGGL(k_sah_scatter, dim3((n + B - 1) / B), dim3(B), 0, stream, n, nleaf_base, prim[cur], node_of[cur], first, cnt, flag, scan, left, right,
                            prim[cur ^ 1], node_of[cur ^ 1]);

@@ -1241,15 +1241,60 @@ __device__ __forceinline__ void sah_accumulate(uint32_t* w, const float* b) {
     }
 #endif
 }
+// The same for a whole wave whose lanes mostly fall into the SAME bin (the position windows of the top levels: the leaves are in Morton order,
+// 64 neighbours share a bin, and 64 lanes on one LDS word serialise: 286 us per level for a million leaves): the lanes are grouped by bin with
+// ballots, every group's boxes are reduced by a butterfly, and the group's first lane updates the bin with plain loads and stores — `w_base`
+// must be bins only this wave touches.
+__device__ __forceinline__ void sah_accumulate_wave(uint32_t* w_base, int bin, const float* b, bool valid) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(valid);
+    while (todo != 0ull) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int bsel = __shfl(bin, leader);
+        const bool mine = valid && bin == bsel;
+        const unsigned long long grp = __ballot(mine);
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) { lo[k] = mine ? b[k] : INFINITY; hi[k] = mine ? b[3 + k] : -INFINITY; }
+#if SAH_CENTROID_BINS
+        float clo[3], chi[3];
+        for (int k = 0; k < 3; ++k) { const float c = 0.5f * (b[k] + b[3 + k]); clo[k] = mine ? c : INFINITY; chi[k] = mine ? c : -INFINITY; }
+#endif
+        for (int off = 32; off > 0; off >>= 1)
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+#if SAH_CENTROID_BINS
+                clo[k] = fminf(clo[k], __shfl_xor(clo[k], off));
+                chi[k] = fmaxf(chi[k], __shfl_xor(chi[k], off));
+#endif
+            }
+        if (lane == leader) {
+            uint32_t* w = w_base + bsel * SAH_W;
+            for (int k = 0; k < 3; ++k) {
+                w[k] = min(w[k], f2ord(lo[k]));
+                w[3 + k] = max(w[3 + k], f2ord(hi[k]));
+#if SAH_CENTROID_BINS
+                w[7 + k] = min(w[7 + k], f2ord(clo[k]));
+                w[10 + k] = max(w[10 + k], f2ord(chi[k]));
+#endif
+            }
+            w[6] += (uint32_t)__popcll(grp);
+        }
+        todo &= ~grp;
+    }
+}
 // every leaf of a large node into its three bins
 // One wave per node of at most SAH_BIG leaves: the node's leaves binned in LDS that only this wave touches, the bins then stored as they are — no
 // global atomic (the first version binned every leaf of every node with 21 device-scope atomics: 21 M per level, 0.5 ms per level).
 __global__ void __launch_bounds__(256) k_sah_bin_node(const int* __restrict__ active, int nactive, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ first,
                                                       const int* __restrict__ cnt, const int* __restrict__ slot_of, const float* __restrict__ box, const float* __restrict__ cbox,
-                                                      SahBin* __restrict__ bins) {
+                                                      SahBin* __restrict__ bins, int per_node) {
     __shared__ uint32_t s_all[4][3 * SAH_BINS * SAH_W];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + wave;
+    // per_node = 1: a wave per node (levels with many nodes); per_node = 4: the four waves of the workgroup share a node (levels with few, large nodes:
+    // a lone wave looping over 8192 leaves is 128 dependent iterations, 0.3 ms)
+    const int t = per_node == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const int part = per_node == 4 ? wave : 0;
     uint32_t* s_bins = s_all[wave];
     for (int k = lane; k < 3 * SAH_BINS * SAH_W; k += 64) s_bins[k] = sah_word_init(k % SAH_W);
     __syncthreads();
@@ -1259,7 +1304,7 @@ __global__ void __launch_bounds__(256) k_sah_bin_node(const int* __restrict__ ac
         const int f = first[node];
         const float* nb = &cbox[(size_t)node * 6]; // what the bins span
         const float nlo[3] = {nb[0], nb[1], nb[2]}, nhi[3] = {nb[3], nb[4], nb[5]};
-        for (int i = f + lane; i < f + m; i += 64) {
+        for (int i = f + part * 64 + lane; i < f + m; i += 64 * per_node) {
             const float* bp = &box[(size_t)(nleaf_base + prim[i]) * 6];
             const float b[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
             for (int a = 0; a < 3; ++a) sah_accumulate(&s_bins[(a * SAH_BINS + sah_bin_of(0.5f * (b[a] + b[3 + a]), nlo[a], nhi[a])) * SAH_W], b);
@@ -1268,54 +1313,75 @@ __global__ void __launch_bounds__(256) k_sah_bin_node(const int* __restrict__ ac
     __syncthreads();
     if (node >= 0 && m <= SAH_BIG) {
         uint32_t* g = reinterpret_cast<uint32_t*>(&bins[(size_t)slot_of[node] * 3 * SAH_BINS]);
-        for (int k = lane; k < 3 * SAH_BINS * SAH_W; k += 64) g[k] = s_bins[k];
+        if (per_node == 4) {
+            for (int k = threadIdx.x; k < 3 * SAH_BINS * SAH_W; k += 256) {
+                const int kind = sah_word_kind(k % SAH_W);
+                uint32_t acc = s_all[0][k];
+                for (int v = 1; v < 4; ++v) acc = kind == 0 ? min(acc, s_all[v][k]) : (kind == 1 ? max(acc, s_all[v][k]) : acc + s_all[v][k]);
+                g[k] = acc;
+            }
+        } else {
+            for (int k = lane; k < 3 * SAH_BINS * SAH_W; k += 64) g[k] = s_bins[k];
+        }
     }
 }
-// (big nodes: the window's LDS bins go to partial[window] with plain stores and k_sah_reduce merges the windows of a node — 1024 workgroups
-// flushing 336 atomics each into the same eleven cache lines serialised at 10.5 ns per atomic: 290 us per level)
-__global__ void __launch_bounds__(SAH_WG) k_sah_bin(int n, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ node_of, const int* __restrict__ slot_of,
-                                                    const int* __restrict__ cnt, const float* __restrict__ box, const float* __restrict__ cbox, SahBin* __restrict__ bins,
-                                                    uint32_t* __restrict__ partial, int* __restrict__ partial_node) {
-    // a set of bins per wave (16 x 1344 bytes): a thousand threads on one set spend their time in LDS atomic conflicts (284 us per level)
-    __shared__ uint32_t s_wbins[SAH_WG / 64][3 * SAH_BINS * SAH_W];
-    __shared__ int s_first;
+// Big nodes (more than SAH_BIG leaves) by position windows of SAH_WG leaves.  A big node spans at least eight windows, so a window meets at most TWO of them
+// (one ending, one starting): each gets a set of bins per wave in LDS (grouped accumulation, sah_accumulate_wave), the sets are merged per window and
+// stored to partial[2 window + j] with plain stores, and k_sah_reduce merges the windows of a node.  No global atomic: the first versions sent the second
+// node's leaves of a straddling window — a thousand leaves, 21 000 atomics on eleven cache lines, 10.5 ns each — to the global bins, and that one window
+// made every level take 260 us whatever the other 1023 windows did (level 0, which has no straddling window: 42 us).
+__global__ void __launch_bounds__(SAH_WG) k_sah_bin(int n, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ node_of, const int* __restrict__ cnt,
+                                                    const float* __restrict__ box, const float* __restrict__ cbox, uint32_t* __restrict__ partial,
+                                                    int* __restrict__ partial_node) {
+    __shared__ uint32_t s_wbins[SAH_WG / 64][2][3 * SAH_BINS * SAH_W];
+    __shared__ int s_first, s_second;
     const int i = blockIdx.x * SAH_WG + threadIdx.x;
-    uint32_t* const s_bins = s_wbins[threadIdx.x >> 6];
-    for (int k = threadIdx.x; k < (SAH_WG / 64) * 3 * SAH_BINS * SAH_W; k += SAH_WG) (&s_wbins[0][0])[k] = sah_word_init(k % SAH_W);
-    if (threadIdx.x == 0) s_first = 0x7fffffff;
+    for (int k = threadIdx.x; k < (SAH_WG / 64) * 2 * 3 * SAH_BINS * SAH_W; k += SAH_WG) (&s_wbins[0][0][0])[k] = sah_word_init(k % SAH_W);
+    if (threadIdx.x == 0) { s_first = 0x7fffffff; s_second = 0x7fffffff; }
     __syncthreads();
     int node = i < n ? node_of[i] : -1;
     if (node >= 0 && cnt[node] <= SAH_BIG) node = -1; // a wave of its own bins that node (k_sah_bin_node)
     if (node >= 0) atomicMin(&s_first, (int)threadIdx.x);
     __syncthreads();
     if (s_first == 0x7fffffff) { // no big node in this window
-        if (threadIdx.x == 0) partial_node[blockIdx.x] = -1;
+        if (threadIdx.x < 2) partial_node[2 * blockIdx.x + threadIdx.x] = -1;
         return;
     }
-    const int node0 = node_of[blockIdx.x * SAH_WG + s_first]; // the node of the window's first active position: privatised in LDS
-    if (node >= 0) {
-        const float* bp = &box[(size_t)(nleaf_base + prim[i]) * 6];
-        const float b[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
-        const float* nb = &cbox[(size_t)node * 6];
-        for (int a = 0; a < 3; ++a) {
-            const int bi = sah_bin_of(0.5f * (b[a] + b[3 + a]), nb[a], nb[3 + a]);
-            sah_accumulate(node == node0 ? &s_bins[(a * SAH_BINS + bi) * SAH_W] : reinterpret_cast<uint32_t*>(&bins[((size_t)slot_of[node] * 3 + a) * SAH_BINS + bi]), b);
+    const int node0 = node_of[blockIdx.x * SAH_WG + s_first];
+    if (node >= 0 && node != node0) atomicMin(&s_second, (int)threadIdx.x);
+    __syncthreads();
+    const int node1 = s_second == 0x7fffffff ? -1 : node_of[blockIdx.x * SAH_WG + s_second];
+    {
+        float b[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float nlo[3] = {0.f, 0.f, 0.f}, nhi[3] = {0.f, 0.f, 0.f};
+        if (node >= 0) {
+            const float* bp = &box[(size_t)(nleaf_base + prim[i]) * 6];
+            const float* nb = &cbox[(size_t)node * 6];
+            for (int k = 0; k < 6; ++k) b[k] = bp[k];
+            for (int k = 0; k < 3; ++k) { nlo[k] = nb[k]; nhi[k] = nb[3 + k]; }
+        }
+        const int wv = threadIdx.x >> 6;
+        for (int a = 0; a < 3; ++a) { // (every lane of the wave runs the loop: the wave-level accumulation uses ballots and shuffles)
+            const int bi = node >= 0 ? sah_bin_of(0.5f * (b[a] + b[3 + a]), nlo[a], nhi[a]) : 0;
+            sah_accumulate_wave(&s_wbins[wv][0][a * SAH_BINS * SAH_W], bi, b, node >= 0 && node == node0);
+            if (node1 >= 0) sah_accumulate_wave(&s_wbins[wv][1][a * SAH_BINS * SAH_W], bi, b, node >= 0 && node == node1);
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) partial_node[blockIdx.x] = node0;
-    for (int k = threadIdx.x; k < 3 * SAH_BINS * SAH_W; k += SAH_WG) {
-        const int kind = sah_word_kind(k % SAH_W);
+    if (threadIdx.x == 0) { partial_node[2 * blockIdx.x] = node0; partial_node[2 * blockIdx.x + 1] = node1; }
+    for (int k = threadIdx.x; k < 2 * 3 * SAH_BINS * SAH_W; k += SAH_WG) {
+        const int j = k / (3 * SAH_BINS * SAH_W), kk = k % (3 * SAH_BINS * SAH_W);
+        if (j == 1 && node1 < 0) continue;
+        const int kind = sah_word_kind(kk % SAH_W);
         uint32_t acc = kind == 0 ? 0xffffffffu : 0u;
         for (int v = 0; v < SAH_WG / 64; ++v) {
-            const uint32_t x = s_wbins[v][k];
+            const uint32_t x = s_wbins[v][j][kk];
             acc = kind == 0 ? min(acc, x) : (kind == 1 ? max(acc, x) : acc + x);
         }
-        partial[(size_t)blockIdx.x * (3 * SAH_BINS * SAH_W) + k] = acc;
+        partial[((size_t)2 * blockIdx.x + j) * (3 * SAH_BINS * SAH_W) + kk] = acc;
     }
 }
-// one workgroup per big node: merges the partial bins of the windows the node covers into its (cleared) bins, where the few leaves that
-// shared a window with another big node already arrived by atomics
+// gridDim.y workgroups per big node: merge the partial bins of the windows the node covers into its (cleared) bins
 __global__ void __launch_bounds__(256) k_sah_reduce(const int* __restrict__ active, int nactive, const int* __restrict__ first, const int* __restrict__ cnt,
                                                                   const int* __restrict__ slot_of, const uint32_t* __restrict__ partial, const int* __restrict__ partial_node,
                                                                   SahBin* __restrict__ bins) {
@@ -1327,11 +1393,12 @@ __global__ void __launch_bounds__(256) k_sah_reduce(const int* __restrict__ acti
     for (int k = threadIdx.x; k < 3 * SAH_BINS * SAH_W; k += 256) {
         const int kind = sah_word_kind(k % SAH_W);
         uint32_t acc = kind == 0 ? 0xffffffffu : 0u;
-        for (int win = w0; win <= w1; ++win) {
-            if (partial_node[win] != node) continue;
-            const uint32_t v = partial[(size_t)win * (3 * SAH_BINS * SAH_W) + k];
-            acc = kind == 0 ? min(acc, v) : (kind == 1 ? max(acc, v) : acc + v);
-        }
+        for (int win = w0 + (int)blockIdx.y; win <= w1; win += (int)gridDim.y) // (the windows of a node are dealt to gridDim.y workgroups: one looping over a thousand windows took 0.6 ms)
+            for (int j = 0; j < 2; ++j) {
+                if (partial_node[2 * win + j] != node) continue;
+                const uint32_t v = partial[((size_t)2 * win + j) * (3 * SAH_BINS * SAH_W) + k];
+                acc = kind == 0 ? min(acc, v) : (kind == 1 ? max(acc, v) : acc + v);
+            }
         if (kind == 0) { if (acc != 0xffffffffu) atomicMin(&g[k], acc); }
         else if (kind == 1) { if (acc != 0u) atomicMax(&g[k], acc); }
         else if (acc != 0u) atomicAdd(&g[k], acc);
@@ -1579,8 +1646,8 @@ static hipError_t build_sah(int n, int* left, int* right, float* box, int* cnt, 
     uint32_t* partial = nullptr; // per position window: the LDS bins of the window's first big node, and which node that was
     int* partial_node = nullptr;
     const size_t nwin = ((size_t)n + SAH_WG - 1) / SAH_WG;
-    HIPCHK(mem.alloc(&partial, sizeof(uint32_t) * 3 * SAH_BINS * SAH_W * nwin));
-    HIPCHK(mem.alloc(&partial_node, sizeof(int) * nwin));
+    HIPCHK(mem.alloc(&partial, sizeof(uint32_t) * 2 * 3 * SAH_BINS * SAH_W * nwin));
+    HIPCHK(mem.alloc(&partial_node, sizeof(int) * 2 * nwin));
     // bins of the large nodes of one level: at most n / (SAH_SMALL + 1) of them
     const size_t max_large = (size_t)n / (SAH_SMALL + 1) + 2;
     SahBin* bins = nullptr;
@@ -1611,10 +1678,14 @@ static hipError_t build_sah(int n, int* left, int* right, float* box, int* cnt, 
         const uint32_t nwords = (uint32_t)((size_t)nactive * 3 * SAH_BINS * SAH_W);
         hipLaunchKernelGGL(k_sah_clear_bins, dim3((nwords + B - 1) / B), dim3(B), 0, stream, bins, nwords);
         if (nbig > 0) {
-            hipLaunchKernelGGL(k_sah_bin, dim3((n + SAH_WG - 1) / SAH_WG), dim3(SAH_WG), 0, stream, n, nleaf_base, prim[cur], node_of[cur], slot[cur], cnt, box, cbox, bins, partial, partial_node);
-            hipLaunchKernelGGL(k_sah_reduce, dim3(nactive), dim3(256), 0, stream, active[cur], nactive, first, cnt, slot[cur], partial, partial_node, bins);
+            hipLaunchKernelGGL(k_sah_bin, dim3((n + SAH_WG - 1) / SAH_WG), dim3(SAH_WG), 0, stream, n, nleaf_base, prim[cur], node_of[cur], cnt, box, cbox, partial, partial_node);
+            hipLaunchKernelGGL(k_sah_reduce, dim3(nactive, 32), dim3(256), 0, stream, active[cur], nactive, first, cnt, slot[cur], partial, partial_node, bins);
         }
-        hipLaunchKernelGGL(k_sah_bin_node, dim3((nactive + 3) / 4), dim3(256), 0, stream, active[cur], nactive, nleaf_base, prim[cur], first, cnt, slot[cur], box, cbox, bins);
+        {
+            const int per_node = nactive <= 4096 ? 4 : 1;
+            hipLaunchKernelGGL(k_sah_bin_node, dim3(per_node == 4 ? nactive : (nactive + 3) / 4), dim3(256), 0, stream, active[cur], nactive, nleaf_base, prim[cur], first, cnt, slot[cur], box,
+                               cbox, bins, per_node);
+        }
         hipLaunchKernelGGL(k_sah_split, dim3((nactive + 63) / 64), dim3(64), 0, stream, active[cur], nactive, n, bins, slot[cur], first, cnt, box, left, right, split,
                            slot[cur ^ 1], active[cur ^ 1], small_list, ctl, cbox);
         hipLaunchKernelGGL(k_sah_flag, dim3((n + 1 + B - 1) / B), dim3(B), 0, stream, n, nleaf_base, prim[cur], node_of[cur], first, split, box, cbox, flag);

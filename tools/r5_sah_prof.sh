@@ -2,15 +2,7 @@
 # tools/r5_sah_prof.sh: kernel trace of two pt_create calls on the C3 terrain (the second build is the warm one): where the SAH hierarchy's time goes
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/sah_prof; rm -rf "$OUT"; mkdir -p "$OUT"
-cat > gpurun_out/sah_prof.py <<'PY'
-import os, sys
-sys.path.insert(0, os.getcwd())
-from optixpathtracer_amd import renderer as R, scenes
-m = scenes.voxel_terrain()
-for k in range(2):
-    r = R.SampleRenderer(m); print(r.stats()["bvh_build_ms"], r.stats()["bvh_builder"]); r.close()
-PY
-PT_DEBUG_BVH=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 gpurun_out/sah_prof.py > "$OUT/log" 2>&1
+PT_DEBUG_BVH=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 tools/sah_prof.py > "$OUT/log" 2>&1
 grep "pt_bvh\|^[0-9]" "$OUT/log" | tail -30
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys

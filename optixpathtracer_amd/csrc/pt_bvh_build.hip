@@ -1008,7 +1008,8 @@ static hipError_t build_bvh8(int n, int root, const int* left, const int* right,
     uint8_t* dec = nullptr;
     const char* collapse = getenv("PT_BVH_COLLAPSE");
     if (!(collapse && strcmp(collapse, "greedy") == 0)) {
-        float cp = 0.3f; // cost of a triangle test relative to a wide-node step
+        float cp = 1.0f; // cost of a triangle test relative to a wide-node step (PT_BVH_CP).  Rounds 1-4: 0.3; re-swept on the SAH hierarchy (round 5, profiles/r5_09_collapse_cp.log):
+                         // stadium 12.14 ms at 0.3, 11.84-11.92 from 1.2 to 10, C3 and the textured terrain flat within 0.3 %
         if (const char* e = getenv("PT_BVH_CP")) cp = (float)atof(e);
         int *parent = nullptr, *visits = nullptr;
         float* cost = nullptr;

@@ -107,8 +107,12 @@ bool try_parse_double(const char* s, const char* s_end, double* result) {
             read = 0;
             end_not_reached = (curr != s_end);
             while (end_not_reached && is_digit(*curr)) {
-                exponent *= 10;
-                exponent += static_cast<int>(*curr - 0x30);
+                // (the reference's `exponent *= 10` overflows a signed int on a field like 1e99999999999 — undefined behaviour there; beyond 10^8 the
+                // value is +-inf, 0 or NaN whatever the digits, so the accumulation saturates)
+                if (exponent < 100000000) {
+                    exponent *= 10;
+                    exponent += static_cast<int>(*curr - 0x30);
+                }
                 curr++;
                 read++;
                 end_not_reached = (curr != s_end);

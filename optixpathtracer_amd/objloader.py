@@ -116,10 +116,17 @@ def _try_parse_double(s: str):
             if read == 0:
                 return None
     if exponent:
+        # C semantics where Python raises: pow overflows to inf (so 0e999 is 0 * inf = NaN, as in the reference), ldexp to +-inf
+        exponent = max(-1000000, min(1000000, exponent))  # (beyond, the value is +-inf, 0 or NaN whatever the digits)
         try:
-            return sign * math.ldexp(mant * math.pow(5.0, exponent), exponent)
+            p5 = math.pow(5.0, exponent)
         except OverflowError:
-            return sign * math.inf
+            p5 = math.inf
+        v = mant * p5
+        try:
+            return sign * math.ldexp(v, exponent)
+        except OverflowError:
+            return sign * math.copysign(math.inf, v)
     return sign * mant
 
 
@@ -622,7 +629,22 @@ def _load_obj_native(obj_file: str, per_mesh_vertex_map: bool) -> Model:
 
     from . import _lib
 
-    L = _lib.load_library()
+    if os.environ.get("PT_OBJ_LIB"):  # a build of csrc/pt_objload.cpp alone (tools/sanitize.sh: the parser under AddressSanitizer / UBSan)
+        L = C.CDLL(os.environ["PT_OBJ_LIB"])
+        vp, u32 = C.c_void_p, C.c_uint32
+        L.pt_load_obj.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+        L.pt_obj_free.argtypes = [vp]
+        L.pt_obj_free.restype = None
+        L.pt_obj_num_meshes.argtypes = [vp]
+        L.pt_obj_num_meshes.restype = u32
+        L.pt_obj_get_mesh.argtypes = [vp, u32, C.POINTER(_lib.ObjMesh)]
+        L.pt_obj_num_textures.argtypes = [vp]
+        L.pt_obj_num_textures.restype = u32
+        L.pt_obj_texture_path.argtypes = [vp, u32]
+        L.pt_obj_texture_path.restype = C.c_char_p
+        L.pt_obj_last_error.restype = C.c_char_p
+    else:
+        L = _lib.load_library()
     h = C.c_void_p()
     # (the path goes through as bytes; latin-1 keeps every byte of an odd file name)
     if L.pt_load_obj(os.fsencode(obj_file), 1 if per_mesh_vertex_map else 0, C.byref(h)) != 0:

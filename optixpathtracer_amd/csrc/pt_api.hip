@@ -107,9 +107,6 @@ struct pt_ctx {
     float4* d_probe_data = nullptr;
     float *d_pdfX = nullptr, *d_cdfX = nullptr, *d_pdfY = nullptr, *d_cdfY = nullptr, *d_c64Y = nullptr, *d_c8Y = nullptr;
     float4* d_tri_nrm = nullptr; // per leaf triangle of the traversal structure: (geometric normal, mesh) for k_shade
-    uint32_t* d_prim2leaf = nullptr; // per primitive: its leaf triangle (cross-wave stealing: the winner of a ray split over several waves, pt_bvh8.h)
-    int xw_mode = 0;                 // PT_XW: 0 never (default while it is being measured), 1 launches of passes up to xw_max_paths paths, 2 every launch
-    uint64_t xw_max_paths = 1u << 20;
     ProbeLine* d_lines = nullptr; // ProbeSample's column tables: six columns' cdf + (rgb, pdfX) per 128-byte line
     uint16_t* d_guide = nullptr;
     // frame
@@ -148,8 +145,6 @@ struct pt_ctx {
         uint32_t* squeueB = nullptr; // asynchronous shadow rays: one shadow queue per bounce
         uint32_t* ovf3 = nullptr;
         uint32_t* counters = nullptr; // [nq][PT_NSUB*PT_CSTRIDE] radiance sub-queue counts, same for shadow, then 2*nq work counters of PT_WSTRIDE words
-        XwShared* xw = nullptr;       // mailboxes and records of the cross-wave stealing launches of this set (pt_bvh8.h)
-        uint32_t xw_epoch = 0;        // number of the set's last cross-wave launch (the cells of older epochs are free)
         uint32_t *ovf = nullptr, *ovf2 = nullptr;
         float4 *pixResult = nullptr, *pixAlpha = nullptr, *pixNormal = nullptr, *pixAlbedo = nullptr;
         unsigned long long* totals = nullptr; // this set's ray counters of the frame being enqueued (a slice of d_totals)
@@ -280,10 +275,9 @@ static void default_options(pt_options* o) {
 }
 
 // words of a batch set's counter block, zeroed at the start of every pass: [nq][PT_NSUB * PT_CSTRIDE] radiance sub-queue counts, the same
-// for the shadow queues, 2 nq chunk counters of the traversal launches (PT_WSTRIDE words apart), 2 nq x PT8_XW_GROUPS counter blocks of
-// the cross-wave stealing launches
+// for the shadow queues, 2 nq chunk counters of the traversal launches (PT_WSTRIDE words apart)
 static size_t counter_words(int nq) {
-    return (size_t)2 * nq * PT_NSUB * PT_CSTRIDE + (size_t)2 * nq * PT_WSTRIDE + (size_t)2 * nq * PT8_XW_GROUPS * (sizeof(XwCtr) / sizeof(uint32_t));
+    return (size_t)2 * nq * PT_NSUB * PT_CSTRIDE + (size_t)2 * nq * PT_WSTRIDE;
 }
 static size_t ovf_words(const pt_ctx* ctx);
 static const int PT_MAX_SETS = 16;
@@ -445,8 +439,6 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     CKC(pt_bvh_build(ctx->d_verts, ctx->d_idx, ctx->d_tri_mesh, (uint32_t)nt, ctx->stream, &ctx->bvh));
     CKC(dalloc(&ctx->d_tri_nrm, (size_t)ctx->bvh.num_tris8));
     hipLaunchKernelGGL(k_shade_normals, dim3((ctx->bvh.num_tris8 + 255) / 256), dim3(256), 0, ctx->stream, ctx->bvh.tris8, ctx->bvh.num_tris8, ctx->d_tri_nrm);
-    CKC(dalloc(&ctx->d_prim2leaf, nt));
-    hipLaunchKernelGGL(k_prim2leaf, dim3((ctx->bvh.num_tris8 + 255) / 256), dim3(256), 0, ctx->stream, ctx->bvh.tris8, ctx->bvh.num_tris8, (uint32_t)nt, ctx->d_prim2leaf);
     if (ctx->d_uvs) { // textured scene: the 64-byte records a textured hit reads, in leaf order
         CKC(dalloc(&ctx->d_textris, (size_t)ctx->bvh.num_tris8));
         hipLaunchKernelGGL(k_emit_textris, dim3((ctx->bvh.num_tris8 + 255) / 256), dim3(256), 0, ctx->stream, ctx->bvh.tris8, ctx->d_uvs, ctx->bvh.num_tris8, ctx->d_textris);
@@ -465,8 +457,6 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
         CKC(hipGetDeviceProperties(&prop, device));
         int wpe = PT8_WAVES_PER_EU; // persistent waves per SIMD = the occupancy the traversal kernels are compiled for
         if (const char* e = getenv("PT_TRACE_WAVES")) wpe = atoi(e);
-        if (const char* e = getenv("PT_XW")) ctx->xw_mode = atoi(e);
-        if (const char* e = getenv("PT_XW_MAX_PATHS")) ctx->xw_max_paths = strtoull(e, nullptr, 10);
         if (const char* e = getenv("PT_GRID_MIN")) ctx->trace_grid_min = std::max(64, atoi(e));
         if (const char* e = getenv("PT_GRID_CHUNKS")) ctx->grid_chunks = std::max(1, atoi(e));
         if (const char* e = getenv("PT_STACK_LDS_SKIP")) ctx->lds_skip = std::max(0, std::min(PT8_LDS_DEPTH, atoi(e)));
@@ -509,7 +499,7 @@ static void free_path_state(pt_ctx* ctx) {
         for (auto& x : b.X) { dfree(x.rayO); dfree(x.rayD); dfree(x.thr); dfree(x.rf); dfree(x.hit); }
         dfree(b.shO); dfree(b.shD); dfree(b.shPend); dfree(s.pflags);
         dfree(s.direct); dfree(s.indirect); dfree(s.alpha); dfree(s.nrm); dfree(s.alb); dfree(s.prdN); dfree(s.prdA);
-        dfree(b.queueA); dfree(b.queueB); dfree(b.squeue); dfree(b.counters); dfree(b.xw); dfree(b.ovf); dfree(b.ovf2);
+        dfree(b.queueA); dfree(b.queueB); dfree(b.squeue); dfree(b.counters); dfree(b.ovf); dfree(b.ovf2);
         dfree(b.squeueB); dfree(b.ovf3); dfree(s.sO); dfree(s.sD); dfree(s.pendB); dfree(s.vis);
         dfree(b.pixResult); dfree(b.pixAlpha); dfree(b.pixNormal); dfree(b.pixAlbedo);
     }
@@ -544,7 +534,6 @@ extern "C" int pt_destroy(pt_ctx* ctx) {
     for (uint32_t*& px : ctx->d_tex_pixels) dfree(px);
     pt_bvh_free(&ctx->bvh);
     dfree(ctx->d_tri_nrm);
-    dfree(ctx->d_prim2leaf);
     dfree(ctx->d_probe_data); dfree(ctx->d_pdfX); dfree(ctx->d_cdfX); dfree(ctx->d_pdfY); dfree(ctx->d_cdfY);
     dfree(ctx->d_c64Y); dfree(ctx->d_c8Y); dfree(ctx->d_lines); dfree(ctx->d_guide);
     dfree(ctx->d_totals);
@@ -956,13 +945,6 @@ static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_
         if (ctx->has_catcher) { CK(dalloc(&s.alpha, cap)); CK(dalloc(&s.prdN, cap)); CK(dalloc(&s.prdA, cap)); }
         CK(dalloc(&b.queueA, qsize)); CK(dalloc(&b.queueB, qsize)); CK(dalloc(&b.squeue, qsize));
         CK(dalloc(&b.counters, counter_words(nq)));
-        {
-            XwShared* x = nullptr;
-            CK(hipMalloc((void**)&x, sizeof(XwShared)));
-            b.xw = x;
-            b.xw_epoch = 0;
-            CK(hipMemsetAsync(x, 0, sizeof(XwShared), ctx->stream)); // epoch 0: every cell is free for the first launch (epoch 1)
-        }
         CK(dalloc(&b.ovf, ovf_words(ctx))); CK(dalloc(&b.ovf2, ovf_words(ctx)));
         CK(dalloc(&b.pixResult, pix_cap)); CK(dalloc(&b.pixAlpha, pix_cap)); CK(dalloc(&b.pixNormal, pix_cap)); CK(dalloc(&b.pixAlbedo, pix_cap));
         if (async) {
@@ -1058,11 +1040,9 @@ static void launch_shade(pt_ctx* ctx, pt_ctx::BatchSet& bs, const PathState& st,
 // Closest-hit launch of a bounce chain.  The identity queue of bounce 0 holds camera rays in pixel-block order: they are traversed as
 // packets, one wave per 64 consecutive rays (k_trace8_cam, pt_bvh8.h: 55 VGPRs, so eight waves per SIMD instead of five); every other queue
 // (later bounces, foveated launches, whose paths arrive through the sub-queues) takes the per-ray kernel.  PT_CAM_PACKETS=0: per-ray always.
-// a per-ray traversal launch: with cross-wave stealing when the arguments carry a mailbox (pt_bvh8.h)
 template <int MODE>
 static void launch_trace8(hipStream_t stream, unsigned tgrid, const Trace8Args& ta) {
-    if (ta.xw) hipLaunchKernelGGL((k_trace8<MODE, true>), dim3(tgrid), dim3(64), 0, stream, ta);
-    else hipLaunchKernelGGL((k_trace8<MODE, false>), dim3(tgrid), dim3(64), 0, stream, ta);
+    hipLaunchKernelGGL((k_trace8<MODE>), dim3(tgrid), dim3(64), 0, stream, ta);
 }
 static Bvh8Dev bvh_dev(const pt_ctx* ctx) {
 #if PT8_NODE64
@@ -1112,9 +1092,6 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             : (unsigned)std::min<uint64_t>((uint64_t)ctx->trace_grid, std::max<uint64_t>((uint64_t)ctx->trace_grid_min, pass_paths / (64ull * (uint64_t)ctx->grid_chunks)));
         BatchParams bp{ctx->d_pixels + pix0, npix, s0, Sc, ctx->has_catcher ? 1 : 0, bs.pixResult, bs.pixAlpha, bs.pixNormal, bs.pixAlbedo};
         hipMemsetAsync(bs.counters, 0, sizeof(uint32_t) * counter_words(nq), bs.stream);
-        XwCtr* const xwc = reinterpret_cast<XwCtr*>(bs.counters + (size_t)2 * nq * CS + (size_t)2 * nq * PT_WSTRIDE); // [2 nq][PT8_XW_GROUPS], indexed like `work`
-        // cross-wave stealing for this pass's launches (pt_bvh8.h): the default schedule only (one unified launch per bounce)
-        XwShared* const xw = (ctx->xw_mode == 2 || (ctx->xw_mode == 1 && pass_paths <= ctx->xw_max_paths)) && ctx->opt.split_shadow == 0 && !ctx->cap_async ? bs.xw : nullptr;
         uint32_t* cntA = bs.counters;                       // radiance queue counters, per bounce
         uint32_t* cntS = bs.counters + (size_t)nq * CS;     // shadow queue counters, per bounce
         uint32_t* work = bs.counters + (size_t)2 * nq * CS; // work counters of the persistent traversal
@@ -1190,7 +1167,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             // and a frame has max_depth+1 traversal launches instead of 2*max_depth.
             {
                 SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8, xw, xwc, ++bs.xw_epoch, ctx->d_prim2leaf};
+                Trace8Args ta{stream_view(bs, sin), bvh8, qcur, QView{}, work, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                 launch_closest(ctx, bs.stream, ta, tgrid, pass_paths);
                 ++lc.trace;
             }
@@ -1206,12 +1183,12 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
                 }
                 if (b < last_bounce) {
                     SpanGuard g(ctx, CLS_TRACE, bs.stream);
-                    Trace8Args ta{stream_view(bs, sin ^ 1), bvh8, qnext, qshadow, work + (size_t)(b + 1) * PT_WSTRIDE, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8, xw, xwc + (size_t)(b + 1) * PT8_XW_GROUPS, ++bs.xw_epoch, ctx->d_prim2leaf};
+                    Trace8Args ta{stream_view(bs, sin ^ 1), bvh8, qnext, qshadow, work + (size_t)(b + 1) * PT_WSTRIDE, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     launch_trace8<TR_UNIFIED>(bs.stream, tgrid, ta);
                     ++lc.trace;
                 } else {
                     SpanGuard g(ctx, CLS_SHADOW, bs.stream);
-                    Trace8Args ta{stream_view(bs, sin), bvh8, qshadow, QView{}, work + (size_t)(nq + b) * PT_WSTRIDE, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8, xw, xwc + (size_t)(nq + b) * PT8_XW_GROUPS, ++bs.xw_epoch, ctx->d_prim2leaf};
+                    Trace8Args ta{stream_view(bs, sin), bvh8, qshadow, QView{}, work + (size_t)(nq + b) * PT_WSTRIDE, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
                     launch_trace8<TR_SHADOW_APPLY>(bs.stream, tgrid, ta);
                     ++lc.shadow;
                 }
@@ -1488,15 +1465,6 @@ static int render_finish(pt_ctx* ctx, int slot = 0) {
         totals[2] |= per_set[i * 4 + 2];
         totals[3] += per_set[i * 4 + 3];
     }
-    if (totals[2] & 2ull) { // leave the mailboxes empty and consistent for the next frame
-        for (auto& b : ctx->sets)
-            if (b.xw) {
-                hipMemsetAsync(b.xw, 0, sizeof(XwShared), ctx->stream);
-                b.xw_epoch = 0;
-            }
-        hipStreamSynchronize(ctx->stream);
-    }
-    if (totals[2] & 2ull) return fail(ctx, PT_ERR_HIP, "cross-wave stealing: a traversal wave waited 0.2 s for a mailbox cell; the frame is invalid");
     if (totals[2] & 1ull) return fail(ctx, PT_ERR_UNSUPPORTED, "traversal stack overflow: the acceleration structure is deeper than the traversal stack; the frame is invalid");
     if (ctx->dbg) {
         unsigned long long h[64];

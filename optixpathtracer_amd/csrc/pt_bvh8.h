@@ -212,100 +212,7 @@ static __global__ void k_nodes_to80(const Node64* __restrict__ in, uint32_t n, G
 #define PT_WLOG(x)
 #endif
 
-// ------------------------------------------------------------------------------------------------------------------------------------
-// Cross-wave work stealing (k_trace8<MODE, XW = true>; round 5).  In-wave stealing spreads a wave's long rays over its own 64 lanes; what
-// it cannot reach is imbalance BETWEEN waves: a launch of 30-350 k rays gives every wave one chunk of 64, the launch is as long as its
-// slowest wave, and the mean wave is busy for 58 % of its launch (profiles/r5_01_wavelog_*.txt; camera rays: 25-37 %).  With XW a wave
-// that has run dry — or never had rays — does not exit at once: it announces itself (`hungry`) and polls a mailbox in global memory; a
-// wave in its stealing phase that sees hungry waves DONATES the bottom stack entries its own idle lanes do not take: per entry one
-// 64-byte cell (ray, entry, the ray's best key so far).  The taker's lanes become co-workers of that ray exactly like in-wave
-// co-workers, with one more level of merging: a ray with co-workers in several waves owns a global record (key, count of wave groups)
-// beside the per-wave LDS record; the last lane of a group merges the group's key into it (atomic minimum: closest hit = lexicographic
-// minimum of (t, primitive), the kernel's tie-break rule; shadow ray: 0 = occluded), the last group writes the ray's result.  The answer
-// is the minimum over the same set of accepted triangles whatever the split, so images do not change by a bit.  The winner's leaf index
-// is looked up by primitive (prim2leaf: the LDS s_leaf trick needs one wave).
-// Same-address traffic decides the design (first version: one mailbox, one `done` counter, every wave polling and counting on single
-// words — 10 ns per same-address atomic x 4 x 5120 waves: a 1/8 share went from 1.8 to 16 ms).  So the waves of a launch form
-// PT8_XW_GROUPS groups (block index mod 8); a group has its own mailbox, records and counters, each counter on a line of its own, and
-// exchanges work only inside the group.  Termination costs one atomic per wave: a group's `state` word counts finished work units in
-// its low half (a wave's own share = 1 unit, a taken cell = 1 unit, added when the wave next runs dry) and donated cells in its high
-// half (added before the cells are published); the wave whose addition makes finished == shares + donated — it sees both halves in the
-// atomic's return value — sets `closed`, and hungry waves leave when they see it.  Exact closure is only for promptness: a hungry wave
-// also leaves after PT8_XW_LINGER without work, because the wave whose rays it is waiting for may itself be waiting for a wave slot
-// (other streams' kernels; a grid above the residency), and hungry waves holding those slots would deadlock the launch.  Nothing is
-// lost by leaving: a cell is only ever published by a wave that has not run dry, and every wave empties its group's mailbox before it
-// leaves.
-// Memory model: the L2s of different XCDs are not coherent, so EVERY access to the mailbox / records / counters is an agent-scope atomic
-// (write-through stores, L2-bypassing loads, RMWs at memory); "payload before flag" is s_waitcnt vmcnt(0) between them — no agent-scope
-// fence (its L2 write-back costs microseconds with the path state dirty in L2, as the round-4 builder found).
-// Mailbox = bounded MPMC ring after Vyukov: positions are claimed in order by CAS on tail (donor, lane 0, a batch at a time) / head
-// (taker); positions restart at 0 in every launch (the counters are zeroed with the pass's queue counters) and the cells carry the
-// launch's epoch: seq == (epoch, pos): free for the donor of position pos — as is any cell of an older epoch for pos < CELLS —,
-// (epoch, pos + 1): published, (epoch, pos + CELLS) after the taker has read it.
-#ifndef PT8_XW_GROUPS
-#define PT8_XW_GROUPS 16u
-#endif
-#define PT8_XW_CELLS 256u  // per group
-#define PT8_XW_RECS 4096u  // per group
-#ifndef PT8_XW_MAXHUNGRY
-#define PT8_XW_MAXHUNGRY 4u // hungry waves per group at a time: every poll is a same-address access at the memory side (about 10 ns each, serialised —
-                            // a thousand pollers slow the whole chip: 1/8 share 1.8 -> 3.4 ms before a single cell is donated)
-#endif
-#ifndef PT8_XW_TIMEOUT
-#define PT8_XW_TIMEOUT 20000000ll // wall-clock ticks (100 MHz), 0.2 s: a spin on a cell that never ends fails the launch instead of hanging the device
-#endif
-#ifndef PT8_XW_LINGER
-#define PT8_XW_LINGER 5000ll // ticks a hungry wave stays without work: 50 us
-#endif
-#ifndef PT8_XW_DONATE
-#define PT8_XW_DONATE 32 // cells a wave donates per steal round at most
-#endif
-#ifndef PT8_XW_TAKE
-#define PT8_XW_TAKE 16 // cells a hungry wave takes per claim at most (its other lanes then steal from those in LDS)
-#endif
-#ifndef PT8_XW_EXPERIMENT
-#define PT8_XW_EXPERIMENT 0
-#endif
-#ifndef PT8_XW_POLL
-#define PT8_XW_POLL 2 // a wave in its stealing phase reads its group's `hungry` every this many iterations at least (more for large groups, see
-                      // poll_period; 0: never — lingering only; < 0: assumes hungry waves)
-#endif
-#ifndef PT8_XW_WAVES_PER_EU
-#define PT8_XW_WAVES_PER_EU 4 // the XW variants need ~125 VGPRs; their launches are small, occupancy is not what limits them
-#endif
 #define PT_WSTRIDE 16 // words between the chunk counters of two launches (a line each)
-struct XwCell {
-    unsigned long long w[7]; // o.x o.y | o.z tmin | d.x d.y | d.z tmax | stack entry e0 e1 | slot, record id + 1 | shadow << 31 | key
-    unsigned long long seq;  // epoch << 32 | position state
-};
-struct XwRec {
-    unsigned long long key;
-    uint32_t cnt, pad;
-};
-#define PT8_XW_CLOSED 0x80000000u
-struct XwCtr { // per launch and group, zeroed with the pass's counters; every word that is hammered has a line of its own
-    uint32_t tail, head; // one 8-byte load reads both; tail's top bit: the group is closed (set when nothing can be donated any more)
-    uint32_t pad0[14];
-    uint32_t hungry;
-    uint32_t pad1[15];
-    unsigned long long state; // finished units | donated cells << 32
-    uint32_t pad2[14];
-    uint32_t nrec; // global records allocated
-    uint32_t pad3[15];
-};
-static_assert(sizeof(XwCtr) == 256, "");
-struct XwShared { // per batch set, persistent
-    XwCell cells[PT8_XW_GROUPS][PT8_XW_CELLS];
-    XwRec recs[PT8_XW_GROUPS][PT8_XW_RECS];
-};
-PT_DEV uint32_t xw_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-PT_DEV unsigned long long xw_ld64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-PT_DEV void xw_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-PT_DEV void xw_st64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-PT_DEV unsigned long long xw_pack(float a, float b) { return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32); }
-PT_DEV unsigned long long xw_pack(uint32_t a, uint32_t b) { return (unsigned long long)a | ((unsigned long long)b << 32); }
-#define XW_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-
 struct Trace8Args {
     PathState st;
     Bvh8Dev bvh;
@@ -319,16 +226,12 @@ struct Trace8Args {
     int bounce;   // shadow modes with asynchronous shadow records (st.vis != null): the bounce whose records this launch traces
     int lds_skip; // test hook (PT_STACK_LDS_SKIP): keep this many fewer stack levels in LDS, so shallow trees exercise the global spill path
     int ovf_depth;  // spill levels available (PT8_OVF_DEPTH; the test hook PT_STACK_CAP lowers it)
-    uint32_t* fault; // device word: bit 0 set when a push found the stack full, bit 1 when a hungry wave timed out — the host turns either into an error
+    uint32_t* fault; // device word: bit 0 set when a push found the stack full — the host turns it into PT_ERR_UNSUPPORTED
     uint32_t num_nodes;
-    XwShared* xw;              // XW launches: the batch set's mailboxes and records
-    XwCtr* xwc;                // XW launches: this launch's PT8_XW_GROUPS counter blocks (zero at launch)
-    uint32_t xw_epoch;         // XW launches: a number no earlier launch on this batch set had
-    const uint32_t* prim2leaf; // XW launches: leaf triangle of every primitive
 };
 
-template <int MODE, bool XW = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XW ? PT8_XW_WAVES_PER_EU : PT8_WAVES_PER_EU, XW ? PT8_XW_WAVES_PER_EU : PT8_WAVES_PER_EU)))
+template <int MODE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT8_WAVES_PER_EU, PT8_WAVES_PER_EU)))
 k_trace8(Trace8Args a) {
     __shared__ uint32_t s_stack[PT8_LDS_DEPTH * 2 * 64];
     __shared__ uint32_t s_prefix[PT_NSUB + 1];
@@ -339,8 +242,6 @@ k_trace8(Trace8Args a) {
     __shared__ int32_t s_leaf[64];           // per owner lane: leaf triangle of the hit s_key holds (written by whoever lowered the key — one wave per
                                              // workgroup, so after every lane's atomic minimum exactly the lanes whose key IS the minimum write it)
     __shared__ uint32_t s_vlane[64];         // steal round: victim lane by rank
-    __shared__ uint32_t s_gid[XW ? 64 : 1];  // XW, per owner lane: 0 = the ray lives in this wave only; id + 1 of its global record; 0xffffffff while one lane
-                                             // allocates it, 0xfffffffe: none to be had in this launch
 #endif
     const uint32_t lane = threadIdx.x;
     const uint32_t gtid = blockIdx.x * 64u + lane;
@@ -364,26 +265,13 @@ k_trace8(Trace8Args a) {
 #endif
     const bool no_share = (unsigned long long)blockIdx.x * chunk >= n; // this wave has no chunk of its own
     const uint32_t nchunks = (n + chunk - 1u) / chunk;
-    const uint32_t nshare = nchunks < gridDim.x ? nchunks : gridDim.x; // waves that start with a chunk of their own (chunk blockIdx.x)
-    // XW: the wave's group — its mailbox, records and counters — and the number of the group's waves that start with a share
-    const uint32_t grp = blockIdx.x % PT8_XW_GROUPS;
-    const uint32_t nshare_g = (nshare + PT8_XW_GROUPS - 1u - grp) / PT8_XW_GROUPS;
-    XwCtr* const ctr = XW ? a.xwc + grp : nullptr;
-    XwCell* const cells = XW ? a.xw->cells[grp] : nullptr;
-    XwRec* const recs = XW ? a.xw->recs[grp] : nullptr;
-    if (no_share) {
-        // XW: some waves without a share stay as helpers of their group (a group without shares never closes: its helpers leave at once)
-        if (!XW || PT8_XW_EXPERIMENT != 0 || nshare_g == 0u || blockIdx.x >= nshare + PT8_XW_GROUPS * PT8_XW_MAXHUNGRY) return;
-    }
-    uint32_t units = no_share ? 0u : 1u; // XW, wave-uniform: work units this wave will report finished when it next runs dry
-    // XW: a busy wave reads `hungry` every poll_period iterations of its stealing phase, so that a group's polls stay near ten per microsecond
-    const uint32_t poll_period = PT8_XW_POLL > 0 ? ((uint32_t)PT8_XW_POLL > nshare_g / 16u ? (uint32_t)PT8_XW_POLL : nshare_g / 16u) : 1u;
-    uint32_t chunk_next = no_share ? n : blockIdx.x * chunk;
+    if (no_share) return;
+    uint32_t chunk_next = blockIdx.x * chunk;
     uint32_t chunk_end = (chunk_next + chunk < n) ? chunk_next + chunk : n;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     bool shadow_lane = (MODE == TR_SHADOW_APPLY); // TR_UNIFIED: per lane, set at refill
 
-    bool active = false, exhausted = no_share;
+    bool active = false, exhausted = false;
     RaySetup r;
     r.o = r.d = r.idir = r.dn = mk3(0.f);
     float tmin = 0.f, tmax = 0.f, best = 0.f;
@@ -408,7 +296,7 @@ k_trace8(Trace8Args a) {
 #endif
     PT_STAT(uint32_t c_nodes = 0; uint32_t c_tris = 0; uint32_t c_maxsp = 0; uint32_t c_push = 0; uint32_t c_ray = 0; uint32_t c_raymax = 0; uint32_t c_iters = 0;
             uint32_t c_act = 0; uint32_t c_exec = 0; uint32_t c_nodeit = 0;)
-    PT_WLOG(const unsigned long long w_t0 = wall_clock64(); unsigned long long w_tex = 0; uint32_t w_iters = 0; unsigned long long w_linger = 0; uint32_t w_taken = 0; uint32_t w_donated = 0;)
+    PT_WLOG(const unsigned long long w_t0 = wall_clock64(); unsigned long long w_tex = 0; uint32_t w_iters = 0;)
 
     auto push = [&](uint32_t v0, uint32_t v1) {
         PT_STAT(++c_push; if ((uint32_t)sp + 1 > c_maxsp) c_maxsp = sp + 1;)
@@ -477,22 +365,8 @@ k_trace8(Trace8Args a) {
         if (stealing) {
             atomicMin(&s_key[OWNER], local_key());
             if (atomicSub(&s_cnt[OWNER], 1u) == 1u) { // the last co-worker publishes the merged result
-                unsigned long long k = s_key[OWNER];
-                const uint32_t g = XW ? s_gid[OWNER] : 0u;
-                if (XW && g != 0u && g < 0xfffffffeu) {
-                    // the ray has co-workers in other waves: merge this wave's key into its global record; the last GROUP writes the result.
-                    // Every group's minimum is performed before its decrement (the decrement waits for the minimum's return), so the group
-                    // whose decrement finds 1 reads the minimum over all groups.
-                    XwRec* rc = &recs[g - 1u];
-                    const unsigned long long old = atomicMin(&rc->key, k);
-                    uint32_t left = 0u;
-                    if (old != 1ull) left = atomicSub(&rc->cnt, 1u); // (old is never 1: a data dependence that orders the two atomics)
-                    if (left == 1u) {
-                        k = xw_ld64(&rc->key);
-                        if (is_shadow()) write_result(0.f, k == 0ull ? 1 : 0);
-                        else write_result(__uint_as_float((uint32_t)(k >> 32)), (int32_t)(uint32_t)k < 0 ? -1 : (int32_t)a.prim2leaf[(uint32_t)k]);
-                    }
-                } else if (is_shadow()) write_result(0.f, k == 0ull ? 1 : 0);
+                const unsigned long long k = s_key[OWNER];
+                if (is_shadow()) write_result(0.f, k == 0ull ? 1 : 0);
                 else write_result(__uint_as_float((uint32_t)(k >> 32)), (int32_t)(uint32_t)k < 0 ? -1 : s_leaf[OWNER]);
             }
             active = false;
@@ -513,7 +387,7 @@ k_trace8(Trace8Args a) {
                 c_ray = 0;)
     };
 
-    // a lane takes up a ray (refill from the queue; XW: from a mailbox cell — the same instructions, so a taker sees the donor's ray bit for bit)
+    // a lane takes up a ray
     auto start_ray = [&](float ox, float oy, float oz, float dx, float dy, float dz) {
         r.o = mk3(ox, oy, oz);
         r.d = mk3(dx, dy, dz);
@@ -532,8 +406,6 @@ k_trace8(Trace8Args a) {
         SET_SB(0);
         t_mask = 0;
     };
-    uint32_t hs = 0u; // XW, wave-uniform: hungry waves seen by the last poll
-    uint32_t since_poll = 0u;
 
     for (;;) {
 #if PT8_DEFER_WRITE
@@ -634,7 +506,6 @@ k_trace8(Trace8Args a) {
                     s_cnt[lane] = 1u;
                     s_key[lane] = local_key();
                 }
-                if (XW) s_gid[lane] = 0u;
                 __syncthreads(); // one wave per workgroup: orders the LDS writes above before other lanes' reads
             }
             // ---------------- steal round: idle lane k takes the bottom stack entry of victim k
@@ -695,208 +566,15 @@ k_trace8(Trace8Args a) {
                     if (nsb == sp) sp = 0;
                 }
             }
-            // ---------------- XW: waves of the group are hungry — the victims this wave's own idle lanes did not take donate their bottom entries
-            if (XW && hs != 0u) {
-                const uint32_t nv2 = (uint32_t)__popcll(vmask), ni2 = (uint32_t)__popcll(idle2);
-                const uint32_t m2 = ni2 < nv2 ? ni2 : nv2; // victims [0, m2) gave to lanes of this wave above
-                uint32_t want = nv2 - m2;
-                want = want > (uint32_t)PT8_XW_DONATE ? (uint32_t)PT8_XW_DONATE : want;
-                want = want > hs * (uint32_t)PT8_XW_TAKE ? hs * (uint32_t)PT8_XW_TAKE : want;
-                if (want != 0u) {
-                    const uint32_t vr = (uint32_t)__popcll(vmask & lt_mask);
-                    bool donor = victim && vr >= m2 && vr - m2 < want;
-                    // the ray's global record, allocated by the first lane that donates a piece of it (co-workers of one ray may donate together)
-                    if (donor && s_gid[OWNER] == 0u && atomicCAS(&s_gid[OWNER], 0u, 0xffffffffu) == 0u) {
-                        const uint32_t id = atomicAdd(&ctr->nrec, 1u);
-                        if (id < PT8_XW_RECS) {
-                            XwRec* rc = &recs[id];
-                            xw_st64(&rc->key, s_key[OWNER]);
-                            xw_st(&rc->cnt, 1u); // this wave's group of co-workers
-                            XW_DRAIN();
-                            s_gid[OWNER] = id + 1u;
-                        } else {
-                            s_gid[OWNER] = 0xfffffffeu;
-                        }
-                    }
-                    __syncthreads();
-                    uint32_t g = 0u;
-                    if (donor) {
-                        g = s_gid[OWNER];
-                        donor = g < 0xfffffffeu;
-                    }
-                    const unsigned long long dmask = __ballot(donor);
-                    const uint32_t nd = (uint32_t)__popcll(dmask);
-                    uint32_t pos0 = 0u, okk = 0u;
-                    if (nd != 0u) {
-                        if (lane == 0) { // one claim for the wave's cells; a full ring or a lost race: no donation this round
-                            const unsigned long long th = xw_ld64(reinterpret_cast<const unsigned long long*>(&ctr->tail));
-                            const uint32_t t = (uint32_t)th, h = (uint32_t)(th >> 32);
-                            if (t - h + nd <= PT8_XW_CELLS && atomicCAS(&ctr->tail, t, t + nd) == t) {
-                                okk = 1u;
-                                pos0 = t;
-                                atomicAdd(&ctr->state, (unsigned long long)nd << 32); // donated cells: counted before they can be seen (XW_DRAIN below)
-                            }
-                        }
-                        okk = (uint32_t)__builtin_amdgcn_readfirstlane((int)okk);
-                        pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos0);
-                        PT_WLOG(if (okk) w_donated += nd;)
-                    }
-                    if (okk != 0u && donor) {
-                        const uint32_t pos = pos0 + (uint32_t)__popcll(dmask & lt_mask);
-                        XwCell* c = &cells[pos & (PT8_XW_CELLS - 1u)];
-                        atomicAdd(&recs[g - 1u].cnt, 1u); // the taker's group of co-workers, counted before the cell can be seen
-                        const unsigned long long want_seq = ((unsigned long long)a.xw_epoch << 32) | pos;
-                        const long long t_w = wall_clock64();
-                        for (;;) { // the previous lap's taker may still be reading the cell (rare: the ring has 512 cells)
-                            const unsigned long long sq = xw_ld64(&c->seq);
-                            if (sq == want_seq || ((uint32_t)(sq >> 32) != a.xw_epoch && pos < PT8_XW_CELLS)) break;
-                            if (wall_clock64() - t_w > (long long)PT8_XW_TIMEOUT) {
-                                atomicOr(a.fault, 2u);
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                        const int b = SB;
-                        const uint32_t e0 = s_stack[(b * 2) * 64 + lane], e1 = s_stack[(b * 2 + 1) * 64 + lane];
-                        xw_st64(&c->w[0], xw_pack(r.o.x, r.o.y));
-                        xw_st64(&c->w[1], xw_pack(r.o.z, tmin));
-                        xw_st64(&c->w[2], xw_pack(r.d.x, r.d.y));
-                        xw_st64(&c->w[3], xw_pack(r.d.z, tmax));
-                        xw_st64(&c->w[4], xw_pack(e0, e1));
-                        xw_st64(&c->w[5], xw_pack(slot, g | (is_shadow() ? 0x80000000u : 0u)));
-                        xw_st64(&c->w[6], s_key[OWNER]);
-                        XW_DRAIN();
-                        xw_st64(&c->seq, want_seq + 1ull);
-                        const int nsb = b + 1;
-                        SET_SB(nsb == sp ? 0 : nsb);
-                        if (nsb == sp) sp = 0;
-                    }
-                }
-            }
         }
 #endif
         unsigned long long act = __ballot(active);
-#if PT8_STEAL
-#if PT8_XW_EXPERIMENT == 1
-        if (XW && act == 0ull) break; // experiment: the XW kernel variant without any of its protocol
-#endif
-        if (XW && act == 0ull) {
-            // ---------------- XW: this wave is dry (so the queue is exhausted and `stealing` is set): report the work units it finished,
-            // announce itself and poll its group's mailbox until cells arrive, the group closes, or PT8_XW_LINGER has passed without work
-            uint32_t cl = 0u;
-            if (lane == 0) {
-                if (units != 0u) {
-                    const unsigned long long old = atomicAdd(&ctr->state, (unsigned long long)units);
-                    if ((uint32_t)old + units == nshare_g + (uint32_t)(old >> 32)) { // every share and every donated cell of the group is finished
-                        atomicOr(&ctr->tail, PT8_XW_CLOSED);
-                        cl = 1u;
-                    }
-                }
-#if PT8_XW_EXPERIMENT == 2
-                cl = 1u; // experiment: report, never linger
-#endif
-                // at most PT8_XW_MAXHUNGRY waves of a group linger; a wave that has just seen that many leaves without touching the counter
-                if (cl == 0u) {
-                    if (hs >= PT8_XW_MAXHUNGRY) cl = 1u;
-                    else if (atomicAdd(&ctr->hungry, 1u) >= PT8_XW_MAXHUNGRY) {
-                        atomicSub(&ctr->hungry, 1u);
-                        cl = 1u;
-                    }
-                }
-            }
-            units = 0u;
-            cl = (uint32_t)__builtin_amdgcn_readfirstlane((int)cl);
-            if (cl != 0u) { // closed, or enough hungry waves: but never leave cells behind (they were published while this wave was busy)
-                const unsigned long long th0 = xw_ld64(reinterpret_cast<const unsigned long long*>(&ctr->tail));
-                if ((int32_t)(((uint32_t)th0 & ~PT8_XW_CLOSED) - (uint32_t)(th0 >> 32)) <= 0) break;
-                if (lane == 0) atomicAdd(&ctr->hungry, 1u); // there are cells: take them as a hungry wave like any other
-            }
-            bool got = false;
-            const long long t_h = wall_clock64();
-            uint32_t nap = 4u;
-            for (;;) {
-                const unsigned long long th = xw_ld64(reinterpret_cast<const unsigned long long*>(&ctr->tail));
-                const uint32_t tw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)th), h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(th >> 32));
-                const uint32_t t = tw & ~PT8_XW_CLOSED;
-                const int32_t avail = (int32_t)(t - h);
-                if (avail > 0) {
-                    const uint32_t m = avail > PT8_XW_TAKE ? (uint32_t)PT8_XW_TAKE : (uint32_t)avail;
-                    uint32_t okk = 0u;
-                    if (lane == 0) okk = atomicCAS(&ctr->head, h, h + m) == h ? 1u : 0u;
-                    okk = (uint32_t)__builtin_amdgcn_readfirstlane((int)okk);
-                    if (okk != 0u) {
-                        if (lane < m) {
-                            const uint32_t pos = h + lane;
-                            XwCell* c = &cells[pos & (PT8_XW_CELLS - 1u)];
-                            const unsigned long long want_seq = (((unsigned long long)a.xw_epoch << 32) | pos) + 1ull;
-                            const long long t_w = wall_clock64();
-                            while (xw_ld64(&c->seq) != want_seq) { // claimed by its donor, not yet published
-                                if (wall_clock64() - t_w > (long long)PT8_XW_TIMEOUT) {
-                                    atomicOr(a.fault, 2u);
-                                    break;
-                                }
-                                __builtin_amdgcn_s_sleep(1);
-                            }
-                            const unsigned long long w0 = xw_ld64(&c->w[0]), w1 = xw_ld64(&c->w[1]), w2 = xw_ld64(&c->w[2]), w3 = xw_ld64(&c->w[3]);
-                            const unsigned long long w4 = xw_ld64(&c->w[4]), w5 = xw_ld64(&c->w[5]), w6 = xw_ld64(&c->w[6]);
-                            XW_DRAIN(); // the cell is read before it is released
-                            xw_st64(&c->seq, want_seq - 1ull + PT8_XW_CELLS);
-                            start_ray(__uint_as_float((uint32_t)w0), __uint_as_float((uint32_t)(w0 >> 32)), __uint_as_float((uint32_t)w1),
-                                      __uint_as_float((uint32_t)w2), __uint_as_float((uint32_t)(w2 >> 32)), __uint_as_float((uint32_t)w3));
-                            tmin = __uint_as_float((uint32_t)(w1 >> 32));
-                            tmax = __uint_as_float((uint32_t)(w3 >> 32));
-                            slot = (uint32_t)w5;
-                            const uint32_t gf = (uint32_t)(w5 >> 32);
-                            shadow_lane = (gf >> 31) != 0u;
-                            if (is_shadow()) {
-                                best = tmax;
-                                bprim = 0; // an occluder found elsewhere (key 0) is picked up by the refresh at the top of the traversal loop
-                            } else {
-                                best = __uint_as_float((uint32_t)(w6 >> 32));
-                                bprim = (int32_t)(uint32_t)w6;
-                            }
-                            bleaf = -1;
-                            g_base = (uint32_t)w4;
-                            g_imask = (uint32_t)(w4 >> 32) & 0xffu;
-                            g_hits = (uint32_t)(w4 >> 40);
-                            SET_OWNER(lane);
-                            s_key[lane] = w6;
-                            s_cnt[lane] = 1u;
-                            s_leaf[lane] = -1;
-                            s_gid[lane] = gf & 0x7fffffffu;
-                            active = true;
-                        }
-                        units = m;
-                        got = true;
-                        break;
-                    }
-                    continue; // another taker was faster: look again at once
-                }
-                if ((tw & PT8_XW_CLOSED) != 0u) break;
-                if (wall_clock64() - t_h > (long long)PT8_XW_LINGER) break;
-                __builtin_amdgcn_s_sleep(8); // (the s_sleep operand is an immediate) 0.25 us, then 0.5 us between polls
-                if (nap >= 8u) __builtin_amdgcn_s_sleep(8);
-                nap = 8u;
-            }
-            if (lane == 0) atomicSub(&ctr->hungry, 1u);
-            PT_WLOG(w_linger += (unsigned long long)(wall_clock64() - t_h); w_taken += units;)
-            if (!got) break;
-            __syncthreads(); // the takers' LDS records before other lanes' reads
-            continue;
-        }
-#endif
         if (act == 0ull) break;
         const uint32_t thresh = exhausted ? 1u : (uint32_t)PT8_REFILL;
         uint32_t it = 0;
         // ---------------- traverse
         do {
 #if PT8_STEAL
-            uint32_t hs_v = 0u;
-#if PT8_XW_POLL > 0
-            const bool polled = XW && stealing && (++since_poll >= poll_period);
-            if (polled) since_poll = 0u;
-            if (polled) hs_v = xw_ld(&ctr->hungry); // waited for at the end of the iteration, behind the node loads
-#endif
             if (stealing && active) { // pick up what the ray's other workers found
                 const unsigned long long k = s_key[OWNER];
                 if (is_shadow()) {
@@ -1043,13 +721,8 @@ k_trace8(Trace8Args a) {
             act = __ballot(active);
             ++it;
 #if PT8_STEAL
-            // with idle lanes around (XW: or hungry waves elsewhere), return to the steal round every PT8_STEAL_PERIOD iterations
-#if PT8_XW_POLL > 0
-            if (polled) hs = (uint32_t)__builtin_amdgcn_readfirstlane((int)hs_v);
-#elif PT8_XW_POLL < 0
-            if (XW) hs = 1u; // experiment: donate whenever the mailbox has room
-#endif
-            if (stealing && it >= (uint32_t)PT8_STEAL_PERIOD && (act != ~0ull || (XW && hs != 0u))) break;
+            // with idle lanes around, return to the steal round every PT8_STEAL_PERIOD iterations
+            if (stealing && act != ~0ull && it >= (uint32_t)PT8_STEAL_PERIOD) break;
 #endif
         } while ((uint32_t)__popcll(act) >= thresh);
     }
@@ -1074,8 +747,8 @@ k_trace8(Trace8Args a) {
         const unsigned long long k = atomicAdd(&a.dbg[63], 1ull);
         if (k < (unsigned long long)PT_WAVELOG_CAP) {
             unsigned long long* w = a.dbg + 64 + 8 * k;
-            w[6] = w_linger;
-            w[7] = (unsigned long long)w_taken | ((unsigned long long)w_donated << 32);
+            w[6] = 0ull; // (round 5's cross-wave stealing experiment logged its lingering time and cells here: tools/patches/r5_xw_stealing.patch)
+            w[7] = 0ull;
             w[0] = (unsigned long long)(uintptr_t)a.work;
             w[1] = ((unsigned long long)MODE << 32) | n;
             w[2] = w_t0;
@@ -1263,12 +936,5 @@ __global__ void __launch_bounds__(64) k_trace8_cam(Trace8Args a) {
         })
     }
 #endif
-}
-// per primitive: its leaf triangle (every primitive has exactly one)
-__global__ void k_prim2leaf(const LeafTri* __restrict__ tris, uint32_t n, uint32_t nprim, uint32_t* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t prim = __float_as_uint(tris[i].t2.y);
-    if (prim < nprim) out[prim] = i;
 }
 #endif // PT_BVH8_NODE_ONLY

@@ -286,21 +286,6 @@ def test_enqueue_threads_do_not_change_a_bit(ptlib, monkeypatch):
             assert np.array_equal(fa[k].view(np.uint8), fb[k].view(np.uint8)), k
 
 
-def test_cross_wave_stealing_is_bit_identical(ptlib, monkeypatch):
-    """Cross-wave work stealing (PT_XW, opt-in: profiles/r5_02_cross_wave_stealing.md measured it slower) splits a ray over several waves and
-    merges through a global record; the result is the minimum over the same accepted triangles, so every buffer and every ray count must
-    equal the default schedule's — in every launch (PT_XW=2) of a frame whose launches are far smaller than the grid (helpers, lingering,
-    donations all happen) and with the stack's LDS levels cut down so that donated entries come from shallow stacks too."""
-    a, sa = _partition_frame(monkeypatch, {"PT_XW": "0"})
-    b, sb = _partition_frame(monkeypatch, {"PT_XW": "2"})
-    c, sc = _partition_frame(monkeypatch, {"PT_XW": "2", "PT_STACK_LDS_SKIP": "7"})
-    assert sa == sb == sc
-    for fa, fb, fc in zip(a, b, c):
-        for k in fa:
-            assert np.array_equal(fa[k].view(np.uint8), fb[k].view(np.uint8)), k
-            assert np.array_equal(fa[k].view(np.uint8), fc[k].view(np.uint8)), k
-
-
 def test_render_device_refuses_plain_host_memory(ptlib):
     """a caller written against the old render(uint32_t* h_pixels) must not reach a device-to-device copy with a
     pageable host destination: pt_render_device answers PT_ERR_INVALID for a pointer HIP does not know, before rendering anything."""

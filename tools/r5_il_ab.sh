@@ -6,5 +6,5 @@ B="--no-cpu-baseline --no-isolated --no-extra-schedules"
 for W in 8 4 1; do
   echo "== simulate-world $W"
   if [ $W = 1 ]; then A=""; else A="--simulate-world $W"; fi
-  ROUNDS=${ROUNDS:-2} BENCH_ARGS="$B --steps 30 $A" bash tools/r3_ab_env.sh "base X=1" "il PT_LIB=$V/libptamd_il.so" "il32k PT_LIB=$V/libptamd_il32k.so" "xw PT_XW=1" "ilxw PT_XW=1 PT_LIB=$V/libptamd_ilx.so" 2>&1 | tail -5
+  ROUNDS=${ROUNDS:-2} BENCH_ARGS="$B --steps 30 $A" bash tools/r3_ab_env.sh "base X=1" "il PT_LIB=$V/libptamd_il.so" "il32k PT_LIB=$V/libptamd_il32k.so" 2>&1 | tail -5
 done

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS tools/patches/r5_xw_stealing.patch applied (git apply; the cross-wave code was taken out of the product after these runs).
 # tools/r5_xw_ab.sh [ROUNDS]: cross-wave stealing A/B (PT_XW=0 off / 1 small passes / 2 every launch) at a 1/8 share, a 1/4 share and the full frame
 B="--no-cpu-baseline --no-isolated --no-extra-schedules"
 R=${1:-2}

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS tools/patches/r5_xw_stealing.patch applied (git apply; the cross-wave code was taken out of the product after these runs).
 # tools/r5_xw_diag.sh: where the time of a cross-wave stealing launch goes at a 1/8 share — the XW kernel variant alone (e1; e1w5: at five
 # waves per SIMD), + the report atomic (e2), + lingering without donations (poll0), everything (xw) — and the per-wave log of poll0
 V=$PWD/optixpathtracer_amd/variants

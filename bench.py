@@ -460,6 +460,9 @@ def main():
             limiter = (f"dependent-load latency at 5 waves/SIMD, not HBM: k_trace8<3> waves wait on memory {100 * ws['wait_mem']:.0f} % of their time, "
                        f"VALU pipe {100 * ws['valu_pipe']:.0f} % used, TA {100 * ws['ta_busy']:.0f} % busy, mean L1->L2 round trip {ws['l2_round_trip_cycles']:.0f} cycles")
         kname = "k_trace8<3> + k_trace8_cam"
+        fused_passes = int(st.get("fused_passes", 0))  # small synchronous frames (a 1/4 or 1/8 share): generate -> trace -> shade rounds inside ONE persistent kernel (csrc/pt_fused.h)
+        if fused_passes:
+            kname = "k_path_loop (fused bounce loop: its time holds generate, traversal and shading of the whole pass)"
         strong = world > 1 and args.scaling == "strong"
         out = {
             "metric": "Mrays/s (and ms/frame) at 1080p 4spp depth8; 1/2/4/8 MI355X scaling",
@@ -483,6 +486,7 @@ def main():
             # schedule of the timed loop: frames_in_flight 1 = every frame a device-synchronised pt_render (the reference's render()); subframes_per_batch 1 = one frame per launch chain
             "frames_in_flight": opts["frames_in_flight"] if pipelined else 1,
             "subframes_per_batch": args.batch,
+            "fused_bounce_loop_passes_per_frame": fused_passes,  # 0: the launch chain (every frame of more than PT_FUSED_MAX_PATHS = 2.5 M paths; the N=1 headline always)
             # the same frames on the library's other schedules, measured after the timed region (same images bit for bit; not `value`)
             "mrays_per_s_pipelined": extra_out.get("pipelined", {}).get("mrays_per_s"),
             "ms_per_frame_pipelined": extra_out.get("pipelined", {}).get("ms_per_frame"),

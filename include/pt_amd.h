@@ -155,7 +155,8 @@ typedef struct pt_stats {
                              * pt_create builds the three and keeps the one through which a fixed batch of calibration rays takes fewest traversal
                              * steps; PT_BVH_BUILDER=lbvh|ploc|sah forces one, PT_BVH_SAH=0 leaves the SAH candidate out.  Images do not
                              * depend on the choice (closest hit, lowest primitive on ties, hits confined to the triangle's padded box). */
-    uint32_t reserved_;
+    uint32_t fused_passes;  /* passes of the last render that ran as ONE persistent kernel (generate -> trace -> shade rounds per wave, no launch
+                             * chain: small synchronous frames, PT_FUSED; csrc/pt_fused.h); trace_launches counts each of them once */
 } pt_stats;
 
 /* SampleRenderer::SampleRenderer(const Model*) (SimplePathtracer.cpp:39-71): uploads the meshes

@@ -20,11 +20,12 @@
 #include "pt_host.h"
 #include "pt_kernels.h"
 #include "pt_bvh8.h"
+#include "pt_fused.h"
 
 static thread_local std::string g_create_error;
 
 struct LaunchCounts {
-    uint32_t trace = 0, shadow = 0, shade = 0;
+    uint32_t trace = 0, shadow = 0, shade = 0, fused = 0;
 };
 
 // A host thread that enqueues on behalf of a context (pt_multi: one per rank; a synchronous frame: one per pixel chunk).  A frame is 21
@@ -173,6 +174,13 @@ struct pt_ctx {
     int shade_cus = 0;       // PT_SHADE_CUS (experiment): CUs the chunk chains' streams may NOT use; k_shade launches go to unmasked streams
     std::vector<hipStream_t> masked_streams; // [set]: the set's stream when shade_cus > 0 (set_streams[set] then carries its k_shade launches)
     int cam_grid = 0;        // PT_CAM_GRID (tuning hook): waves of a packet launch, 0 = the policy of launch_closest
+    // the bounce loop of a small frame as ONE persistent kernel (pt_fused.h): PT_FUSED=0 never / 1 (default) synchronous frames of at most
+    // fused_max_paths paths (PT_FUSED_MAX_PATHS), as one pass / 2 every pass the kernel covers, chunked as usual (tests); fused_cap: window entries per wave (PT_FUSED_CAP, a multiple of 64)
+    int fused = 1;
+    uint64_t fused_max_paths = 2500000;
+    uint32_t fused_cap = 128;
+    bool fused_frame = false; // the frame being enqueued is one fused pass (render_enqueue)
+    int fused_grid = 0; // PT_FUSED_GRID: waves of the fused kernel (0: the traversal grid)
     int enqueue_threads = 1; // PT_ENQUEUE_THREADS: 0 one enqueue thread, 1 one thread per pixel chunk for small synchronous frames (default), 2 at every size
     bool adapt_grid = false; // set around the enqueue of a whole frame (frames_in_flight = 3)
     int trace_grid_min = 2048, grid_chunks = 6; // PT_GRID_MIN / PT_GRID_CHUNKS (tuning hooks): smallest persistent grid, chunks of 64 paths per wave aimed at
@@ -467,6 +475,10 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
         if (const char* e = getenv("PT_SHADE_CUS")) ctx->shade_cus = std::max(0, std::min(prop.multiProcessorCount - 8, atoi(e)));
         ctx->num_cus = prop.multiProcessorCount;
         if (const char* e = getenv("PT_ENQUEUE_THREADS")) ctx->enqueue_threads = atoi(e);
+        if (const char* e = getenv("PT_FUSED")) ctx->fused = atoi(e);
+        if (const char* e = getenv("PT_FUSED_MAX_PATHS")) ctx->fused_max_paths = strtoull(e, nullptr, 10);
+        if (const char* e = getenv("PT_FUSED_GRID")) ctx->fused_grid = atoi(e);
+        if (const char* e = getenv("PT_FUSED_CAP")) ctx->fused_cap = std::min(4096u, std::max(64u, ((uint32_t)atoi(e) + 63u) & ~63u));
         CKC(dalloc(&ctx->ovf, ovf_words(ctx)));
         ctx->ovf_depth = PT8_OVF_DEPTH;
         if (const char* e = getenv("PT_STACK_CAP")) ctx->ovf_depth = std::max(0, std::min(PT8_OVF_DEPTH, atoi(e) - (PT8_LDS_DEPTH - ctx->lds_skip)));
@@ -1097,7 +1109,8 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
         uint32_t* work = bs.counters + (size_t)2 * nq * CS; // work counters of the persistent traversal
         QView qcur{nullptr, cntA, ctx->sub_cap};            // identity for bounce 0 (k_generate wrote the count)
         if (job) qcur.base = bs.queueB;                     // foveated launch: only the paths inside the annulus are queued
-        {
+        const bool fused = !job && ctx->opt.split_shadow == 0 && !ctx->cap_async && !ctx->has_catcher && (ctx->fused == 2 || ctx->fused_frame);
+        if (!fused) {
             SpanGuard g(ctx, CLS_OTHER, bs.stream);
             if (job)
                 hipLaunchKernelGGL(k_generate_region, dim3(GRID), dim3(256), 0, bs.stream, stream_view(bs, 1), fp, job->rg, PartParams{ctx->rank, ctx->world, ctx->tile_w, ctx->tile_h}, tmin_rad, (uint32_t)job->var.initial_depth, job->l0, job->nl, qcur);
@@ -1114,7 +1127,27 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
         hipEvent_t ev_shadow_done = nullptr;
         const bool unified = ctx->opt.split_shadow == 0;
         const bool async = ctx->cap_async;
-        if (async) {
+        if (fused) {
+            // one persistent kernel instead of the chain below: every wave runs generate -> trace -> shade rounds on a private window of the
+            // queue arrays (pt_fused.h); the windows of all waves fit the arrays (grid x cap <= the pass's paths, rounded up to whole waves)
+            SpanGuard g(ctx, CLS_TRACE, bs.stream);
+            const uint32_t cap = std::min<uint32_t>(ctx->fused_cap, ((uint32_t)pass_paths + 63u) & ~63u);
+            const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ctx->fused_grid > 0 ? std::min<unsigned>(tgrid, (unsigned)ctx->fused_grid) : tgrid, pass_paths / cap));
+            PathLoopArgs pa{};
+            pa.ta = Trace8Args{stream_view(bs, 0), bvh8, QView{bs.queueA, nullptr, 0u}, QView{bs.squeue, nullptr, 0u}, work, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};
+            pa.rayO1 = bs.X[1].rayO; pa.rayD1 = bs.X[1].rayD; pa.thr1 = bs.X[1].thr; pa.hit1 = bs.X[1].hit; pa.rf1 = bs.X[1].rf;
+            pa.qbase1 = bs.queueB;
+            pa.sp = ShadeParams{shade_tris, ctx->d_tri_nrm, ctx->d_mats, ctx->d_mesh_tex, ctx->d_textris, ctx->d_textures, ctx->probe, ctx->opt.max_depth, tmin_rad, QView{}, QView{}, QView{}, nullptr, nullptr, nullptr, nullptr, 1, 0};
+            pa.fp = fp;
+            pa.bp = bp;
+            pa.pool = work; // the first traversal launch's chunk counter, unused here (zeroed with the pass's counters)
+            pa.cap = cap;
+            pa.totals = bs.totals;
+            if (ctx->opt.bsdf_mode == PT_BSDF_LAMBERT) hipLaunchKernelGGL((k_path_loop<PT_BSDF_LAMBERT>), dim3(grid), dim3(64), 0, bs.stream, pa);
+            else hipLaunchKernelGGL((k_path_loop<PT_BSDF_DISNEY>), dim3(grid), dim3(64), 0, bs.stream, pa);
+            ++lc.trace;
+            ++lc.fused;
+        } else if (async) {
             // The bounce chain holds closest-hit launches only; the shadow rays of bounce b are traced from their own records
             // on one of two side streams as soon as k_shade(b) has written them, and nothing waits for them before k_resolve.
             const size_t qsize = (size_t)PT_NSUB * ctx->sub_cap;
@@ -1287,7 +1320,7 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
         {
             SpanGuard g(ctx, CLS_OTHER, bs.stream);
             // counters[last_bounce+1] holds paths that would have continued: not traced, not counted
-            hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters, nq, last_bounce + 1, 1, bs.totals);
+            if (!fused) hipLaunchKernelGGL(k_accum_stats, dim3(1), dim3(64), 0, bs.stream, bs.counters, nq, last_bounce + 1, 1, bs.totals);
             if (job)
                 hipLaunchKernelGGL(k_resolve_region, dim3((job->nl + 255) / 256), dim3(256), 0, bs.stream, bs.st, fp, job->rg, PartParams{ctx->rank, ctx->world, ctx->tile_w, ctx->tile_h}, job->var, job->l0, job->nl);
             else
@@ -1327,7 +1360,13 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
     // chunks that run concurrently on separate stream pairs; a chunk holds at most max_paths/streams paths, so
     // samples are split when spp*pixels exceed that; shadow-catcher scenes run one sample per pass so that the
     // per-pixel normal/albedo sums keep the reference order.  None of this changes a bit of the result.
-    const int nsets = std::max(1, std::min(PT_MAX_SETS, ctx->opt.streams > 0 ? ctx->opt.streams : 3));
+    // PT_FUSED=1: a frame small enough for the fused bounce loop (pt_fused.h) is ONE pass on one stream — the persistent waves of one fused
+    // kernel fill the chip, so three chunk kernels would only run one after the other
+    // (pt_options.streams set by the caller is respected: the chain on that many chunk streams)
+    const bool fused_one_pass = ctx->fused == 1 && !pipelined && ctx->opt.streams <= 0 && !ctx->has_catcher && ctx->opt.split_shadow == 0 &&
+                                (uint64_t)owned * vspp <= ctx->fused_max_paths && (uint64_t)owned * vspp <= ctx->opt.max_paths;
+    ctx->fused_frame = fused_one_pass;
+    const int nsets = fused_one_pass ? 1 : std::max(1, std::min(PT_MAX_SETS, ctx->opt.streams > 0 ? ctx->opt.streams : 3));
     const uint32_t max_paths = std::max<uint32_t>(ctx->opt.max_paths, 64u);
     const uint32_t cap = std::max<uint32_t>(64u, whole ? max_paths : max_paths / nsets);
     uint32_t Np = whole ? owned : (owned + nsets - 1) / nsets; // pixels per chunk ...
@@ -1410,7 +1449,7 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
             int wrc = 0;
             for (uint32_t c = 1; c < nchunks; ++c) wrc |= enqueue_worker_wait(ctx->chunk_workers[c - 1].get());
             if (wrc != 0) return fail(ctx, PT_ERR_HIP, "pt_render: a chunk's enqueue thread failed");
-            for (const LaunchCounts& l : lcs) { lc.trace += l.trace; lc.shadow += l.shadow; lc.shade += l.shade; }
+            for (const LaunchCounts& l : lcs) { lc.trace += l.trace; lc.shadow += l.shadow; lc.shade += l.shade; lc.fused += l.fused; }
         } else {
             uint32_t k = 0;
             for (uint32_t pix0 = 0; pix0 < owned; pix0 += Np, ++k)
@@ -1529,6 +1568,7 @@ static int render_finish(pt_ctx* ctx, int slot = 0) {
     st.trace_launches = lc.trace;
     st.shadow_launches = lc.shadow;
     st.shade_launches = lc.shade;
+    st.fused_passes = lc.fused;
     return PT_OK;
 }
 
@@ -2838,6 +2878,7 @@ extern "C" int pt_multi_get_stats(const pt_multi* m, pt_multi_stats* out) {
         out->sum.trace_launches += s.trace_launches;
         out->sum.shadow_launches += s.shadow_launches;
         out->sum.shade_launches += s.shade_launches;
+        out->sum.fused_passes += s.fused_passes;
         out->sum.bvh_nodes = s.bvh_nodes;
         out->sum.bvh_bytes = s.bvh_bytes;
         out->sum.bvh_levels = s.bvh_levels;

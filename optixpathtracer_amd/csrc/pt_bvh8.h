@@ -230,9 +230,12 @@ struct Trace8Args {
     uint32_t num_nodes;
 };
 
-template <int MODE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT8_WAVES_PER_EU, PT8_WAVES_PER_EU)))
-k_trace8(Trace8Args a) {
+// The traversal of one persistent wave.  LOCAL = false: wave `wid` of `nw` of a launch over the queues of `a` (k_trace8 below).
+// LOCAL = true (pt_fused.h): the wave traverses a private window of the queue arrays — entries [woff, woff + ln1) of `a.queue`'s arrays and, in
+// TR_UNIFIED, the shadow entries [woff, woff + ln2) of `a.queue2`'s — on its own: no sub-queue prefix, no chunk counter, every ray taken by
+// this wave (its spare lanes steal from the first iteration it has fewer rays than lanes).  Spill stack and fault word are the launch's.
+template <int MODE, bool LOCAL>
+PT_DEV void trace8_wave(const Trace8Args& a, const uint32_t wid, const uint32_t nw, const uint32_t ln1, const uint32_t ln2, const uint32_t woff) {
     __shared__ uint32_t s_stack[PT8_LDS_DEPTH * 2 * 64];
     __shared__ uint32_t s_prefix[PT_NSUB + 1];
     __shared__ uint32_t s_prefix2[PT_NSUB + 1];
@@ -248,25 +251,26 @@ k_trace8(Trace8Args a) {
     const uint32_t gstride = gridDim.x * 64u;
     const int lds_depth = PT8_LDS_DEPTH - a.lds_skip;
     // index space of the launch: TR_UNIFIED: [0,n2) = shadow rays of `queue2`, [n2, n) = rays of `queue`; else [0,n1) = rays of `queue`
-    const uint32_t n1 = qreader_init(a.queue, s_prefix);
-    const uint32_t n2 = (MODE == TR_UNIFIED) ? qreader_init(a.queue2, s_prefix2) : 0u;
+    const uint32_t n1 = LOCAL ? ln1 : qreader_init(a.queue, s_prefix);
+    const uint32_t n2 = (MODE == TR_UNIFIED) ? (LOCAL ? ln2 : qreader_init(a.queue2, s_prefix2)) : 0u;
     const uint32_t n = n1 + n2;
-    uint32_t chunk = (n / (gridDim.x * 2u)) & ~(uint32_t)(PT8_MIN_CHUNK < 64 ? PT8_MIN_CHUNK - 1 : 63);
+    uint32_t chunk = (n / (nw * 2u)) & ~(uint32_t)(PT8_MIN_CHUNK < 64 ? PT8_MIN_CHUNK - 1 : 63);
     chunk = chunk < (uint32_t)PT8_MIN_CHUNK ? (uint32_t)PT8_MIN_CHUNK : (chunk > (uint32_t)PT8_CHUNK ? (uint32_t)PT8_CHUNK : chunk);
 #if PT8_WIDE_MIN < 64
     // Wide start (round 5): a launch with fewer rays than the grid has lanes is not throughput-bound but as long as its slowest ray's chain of
     // dependent steps (1.5 us each with a lone wave on a SIMD).  Such a launch is spread over more waves — ceil(n / waves) rays each, at least
     // PT8_WIDE_MIN — whose spare lanes take stack entries of the wave's rays from the first iteration on (the stealing phase below), so a
     // ray's subtrees are traversed side by side.  The split is static: no chunk counter is touched.
-    if (n < gridDim.x * 64u) {
-        chunk = ((n + gridDim.x - 1u) / gridDim.x + 15u) & ~15u;
+    if (n < nw * 64u) {
+        chunk = ((n + nw - 1u) / nw + 15u) & ~15u;
         chunk = chunk < (uint32_t)PT8_WIDE_MIN ? (uint32_t)PT8_WIDE_MIN : chunk;
     }
 #endif
-    const bool no_share = (unsigned long long)blockIdx.x * chunk >= n; // this wave has no chunk of its own
+    if (LOCAL) chunk = n; // one chunk: this wave's
+    const bool no_share = (unsigned long long)wid * chunk >= n; // this wave has no chunk of its own
     const uint32_t nchunks = (n + chunk - 1u) / chunk;
     if (no_share) return;
-    uint32_t chunk_next = blockIdx.x * chunk;
+    uint32_t chunk_next = wid * chunk;
     uint32_t chunk_end = (chunk_next + chunk < n) ? chunk_next + chunk : n;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     bool shadow_lane = (MODE == TR_SHADOW_APPLY); // TR_UNIFIED: per lane, set at refill
@@ -297,6 +301,7 @@ k_trace8(Trace8Args a) {
     PT_STAT(uint32_t c_nodes = 0; uint32_t c_tris = 0; uint32_t c_maxsp = 0; uint32_t c_push = 0; uint32_t c_ray = 0; uint32_t c_raymax = 0; uint32_t c_iters = 0;
             uint32_t c_act = 0; uint32_t c_exec = 0; uint32_t c_nodeit = 0;)
     PT_WLOG(const unsigned long long w_t0 = wall_clock64(); unsigned long long w_tex = 0; uint32_t w_iters = 0;)
+    PT_WLOG(unsigned long long w_c01 = 0; unsigned long long w_c12 = 0; unsigned long long w_c23 = 0; const unsigned long long w_c0 = clock64();) // shader-clock cycles: vote + pop + addresses | waiting for the loads | arithmetic
 
     auto push = [&](uint32_t v0, uint32_t v1) {
         PT_STAT(++c_push; if ((uint32_t)sp + 1 > c_maxsp) c_maxsp = sp + 1;)
@@ -419,12 +424,12 @@ k_trace8(Trace8Args a) {
         if (idle != 0ull && !exhausted) {
             const uint32_t cnt = (uint32_t)__popcll(idle);
             if (chunk_next == chunk_end) {
-                if (nchunks <= gridDim.x) { // every chunk belongs to a wave by its block index: nothing to fetch (and no same-address atomic: 10 ns each, serialised)
+                if (nchunks <= nw) { // every chunk belongs to a wave by its block index: nothing to fetch (and no same-address atomic: 10 ns each, serialised)
                     exhausted = true;
                 } else {
                     uint32_t c = 0;
                     if (lane == 0) c = atomicAdd(a.work, 1u);
-                    c = __shfl(c, 0) + gridDim.x;
+                    c = __shfl(c, 0) + nw;
                     const unsigned long long b0 = (unsigned long long)c * chunk;
                     chunk_next = b0 < n ? (uint32_t)b0 : n;
                     chunk_end = (b0 + chunk < n) ? (uint32_t)(b0 + chunk) : n;
@@ -435,20 +440,23 @@ k_trace8(Trace8Args a) {
             const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
             const uint32_t first = chunk_next;
             chunk_next += take;
-            if (chunk_next == chunk_end && nchunks <= gridDim.x) exhausted = true; // the wave's only chunk is taken: its spare lanes start stealing at once
+            if (chunk_next == chunk_end && nchunks <= nw) exhausted = true; // the wave's only chunk is taken: its spare lanes start stealing at once
 #if PT8_INTERLEAVE
             // A launch of one static chunk per wave: wave w's lane l takes ray l * (waves with a share) + w instead of ray 64 w + l, so every wave
             // holds rays from all over the queue — which is in image order: a wave of 64 neighbouring camera rays that all graze the terrain has
             // no idle lane to help (max / mean wave time 2.7-3.4 in camera launches of a 1/8 share, profiles/r5_01_wavelog_w8.txt).
-            const bool spread = nchunks <= gridDim.x && chunk == 64u && n >= (uint32_t)PT8_INTERLEAVE;
-            const uint32_t gi_spread = lane * nshare + blockIdx.x;
+            const bool spread = nchunks <= nw && chunk == 64u && n >= (uint32_t)PT8_INTERLEAVE;
+            const uint32_t gi_spread = lane * (nchunks < nw ? nchunks : nw) + wid;
             if (!active && (spread ? gi_spread < n : rank < take)) {
                 const uint32_t gi = spread ? gi_spread : first + rank;
 #else
             if (!active && rank < take) {
                 const uint32_t gi = first + rank;
 #endif
-                if (MODE == TR_UNIFIED) {
+                if (LOCAL) {
+                    shadow_lane = (MODE == TR_SHADOW_APPLY) || (MODE == TR_UNIFIED && gi < n2);
+                    slot = woff + ((MODE == TR_UNIFIED && !shadow_lane) ? gi - n2 : gi);
+                } else if (MODE == TR_UNIFIED) {
                     // shadow rays first: the longest rays of a launch are probe shadow rays that graze the terrain and hit nothing;
                     // started early, their tails overlap the closest-hit bulk instead of trailing it
                     shadow_lane = gi < n2;
@@ -585,6 +593,7 @@ k_trace8(Trace8Args a) {
                 }
             }
 #endif
+            PT_WLOG(const unsigned long long w_a = clock64();)
             const bool want_tri = active && t_mask != 0u;
             const bool want_node = active && t_mask == 0u; // node step also covers "group empty → pop"
             const unsigned long long m_tri = __ballot(want_tri), m_node = __ballot(want_node);
@@ -640,6 +649,7 @@ k_trace8(Trace8Args a) {
                 r0 = tp->t0; r1 = tp->t1; r2 = tp->t2;
                 r3.x = __uint_as_float(leaf); // rides to phase 2 in a register the node lanes keep live anyway
             }
+            PT_WLOG(const unsigned long long w_b = clock64(); __builtin_amdgcn_s_waitcnt(0); const unsigned long long w_c = clock64();)
             // ---- phase 2: the arithmetic
             if (do_node) {
                 const float4 n2 = r2, n3 = r3, n4 = r4;
@@ -717,7 +727,7 @@ k_trace8(Trace8Args a) {
                 c_exec += (uint32_t)__popcll(node_step ? m_node : m_tri);
                 c_nodeit += node_step ? 1u : 0u;
             })
-            PT_WLOG(++w_iters;)
+            PT_WLOG(++w_iters; w_c01 += w_b - w_a; w_c12 += w_c - w_b; w_c23 += clock64() - w_c;)
             act = __ballot(active);
             ++it;
 #if PT8_STEAL
@@ -747,8 +757,8 @@ k_trace8(Trace8Args a) {
         const unsigned long long k = atomicAdd(&a.dbg[63], 1ull);
         if (k < (unsigned long long)PT_WAVELOG_CAP) {
             unsigned long long* w = a.dbg + 64 + 8 * k;
-            w[6] = 0ull; // (round 5's cross-wave stealing experiment logged its lingering time and cells here: tools/patches/r5_xw_stealing.patch)
-            w[7] = 0ull;
+            w[6] = (w_c01 << 32) | (w_c12 & 0xffffffffull); // cycles in vote + pop + addresses | cycles waiting for the step's loads
+            w[7] = (w_c23 << 32) | ((clock64() - w_c0 - w_c01 - w_c12 - w_c23) & 0xffffffffull); // cycles in the arithmetic | outside the steps (refill, steal rounds, write-back)
             w[0] = (unsigned long long)(uintptr_t)a.work;
             w[1] = ((unsigned long long)MODE << 32) | n;
             w[2] = w_t0;
@@ -762,6 +772,12 @@ k_trace8(Trace8Args a) {
 #undef SB
 #undef SET_OWNER
 #undef SET_SB
+
+template <int MODE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT8_WAVES_PER_EU, PT8_WAVES_PER_EU)))
+k_trace8(Trace8Args a) {
+    trace8_wave<MODE, false>(a, blockIdx.x, gridDim.x, 0u, 0u, 0u);
+}
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // Camera rays as PACKETS: k_generate writes the paths of a pass sample-major in the order of the pixel list, which is made of 8 x 8-pixel

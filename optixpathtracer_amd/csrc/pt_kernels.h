@@ -160,38 +160,41 @@ PT_DEV uint32_t qreader_get(const QView& q, const uint32_t* s_prefix, uint32_t i
 }
 
 // ------------------------------------------------------------------ generate
+// raygen prologue of path i (sample-major over the chunk's pixel list): the camera ray and random state go to position `pos` of the
+// queue-order arrays (k_generate: pos = i, the identity queue), what is summed per path to slot i
+PT_DEV void generate_path(const PathState& st, const FrameParams& fp, const BatchParams& bp, uint32_t i, uint32_t pos) {
+    const uint32_t vl = i / bp.npix, pix = i - vl * bp.npix;
+    const uint32_t xy = bp.pixels[pix];
+    const uint32_t x = xy & 0xffffu, y = xy >> 16;
+    const uint32_t v = bp.s0 + vl, sub = v / fp.spp, sl = v - sub * fp.spp; // sample sl of subframe subframe_index + sub
+    uint32_t seed = tea4(y * (uint32_t)fp.width + x, fp.subframe_index + sub);
+    for (uint32_t k = 0; k < 2u * sl; ++k) lcg(seed); // earlier samples drew 2 rnd() each (:388)
+    Rng r;
+    r.init(seed); // prd.rand = Random(seed) BEFORE the jitter draws (:375-376)
+    const float jx = rnd(seed), jy = rnd(seed);
+    const float dx = 2.0f * (((float)x + jx) / (float)fp.width) - 1.0f;
+    const float dy = 2.0f * (((float)y + jy) / (float)fp.height) - 1.0f;
+    const v3 dir = normalize3(add3(add3(scl3(fp.U, dx), scl3(fp.V, dy)), fp.W));
+    st.rayO[pos] = make_float4(fp.eye.x, fp.eye.y, fp.eye.z, 0.001f);
+    st.rayD[pos] = make_float4(dir.x, dir.y, dir.z, 1e16f);
+    st.rf[pos] = make_uint4(r.seed1, r.seed2, 0u, 0u);
+    st.pflags[i] = 0u;
+    if (st.vis) st.vis[i] = 0u;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    st.direct[i] = z;
+    st.indirect[i] = z;
+    if (st.prdN) { // shadow-catcher scenes
+        st.alpha[i] = z;
+        st.nrm[i] = (bp.carry && sl > 0) ? bp.pixNormal[pix] : z; // carry-in of the running per-pixel sum of this subframe
+        st.alb[i] = (bp.carry && sl > 0) ? bp.pixAlbedo[pix] : z;
+        st.prdN[i] = z;
+        st.prdA[i] = z;
+    }
+}
 __global__ void __launch_bounds__(256) k_generate(PathState st, FrameParams fp, BatchParams bp, uint32_t* qcount0) {
     const uint32_t total = bp.npix * bp.S;
     if (blockIdx.x == 0 && threadIdx.x == 0) *qcount0 = total;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const uint32_t vl = i / bp.npix, pix = i - vl * bp.npix;
-        const uint32_t xy = bp.pixels[pix];
-        const uint32_t x = xy & 0xffffu, y = xy >> 16;
-        const uint32_t v = bp.s0 + vl, sub = v / fp.spp, sl = v - sub * fp.spp; // sample sl of subframe subframe_index + sub
-        uint32_t seed = tea4(y * (uint32_t)fp.width + x, fp.subframe_index + sub);
-        for (uint32_t k = 0; k < 2u * sl; ++k) lcg(seed); // earlier samples drew 2 rnd() each (:388)
-        Rng r;
-        r.init(seed); // prd.rand = Random(seed) BEFORE the jitter draws (:375-376)
-        const float jx = rnd(seed), jy = rnd(seed);
-        const float dx = 2.0f * (((float)x + jx) / (float)fp.width) - 1.0f;
-        const float dy = 2.0f * (((float)y + jy) / (float)fp.height) - 1.0f;
-        const v3 dir = normalize3(add3(add3(scl3(fp.U, dx), scl3(fp.V, dy)), fp.W));
-        st.rayO[i] = make_float4(fp.eye.x, fp.eye.y, fp.eye.z, 0.001f);
-        st.rayD[i] = make_float4(dir.x, dir.y, dir.z, 1e16f);
-        st.rf[i] = make_uint4(r.seed1, r.seed2, 0u, 0u);
-        st.pflags[i] = 0u;
-        if (st.vis) st.vis[i] = 0u;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        st.direct[i] = z;
-        st.indirect[i] = z;
-        if (st.prdN) { // shadow-catcher scenes
-            st.alpha[i] = z;
-            st.nrm[i] = (bp.carry && sl > 0) ? bp.pixNormal[pix] : z; // carry-in of the running per-pixel sum of this subframe
-            st.alb[i] = (bp.carry && sl > 0) ? bp.pixAlbedo[pix] : z;
-            st.prdN[i] = z;
-            st.prdA[i] = z;
-        }
-    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) generate_path(st, fp, bp, i, i);
 }
 
 // ------------------------------------------------------------------ shade
@@ -227,7 +230,20 @@ struct ShadeParams {
 
 // wave-aggregated queue append: one atomic per wave (over the lanes that are active at the call: it may sit in divergent code).  Returns the
 // position of the lane's entry in the queue's arrays (meaningful where pred holds); the slot is written there.
+// LOCAL (pt_fused.h): the queue is a wave's private window of the arrays — q.counts is the wave's own count (LDS), q.sub_cap the window's first
+// position; no atomic, the wave is the only producer.
+template <bool LOCAL = false>
 PT_DEV uint32_t queue_push(bool pred, uint32_t value, const QView& q) {
+    if (LOCAL) {
+        const unsigned long long lmask = __ballot(pred);
+        if (lmask == 0ull) return 0u;
+        const uint32_t llane = __lane_id();
+        const uint32_t lbase = __hip_atomic_load(q.counts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (llane == (uint32_t)__ffsll((long long)lmask) - 1u) __hip_atomic_store(q.counts, lbase + (uint32_t)__popcll(lmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const uint32_t lpos = q.sub_cap + lbase + (uint32_t)__popcll(lmask & ((1ull << llane) - 1ull));
+        if (pred) q.base[lpos] = value;
+        return lpos;
+    }
     const uint32_t sub = blockIdx.x & (PT_NSUB - 1);
     uint32_t* counter = q.counts + sub * PT_CSTRIDE;
     const unsigned long long mask = __ballot(pred);
@@ -259,7 +275,7 @@ PT_DEV void shade_miss(const PathState& st, const ShadeParams& sp, uint32_t pos,
 // __miss__radiance plus the raygen loop's bookkeeping).  A path that continues is pushed into next_queue and its state written at the
 // position of that entry; a pending shadow ray is pushed into shadow_queue with its record (or, with asynchronous shadow rays, written
 // to the per-bounce record of the slot).
-template <int MODE, bool CATCHER>
+template <int MODE, bool CATCHER, bool LOCAL = false>
 PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMarg& pm, const float* u8lut, uint32_t pos, uint32_t p, float2 h) {
     const int32_t leaf = __float_as_int(h.y);
     if (leaf < 0) {
@@ -406,7 +422,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             if (CATCHER && is_catcher) {
                 // SampleShadow: alpha += T * shadowSample when OCCLUDED (:550-551), whatever happens next
                 if (has_val) {
-                    const uint32_t sq = queue_push(true, p, sp.shadow_queue);
+                    const uint32_t sq = queue_push<LOCAL>(true, p, sp.shadow_queue);
                     st_st<PT_NT_SHADE_ST>(&st.shO[sq], make_float4(P.x, P.y, P.z, 0.f));
                     st_st<PT_NT_SHADE_ST>(&st.shD[sq], make_float4(wi.x, wi.y, wi.z, 0.f));
                     st_st<PT_NT_SHADE_ST>(&st.shPend[sq], make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(PEND_ALPHA)));
@@ -424,7 +440,7 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                 }
                 if (has_val) {
                     const float4 pe = make_float4(contrib.x, contrib.y, contrib.z, __int_as_float(depth == 0 ? PEND_DIRECT : PEND_INDIRECT));
-                    const uint32_t sq = queue_push(true, p, sp.shadow_queue);
+                    const uint32_t sq = queue_push<LOCAL>(true, p, sp.shadow_queue);
                     if (st.vis) { // asynchronous shadow rays: a self-contained record of this bounce, by slot (the queue entry names the slot)
                         const size_t bi = (size_t)depth * st.bstride + p;
                         st.sO[bi] = make_float4(P.x, P.y, P.z, 0.f);
@@ -443,7 +459,17 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             }
         }
     }
-    const uint32_t nq = queue_push(push_next, p, sp.next_queue);
+    if (LOCAL) {
+        // the fused loop has no launch that simply is not made: a path that "would continue" past the depth cutoff (the provably dead trace at
+        // depth == max_depth, pt_api.hip enqueue_chunk) is counted as a shaded hit (sp.next_queue.counts[1]) and not queued
+        const unsigned long long cm = __ballot(push_next);
+        if (cm != 0ull && __lane_id() == (uint32_t)__ffsll((long long)cm) - 1u) {
+            uint32_t* hc = sp.next_queue.counts + 1;
+            __hip_atomic_store(hc, __hip_atomic_load(hc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + (uint32_t)__popcll(cm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        if (!CATCHER && depth >= sp.max_depth) push_next = false;
+    }
+    const uint32_t nq = queue_push<LOCAL>(push_next, p, sp.next_queue);
     if (push_next) {
         st_st<PT_NT_SHADE_ST>(&sp.oRayO[nq], make_float4(P_out.x, P_out.y, P_out.z, sp.tmin_radiance));
         st_st<PT_NT_SHADE_ST>(&sp.oRayD[nq], make_float4(dir_out.x, dir_out.y, dir_out.z, 1e16f));

@@ -272,18 +272,41 @@ def _partition_frame(monkeypatch, env):
     r.close()
     for k in env:
         monkeypatch.delenv(k)
+    _partition_frame.last_stats = st
     return out, {k: st[k] for k in ("radiance_rays", "shadow_rays", "shaded_hits", "paths")}
 
 
 def test_enqueue_threads_do_not_change_a_bit(ptlib, monkeypatch):
     """small synchronous frames enqueue each pixel chunk's chain from its own thread (PT_ENQUEUE_THREADS, read per context at
     pt_create since round 5); the single-thread path and the threaded path must leave the same five buffers and the same ray counts."""
-    a, sa = _partition_frame(monkeypatch, {"PT_ENQUEUE_THREADS": "0"})
-    b, sb = _partition_frame(monkeypatch, {"PT_ENQUEUE_THREADS": "2"})
+    a, sa = _partition_frame(monkeypatch, {"PT_ENQUEUE_THREADS": "0", "PT_FUSED": "0"})  # (PT_FUSED=0: the launch chain in three pixel chunks)
+    assert _partition_frame.last_stats["fused_passes"] == 0 and _partition_frame.last_stats["trace_launches"] > 3
+    b, sb = _partition_frame(monkeypatch, {"PT_ENQUEUE_THREADS": "2", "PT_FUSED": "0"})
     assert sa == sb
     for fa, fb in zip(a, b):
         for k in fa:
             assert np.array_equal(fa[k].view(np.uint8), fb[k].view(np.uint8)), k
+
+
+@pytest.mark.parametrize("cap", ["64", "128", "320"])
+def test_fused_bounce_loop_is_bit_identical(ptlib, monkeypatch, cap):
+    """pt_fused.h: the bounce loop of a pass as one persistent kernel (every wave runs generate -> trace -> shade rounds on a private window
+    of the queue arrays, no barrier between bounces).  Per path the arithmetic, the random numbers and the order of its contributions are the
+    launch chain's, so all five buffers and the three device-counted ray totals must be equal — with windows of one, two and five waves'
+    worth of entries (refills at every round, paths of different depth side by side in one wave), and with the traversal stack's LDS levels
+    cut down so that the spill path is exercised inside the fused kernel too."""
+    a, sa = _partition_frame(monkeypatch, {"PT_FUSED": "0"})
+    assert _partition_frame.last_stats["fused_passes"] == 0
+    b, sb = _partition_frame(monkeypatch, {"PT_FUSED": "2", "PT_FUSED_CAP": cap})  # every pixel chunk's pass fused (three kernels)
+    assert _partition_frame.last_stats["fused_passes"] == 3
+    c, sc = _partition_frame(monkeypatch, {"PT_FUSED": "2", "PT_FUSED_CAP": cap, "PT_STACK_LDS_SKIP": "7"})
+    d, sd = _partition_frame(monkeypatch, {"PT_FUSED_CAP": cap})  # the default policy: a frame this small is ONE fused pass
+    assert _partition_frame.last_stats["fused_passes"] == 1 and _partition_frame.last_stats["trace_launches"] == 1
+    assert sa == sb == sc == sd
+    for fa, fb, fc, fd in zip(a, b, c, d):
+        for k in fa:
+            for other in (fb, fc, fd):
+                assert np.array_equal(fa[k].view(np.uint8), other[k].view(np.uint8)), k
 
 
 def test_render_device_refuses_plain_host_memory(ptlib):

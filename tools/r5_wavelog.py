@@ -25,14 +25,32 @@ for (s, k, m, t0, t1, tex) in rows:
     mode = int(m[0, 1] >> np.uint64(32))
     n = int(m[0, 1] & np.uint64(0xffffffff))
     d = (t1 - t0) / 100.0  # 100 MHz -> us
+    if mode == 7:  # a fused bounce-loop kernel (pt_fused.h): one entry per wave: rounds, ticks in traversal, ticks in shading
+        span = (t1.max() - t0.min()) / 100.0
+        live = m[:, 5] > 0
+        rounds = m[live, 5].astype(np.int64)
+        tr = m[live, 6].astype(np.int64) / 100.0
+        sh = m[live, 7].astype(np.int64) / 100.0
+        dl = d[live]
+        tp = (tex[live] - t0.min()) / 100.0
+        print(f"{(s - T0) / 100.0:9.1f} fused {n:8d} paths, {len(m)} waves ({int(live.sum())} with work): span {span:.1f} us, wave mean {dl.mean():.1f} p90 {np.percentile(dl, 90):.1f} max {dl.max():.1f} us; "
+              f"rounds mean {rounds.mean():.1f} max {rounds.max()}; per round: {dl.sum() / rounds.sum():.1f} us = traversal {tr.sum() / rounds.sum():.1f} + shading {sh.sum() / rounds.sum():.1f} + refill/other {(dl.sum() - tr.sum() - sh.sum()) / rounds.sum():.1f}; "
+              f"pool empty (as waves saw it) at {np.percentile(tp, 5):.0f}..{np.percentile(tp, 95):.0f} us")
+        tot_span += span
+        tot_ideal += dl.mean()
+        continue
     span = (t1.max() - t0.min()) / 100.0
     steal = np.where(tex > 0, (t1 - tex) / 100.0, 0.0)
     it = m[:, 5].astype(np.int64)
-    linger = m[:, 6].astype(np.int64) / 100.0
-    taken = int((m[:, 7] & np.uint64(0xffffffff)).sum())
-    donated = int((m[:, 7] >> np.uint64(32)).sum())
+    linger = np.zeros(len(m))
+    taken = donated = 0
+    # shader-clock cycles of the wave's traversal steps (PT_DEBUG_WAVELOG builds since the cross-wave experiment left): per iteration, over all waves
+    c01 = (m[:, 6] >> np.uint64(32)).astype(np.int64).sum(); c12 = (m[:, 6] & np.uint64(0xffffffff)).astype(np.int64).sum()
+    c23 = (m[:, 7] >> np.uint64(32)).astype(np.int64).sum(); cout = (m[:, 7] & np.uint64(0xffffffff)).astype(np.int64).sum()
+    nit = max(1, int(m[:, 5].astype(np.int64).sum()))
+    cyc = f"  cycles/iteration: select {c01 / nit:.0f} + wait {c12 / nit:.0f} + arithmetic {c23 / nit:.0f} + outside {cout / nit:.0f}"
     print(f"{(s - T0) / 100.0:9.1f} {mode:4d} {n:8d} {len(m):6d} {span:8.1f} {d.mean():7.1f} {np.percentile(d, 50):7.1f} {np.percentile(d, 90):7.1f} {d.max():7.1f} "
-          f"{d.max() / max(d.mean(), 1e-9):8.2f} {100 * d.mean() / max(span, 1e-9):7.1f} {100 * steal.sum() / max(d.sum(), 1e-9):8.1f} {it.mean():7.1f}/{it.max():5d} {100 * linger.sum() / max(d.sum(), 1e-9):8.1f} {taken:6d} {donated:7d}")
+          f"{d.max() / max(d.mean(), 1e-9):8.2f} {100 * d.mean() / max(span, 1e-9):7.1f} {100 * steal.sum() / max(d.sum(), 1e-9):8.1f} {it.mean():7.1f}/{it.max():5d} {100 * linger.sum() / max(d.sum(), 1e-9):8.1f} {taken:6d} {donated:7d}" + cyc)
     tot_span += span
     tot_ideal += d.mean()
 print(f"# sum of launch spans {tot_span:.1f} us, sum of mean wave durations {tot_ideal:.1f} us ({100 * tot_ideal / tot_span:.1f} %)")

@@ -198,6 +198,22 @@ static __global__ void k_nodes_to80(const Node64* __restrict__ in, uint32_t n, G
 #define PT8_STEAL_PERIOD 3 // traversal iterations between two steal rounds while lanes are idle
 #endif
 
+// The stealing phase is where a small launch spends its whole life, one wave per SIMD, and there every stall is paid in full (per-wave cycle
+// log, profiles/r5_15_tail_cycles.md: of 4500 cycles per iteration only 650 wait for the step's own loads).
+// PT8_STEAL_WSYNC: the lanes of a steal round talk through LDS only and the workgroup IS one wave, whose LDS operations execute in order — a
+//   compiler-level barrier orders them; __syncthreads() also drains every outstanding global load and store (vmcnt(0)), twice per round:
+//   1/8 share 1.803 -> 1.781 ms, full frame 7.881 -> 7.844.
+// (Measured and rejected with it: writing back the rays that finish in the stealing phase together, at the top of the outer loop, like those
+// that finish before it, instead of one by one where they finish: 1/8 share 1.78 -> 1.90 ms, full frame 7.84 -> 8.16.)
+#ifndef PT8_STEAL_WSYNC
+#define PT8_STEAL_WSYNC 1
+#endif
+#if PT8_STEAL_WSYNC
+#define PT8_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define PT8_WAVE_SYNC() __syncthreads()
+#endif
+
 #define PT_WAVELOG_CAP (1u << 20)
 #ifdef PT_DEBUG_STATS
 #define PT_STAT(x) x
@@ -301,6 +317,7 @@ PT_DEV void trace8_wave(const Trace8Args& a, const uint32_t wid, const uint32_t 
     PT_STAT(uint32_t c_nodes = 0; uint32_t c_tris = 0; uint32_t c_maxsp = 0; uint32_t c_push = 0; uint32_t c_ray = 0; uint32_t c_raymax = 0; uint32_t c_iters = 0;
             uint32_t c_act = 0; uint32_t c_exec = 0; uint32_t c_nodeit = 0;)
     PT_WLOG(const unsigned long long w_t0 = wall_clock64(); unsigned long long w_tex = 0; uint32_t w_iters = 0;)
+    PT_WLOG(unsigned long long w_cw = 0; unsigned long long w_cr = 0; unsigned long long w_cs = 0; uint32_t w_np = 0;) // -DPT_DEBUG_WAVELOG=2: cycles in the loop-top write-back | refill | steal round, outer passes
     PT_WLOG(unsigned long long w_c01 = 0; unsigned long long w_c12 = 0; unsigned long long w_c23 = 0; const unsigned long long w_c0 = clock64();) // shader-clock cycles: vote + pop + addresses | waiting for the loads | arithmetic
 
     auto push = [&](uint32_t v0, uint32_t v1) {
@@ -413,12 +430,14 @@ PT_DEV void trace8_wave(const Trace8Args& a, const uint32_t wid, const uint32_t 
     };
 
     for (;;) {
+        PT_WLOG(const unsigned long long w_p0 = clock64(); ++w_np;)
 #if PT8_DEFER_WRITE
         if (unwritten) { // results of the rays that finished since the last pass: all finished lanes at once
             write_result(best, is_shadow() ? bprim : bleaf);
             unwritten = false;
         }
 #endif
+        PT_WLOG(__builtin_amdgcn_s_waitcnt(0); const unsigned long long w_p1 = clock64(); w_cw += w_p1 - w_p0;)
         // ---------------- refill idle lanes
         const unsigned long long idle = __ballot(!active);
         if (idle != 0ull && !exhausted) {
@@ -503,6 +522,7 @@ PT_DEV void trace8_wave(const Trace8Args& a, const uint32_t wid, const uint32_t 
                 active = true;
             }
         }
+        PT_WLOG(__builtin_amdgcn_s_waitcnt(0); const unsigned long long w_p2 = clock64(); w_cr += w_p2 - w_p1;)
 #if PT8_STEAL
         if (exhausted) {
             if (!stealing) { // the wave took its last chunk: from here on its rays are shared work
@@ -514,7 +534,7 @@ PT_DEV void trace8_wave(const Trace8Args& a, const uint32_t wid, const uint32_t 
                     s_cnt[lane] = 1u;
                     s_key[lane] = local_key();
                 }
-                __syncthreads(); // one wave per workgroup: orders the LDS writes above before other lanes' reads
+                PT8_WAVE_SYNC(); // one wave per workgroup: orders the LDS writes above before other lanes' reads
             }
             // ---------------- steal round: idle lane k takes the bottom stack entry of victim k
             const unsigned long long idle2 = __ballot(!active);
@@ -526,7 +546,7 @@ PT_DEV void trace8_wave(const Trace8Args& a, const uint32_t wid, const uint32_t 
                 const uint32_t vrank = (uint32_t)__popcll(vmask & lt_mask), irank = (uint32_t)__popcll(idle2 & lt_mask);
                 const bool give = victim && vrank < m, take = !active && irank < m;
                 if (give) s_vlane[vrank] = lane;
-                __syncthreads();
+                PT8_WAVE_SYNC();
                 const uint32_t v = take ? s_vlane[irank] : lane; // every lane runs the shuffles; only takers keep what they read
                 const float ox = __shfl(r.o.x, (int)v), oy = __shfl(r.o.y, (int)v), oz = __shfl(r.o.z, (int)v);
                 const float dx = __shfl(r.d.x, (int)v), dy = __shfl(r.d.y, (int)v), dz = __shfl(r.d.z, (int)v);
@@ -567,7 +587,7 @@ PT_DEV void trace8_wave(const Trace8Args& a, const uint32_t wid, const uint32_t 
                     atomicAdd(&s_cnt[OWNER], 1u);
                     active = true;
                 }
-                __syncthreads(); // takers have read the entries before their victims may overwrite those levels
+                PT8_WAVE_SYNC(); // takers have read the entries before their victims may overwrite those levels
                 if (give) {
                     const int nsb = SB + 1;
                     SET_SB(nsb == sp ? 0 : nsb);
@@ -576,6 +596,7 @@ PT_DEV void trace8_wave(const Trace8Args& a, const uint32_t wid, const uint32_t 
             }
         }
 #endif
+        PT_WLOG(w_cs += clock64() - w_p2;)
         unsigned long long act = __ballot(active);
         if (act == 0ull) break;
         const uint32_t thresh = exhausted ? 1u : (uint32_t)PT8_REFILL;
@@ -757,8 +778,13 @@ PT_DEV void trace8_wave(const Trace8Args& a, const uint32_t wid, const uint32_t 
         const unsigned long long k = atomicAdd(&a.dbg[63], 1ull);
         if (k < (unsigned long long)PT_WAVELOG_CAP) {
             unsigned long long* w = a.dbg + 64 + 8 * k;
+#if PT_DEBUG_WAVELOG + 0 == 2
+            w[6] = (w_cw << 32) | (w_cr & 0xffffffffull); // cycles in the loop-top write-back | in the refill
+            w[7] = (w_cs << 32) | w_np;                   // cycles in the steal round | outer passes
+#else
             w[6] = (w_c01 << 32) | (w_c12 & 0xffffffffull); // cycles in vote + pop + addresses | cycles waiting for the step's loads
             w[7] = (w_c23 << 32) | ((clock64() - w_c0 - w_c01 - w_c12 - w_c23) & 0xffffffffull); // cycles in the arithmetic | outside the steps (refill, steal rounds, write-back)
+#endif
             w[0] = (unsigned long long)(uintptr_t)a.work;
             w[1] = ((unsigned long long)MODE << 32) | n;
             w[2] = w_t0;

@@ -49,6 +49,8 @@ for (s, k, m, t0, t1, tex) in rows:
     c23 = (m[:, 7] >> np.uint64(32)).astype(np.int64).sum(); cout = (m[:, 7] & np.uint64(0xffffffff)).astype(np.int64).sum()
     nit = max(1, int(m[:, 5].astype(np.int64).sum()))
     cyc = f"  cycles/iteration: select {c01 / nit:.0f} + wait {c12 / nit:.0f} + arithmetic {c23 / nit:.0f} + outside {cout / nit:.0f}"
+    if "--fine" in sys.argv:  # -DPT_DEBUG_WAVELOG=2 builds: the same words hold the outer loop's parts
+        cyc = f"  outer passes/wave {cout / len(m):.1f}, iterations per pass {nit / max(1, cout):.1f}; cycles per PASS: write-back {c01 / max(1, cout):.0f} + refill {c12 / max(1, cout):.0f} + steal round {c23 / max(1, cout):.0f}"
     print(f"{(s - T0) / 100.0:9.1f} {mode:4d} {n:8d} {len(m):6d} {span:8.1f} {d.mean():7.1f} {np.percentile(d, 50):7.1f} {np.percentile(d, 90):7.1f} {d.max():7.1f} "
           f"{d.max() / max(d.mean(), 1e-9):8.2f} {100 * d.mean() / max(span, 1e-9):7.1f} {100 * steal.sum() / max(d.sum(), 1e-9):8.1f} {it.mean():7.1f}/{it.max():5d} {100 * linger.sum() / max(d.sum(), 1e-9):8.1f} {taken:6d} {donated:7d}" + cyc)
     tot_span += span

@@ -99,7 +99,7 @@ def source_hash():
     rejected experiment)."""
     h = hashlib.sha256()
     src = os.path.join(ROOT, "optixpathtracer_amd", "csrc")
-    files = [os.path.join(src, f) for f in ("pt_device.h", "pt_bvh.h", "pt_bvh8.h", "pt_kernels.h", "pt_host.h", "pt_api.hip", "pt_bvh_build.hip")]
+    files = [os.path.join(src, f) for f in ("pt_device.h", "pt_bvh.h", "pt_bvh8.h", "pt_kernels.h", "pt_fused.h", "pt_host.h", "pt_api.hip", "pt_bvh_build.hip")]
     files.append(os.path.join(ROOT, "include", "pt_detmath.h"))  # (the facade header and the C ABI's comments are not kernel sources)
     for f in files:
         h.update(os.path.basename(f).encode())
@@ -242,7 +242,7 @@ def main():
     for k in range(0, warm, args.batch):
         render_frame(k, args.batch)
     barrier()
-    keys = ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms", "trace_launches", "shadow_launches", "shade_launches", "radiance_rays", "shadow_rays", "shaded_hits")
+    keys = ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms", "trace_launches", "shadow_launches", "shade_launches", "radiance_rays", "shadow_rays", "shaded_hits", "fused_passes")
     agg = dict.fromkeys(keys, 0.0)
     # rays are counted on the device for every frame; pt_stats also keeps the totals since pt_create, so that a loop with frames in
     # flight does not have to read (= wait for) each frame's statistics
@@ -460,8 +460,8 @@ def main():
             limiter = (f"dependent-load latency at 5 waves/SIMD, not HBM: k_trace8<3> waves wait on memory {100 * ws['wait_mem']:.0f} % of their time, "
                        f"VALU pipe {100 * ws['valu_pipe']:.0f} % used, TA {100 * ws['ta_busy']:.0f} % busy, mean L1->L2 round trip {ws['l2_round_trip_cycles']:.0f} cycles")
         kname = "k_trace8<3> + k_trace8_cam"
-        fused_passes = int(st.get("fused_passes", 0))  # small synchronous frames (a 1/4 or 1/8 share): generate -> trace -> shade rounds inside ONE persistent kernel (csrc/pt_fused.h)
-        if fused_passes:
+        fused_passes = int(round(agg["fused_passes"] / args.steps))  # small synchronous frames (a 1/4 or 1/8 share): generate -> trace -> shade rounds inside ONE persistent kernel (csrc/pt_fused.h)
+        if src["fused_passes"] > 0:  # (the isolated single-stream frames always run the launch chain)
             kname = "k_path_loop (fused bounce loop: its time holds generate, traversal and shading of the whole pass)"
         strong = world > 1 and args.scaling == "strong"
         out = {

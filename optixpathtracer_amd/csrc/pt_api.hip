@@ -179,6 +179,7 @@ struct pt_ctx {
     int fused = 1;
     uint64_t fused_max_paths = 2500000;
     uint32_t fused_cap = 128;
+    float fused_max_cost = 22.f; // PT_FUSED_MAX_COST: fused_one_pass only for trees whose calibration rays cost at most this many steps (see render_enqueue)
     bool fused_frame = false; // the frame being enqueued is one fused pass (render_enqueue)
     int fused_grid = 0; // PT_FUSED_GRID: waves of the fused kernel (0: the traversal grid)
     int enqueue_threads = 1; // PT_ENQUEUE_THREADS: 0 one enqueue thread, 1 one thread per pixel chunk for small synchronous frames (default), 2 at every size
@@ -478,6 +479,7 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
         if (const char* e = getenv("PT_FUSED")) ctx->fused = atoi(e);
         if (const char* e = getenv("PT_FUSED_MAX_PATHS")) ctx->fused_max_paths = strtoull(e, nullptr, 10);
         if (const char* e = getenv("PT_FUSED_GRID")) ctx->fused_grid = atoi(e);
+        if (const char* e = getenv("PT_FUSED_MAX_COST")) ctx->fused_max_cost = (float)atof(e);
         if (const char* e = getenv("PT_FUSED_CAP")) ctx->fused_cap = std::min(4096u, std::max(64u, ((uint32_t)atoi(e) + 63u) & ~63u));
         CKC(dalloc(&ctx->ovf, ovf_words(ctx)));
         ctx->ovf_depth = PT8_OVF_DEPTH;
@@ -1362,8 +1364,12 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
     // per-pixel normal/albedo sums keep the reference order.  None of this changes a bit of the result.
     // PT_FUSED=1: a frame small enough for the fused bounce loop (pt_fused.h) is ONE pass on one stream — the persistent waves of one fused
     // kernel fill the chip, so three chunk kernels would only run one after the other
-    // (pt_options.streams set by the caller is respected: the chain on that many chunk streams)
+    // (pt_options.streams set by the caller is respected: the chain on that many chunk streams).  Scenes whose rays are expensive and heavy-tailed keep
+    // the chain: every round of every fused wave ends with its own slowest ray, and on the stadium (27 steps per calibration ray; terrain 14) a
+    // 1/8 share runs 7-13 % slower fused while the terrain, the textured terrain and the Cornell box run 3-11 % faster (profiles/r5_14_fused_bounce_loop.md).
+    // One scene family on either side of the threshold: a rule of thumb, PT_FUSED_MAX_COST moves it.
     const bool fused_one_pass = ctx->fused == 1 && !pipelined && ctx->opt.streams <= 0 && !ctx->has_catcher && ctx->opt.split_shadow == 0 &&
+                                (ctx->bvh.calib_cost <= 0.f || ctx->bvh.calib_cost <= ctx->fused_max_cost) &&
                                 (uint64_t)owned * vspp <= ctx->fused_max_paths && (uint64_t)owned * vspp <= ctx->opt.max_paths;
     ctx->fused_frame = fused_one_pass;
     const int nsets = fused_one_pass ? 1 : std::max(1, std::min(PT_MAX_SETS, ctx->opt.streams > 0 ? ctx->opt.streams : 3));

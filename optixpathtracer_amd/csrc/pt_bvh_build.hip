@@ -1955,6 +1955,7 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
                 if (getenv("PT_DEBUG_BVH"))
                     fprintf(stderr, "[pt_bvh] calibration (%u rays): %s %.2f node steps + %.2f triangle tests per ray, %s %.2f + %.2f -> %s\n", nrays, names[out->builder],
                             (double)hcnt[0] / nrays, (double)hcnt[1] / nrays, names[kind], (double)hcnt[2] / nrays, (double)hcnt[3] / nrays, cost_alt < cost_cur ? names[kind] : names[out->builder]);
+                out->calib_cost = (float)(std::min(cost_cur, cost_alt) / (double)nrays);
                 if (cost_alt < cost_cur) {
                     hipFree((void*)out->nodes8); hipFree((void*)out->tris8);
                     out->nodes8 = alt.nodes8; out->tris8 = alt.tris8; out->num_nodes8 = alt.num_nodes8; out->num_tris8 = alt.num_tris8; out->levels8 = alt.levels8;

@@ -302,6 +302,9 @@ def test_fused_bounce_loop_is_bit_identical(ptlib, monkeypatch, cap):
     c, sc = _partition_frame(monkeypatch, {"PT_FUSED": "2", "PT_FUSED_CAP": cap, "PT_STACK_LDS_SKIP": "7"})
     d, sd = _partition_frame(monkeypatch, {"PT_FUSED_CAP": cap})  # the default policy: a frame this small is ONE fused pass
     assert _partition_frame.last_stats["fused_passes"] == 1 and _partition_frame.last_stats["trace_launches"] == 1
+    if cap == "128":  # scenes whose calibration rays cost more than PT_FUSED_MAX_COST steps keep the launch chain (this terrain: 11 steps; default limit 22)
+        _partition_frame(monkeypatch, {"PT_FUSED_MAX_COST": "5"})
+        assert _partition_frame.last_stats["fused_passes"] == 0
     assert sa == sb == sc == sd
     for fa, fb, fc, fd in zip(a, b, c, d):
         for k in fa:

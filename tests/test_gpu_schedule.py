@@ -312,6 +312,20 @@ def test_fused_bounce_loop_is_bit_identical(ptlib, monkeypatch, cap):
                 assert np.array_equal(fa[k].view(np.uint8), other[k].view(np.uint8)), k
 
 
+def test_fused_bounce_loop_soak(ptlib):
+    """tools/r5_fused_soak.py for a few seconds: random frame sizes, partitions, samples, depth limits, BSDF modes, window sizes, grids of 1 .. 5120
+    waves, chunkings and progressive subframes on four small scenes (terrain, stadium, Cornell box, textured) — accumulation buffer, rgba8 frame
+    and ray totals of a PT_FUSED=2 context equal a PT_FUSED=0 context's on every frame (150 s on the GPU box: 5960 frames, profiles/r5_14_fused_soak.log)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "r5_fused_soak.py"), "6"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert "every buffer and every ray count equal" in res.stdout
+
+
 def test_render_device_refuses_plain_host_memory(ptlib):
     """a caller written against the old render(uint32_t* h_pixels) must not reach a device-to-device copy with a
     pageable host destination: pt_render_device answers PT_ERR_INVALID for a pointer HIP does not know, before rendering anything."""

@@ -10,6 +10,8 @@ python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload terrain10M_10
 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload sv4_uniform_terrain1M_4k_8spp_d4 > $D/sv4_uniform.json 2> $D/sv4u.err
 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --workload sv4_foveated_terrain1M_4k_d4 > $D/sv4_foveated.json 2> $D/sv4f.err
 for N in 2 4 8; do python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-isolated --simulate-world $N > $D/simworld$N.json 2> $D/simworld$N.err; done
+# the same shares as launch chains (PT_FUSED=0), for the before / after of the fused bounce loop
+for N in 4 8; do PT_FUSED=0 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-isolated --no-extra-schedules --simulate-world $N > $D/simworld${N}_chain.json 2> $D/simworld${N}_chain.err; done
 python bench.py --gpus 2 --backend gloo --share-device --steps 10 --warmup 3 --no-cpu-baseline --no-isolated > $D/gloo2_selflaunch.json 2> $D/gloo2.err
 python bench.py --gpus 2 --backend gloo --share-device --launch-check --launch-render > $D/launch_check2.json 2> $D/lc2.err
 # the round-4 hierarchy pair (LBVH | PLOC) on the same box, for the before / after of the SAH hierarchy

@@ -175,10 +175,10 @@ struct pt_ctx {
     std::vector<hipStream_t> masked_streams; // [set]: the set's stream when shade_cus > 0 (set_streams[set] then carries its k_shade launches)
     int cam_grid = 0;        // PT_CAM_GRID (tuning hook): waves of a packet launch, 0 = the policy of launch_closest
     // the bounce loop of a small frame as ONE persistent kernel (pt_fused.h): PT_FUSED=0 never / 1 (default) synchronous frames of at most
-    // fused_max_paths paths (PT_FUSED_MAX_PATHS), as one pass / 2 every pass the kernel covers, chunked as usual (tests); fused_cap: window entries per wave (PT_FUSED_CAP, a multiple of 64)
+    // fused_max_paths paths (PT_FUSED_MAX_PATHS), as one pass / 2 every pass the kernel covers, chunked as usual (tests); fused_cap: window entries per wave (PT_FUSED_CAP, a multiple of 64; default: 128 or 64 by frame size)
     int fused = 1;
     uint64_t fused_max_paths = 2500000;
-    uint32_t fused_cap = 128;
+    uint32_t fused_cap = 0; // 0: by frame size (enqueue_chunk)
     float fused_max_cost = 22.f; // PT_FUSED_MAX_COST: fused_one_pass only for trees whose calibration rays cost at most this many steps (see render_enqueue)
     bool fused_frame = false; // the frame being enqueued is one fused pass (render_enqueue)
     int fused_grid = 0; // PT_FUSED_GRID: waves of the fused kernel (0: the traversal grid)
@@ -1133,7 +1133,12 @@ static void enqueue_chunk(pt_ctx* ctx, pt_ctx::BatchSet& bs, const FrameParams& 
             // one persistent kernel instead of the chain below: every wave runs generate -> trace -> shade rounds on a private window of the
             // queue arrays (pt_fused.h); the windows of all waves fit the arrays (grid x cap <= the pass's paths, rounded up to whole waves)
             SpanGuard g(ctx, CLS_TRACE, bs.stream);
-            const uint32_t cap = std::min<uint32_t>(ctx->fused_cap, ((uint32_t)pass_paths + 63u) & ~63u);
+            // Window entries per wave.  The pool of unstarted paths is what balances the waves, so the windows of all waves together should hold well
+            // under the pass: 128 entries (two lane-fulls per round: fewer, fuller rounds) when at least 30 % of the paths stay in the pool at the
+            // start, else 64 (measured, C3: 2.07 M paths 2.77 ms with 128 / 2.97 with 64; 1.04 M 1.71 / 1.77; 0.69 M 1.67 / 1.41; 0.52 M 1.47 / 1.13;
+            // 0.26 M 1.19 / 0.97 — profiles/r5_14_fused_bounce_loop.md)
+            const uint32_t cap_auto = pass_paths * 10ull >= 13ull * (uint64_t)tgrid * 128ull ? 128u : 64u;
+            const uint32_t cap = std::min<uint32_t>(ctx->fused_cap ? ctx->fused_cap : cap_auto, ((uint32_t)pass_paths + 63u) & ~63u);
             const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ctx->fused_grid > 0 ? std::min<unsigned>(tgrid, (unsigned)ctx->fused_grid) : tgrid, pass_paths / cap));
             PathLoopArgs pa{};
             pa.ta = Trace8Args{stream_view(bs, 0), bvh8, QView{bs.queueA, nullptr, 0u}, QView{bs.squeue, nullptr, 0u}, work, bs.ovf, cull, ctx->dbg, 0, ctx->lds_skip, ctx->ovf_depth, fault_word(bs), ctx->bvh.num_nodes8};

@@ -305,10 +305,12 @@ def test_fused_bounce_loop_is_bit_identical(ptlib, monkeypatch, cap):
     if cap == "128":  # scenes whose calibration rays cost more than PT_FUSED_MAX_COST steps keep the launch chain (this terrain: 11 steps; default limit 22)
         _partition_frame(monkeypatch, {"PT_FUSED_MAX_COST": "5"})
         assert _partition_frame.last_stats["fused_passes"] == 0
-    assert sa == sb == sc == sd
-    for fa, fb, fc, fd in zip(a, b, c, d):
+    e, se = _partition_frame(monkeypatch, {})  # ... with the window size chosen by frame size
+    assert _partition_frame.last_stats["fused_passes"] == 1
+    assert sa == sb == sc == sd == se
+    for fa, fb, fc, fd, fe in zip(a, b, c, d, e):
         for k in fa:
-            for other in (fb, fc, fd):
+            for other in (fb, fc, fd, fe):
                 assert np.array_equal(fa[k].view(np.uint8), other[k].view(np.uint8)), k
 
 

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <unordered_map>
@@ -47,82 +48,55 @@ struct Shape {
 inline bool is_digit(char c) { return c >= '0' && c <= '9'; }
 inline bool is_blank(char c) { return c == ' ' || c == '\t'; }
 
-// tryParseDouble (tiny_obj_loader.h:836-960) on [s, s_end)
+// A decimal field of an OBJ / MTL line, read the way tinyobjloader 2.0.0 reads it (tryParseDouble, tiny_obj_loader.h:836-960).  Restated in
+// this file's own terms, not copied: what has to agree with the reference is the grammar and the SEQUENCE of double operations, because
+// loadOBJ's float arrays are compared bit for bit (tests/test_objloader.py).
+//   grammar    [+|-] digits [ . digits ] [ (e|E) [+|-] digits ]   or   [+|-] . digits [ exponent ]
+//              anything else after a complete whole part or fraction ends the number (the field still parses); an exponent marker without
+//              digits, or no digit before it, fails the field
+//   arithmetic whole part: v = v * 10 + d per digit; fraction digit at decimal place k: v += d * 10^-k, the first seven powers from a table of
+//              literals, later ones from pow(10, -k); exponent e != 0: ldexp(v * pow(5, e), e); the sign is a final multiplication by +-1
+struct NumberScan {
+    const char* at;
+    const char* stop;
+    bool here(char c) const { return at != stop && *at == c; }
+    bool digit_here() const { return at != stop && is_digit(*at); }
+    int take_digit() { return *at++ - '0'; }
+};
 bool try_parse_double(const char* s, const char* s_end, double* result) {
     if (s >= s_end) return false;
-    static const double pow_lut[] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001};
-    double mantissa = 0.0;
-    int exponent = 0;
-    char sign = '+', exp_sign = '+';
-    const char* curr = s;
-    int read = 0;
-    bool end_not_reached = false, leading_decimal_dots = false;
-    if (*curr == '+' || *curr == '-') {
-        sign = *curr;
-        curr++;
-        if ((curr != s_end) && (*curr == '.')) leading_decimal_dots = true;
-    } else if (is_digit(*curr)) {
-    } else if (*curr == '.') {
-        leading_decimal_dots = true;
-    } else {
-        return false;
-    }
-    end_not_reached = (curr != s_end);
-    if (!leading_decimal_dots) {
-        while (end_not_reached && is_digit(*curr)) {
-            mantissa *= 10;
-            mantissa += static_cast<int>(*curr - 0x30);
-            curr++;
-            read++;
-            end_not_reached = (curr != s_end);
-        }
-        if (read == 0) return false;
-    }
-    if (end_not_reached) {
-        if (*curr == '.') {
-            curr++;
-            read = 1;
-            end_not_reached = (curr != s_end);
-            while (end_not_reached && is_digit(*curr)) {
-                const int lut_entries = sizeof pow_lut / sizeof pow_lut[0];
-                mantissa += static_cast<int>(*curr - 0x30) * (read < lut_entries ? pow_lut[read] : std::pow(10.0, -read));
-                read++;
-                curr++;
-                end_not_reached = (curr != s_end);
-            }
-        } else if (*curr == 'e' || *curr == 'E') {
-        } else {
-            goto assemble;
-        }
-        if (end_not_reached && (*curr == 'e' || *curr == 'E')) {
-            curr++;
-            end_not_reached = (curr != s_end);
-            if (end_not_reached && (*curr == '+' || *curr == '-')) {
-                exp_sign = *curr;
-                curr++;
-            } else if (end_not_reached && is_digit(*curr)) {
-            } else {
-                return false;
-            }
-            read = 0;
-            end_not_reached = (curr != s_end);
-            while (end_not_reached && is_digit(*curr)) {
-                // (the reference's `exponent *= 10` overflows a signed int on a field like 1e99999999999 — undefined behaviour there; beyond 10^8 the
-                // value is +-inf, 0 or NaN whatever the digits, so the accumulation saturates)
-                if (exponent < 100000000) {
-                    exponent *= 10;
-                    exponent += static_cast<int>(*curr - 0x30);
-                }
-                curr++;
-                read++;
-                end_not_reached = (curr != s_end);
-            }
-            exponent *= (exp_sign == '+' ? 1 : -1);
-            if (read == 0) return false;
+    static const double decimal_place[8] = {1e0, 1e-1, 1e-2, 1e-3, 1e-4, 1e-5, 1e-6, 1e-7};
+    NumberScan in{s, s_end};
+    const bool negative = in.here('-');
+    if (negative || in.here('+')) ++in.at;
+    else if (!in.digit_here() && !in.here('.')) return false;
+    double v = 0.0;
+    if (!in.here('.')) { // a whole part, at least one digit
+        if (!in.digit_here()) return false;
+        while (in.digit_here()) {
+            v *= 10;
+            v += in.take_digit();
         }
     }
-assemble:
-    *result = (sign == '+' ? 1 : -1) * (exponent ? std::ldexp(mantissa * std::pow(5.0, exponent), exponent) : mantissa);
+    if (in.here('.')) {
+        ++in.at;
+        for (int place = 1; in.digit_here(); ++place) v += in.take_digit() * (place < 8 ? decimal_place[place] : std::pow(10.0, -place));
+    }
+    int power = 0;
+    if (in.here('e') || in.here('E')) {
+        ++in.at;
+        const bool shrink = in.here('-');
+        if (shrink || in.here('+')) ++in.at;
+        if (!in.digit_here()) return false;
+        // (the reference's `exponent *= 10` overflows a signed int on a field like 1e99999999999 — undefined behaviour there; beyond 10^8 the
+        // value is +-inf, 0 or NaN whatever the digits, so the accumulation saturates)
+        while (in.digit_here()) {
+            const int d = in.take_digit();
+            if (power < 100000000) power = power * 10 + d;
+        }
+        if (shrink) power = -power;
+    }
+    *result = (negative ? -1 : 1) * (power ? std::ldexp(v * std::pow(5.0, power), power) : v);
     return true;
 }
 
@@ -173,12 +147,17 @@ void split_lines(const std::string& text, std::vector<std::pair<const char*, con
     if (s < e) out.emplace_back(s, e);
 }
 bool read_file(const std::string& path, std::string& text) {
+    struct stat st;
+    if (::stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return false; // a directory opens with fopen and reports a huge size
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
-    std::fseek(f, 0, SEEK_END);
-    const long n = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    text.resize(n > 0 ? (size_t)n : 0);
+    long n = -1;
+    if (std::fseek(f, 0, SEEK_END) == 0) n = std::ftell(f);
+    if (n < 0 || std::fseek(f, 0, SEEK_SET) != 0) {
+        std::fclose(f);
+        return false;
+    }
+    text.resize((size_t)n);
     const size_t got = n > 0 ? std::fread(&text[0], 1, (size_t)n, f) : 0;
     std::fclose(f);
     text.resize(got);
@@ -587,15 +566,13 @@ struct pt_obj {
 
 extern "C" const char* pt_obj_last_error(void) { return g_obj_error.c_str(); }
 
-extern "C" int pt_load_obj(const char* obj_path, int per_mesh_vertex_map, pt_obj** out) {
-    if (!obj_path || !out) return PT_ERR_INVALID;
-    *out = nullptr;
+static int load_obj(const char* obj_path, int per_mesh_vertex_map, pt_obj** out) {
     const std::string obj_file(obj_path);
     const size_t slash = obj_file.rfind('/');
     const std::string model_dir = slash == std::string::npos ? std::string() : obj_file.substr(0, slash + 1);
     Parsed P;
     if (!parse_obj(obj_file, model_dir, P, g_obj_error)) return PT_ERR_INVALID;
-    pt_obj* obj = new pt_obj;
+    std::unique_ptr<pt_obj> obj(new pt_obj);
     const int nV = (int)(P.V.size() / 3), nVN = (int)(P.VN.size() / 3), nVT = (int)(P.VT.size() / 2);
     for (const Shape& sh : P.shapes) {
         std::unordered_map<Idx, int, IdxHash, IdxEq> known_vertices;
@@ -618,7 +595,6 @@ extern "C" int pt_load_obj(const char* obj_path, int per_mesh_vertex_map, pt_obj
                     }
                     if (!(key.v >= 0 && key.v < nV) || key.vn >= nVN || key.vt >= nVT) {
                         g_obj_error = obj_file + ": index (" + std::to_string(key.v) + ", " + std::to_string(key.vt) + ", " + std::to_string(key.vn) + ") out of range";
-                        delete obj;
                         return PT_ERR_INVALID;
                     }
                     const int new_id = (int)(mesh.vertex.size() / 3);
@@ -659,8 +635,21 @@ extern "C" int pt_load_obj(const char* obj_path, int per_mesh_vertex_map, pt_obj
             obj->meshes.push_back(std::move(mesh));
         }
     }
-    *out = obj;
+    *out = obj.release();
     return PT_OK;
+}
+// No C++ exception crosses the C ABI: a file of several hundred megabytes can run the host out of memory in the middle of a parse
+extern "C" int pt_load_obj(const char* obj_path, int per_mesh_vertex_map, pt_obj** out) {
+    if (!obj_path || !out) return PT_ERR_INVALID;
+    *out = nullptr;
+    try {
+        return load_obj(obj_path, per_mesh_vertex_map, out);
+    } catch (const std::exception& e) {
+        try { g_obj_error = std::string(obj_path) + ": " + e.what(); } catch (...) {}
+    } catch (...) {
+        try { g_obj_error = std::string(obj_path) + ": unknown failure"; } catch (...) {}
+    }
+    return PT_ERR_INVALID;
 }
 
 extern "C" void pt_obj_free(pt_obj* obj) { delete obj; }

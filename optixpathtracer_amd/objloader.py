@@ -646,15 +646,15 @@ def _load_obj_native(obj_file: str, per_mesh_vertex_map: bool) -> Model:
     else:
         L = _lib.load_library()
     h = C.c_void_p()
-    # (the path goes through as bytes; latin-1 keeps every byte of an odd file name)
+    # (the path goes through as the file system's bytes, and comes back through the same codec: os.fsencode / os.fsdecode round-trip any name)
     if L.pt_load_obj(os.fsencode(obj_file), 1 if per_mesh_vertex_map else 0, C.byref(h)) != 0:
-        msg = L.pt_obj_last_error().decode("latin-1")
+        msg = os.fsdecode(L.pt_obj_last_error())
         raise (ValueError if "out of range" in msg else RuntimeError)(msg)
     try:
         model = Model()
         final_id = {}
         for k in range(L.pt_obj_num_textures(h)):  # loadTexture's order; unreadable files get -1 and no number
-            px = _decode_texture(L.pt_obj_texture_path(h, k).decode("latin-1"))
+            px = _decode_texture(os.fsdecode(L.pt_obj_texture_path(h, k)))
             if px is None:
                 final_id[k] = -1
             else:

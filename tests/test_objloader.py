@@ -343,3 +343,50 @@ def test_load_obj_live_many_quads(tmp_path):
     _check_model(objloader.load_obj(str(tmp_path / "q.obj"), native=True), out[0], out[1], "many quads (native)")
     _check_model(objloader.load_obj(str(tmp_path / "q.obj"), native=False), out[0], out[1], "many quads (python)")
     assert len(out[0][0]["index"]) > 1.5 * n
+
+
+def test_native_loader_refuses_a_directory_without_throwing():
+    """pt_load_obj itself (not only the Python wrapper's isfile check) must refuse a path that is a directory — fopen opens
+    it and ftell reports a huge size — and no C++ exception may cross the C ABI."""
+    import ctypes as C
+
+    from optixpathtracer_amd import _lib
+
+    L = _lib.load_library()
+    L.pt_load_obj.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.pt_obj_last_error.restype = C.c_char_p
+    h = C.c_void_p()
+    assert L.pt_load_obj(os.fsencode(FIX), 1, C.byref(h)) != 0 and not h.value
+    assert b"Cannot open file" in L.pt_obj_last_error()
+
+
+def test_native_loader_non_ascii_directory(tmp_path):
+    """texture paths come back through the file system's codec (os.fsdecode), so a model directory with a non-ASCII name
+    keeps its textures."""
+    import shutil
+
+    d = tmp_path / "modèle_日本"
+    shutil.copytree(FIX, d)
+    a = objloader.load_obj(os.path.join(FIX, "basic.obj"), native=True)
+    b = objloader.load_obj(str(d / "basic.obj"), native=True)
+    assert len(a.textures) == len(b.textures) and len(a.textures) > 0
+    assert [m.diffuseTextureID for m in a.meshes] == [m.diffuseTextureID for m in b.meshes]
+    assert any(m.diffuseTextureID >= 0 for m in b.meshes)
+
+
+def test_number_grammar_native_equals_restatement(tmp_path):
+    """The decimal-field reader (tinyobjloader's tryParseDouble, restated in pt_objload.cpp and in objloader.py) on the grammar's corners: the native
+    parser and the line-cited Python restatement produce the same float32 bits for every field, accepted or defaulted."""
+    fields = ["1", "-1", "+1", "0", "-0", ".5", "-.5", "+.5", ".", "-.", "1.", "1.e2", ".e2", "1e", "1e+", "1e-", "1ex", "1x", "1.5x", "x", "e5", "--1", "+", "-",
+              "1e5", "1E5", "1e-5", "1e+05", "12345678.123456789012", "0.1234567", "0.12345678", "0.123456789", "3.14159265358979", "1e38", "1e39", "1e-46",
+              "1e400", "1e-400", "1e99999999999", "-1e99999999999", "1e-99999999999", "0e99999999999", "123456789012345678901234567890", "1.5e3.2", "7e2e3",
+              "00012", "1.0000000000000000000000001", "4.9e-324", "2.2250738585072014e-308", "9007199254740993"]
+    lines = [f"v {f} 0 0" for f in fields] + [f"v 0 {f} {f}" for f in fields]
+    n = len(lines)
+    faces = [f"f {k + 1} {(k + 1) % n + 1} {(k + 2) % n + 1}" for k in range(n)]
+    p = tmp_path / "numbers.obj"
+    p.write_text("\n".join(lines + faces) + "\n")
+    a = objloader.load_obj(str(p), per_mesh_vertex_map=True, native=True)
+    b = objloader.load_obj(str(p), per_mesh_vertex_map=True, native=False)
+    assert len(a.meshes) == len(b.meshes) == 1
+    assert _same_bits(a.meshes[0].vertex, b.meshes[0].vertex) and _same_bits(a.meshes[0].index, b.meshes[0].index)

@@ -4,10 +4,10 @@
 #  1b. csrc/pt_objload.cpp (the native OBJ parser: untrusted input) with -fsanitize=address,undefined under tests/test_objloader.py and tools/fuzz_objloader.py;
 #  2. the C++ facade (csrc/SampleRenderer.h through examples/facade_demo.cpp) compiled -fsanitize=undefined -Wall -Wextra -Werror;
 #  3. include/pt_amd.h compiled as C99 and C++17 with -Wall -Wextra -pedantic -Werror.
-# Log: profiles/r5_04_sanitizers.log
+# Log: profiles/r6_02_sanitizers.log (round 5: profiles/r5_04_sanitizers.log)
 set -e
 cd "$(dirname "$0")/.."
-LOG=profiles/r5_04_sanitizers.log
+LOG=${LOG:-profiles/r6_02_sanitizers.log}
 : > $LOG
 make -C oracle asan 2>&1 | tee -a $LOG
 ASAN_LIB=$(gcc -print-file-name=libasan.so)

@@ -157,6 +157,9 @@ typedef struct pt_stats {
                              * depend on the choice (closest hit, lowest primitive on ties, hits confined to the triangle's padded box). */
     uint32_t fused_passes;  /* passes of the last render that ran as ONE persistent kernel (generate -> trace -> shade rounds per wave, no launch
                              * chain: small synchronous frames, PT_FUSED; csrc/pt_fused.h); trace_launches counts each of them once */
+    uint32_t path_state_allocs; /* (re-)allocations of the per-path device state since pt_create.  The state only grows (sets, paths per set,
+                             * pixels per set, each kept at the largest value any frame asked for), so alternating schedules — a fused-size
+                             * synchronous frame, a foveated frame, frames in flight — re-allocates at most once per dimension. */
 } pt_stats;
 
 /* SampleRenderer::SampleRenderer(const Model*) (SimplePathtracer.cpp:39-71): uploads the meshes

@@ -159,6 +159,7 @@ struct pt_ctx {
     std::vector<hipStream_t> set_streams, side_streams; // [set], [2 * set + {0,1}]
     bool streams_probed = false; // pick_streams ran: the context's stream and the first three set streams sit on different hardware queues
     uint32_t set_cap = 0, set_pix_cap = 0, sub_cap = 0;
+    uint32_t path_state_allocs = 0; // (re-)allocations of the path state so far (pt_stats.path_state_allocs)
     bool cap_catcher = false, cap_async = false;
     int nq = 0;
     // [frame slot 0..2][batch set 0..15][4]: [0] radiance rays, [1] shadow rays, [2] low word = traversal fault bits (pt_bvh8.h push), [3] shaded hits
@@ -930,18 +931,28 @@ static int assign_streams(pt_ctx* ctx, int nsets) {
     return PT_OK;
 }
 
+// Path state for a frame cut into `nsets` chunks of at most `cap` paths over `pix_cap` pixels: the first `nsets` batch sets are the frame's.
+// The state only ever GROWS — in the number of sets, in paths per set and in pixels per set, each kept at the largest value any frame asked
+// for — so an application that alternates schedules (a fused-size synchronous frame = one set holding the whole frame; a foveated or
+// pipelined frame = three sets) re-allocates at most once per dimension and never again (the one-set / three-set switch used
+// to drain, free and re-allocate every buffer on every alternation).  pt_stats.path_state_allocs counts the (re-)allocations.
 static int ensure_path_state(pt_ctx* ctx, int nsets, uint32_t cap, uint32_t pix_cap) {
     // one queue-counter slot per bounce plus the "would continue" slot; shadow-catcher scenes get two more for the extra
     // iterations of paths that passed through catcher surfaces (enqueue_chunk)
-    const int nq = ctx->opt.max_depth + 2 + (ctx->has_catcher ? 2 : 0);
+    int nq = ctx->opt.max_depth + 2 + (ctx->has_catcher ? 2 : 0);
     const bool async = async_shadows(ctx);
-    if ((int)ctx->sets.size() == nsets && cap <= ctx->set_cap && pix_cap <= ctx->set_pix_cap && nq <= ctx->nq &&
+    if ((int)ctx->sets.size() >= nsets && cap <= ctx->set_cap && pix_cap <= ctx->set_pix_cap && nq <= ctx->nq &&
         (!ctx->has_catcher || ctx->cap_catcher) && async == ctx->cap_async)
-        return assign_streams(ctx, nsets);
+        return assign_streams(ctx, (int)ctx->sets.size());
     {
         int rc = drain(ctx); // frames in flight still use the old buffers
         if (rc) return rc;
     }
+    nsets = std::max(nsets, (int)ctx->sets.size());
+    cap = std::max(cap, ctx->set_cap);
+    pix_cap = std::max(pix_cap, ctx->set_pix_cap);
+    nq = std::max(nq, ctx->nq);
+    ++ctx->path_state_allocs;
     free_path_state(ctx);
     CK(dclear(ctx->stream, ctx->d_totals, sizeof(unsigned long long) * PT_MAX_FRAMES * PT_MAX_SETS * 4)); // slices of sets that no longer exist
     ctx->sets.resize(nsets);
@@ -1421,10 +1432,10 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
         end_stream = bs.stream; // the whole frame is on this stream: the context's own stream stays out of the way (one hardware queue fewer)
     } else if (owned) {
         if (!pipelined) {
-            for (auto& b : ctx->sets) hipStreamWaitEvent(b.stream, ev_begin, 0);
+            for (int i = 0; i < nsets; ++i) hipStreamWaitEvent(ctx->sets[i].stream, ev_begin, 0); // (the context may hold more sets than this frame uses)
         } else {
             // no frame-wide start: every set clears its own counters behind its own previous chunk and goes on
-            for (auto& b : ctx->sets) CK(hipMemsetAsync(b.totals, 0, sizeof(unsigned long long) * 4, b.stream));
+            for (int i = 0; i < nsets; ++i) CK(hipMemsetAsync(ctx->sets[i].totals, 0, sizeof(unsigned long long) * 4, ctx->sets[i].stream));
             CK(hipEventRecord(ev_begin, ctx->sets[0].stream));
         }
         // Chunk c of consecutive pt_render frames runs on the same stream, which orders their resolves; a foveated frame (pt_render_regions)
@@ -1466,9 +1477,9 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
             for (uint32_t pix0 = 0; pix0 < owned; pix0 += Np, ++k)
                 enqueue_chunk(ctx, ctx->sets[k % nsets], fp, pix0, std::min(Np, owned - pix0), vspp, S, lc, nullptr, before.empty() ? nullptr : &before);
         }
-        for (auto& b : ctx->sets) {
+        for (int i = 0; i < nsets; ++i) {
             hipEvent_t e = next_event(ctx);
-            hipEventRecord(e, b.stream);
+            hipEventRecord(e, ctx->sets[i].stream);
             hipStreamWaitEvent(ctx->stream, e, 0);
         }
     } else if (pipelined) {
@@ -1739,9 +1750,9 @@ static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, co
     if (!pipelined) {
         CK(hipMemsetAsync(totals_of(ctx, slot, 0), 0, sizeof(unsigned long long) * PT_MAX_SETS * 4, ctx->stream));
         CK(hipEventRecord(ev_begin, ctx->stream));
-        for (auto& b : ctx->sets) hipStreamWaitEvent(b.stream, ev_begin, 0);
+        for (int i = 0; i < nsets; ++i) hipStreamWaitEvent(ctx->sets[i].stream, ev_begin, 0);
     } else {
-        for (auto& b : ctx->sets) CK(hipMemsetAsync(b.totals, 0, sizeof(unsigned long long) * 4, b.stream));
+        for (int i = 0; i < nsets; ++i) CK(hipMemsetAsync(ctx->sets[i].totals, 0, sizeof(unsigned long long) * 4, ctx->sets[i].stream));
         CK(hipEventRecord(ev_begin, ctx->sets[0].stream));
     }
     LaunchCounts lc;
@@ -1777,9 +1788,9 @@ static int regions_enqueue(pt_ctx* ctx, const pt_region* regions, uint32_t n, co
         prev_done = cur_done; // these resolves waited for the older launches themselves: the order is transitive
         paths += (uint64_t)nlaunch * g.spp;
     }
-    for (auto& b : ctx->sets) {
+    for (int i = 0; i < nsets; ++i) {
         hipEvent_t e = next_event(ctx);
-        hipEventRecord(e, b.stream);
+        hipEventRecord(e, ctx->sets[i].stream);
         hipStreamWaitEvent(ctx->stream, e, 0);
     }
     CK(hipMemcpyAsync(ctx->h_totals + (size_t)slot * PT_MAX_SETS * 4, totals_of(ctx, slot, 0), sizeof(unsigned long long) * PT_MAX_SETS * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2069,6 +2080,7 @@ extern "C" int pt_get_stats(const pt_ctx* ctx, pt_stats* out) {
     out->bvh_build_ms = ctx->bvh_build_ms;
     out->bvh_levels = (uint32_t)ctx->bvh.levels8;
     out->bvh_builder = (uint32_t)ctx->bvh.builder;
+    out->path_state_allocs = ctx->path_state_allocs;
     return PT_OK;
 }
 

@@ -436,3 +436,58 @@ def test_sized_stats_getter(ptlib):
     assert L.pt_get_stats_n(r._ctx, small, 24) == 0 and L.pt_get_stats_n(r._ctx, big, n + 32) == 0
     assert bytes(small) == bytes(full)[:24] and bytes(big)[:n] == bytes(full) and set(bytes(big)[n:]) == {0}
     r.close()
+
+
+def test_alternating_schedules_do_not_reallocate_the_path_state(ptlib, monkeypatch):
+    """a fused-size synchronous frame takes ONE batch set holding the whole frame, a foveated frame or a frame of more
+    samples takes three; the switch used to drain, free and re-allocate every path buffer on EVERY alternation.  The state now only grows:
+    after the first cycle pt_stats.path_state_allocs stays put, and every frame equals the frame of a context that never leaves the launch
+    chain (PT_FUSED=0), bit for bit."""
+    from optixpathtracer_amd import renderer as R
+
+    m = scenes.voxel_terrain(n=64, target_tris=30000)
+    probe = scenes.sky_probe(256, 128).BuildCDF()
+    w, h = 480, 272
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = R.SampleRenderer(m)
+        for k in env:
+            monkeypatch.delenv(k)
+        r.setProbe(probe)
+        r.resize((w, h))
+        r.setCamera(R.make_camera(scenes.TERRAIN_CAMERA, w / h))
+        frames, allocs, fused = [], [], []
+        sf = 0
+        for cycle in range(3):
+            # (a) a small synchronous frame: one fused pass by default
+            r.launchParams.samples_per_launch = 2
+            r.launchParams.frame.subframe_index = sf
+            r.render()
+            sf += 1
+            fused.append(r.stats()["fused_passes"])
+            frames.append(r.download(R.PT_BUF_ACCUM).copy())
+            # (b) a foveated frame: always three sets
+            r.launchParams.frame.subframe_index = sf
+            r.renderFoveated((240, 136), inner_radius=40, outer_radius=120, variant=dict(R.SampleRenderer.SV4_VARIANT))
+            sf = r.launchParams.frame.subframe_index
+            frames.append(r.download(R.PT_BUF_ACCUM).copy())
+            # (c) the camera stopped: 40 samples per launch — 5.2 M paths, beyond the fused limit: three chunks
+            r.launchParams.samples_per_launch = 40
+            r.launchParams.frame.subframe_index = sf
+            r.render()
+            sf += 1
+            fused.append(r.stats()["fused_passes"])
+            frames.append(r.download(R.PT_BUF_ACCUM).copy())
+            allocs.append(r.stats()["path_state_allocs"])
+        r.close()
+        return frames, allocs, fused
+
+    fa, aa, fused_a = run({})
+    fb, ab, fused_b = run({"PT_FUSED": "0"})
+    assert fused_a == [1, 0] * 3 and fused_b == [0, 0] * 3
+    assert aa[0] <= 3 and aa[1] == aa[0] and aa[2] == aa[0], aa  # nothing re-allocated after the first cycle
+    assert ab[1] == ab[0] and ab[2] == ab[0], ab
+    for k, (x, y) in enumerate(zip(fa, fb)):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), k

@@ -241,6 +241,12 @@ def main():
     warm = ((max(args.warmup, 1) + args.batch - 1) // args.batch) * args.batch
     for k in range(0, warm, args.batch):
         render_frame(k, args.batch)
+    # A context times the two bit-identical schedules of a small synchronous frame (launch chain, fused bounce loop) against each other over
+    # its first frames (pt_stats.schedule bit 8 while it does): that trial belongs to the warm-up, not to the K timed steps — which are then
+    # rendered by whichever schedule measured faster ON THIS BOX.  The N=1 frame of the headline metric is too large to take part.
+    while not sv4 and opts["frames_in_flight"] < 2 and (r.stats()["schedule"] & 0x100) and warm < 64 * args.batch:
+        render_frame(warm, args.batch)
+        warm += args.batch
     barrier()
     keys = ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms", "trace_launches", "shadow_launches", "shade_launches", "radiance_rays", "shadow_rays", "shaded_hits", "fused_passes")
     agg = dict.fromkeys(keys, 0.0)
@@ -486,7 +492,11 @@ def main():
             # schedule of the timed loop: frames_in_flight 1 = every frame a device-synchronised pt_render (the reference's render()); subframes_per_batch 1 = one frame per launch chain
             "frames_in_flight": opts["frames_in_flight"] if pipelined else 1,
             "subframes_per_batch": args.batch,
-            "fused_bounce_loop_passes_per_frame": fused_passes,  # 0: the launch chain (every frame of more than PT_FUSED_MAX_PATHS = 2.5 M paths; the N=1 headline always)
+            "fused_bounce_loop_passes_per_frame": fused_passes,  # 0: the launch chain (every frame of more than PT_SCHED_MAX_PATHS = 4.5 M paths; the N=1 headline always)
+            # small synchronous frames: the context timed its two bit-identical schedules against each other during the warm-up (device time of
+            # the trial frames, ms) and the timed steps ran the faster; warmup_frames = the frames actually rendered before the clock started
+            "schedule": {"timed_steps": "fused" if (st["schedule"] & 1) else "chain", "trial_chain_ms": round(st["sched_chain_ms"], 3) or None, "trial_fused_ms": round(st["sched_fused_ms"], 3) or None,
+                         "warmup_frames": warm},
             # the same frames on the library's other schedules, measured after the timed region (same images bit for bit; not `value`)
             "mrays_per_s_pipelined": extra_out.get("pipelined", {}).get("mrays_per_s"),
             "ms_per_frame_pipelined": extra_out.get("pipelined", {}).get("ms_per_frame"),

@@ -160,6 +160,12 @@ typedef struct pt_stats {
     uint32_t path_state_allocs; /* (re-)allocations of the per-path device state since pt_create.  The state only grows (sets, paths per set,
                              * pixels per set, each kept at the largest value any frame asked for), so alternating schedules — a fused-size
                              * synchronous frame, a foveated frame, frames in flight — re-allocates at most once per dimension. */
+    uint32_t bvh_challengers_skipped; /* candidate hierarchies pt_create could not build (out of device memory, a failed bounds check): the standing
+                             * tree then stayed without a comparison — also reported on stderr; 0 in every healthy build */
+    uint32_t schedule;      /* how the last synchronous pt_render ran: 0 launch chain, 1 fused bounce loop (k_path_loop); bit 8 set while the context
+                             * is still timing the two against each other for this frame configuration (pt_sched_* below) */
+    double sched_chain_ms;  /* best device time of the configuration's trial frames as a launch chain / as one fused pass (0: not measured: */
+    double sched_fused_ms;  /* the configuration is not eligible for both, or PT_SCHED_TRIALS=0) */
 } pt_stats;
 
 /* SampleRenderer::SampleRenderer(const Model*) (SimplePathtracer.cpp:39-71): uploads the meshes

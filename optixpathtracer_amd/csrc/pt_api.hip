@@ -182,6 +182,36 @@ struct pt_ctx {
     uint32_t fused_cap = 0; // 0: by frame size (enqueue_chunk)
     float fused_max_cost = 22.f; // PT_FUSED_MAX_COST: fused_one_pass only for trees whose calibration rays cost at most this many steps (see render_enqueue)
     bool fused_frame = false; // the frame being enqueued is one fused pass (render_enqueue)
+    // Which of the two schedules a synchronous frame takes is MEASURED (round 6): both leave the same bits, so for every frame configuration
+    // (pixels owned x samples, depth limit, BSDF mode, size, partition) the context renders the first frames alternately as a launch chain and as
+    // one fused pass — the first frame of each is warm-up, then `sched_trials` timed frames each (device time between the frame's begin and end
+    // events) — keeps the faster and re-decides when the configuration changes (pt_resize, pt_set_partition, samples, options).  Every
+    // `sched_probe` frames the loser gets one frame; if that beats the winner's running mean by more than 5 % (the camera moved into a part of
+    // the scene with different rays) the trial starts over.  The thresholds of round 5 (fused_max_paths, fused_max_cost) only pick which schedule
+    // the first trial frame uses — and what a context with PT_SCHED_TRIALS=0 does.  Frames of up to sched_max_paths paths take part
+    // (above, a fused pass never won: DESIGN.md §6).  pt_stats.schedule / sched_chain_ms / sched_fused_ms report it.
+    int sched_trials = 3;               // PT_SCHED_TRIALS (0: no measurement, thresholds only)
+    int sched_probe = 64;               // PT_SCHED_PROBE (0: never look at the loser again)
+    uint64_t sched_max_paths = 4500000; // PT_SCHED_MAX_PATHS
+    int sched_initial = -1;             // PT_SCHED_INITIAL=chain|fused (test hook): the schedule of the first trial frame
+    double sched_fake[2] = {0, 0};      // PT_SCHED_FAKE="chain_ms,fused_ms" (test hook): these times instead of the measured ones
+    struct SchedKey {
+        uint32_t owned = 0, vspp = 0, max_paths = 0;
+        int max_depth = 0, bsdf = 0, w = 0, h = 0, rank = 0, world = 0;
+        bool operator==(const SchedKey& o) const {
+            return owned == o.owned && vspp == o.vspp && max_paths == o.max_paths && max_depth == o.max_depth && bsdf == o.bsdf && w == o.w && h == o.h && rank == o.rank && world == o.world;
+        }
+    };
+    struct Sched {
+        SchedKey key;
+        int n[2] = {0, 0};         // frames rendered as [0] launch chain / [1] fused pass during the trial (the first of each is warm-up)
+        double best[2] = {0, 0};   // fastest timed trial frame of each
+        int choice = -1;           // -1 while the trial runs
+        uint64_t since = 0;        // frames since the choice
+        double mean = 0;           // running mean of the chosen schedule's frame time
+    } sched;
+    struct { bool valid = false; int which = 0; bool probe = false; } sched_pending; // the synchronous frame in flight, if it takes part
+    uint32_t sched_flags = 0;      // pt_stats.schedule of the last synchronous frame
     int fused_grid = 0; // PT_FUSED_GRID: waves of the fused kernel (0: the traversal grid)
     int enqueue_threads = 1; // PT_ENQUEUE_THREADS: 0 one enqueue thread, 1 one thread per pixel chunk for small synchronous frames (default), 2 at every size
     bool adapt_grid = false; // set around the enqueue of a whole frame (frames_in_flight = 3)
@@ -481,6 +511,14 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
         if (const char* e = getenv("PT_FUSED_MAX_PATHS")) ctx->fused_max_paths = strtoull(e, nullptr, 10);
         if (const char* e = getenv("PT_FUSED_GRID")) ctx->fused_grid = atoi(e);
         if (const char* e = getenv("PT_FUSED_MAX_COST")) ctx->fused_max_cost = (float)atof(e);
+        if (const char* e = getenv("PT_SCHED_TRIALS")) ctx->sched_trials = std::max(0, std::min(64, atoi(e)));
+        if (const char* e = getenv("PT_SCHED_PROBE")) ctx->sched_probe = std::max(0, atoi(e));
+        if (const char* e = getenv("PT_SCHED_MAX_PATHS")) ctx->sched_max_paths = strtoull(e, nullptr, 10);
+        if (const char* e = getenv("PT_SCHED_INITIAL")) ctx->sched_initial = !strcmp(e, "fused") ? 1 : (!strcmp(e, "chain") ? 0 : -1);
+        if (const char* e = getenv("PT_SCHED_FAKE")) {
+            double c = 0, f = 0;
+            if (sscanf(e, "%lf,%lf", &c, &f) == 2 && c > 0 && f > 0) { ctx->sched_fake[0] = c; ctx->sched_fake[1] = f; }
+        }
         if (const char* e = getenv("PT_FUSED_CAP")) ctx->fused_cap = std::min(4096u, std::max(64u, ((uint32_t)atoi(e) + 63u) & ~63u));
         CKC(dalloc(&ctx->ovf, ovf_words(ctx)));
         ctx->ovf_depth = PT8_OVF_DEPTH;
@@ -1384,9 +1422,30 @@ static int render_enqueue(pt_ctx* ctx, uint32_t spp, uint32_t subframe_index, in
     // the chain: every round of every fused wave ends with its own slowest ray, and on the stadium (27 steps per calibration ray; terrain 14) a
     // 1/8 share runs 7-13 % slower fused while the terrain, the textured terrain and the Cornell box run 3-11 % faster (profiles/r5_14_fused_bounce_loop.md).
     // One scene family on either side of the threshold: a rule of thumb, PT_FUSED_MAX_COST moves it.
-    const bool fused_one_pass = ctx->fused == 1 && !pipelined && ctx->opt.streams <= 0 && !ctx->has_catcher && ctx->opt.split_shadow == 0 &&
-                                (ctx->bvh.calib_cost <= 0.f || ctx->bvh.calib_cost <= ctx->fused_max_cost) &&
-                                (uint64_t)owned * vspp <= ctx->fused_max_paths && (uint64_t)owned * vspp <= ctx->opt.max_paths;
+    const uint64_t frame_paths = (uint64_t)owned * vspp;
+    // what the fused pass needs at all: the default schedule of a scene without shadow-catcher materials, the whole frame in one batch set
+    const bool fused_ok = ctx->fused == 1 && !pipelined && owned > 0 && ctx->opt.streams <= 0 && !ctx->has_catcher && ctx->opt.split_shadow == 0 && frame_paths <= ctx->opt.max_paths;
+    // round 5's rule of thumb, now the first guess: small frames of scenes whose calibration rays are cheap; a tree that was never calibrated
+    // (builder forced or imported, challenger not built) keeps the chain unless the scene is tiny
+    const bool cost_ok = ctx->bvh.calib_cost > 0.f ? ctx->bvh.calib_cost <= ctx->fused_max_cost : ctx->ntri < 4096u;
+    const bool guess = fused_ok && cost_ok && frame_paths <= ctx->fused_max_paths;
+    bool fused_one_pass = guess;
+    ctx->sched_pending.valid = false;
+    if (fused_ok && ctx->sched_trials > 0 && frame_paths <= ctx->sched_max_paths && !ctx->span_timing()) {
+        const pt_ctx::SchedKey key{owned, vspp, ctx->opt.max_paths, ctx->opt.max_depth, ctx->opt.bsdf_mode, ctx->width, ctx->height, ctx->rank, ctx->world};
+        pt_ctx::Sched& sc = ctx->sched;
+        if (!(sc.key == key)) { sc = pt_ctx::Sched{}; sc.key = key; }
+        const int first = ctx->sched_initial >= 0 ? ctx->sched_initial : (guess ? 1 : 0);
+        int use = sc.choice;
+        bool probe = false;
+        if (sc.choice < 0) use = sc.n[first] <= sc.n[1 - first] ? first : 1 - first; // alternate, starting with the guess
+        else if (ctx->sched_probe > 0 && sc.since % (uint64_t)ctx->sched_probe == (uint64_t)ctx->sched_probe - 1) { use = 1 - sc.choice; probe = true; }
+        fused_one_pass = use == 1;
+        ctx->sched_pending.valid = true;
+        ctx->sched_pending.which = use;
+        ctx->sched_pending.probe = probe;
+    }
+    if (!pipelined) ctx->sched_flags = (fused_one_pass ? 1u : 0u) | ((ctx->sched_pending.valid && ctx->sched.choice < 0) ? 0x100u : 0u);
     ctx->fused_frame = fused_one_pass;
     const int nsets = fused_one_pass ? 1 : std::max(1, std::min(PT_MAX_SETS, ctx->opt.streams > 0 ? ctx->opt.streams : 3));
     const uint32_t max_paths = std::max<uint32_t>(ctx->opt.max_paths, 64u);
@@ -1547,6 +1606,9 @@ static int render_finish(pt_ctx* ctx, int slot = 0) {
                 fclose(f);
             }
         }
+        if (h[53] + h[54] + h[55] + h[56]) // -DPT_DEBUG_WAVELOG=3 builds
+            fprintf(stderr, "[pt_render] traversal iterations by lanes active at their start (<=8 | <=16 | <=32 | more): %llu %llu %llu %llu; cycles: %llu %llu %llu %llu\n",
+                    h[53], h[54], h[55], h[56], h[57], h[58], h[59], h[60]);
         if (h[48])
             fprintf(stderr, "[pt_render] camera packets %llu: node steps %.1f per packet (%.1f lanes hit something), triangle tests %.1f per packet (%.1f lanes inside the leaf's box)\n",
                     h[48], (double)h[49] / h[48], h[49] ? (double)h[52] / h[49] : 0.0, (double)h[50] / h[48], h[50] ? (double)h[51] / h[50] : 0.0);
@@ -1577,6 +1639,34 @@ static int render_finish(pt_ctx* ctx, int slot = 0) {
     float ms = 0;
     hipEventElapsedTime(&ms, ev_begin, ev_end);
     st.render_ms = ms;
+    if (ctx->sched_pending.valid && slot == 0) { // the frame took part in the chain-against-fused measurement (render_enqueue)
+        ctx->sched_pending.valid = false;
+        pt_ctx::Sched& sc = ctx->sched;
+        const int w = ctx->sched_pending.which;
+        const double t = ctx->sched_fake[0] > 0 ? ctx->sched_fake[w] : (double)ms;
+        if (sc.choice < 0) {
+            if (sc.n[w] > 0) sc.best[w] = sc.best[w] > 0 ? std::min(sc.best[w], t) : t; // (the first frame of each schedule is warm-up: code objects, cold caches, first-touch of the path state)
+            ++sc.n[w];
+            if (sc.n[0] > ctx->sched_trials && sc.n[1] > ctx->sched_trials) {
+                sc.choice = sc.best[1] < sc.best[0] ? 1 : 0;
+                sc.since = 0;
+                sc.mean = sc.best[sc.choice];
+            }
+        } else if (ctx->sched_pending.probe) {
+            ++sc.since;
+            if (t < 0.95 * sc.mean) { // the loser is clearly ahead now: time both again (they are warm: no warm-up frame)
+                sc.choice = -1;
+                sc.n[0] = sc.n[1] = 1;
+                sc.best[0] = sc.best[1] = 0;
+            }
+        } else {
+            ++sc.since;
+            sc.mean = 0.9 * sc.mean + 0.1 * t;
+        }
+    }
+    st.schedule = ctx->sched_flags;
+    st.sched_chain_ms = ctx->sched.best[0];
+    st.sched_fused_ms = ctx->sched.best[1];
     double cls_ms[4] = {0, 0, 0, 0};
     for (auto& sp : ctx->spans) { // kernel timing implies synchronous frames: the spans are those of this frame
         float m = 0;
@@ -2081,6 +2171,7 @@ extern "C" int pt_get_stats(const pt_ctx* ctx, pt_stats* out) {
     out->bvh_levels = (uint32_t)ctx->bvh.levels8;
     out->bvh_builder = (uint32_t)ctx->bvh.builder;
     out->path_state_allocs = ctx->path_state_allocs;
+    out->bvh_challengers_skipped = (uint32_t)ctx->bvh.challengers_skipped;
     return PT_OK;
 }
 

@@ -244,6 +244,9 @@ struct Trace8Args {
     int ovf_depth;  // spill levels available (PT8_OVF_DEPTH; the test hook PT_STACK_CAP lowers it)
     uint32_t* fault; // device word: bit 0 set when a push found the stack full — the host turns it into PT_ERR_UNSUPPORTED
     uint32_t num_nodes;
+#if PT_DEBUG_WAVELOG + 0 == 3
+    unsigned long long* hist; // dbg + 53 (set from dbg by the kernels' entry points; survives the fused loop's `dbg = nullptr`)
+#endif
 };
 
 // The traversal of one persistent wave.  LOCAL = false: wave `wid` of `nw` of a launch over the queues of `a` (k_trace8 below).
@@ -319,6 +322,11 @@ PT_DEV void trace8_wave(const Trace8Args& a, const uint32_t wid, const uint32_t 
     PT_WLOG(const unsigned long long w_t0 = wall_clock64(); unsigned long long w_tex = 0; uint32_t w_iters = 0;)
     PT_WLOG(unsigned long long w_cw = 0; unsigned long long w_cr = 0; unsigned long long w_cs = 0; uint32_t w_np = 0;) // -DPT_DEBUG_WAVELOG=2: cycles in the loop-top write-back | refill | steal round, outer passes
     PT_WLOG(unsigned long long w_c01 = 0; unsigned long long w_c12 = 0; unsigned long long w_c23 = 0; const unsigned long long w_c0 = clock64();) // shader-clock cycles: vote + pop + addresses | waiting for the loads | arithmetic
+#if PT_DEBUG_WAVELOG + 0 == 3
+    // round 6 (sizing a several-lanes-per-ray mode): iterations and cycles of this wave by the number of lanes that held a ray (or a stolen share of one)
+    // at the top of the iteration: <= 8 | <= 16 | <= 32 | more — summed over all waves and launches of a frame in dbg[53..60]
+    unsigned long long h_i0 = 0, h_i1 = 0, h_i2 = 0, h_i3 = 0, h_c0 = 0, h_c1 = 0, h_c2 = 0, h_c3 = 0;
+#endif
 
     auto push = [&](uint32_t v0, uint32_t v1) {
         PT_STAT(++c_push; if ((uint32_t)sp + 1 > c_maxsp) c_maxsp = sp + 1;)
@@ -749,6 +757,13 @@ PT_DEV void trace8_wave(const Trace8Args& a, const uint32_t wid, const uint32_t 
                 c_nodeit += node_step ? 1u : 0u;
             })
             PT_WLOG(++w_iters; w_c01 += w_b - w_a; w_c12 += w_c - w_b; w_c23 += clock64() - w_c;)
+#if PT_DEBUG_WAVELOG + 0 == 3
+            {
+                const uint32_t nact = (uint32_t)__popcll(act); // lanes that were active when the iteration began
+                const unsigned long long dt = clock64() - w_a;
+                if (nact <= 8u) { ++h_i0; h_c0 += dt; } else if (nact <= 16u) { ++h_i1; h_c1 += dt; } else if (nact <= 32u) { ++h_i2; h_c2 += dt; } else { ++h_i3; h_c3 += dt; }
+            }
+#endif
             act = __ballot(active);
             ++it;
 #if PT8_STEAL
@@ -772,6 +787,12 @@ PT_DEV void trace8_wave(const Trace8Args& a, const uint32_t wid, const uint32_t 
             atomicAdd(&a.dbg[10], (unsigned long long)c_nodeit);
         }
     })
+#if PT_DEBUG_WAVELOG + 0 == 3
+    if (a.hist && lane == 0) {
+        atomicAdd(&a.hist[0], h_i0); atomicAdd(&a.hist[1], h_i1); atomicAdd(&a.hist[2], h_i2); atomicAdd(&a.hist[3], h_i3);
+        atomicAdd(&a.hist[4], h_c0); atomicAdd(&a.hist[5], h_c1); atomicAdd(&a.hist[6], h_c2); atomicAdd(&a.hist[7], h_c3);
+    }
+#endif
     PT_WLOG(if (a.dbg && lane == 0) {
         // per-wave log (tools/r5_wavelog.py): [64 + 8 k ...] = work pointer (names the launch), mode and rays of the launch, start, end, start
         // of the stealing phase (100 MHz clock), loop iterations, ticks spent hungry, cells taken | cells donated << 32
@@ -802,6 +823,9 @@ PT_DEV void trace8_wave(const Trace8Args& a, const uint32_t wid, const uint32_t 
 template <int MODE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT8_WAVES_PER_EU, PT8_WAVES_PER_EU)))
 k_trace8(Trace8Args a) {
+#if PT_DEBUG_WAVELOG + 0 == 3
+    a.hist = a.dbg ? a.dbg + 53 : nullptr;
+#endif
     trace8_wave<MODE, false>(a, blockIdx.x, gridDim.x, 0u, 0u, 0u);
 }
 

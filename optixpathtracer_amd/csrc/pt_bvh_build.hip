@@ -906,16 +906,45 @@ __global__ void __launch_bounds__(64) k_calibrate8(const Node8* __restrict__ nod
 struct Arena {
     char* base = nullptr;
     size_t cap = 0, used = 0;
+    // PT_BVH_GUARD=1 (tests/test_gpu_builder.py, tools): every slice is followed by a 256-byte band of 0xA5 that nothing may write; the bands of a
+    // phase are read back when its mark is released (ArenaMark) and at the end of the build, and one changed byte fails the build — an overflow
+    // INSIDE the arena lands in a neighbouring slice and would otherwise go unnoticed (or corrupt a tree silently), unlike one past a hipMalloc.
+    bool guard = false;
+    struct Band { size_t off, slice_off, slice_bytes; };
+    std::vector<Band> bands;
+    int guard_bad = 0;
+    static const size_t kBand = 256;
     hipError_t init(size_t bytes) {
-        cap = bytes;
+        guard = getenv("PT_BVH_GUARD") != nullptr && atoi(getenv("PT_BVH_GUARD")) != 0;
+        cap = bytes + (guard ? 256 * kBand * 2 : 0); // room for the bands of a few hundred slices
         used = 0;
-        return hipMalloc((void**)&base, bytes);
+        return hipMalloc((void**)&base, cap);
     }
     void* take(size_t bytes) {
         const size_t a = (used + 255) & ~(size_t)255;
-        if (!base || a + bytes > cap) return nullptr;
-        used = a + bytes;
+        const size_t end = guard ? ((a + bytes + 255) & ~(size_t)255) + kBand : a + bytes;
+        if (!base || end > cap) return nullptr;
+        if (guard) {
+            if (hipMemset(base + end - kBand, 0xA5, kBand) != hipSuccess) return nullptr;
+            bands.push_back({end - kBand, a, bytes});
+        }
+        used = end;
         return base + a;
+    }
+    // read back the bands at or above `from` (the device must be idle: the callers synchronise) and forget them
+    void verify(size_t from) {
+        unsigned char h[kBand];
+        while (!bands.empty() && bands.back().off >= from) {
+            const Band b = bands.back();
+            bands.pop_back();
+            if (hipMemcpy(h, base + b.off, kBand, hipMemcpyDeviceToHost) != hipSuccess) { ++guard_bad; continue; }
+            for (size_t k = 0; k < kBand; ++k)
+                if (h[k] != 0xA5) {
+                    fprintf(stderr, "[pt_bvh] ARENA GUARD: byte %zu after the slice at offset %zu (%zu bytes) was overwritten (0x%02x)\n", k, b.slice_off, b.slice_bytes, h[k]);
+                    ++guard_bad;
+                    break;
+                }
+        }
     }
     bool owns(const void* q) const { return base && (const char*)q >= base && (const char*)q < base + cap; }
     ~Arena() { if (base) hipFree(base); }
@@ -933,7 +962,14 @@ static void tfree(const void* q) {
 struct ArenaMark { // arena memory taken after the mark is handed back when the mark goes out of scope
     size_t used;
     ArenaMark() : used(t_arena ? t_arena->used : 0) {}
-    ~ArenaMark() { if (t_arena) t_arena->used = used; }
+    ~ArenaMark() {
+        if (!t_arena) return;
+        if (t_arena->guard) {
+            (void)hipDeviceSynchronize();
+            t_arena->verify(used);
+        }
+        t_arena->used = used;
+    }
 };
 // frees its device allocations on every exit path of the function that owns it
 struct DevFrees {
@@ -1171,45 +1207,62 @@ static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt,
 // ------------------------------------------------------------------ binned SAH, top-down (round 5: the third hierarchy the calibration chooses from)
 // Wald 2007's binned surface-area heuristic, built breadth-first on the GPU.  The leaves are the Morton-sorted triangles (leaf i = node
 // n - 1 + i, its box in box[]), prim[] holds them partitioned by node: a node owns the positions [first, first + count).
-//   * Nodes with more than SAH_SMALL leaves are split level by level: every leaf drops its box into one of SAH_BINS bins per axis (bins
-//     over the node's box, by centroid) — accumulated in LDS for the node that dominates a workgroup, because a same-address global atomic
-//     costs 10.5 ns on this chip and the top levels have a few nodes and a million leaves (tools/micro/xw_probe.hip) —, one thread per node
-//     sweeps the 3 x 15 candidate planes for the smallest A_L N_L + A_R N_R (no candidate with an empty side: the leaves are halved by
-//     position instead), creates the two children with their exact boxes (unions of bins) and the leaves are partitioned by one
-//     exclusive scan of the "goes left" flags and a scatter.  One 16-byte read-back per level tells the host how many large nodes are left.
+//   * Nodes with more than SAH_SMALL leaves ("large") are split level by level.  Every leaf drops its box into one of SAH_BINS bins per axis
+//     (bins over the node's box, by centroid), always in LDS — a same-address global atomic costs 10.5 ns on this chip
+//     (tools/micro/xw_probe.hip): a node of at most SAH_BIG leaves is binned by a wave (or the four waves of a workgroup) of its own
+//     (k_sah_node); a bigger one by position windows of SAH_WG leaves (k_sah_bin), merged per node (k_sah_reduce) into one of the few global
+//     bin sets there can be (at most n / SAH_BIG nodes are that big) which k_sah_node then loads.  The same wave then sweeps the
+//     3 x (SAH_BINS - 1) candidate planes — one lane per plane, from the bins in LDS — for the smallest A_L N_L + A_R N_R (no candidate with
+//     an empty side: the leaves are halved by position instead), and its first lane creates the two children with their exact boxes
+//     (unions of bins).  (Round 5 stored every node's bins to global memory — 1344 bytes per node, 150 MB for a million triangles — for a
+//     kernel with one THREAD per node to sweep: 42 launches of 49 us, 2 of the hierarchy's 5.6 ms.)  The leaves are partitioned by one
+//     exclusive scan of the "goes left" flags and a scatter.  One 20-byte read-back per level tells the host how many large nodes are left.
 //   * A child with at most SAH_SMALL leaves is finished later by ONE thread: exact sweep SAH (every axis, every position of the sorted
 //     centroids) down to single leaves.
 // Node numbering is handed out by atomic counters (like k_collapse8's): the TREE is deterministic, the numbers are not.
+// (Bins over the node's CENTROID bounds instead of its box — the textbook choice — and 32 bins were measured in round 5,
+// profiles/r5_08_sah.md: the same frame times; that variant's code left with round 6, commit 910de7f has it.)
 #ifndef SAH_BINS
 #define SAH_BINS 16
 #endif
 #define SAH_SMALL 8
 #define SAH_WG 1024
-#define SAH_BIG 8192 // nodes with more leaves are binned by position windows (k_sah_bin: LDS per window, global atomics to merge), smaller ones by a wave of their own
-#ifndef SAH_CENTROID_BINS
-#define SAH_CENTROID_BINS 0 // 1: bins span the node's CENTROID bounds (Wald 2007) instead of its box.  Measured (profiles/r5_08_sah.md): the same frame times at 16
-                            // bins (C3 7.84 / 7.83 ms, stadium 12.04 / 12.07, 9.5 M terrain 7.37 / 7.33), 13 instead of 7 words per bin to accumulate — the box stays
-#endif
-#if SAH_CENTROID_BINS
-#define SAH_W 13
-#else
+#define SAH_BIG 8192 // nodes with more leaves are binned by position windows (k_sah_bin + k_sah_reduce), smaller ones by a wave of their own
 #define SAH_W 7
-#endif
-struct SahBin { // per node slot, axis, bin: box of the leaves (ordered-uint floats), their number and (SAH_CENTROID_BINS) the bounds of their centroids
+#define SAH_NODE_WORDS (3 * SAH_BINS * SAH_W)
+struct SahBin { // per axis and bin: box of the leaves (ordered-uint floats) and their number
     uint32_t lo[3], hi[3], count;
-#if SAH_CENTROID_BINS
-    uint32_t clo[3], chi[3];
-#endif
 };
-// word w of a bin: 0-2 minima, 3-5 maxima, 6 count, 7-9 minima, 10-12 maxima
-__device__ __forceinline__ int sah_word_kind(int w) { return w < 3 ? 0 : (w < 6 ? 1 : (w == 6 ? 2 : (w < 10 ? 0 : 1))); } // 0 min, 1 max, 2 sum
+// word w of a bin: 0-2 minima, 3-5 maxima, 6 count
+__device__ __forceinline__ int sah_word_kind(int w) { return w < 3 ? 0 : (w < 6 ? 1 : 2); } // 0 min, 1 max, 2 sum
 __device__ __forceinline__ uint32_t sah_word_init(int w) { return sah_word_kind(w) == 0 ? 0xffffffffu : 0u; }
 struct SahCtl { // device counters of a build
     uint32_t next_id;     // next internal node id
     uint32_t nlarge_next; // large nodes created for the next level
     uint32_t nsmall;      // small subtrees waiting for k_sah_small
-    uint32_t nbig_next;   // of the large nodes of the next level: those with more than SAH_BIG leaves
+    uint32_t nbig_next;   // of the large nodes of the next level: those with more than SAH_BIG leaves (= global bin sets handed out)
+    uint32_t fault;       // -DPT_BVH_CHECK=1 builds: bit 4 k + w = kernel k found index w outside its array (SAH_OK below); build_sah fails the build on any bit
 };
+// Bounds-checked builds of the SAH kernels (tools/variants.sh chk "-DPT_BVH_CHECK=1"; tests/test_gpu_builder.py runs the builder tests against that
+// library): every index a kernel derives from device data — node ids out of active[] / node_of[] / the id counter, bin slots, leaf ranges
+// first + count, scatter positions, the small-subtree sizes that index thread-local arrays — is compared with the size of the array it goes into
+// BEFORE the access; a violation sets a bit of SahCtl::fault and the thread drops the access instead of making it.  Why (round 5 -> 6): a GPU
+// memory access fault was seen once while these kernels were being rewritten (profiles/r6_01_sah_fault.md); the shipped kernels were audited
+// index by index (the table there), and this build is what turns any future overflow into a reported error instead of a fault or silent
+// corruption inside the arena.  K: 0 node, 1 bin (windows), 2 reduce, 3 children, 4 flag, 5 scatter, 6 small.
+// W: 0 node id, 1 leaf range, 2 bin slot / scatter position, 3 leaf id / list position.
+#ifndef PT_BVH_CHECK
+#define PT_BVH_CHECK 0
+#endif
+#if PT_BVH_CHECK
+#define SAH_OK(cond, K, W, ctl) ((cond) ? true : (atomicOr(&(ctl)->fault, 1u << (4 * (K) + (W))), false))
+// fault injection, check builds only (PT_BVH_INJECT, tests/test_gpu_builder.py: the checks and the guard bands must be seen to fire):
+//   1 = the root's second child is given a leaf count beyond the array (caught by k_sah_node's range check on the next level);
+//   2 = k_sah_flag writes 96 words past the end of flag[] (lands in the arena's guard band behind that slice, PT_BVH_GUARD=1)
+__device__ int g_sah_inject = 0;
+#else
+#define SAH_OK(cond, K, W, ctl) (true)
+#endif
 __device__ __forceinline__ int sah_bin_of(float c, float lo, float hi) {
     const float ext = hi - lo;
     if (!(ext > 0.f)) return 0;
@@ -1222,25 +1275,18 @@ __global__ void k_sah_init(int n, int* __restrict__ prim, int* __restrict__ node
     prim[i] = i;
     node_of[i] = large_root ? 0 : -1;
 }
-__global__ void k_sah_clear_bins(SahBin* __restrict__ bins, uint32_t nwords) { // lo = +inf, hi = -inf (ordered), count = 0
+__global__ void k_sah_clear_bins(uint32_t* __restrict__ bins, uint32_t nwords) { // lo = +inf, hi = -inf (ordered), count = 0
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nwords) return;
-    reinterpret_cast<uint32_t*>(bins)[i] = sah_word_init((int)(i % (uint32_t)SAH_W));
+    bins[i] = sah_word_init((int)(i % (uint32_t)SAH_W));
 }
-// a leaf into one bin (LDS or global words): its box, its count, its centroid
+// a leaf into one bin (LDS words): its box, its count
 __device__ __forceinline__ void sah_accumulate(uint32_t* w, const float* b) {
     for (int k = 0; k < 3; ++k) {
         atomicMin(&w[k], f2ord(b[k]));
         atomicMax(&w[3 + k], f2ord(b[3 + k]));
     }
     atomicAdd(&w[6], 1u);
-#if SAH_CENTROID_BINS
-    for (int k = 0; k < 3; ++k) {
-        const uint32_t c = f2ord(0.5f * (b[k] + b[3 + k]));
-        atomicMin(&w[7 + k], c);
-        atomicMax(&w[10 + k], c);
-    }
-#endif
 }
 // The same for a whole wave whose lanes mostly fall into the SAME bin (the position windows of the top levels: the leaves are in Morton order,
 // 64 neighbours share a bin, and 64 lanes on one LDS word serialise: 286 us per level for a million leaves): the lanes are grouped by bin with
@@ -1256,92 +1302,187 @@ __device__ __forceinline__ void sah_accumulate_wave(uint32_t* w_base, int bin, c
         const unsigned long long grp = __ballot(mine);
         float lo[3], hi[3];
         for (int k = 0; k < 3; ++k) { lo[k] = mine ? b[k] : INFINITY; hi[k] = mine ? b[3 + k] : -INFINITY; }
-#if SAH_CENTROID_BINS
-        float clo[3], chi[3];
-        for (int k = 0; k < 3; ++k) { const float c = 0.5f * (b[k] + b[3 + k]); clo[k] = mine ? c : INFINITY; chi[k] = mine ? c : -INFINITY; }
-#endif
         for (int off = 32; off > 0; off >>= 1)
             for (int k = 0; k < 3; ++k) {
                 lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
                 hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
-#if SAH_CENTROID_BINS
-                clo[k] = fminf(clo[k], __shfl_xor(clo[k], off));
-                chi[k] = fmaxf(chi[k], __shfl_xor(chi[k], off));
-#endif
             }
         if (lane == leader) {
-            uint32_t* w = w_base + bsel * SAH_W;
+            uint32_t* w = w_base + bsel * SAH_W; // bsel is a leader's bin: sah_bin_of's result, in [0, SAH_BINS)
             for (int k = 0; k < 3; ++k) {
                 w[k] = min(w[k], f2ord(lo[k]));
                 w[3 + k] = max(w[3 + k], f2ord(hi[k]));
-#if SAH_CENTROID_BINS
-                w[7 + k] = min(w[7 + k], f2ord(clo[k]));
-                w[10 + k] = max(w[10 + k], f2ord(chi[k]));
-#endif
             }
             w[6] += (uint32_t)__popcll(grp);
         }
         todo &= ~grp;
     }
 }
-// every leaf of a large node into its three bins
-// One wave per node of at most SAH_BIG leaves: the node's leaves binned in LDS that only this wave touches, the bins then stored as they are — no
-// global atomic (the first version binned every leaf of every node with 21 device-scope atomics: 21 M per level, 0.5 ms per level).
-__global__ void __launch_bounds__(256) k_sah_bin_node(const int* __restrict__ active, int nactive, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ first,
-                                                      const int* __restrict__ cnt, const int* __restrict__ slot_of, const float* __restrict__ box, const float* __restrict__ cbox,
-                                                      SahBin* __restrict__ bins, int per_node) {
-    __shared__ uint32_t s_all[4][3 * SAH_BINS * SAH_W];
+__device__ __forceinline__ float sah_area(const float* lo, const float* hi) {
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+// union of the bins [j0, j1] of one axis (bins without a leaf hold the sentinels and are skipped)
+__device__ __forceinline__ int sah_union(const uint32_t* axis_bins, int j0, int j1, float* lo, float* hi) {
+    int cn = 0;
+    for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+    for (int j = j0; j <= j1; ++j) {
+        const uint32_t* b = axis_bins + j * SAH_W;
+        if (!b[6]) continue;
+        for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], ord2f(b[k])); hi[k] = fmaxf(hi[k], ord2f(b[3 + k])); }
+        cn += (int)b[6];
+    }
+    return cn;
+}
+// The split of a node whose bins sit in LDS (`s_bins`, written before a barrier by the caller): the wave's lanes take the 3 x (SAH_BINS - 1)
+// candidate planes (axis a, leaves of bins 0..j left), each computes A_L N_L + A_R N_R from the unions of the bins on either side, and a
+// butterfly picks the smallest cost, the lowest (axis, bin) among equal ones — what a sweep in (axis, bin) order with `c < best` picks.
+// Returns axis | bin << 2 and the number of leaves that go left, or -1 when every plane has an empty side.  Every lane gets the result.
+__device__ __forceinline__ int sah_sweep_wave(const uint32_t* s_bins, int lane, int* nl_out) {
+    float best = INFINITY;
+    int best_l = 0x7fffffff, best_nl = 0;
+    for (int L = lane; L < 3 * (SAH_BINS - 1); L += 64) {
+        const int a = L / (SAH_BINS - 1), j = L % (SAH_BINS - 1);
+        float llo[3], lhi[3], rlo[3], rhi[3];
+        const int cn = sah_union(s_bins + a * SAH_BINS * SAH_W, 0, j, llo, lhi);
+        const int rn = sah_union(s_bins + a * SAH_BINS * SAH_W, j + 1, SAH_BINS - 1, rlo, rhi);
+        if (cn == 0 || rn == 0) continue;
+        const float c = sah_area(llo, lhi) * (float)cn + sah_area(rlo, rhi) * (float)rn;
+        if (c < best) { best = c; best_l = L; best_nl = cn; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float oc = __shfl_xor(best, off);
+        const int ol = __shfl_xor(best_l, off), on = __shfl_xor(best_nl, off);
+        if (oc < best || (oc == best && ol < best_l)) { best = oc; best_l = ol; best_nl = on; }
+    }
+    *nl_out = best_nl;
+    if (best_l == 0x7fffffff) return -1;
+    return (best_l / (SAH_BINS - 1)) | ((best_l % (SAH_BINS - 1)) << 2);
+}
+// One thread: the two children of `node` (ids, ranges, exact boxes), who is large next, who gets a global bin set
+__device__ void sah_make_children(int node, int sp, int nl_best, const uint32_t* s_bins, int n, int* __restrict__ first, int* __restrict__ cnt, float* __restrict__ box,
+                                  int* __restrict__ left, int* __restrict__ right, int* __restrict__ split, int* __restrict__ slot_next, int* __restrict__ active_next,
+                                  int* __restrict__ small_list, SahCtl* __restrict__ ctl) {
+    const int m = cnt[node], f = first[node];
+    int nl;
+    float blo[2][3], bhi[2][3]; // boxes of the split's sides
+    if (sp < 0) { // every centroid in one bin on every axis: halve by position; the children's boxes are the node's (a superset: conservative)
+        nl = m / 2;
+        split[node] = -1 - nl;
+        for (int k = 0; k < 3; ++k) { blo[0][k] = blo[1][k] = box[(size_t)node * 6 + k]; bhi[0][k] = bhi[1][k] = box[(size_t)node * 6 + 3 + k]; }
+    } else {
+        nl = nl_best;
+        split[node] = sp;
+        const uint32_t* ab = s_bins + (sp & 3) * SAH_BINS * SAH_W;
+        sah_union(ab, 0, sp >> 2, blo[0], bhi[0]);
+        sah_union(ab, (sp >> 2) + 1, SAH_BINS - 1, blo[1], bhi[1]);
+    }
+    for (int s = 0; s < 2; ++s) {
+        const int cf = s ? f + nl : f, cm = s ? m - nl : nl;
+        int child;
+        if (cm == 1) {
+            child = -2 - cf; // a single leaf: the scatter writes n - 1 + (the leaf that lands on position cf)
+        } else {
+            child = (int)atomicAdd(&ctl->next_id, 1u);
+            if (!SAH_OK(child < n - 1, 3, 0, ctl)) return; // a binary tree over n leaves has n - 1 internal nodes: the id counter cannot pass it
+            first[child] = cf;
+            cnt[child] = cm;
+#if PT_BVH_CHECK
+            if (g_sah_inject == 1 && node == 0 && s == 1) cnt[child] = cm + n;
+#endif
+            for (int k = 0; k < 3; ++k) { box[(size_t)child * 6 + k] = blo[s][k]; box[(size_t)child * 6 + 3 + k] = bhi[s][k]; }
+            if (cm > SAH_SMALL) {
+                const int al = (int)atomicAdd(&ctl->nlarge_next, 1u);
+                if (!SAH_OK(al < n / (SAH_SMALL + 1) + 2, 3, 3, ctl)) return; // active[]: a large node has more than SAH_SMALL leaves
+                active_next[al] = child;
+                if (cm > SAH_BIG) {
+                    const int sl = (int)atomicAdd(&ctl->nbig_next, 1u);
+                    if (!SAH_OK(sl < n / SAH_BIG + 2, 3, 2, ctl)) return; // global bin sets: big nodes are disjoint and hold more than SAH_BIG leaves each
+                    slot_next[child] = sl;
+                }
+            } else {
+                const uint32_t si = atomicAdd(&ctl->nsmall, 1u);
+                if (!SAH_OK(si < (uint32_t)(n / 2 + 2), 3, 3, ctl)) return; // small_list: a small subtree has at least two leaves
+                small_list[si] = child;
+            }
+        }
+        (s ? right : left)[node] = child;
+    }
+}
+// One wave per large node of this level (per_node = 1: levels with many nodes) or the four waves of a workgroup (per_node = 4: levels with few
+// nodes: a lone wave looping over 8192 leaves is 128 dependent iterations, 0.3 ms): the node's bins in LDS that only these waves touch —
+// binned from its leaves, or, for a node of more than SAH_BIG leaves, loaded from the global set the window kernels filled — then the plane
+// sweep and the children, from LDS.  No global atomic on the bins and no bins in global memory for the 99.9 % of the nodes that are not big.
+__global__ void __launch_bounds__(256) k_sah_node(const int* __restrict__ active, int nactive, int n, int nleaf_base, const int* __restrict__ prim, int* __restrict__ first,
+                                                  int* __restrict__ cnt, const int* __restrict__ slot_of, float* __restrict__ box, const uint32_t* __restrict__ bins,
+                                                  int* __restrict__ left, int* __restrict__ right, int* __restrict__ split, int* __restrict__ slot_next,
+                                                  int* __restrict__ active_next, int* __restrict__ small_list, SahCtl* __restrict__ ctl, int per_node) {
+    __shared__ uint32_t s_all[4][SAH_NODE_WORDS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // per_node = 1: a wave per node (levels with many nodes); per_node = 4: the four waves of the workgroup share a node (levels with few, large nodes:
-    // a lone wave looping over 8192 leaves is 128 dependent iterations, 0.3 ms)
     const int t = per_node == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
     const int part = per_node == 4 ? wave : 0;
     uint32_t* s_bins = s_all[wave];
-    for (int k = lane; k < 3 * SAH_BINS * SAH_W; k += 64) s_bins[k] = sah_word_init(k % SAH_W);
+    for (int k = lane; k < SAH_NODE_WORDS; k += 64) s_bins[k] = sah_word_init(k % SAH_W);
     __syncthreads();
-    const int node = t < nactive ? active[t] : -1;
+    int node = t < nactive ? active[t] : -1;
+    // (a dropped node keeps the workgroup's barriers matched: its waves bin nothing and create nothing)
+    if (node >= 0 && !SAH_OK(node < n - 1, 0, 0, ctl)) node = -1;
+    if (node >= 0 && !SAH_OK(first[node] >= 0 && cnt[node] > SAH_SMALL && (long long)first[node] + cnt[node] <= n, 0, 1, ctl)) node = -1;
     const int m = node >= 0 ? cnt[node] : 0;
-    if (node >= 0 && m <= SAH_BIG) {
+    if (node >= 0 && m > SAH_BIG && !SAH_OK(slot_of[node] >= 0 && slot_of[node] < n / SAH_BIG + 2, 0, 2, ctl)) node = -1;
+    if (node >= 0) {
         const int f = first[node];
-        const float* nb = &cbox[(size_t)node * 6]; // what the bins span
-        const float nlo[3] = {nb[0], nb[1], nb[2]}, nhi[3] = {nb[3], nb[4], nb[5]};
-        for (int i = f + part * 64 + lane; i < f + m; i += 64 * per_node) {
-            const float* bp = &box[(size_t)(nleaf_base + prim[i]) * 6];
-            const float b[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
-            for (int a = 0; a < 3; ++a) sah_accumulate(&s_bins[(a * SAH_BINS + sah_bin_of(0.5f * (b[a] + b[3 + a]), nlo[a], nhi[a])) * SAH_W], b);
-        }
-    }
-    __syncthreads();
-    if (node >= 0 && m <= SAH_BIG) {
-        uint32_t* g = reinterpret_cast<uint32_t*>(&bins[(size_t)slot_of[node] * 3 * SAH_BINS]);
-        if (per_node == 4) {
-            for (int k = threadIdx.x; k < 3 * SAH_BINS * SAH_W; k += 256) {
-                const int kind = sah_word_kind(k % SAH_W);
-                uint32_t acc = s_all[0][k];
-                for (int v = 1; v < 4; ++v) acc = kind == 0 ? min(acc, s_all[v][k]) : (kind == 1 ? max(acc, s_all[v][k]) : acc + s_all[v][k]);
-                g[k] = acc;
+        if (m > SAH_BIG) { // binned by the window kernels: the first wave fetches the node's global set (the others' LDS stays neutral)
+            if (part == 0) {
+                const uint32_t* g = bins + (size_t)slot_of[node] * SAH_NODE_WORDS;
+                for (int k = lane; k < SAH_NODE_WORDS; k += 64) s_bins[k] = g[k];
             }
         } else {
-            for (int k = lane; k < 3 * SAH_BINS * SAH_W; k += 64) g[k] = s_bins[k];
+            const float* nb = &box[(size_t)node * 6]; // what the bins span
+            const float nlo[3] = {nb[0], nb[1], nb[2]}, nhi[3] = {nb[3], nb[4], nb[5]};
+            for (int i = f + part * 64 + lane; i < f + m; i += 64 * per_node) {
+                if (!SAH_OK(prim[i] >= 0 && prim[i] < n, 0, 3, ctl)) continue;
+                const float* bp = &box[(size_t)(nleaf_base + prim[i]) * 6];
+                const float b[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
+                for (int a = 0; a < 3; ++a) sah_accumulate(&s_bins[(a * SAH_BINS + sah_bin_of(0.5f * (b[a] + b[3 + a]), nlo[a], nhi[a])) * SAH_W], b);
+            }
         }
     }
+    __syncthreads();
+    if (per_node == 4) { // the four partial sets into the first (every thread reads and writes its own words only)
+        for (int k = threadIdx.x; k < SAH_NODE_WORDS; k += 256) {
+            const int kind = sah_word_kind(k % SAH_W);
+            uint32_t acc = s_all[0][k];
+            for (int v = 1; v < 4; ++v) acc = kind == 0 ? min(acc, s_all[v][k]) : (kind == 1 ? max(acc, s_all[v][k]) : acc + s_all[v][k]);
+            s_all[0][k] = acc;
+        }
+        __syncthreads();
+        if (wave != 0) return;
+    }
+    if (node < 0) return;
+    int nl = 0;
+    const int sp = sah_sweep_wave(s_bins, lane, &nl); // (per_node = 4: wave 0's set is s_all[0], the merged one)
+    if (lane == 0) sah_make_children(node, sp, nl, s_bins, n, first, cnt, box, left, right, split, slot_next, active_next, small_list, ctl);
 }
 // Big nodes (more than SAH_BIG leaves) by position windows of SAH_WG leaves.  A big node spans at least eight windows, so a window meets at most TWO of them
 // (one ending, one starting): each gets a set of bins per wave in LDS (grouped accumulation, sah_accumulate_wave), the sets are merged per window and
 // stored to partial[2 window + j] with plain stores, and k_sah_reduce merges the windows of a node.  No global atomic: the first versions sent the second
 // node's leaves of a straddling window — a thousand leaves, 21 000 atomics on eleven cache lines, 10.5 ns each — to the global bins, and that one window
 // made every level take 260 us whatever the other 1023 windows did (level 0, which has no straddling window: 42 us).
+// Index ranges: window = blockIdx.x < ceil(n / SAH_WG) = the windows partial[] / partial_node[] are sized for (two entries each); s_first, s_second
+// are thread indices < SAH_WG of threads with i < n.
 __global__ void __launch_bounds__(SAH_WG) k_sah_bin(int n, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ node_of, const int* __restrict__ cnt,
-                                                    const float* __restrict__ box, const float* __restrict__ cbox, uint32_t* __restrict__ partial,
-                                                    int* __restrict__ partial_node) {
-    __shared__ uint32_t s_wbins[SAH_WG / 64][2][3 * SAH_BINS * SAH_W];
+                                                    const float* __restrict__ box, uint32_t* __restrict__ partial, int* __restrict__ partial_node, SahCtl* __restrict__ ctl) {
+    __shared__ uint32_t s_wbins[SAH_WG / 64][2][SAH_NODE_WORDS];
     __shared__ int s_first, s_second;
     const int i = blockIdx.x * SAH_WG + threadIdx.x;
-    for (int k = threadIdx.x; k < (SAH_WG / 64) * 2 * 3 * SAH_BINS * SAH_W; k += SAH_WG) (&s_wbins[0][0][0])[k] = sah_word_init(k % SAH_W);
+    for (int k = threadIdx.x; k < (SAH_WG / 64) * 2 * SAH_NODE_WORDS; k += SAH_WG) (&s_wbins[0][0][0])[k] = sah_word_init(k % SAH_W);
     if (threadIdx.x == 0) { s_first = 0x7fffffff; s_second = 0x7fffffff; }
     __syncthreads();
     int node = i < n ? node_of[i] : -1;
-    if (node >= 0 && cnt[node] <= SAH_BIG) node = -1; // a wave of its own bins that node (k_sah_bin_node)
+    if (node >= 0 && !SAH_OK(node < n - 1, 1, 0, ctl)) node = -1;
+    if (node >= 0 && !SAH_OK(prim[i] >= 0 && prim[i] < n, 1, 3, ctl)) node = -1;
+    if (node >= 0 && cnt[node] <= SAH_BIG) node = -1; // a wave of its own bins that node (k_sah_node)
     if (node >= 0) atomicMin(&s_first, (int)threadIdx.x);
     __syncthreads();
     if (s_first == 0x7fffffff) { // no big node in this window
@@ -1357,7 +1498,7 @@ __global__ void __launch_bounds__(SAH_WG) k_sah_bin(int n, int nleaf_base, const
         float nlo[3] = {0.f, 0.f, 0.f}, nhi[3] = {0.f, 0.f, 0.f};
         if (node >= 0) {
             const float* bp = &box[(size_t)(nleaf_base + prim[i]) * 6];
-            const float* nb = &cbox[(size_t)node * 6];
+            const float* nb = &box[(size_t)node * 6];
             for (int k = 0; k < 6; ++k) b[k] = bp[k];
             for (int k = 0; k < 3; ++k) { nlo[k] = nb[k]; nhi[k] = nb[3 + k]; }
         }
@@ -1370,8 +1511,8 @@ __global__ void __launch_bounds__(SAH_WG) k_sah_bin(int n, int nleaf_base, const
     }
     __syncthreads();
     if (threadIdx.x == 0) { partial_node[2 * blockIdx.x] = node0; partial_node[2 * blockIdx.x + 1] = node1; }
-    for (int k = threadIdx.x; k < 2 * 3 * SAH_BINS * SAH_W; k += SAH_WG) {
-        const int j = k / (3 * SAH_BINS * SAH_W), kk = k % (3 * SAH_BINS * SAH_W);
+    for (int k = threadIdx.x; k < 2 * SAH_NODE_WORDS; k += SAH_WG) {
+        const int j = k / SAH_NODE_WORDS, kk = k % SAH_NODE_WORDS;
         if (j == 1 && node1 < 0) continue;
         const int kind = sah_word_kind(kk % SAH_W);
         uint32_t acc = kind == 0 ? 0xffffffffu : 0u;
@@ -1379,25 +1520,29 @@ __global__ void __launch_bounds__(SAH_WG) k_sah_bin(int n, int nleaf_base, const
             const uint32_t x = s_wbins[v][j][kk];
             acc = kind == 0 ? min(acc, x) : (kind == 1 ? max(acc, x) : acc + x);
         }
-        partial[((size_t)2 * blockIdx.x + j) * (3 * SAH_BINS * SAH_W) + kk] = acc;
+        partial[((size_t)2 * blockIdx.x + j) * SAH_NODE_WORDS + kk] = acc;
     }
 }
-// gridDim.y workgroups per big node: merge the partial bins of the windows the node covers into its (cleared) bins
-__global__ void __launch_bounds__(256) k_sah_reduce(const int* __restrict__ active, int nactive, const int* __restrict__ first, const int* __restrict__ cnt,
-                                                                  const int* __restrict__ slot_of, const uint32_t* __restrict__ partial, const int* __restrict__ partial_node,
-                                                                  SahBin* __restrict__ bins) {
+// gridDim.y workgroups per large node (those of at most SAH_BIG leaves leave at once): merge the partial bins of the windows a big node covers
+// into its (cleared) global set
+__global__ void __launch_bounds__(256) k_sah_reduce(const int* __restrict__ active, int nactive, int n, const int* __restrict__ first, const int* __restrict__ cnt,
+                                                    const int* __restrict__ slot_of, const uint32_t* __restrict__ partial, const int* __restrict__ partial_node,
+                                                    uint32_t* __restrict__ bins, SahCtl* __restrict__ ctl) {
     const int node = active[blockIdx.x];
+    if (!SAH_OK(node >= 0 && node < n - 1, 2, 0, ctl)) return; // (no barrier in this kernel)
     const int m = cnt[node];
     if (m <= SAH_BIG) return;
     const int f = first[node], w0 = f / SAH_WG, w1 = (f + m - 1) / SAH_WG;
-    uint32_t* g = reinterpret_cast<uint32_t*>(&bins[(size_t)slot_of[node] * 3 * SAH_BINS]);
-    for (int k = threadIdx.x; k < 3 * SAH_BINS * SAH_W; k += 256) {
+    if (!SAH_OK(f >= 0 && (long long)f + m <= n, 2, 1, ctl)) return; // so w1 < ceil(n / SAH_WG), the windows partial[] holds
+    if (!SAH_OK(slot_of[node] >= 0 && slot_of[node] < n / SAH_BIG + 2, 2, 2, ctl)) return;
+    uint32_t* g = bins + (size_t)slot_of[node] * SAH_NODE_WORDS;
+    for (int k = threadIdx.x; k < SAH_NODE_WORDS; k += 256) {
         const int kind = sah_word_kind(k % SAH_W);
         uint32_t acc = kind == 0 ? 0xffffffffu : 0u;
         for (int win = w0 + (int)blockIdx.y; win <= w1; win += (int)gridDim.y) // (the windows of a node are dealt to gridDim.y workgroups: one looping over a thousand windows took 0.6 ms)
             for (int j = 0; j < 2; ++j) {
                 if (partial_node[2 * win + j] != node) continue;
-                const uint32_t v = partial[((size_t)2 * win + j) * (3 * SAH_BINS * SAH_W) + k];
+                const uint32_t v = partial[((size_t)2 * win + j) * SAH_NODE_WORDS + k];
                 acc = kind == 0 ? min(acc, v) : (kind == 1 ? max(acc, v) : acc + v);
             }
         if (kind == 0) { if (acc != 0xffffffffu) atomicMin(&g[k], acc); }
@@ -1405,125 +1550,34 @@ __global__ void __launch_bounds__(256) k_sah_reduce(const int* __restrict__ acti
         else if (acc != 0u) atomicAdd(&g[k], acc);
     }
 }
-__device__ __forceinline__ float sah_area(const float* lo, const float* hi) {
-    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-    return dx * dy + dy * dz + dz * dx;
-}
-// one thread per large node of this level: the split, the children (ids, ranges, boxes), who is large next
-__global__ void k_sah_split(const int* __restrict__ active, int nactive, int n, const SahBin* __restrict__ bins, const int* __restrict__ slot_of, int* __restrict__ first,
-                            int* __restrict__ cnt, float* __restrict__ box, int* __restrict__ left, int* __restrict__ right, int* __restrict__ split,
-                            int* __restrict__ slot_next, int* __restrict__ active_next, int* __restrict__ small_list, SahCtl* __restrict__ ctl, float* __restrict__ cbox) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nactive) return;
-    const int node = active[t];
-    const SahBin* nb = &bins[(size_t)slot_of[node] * 3 * SAH_BINS];
-    const int m = cnt[node], f = first[node];
-    float best = INFINITY;
-    int best_axis = -1, best_bin = 0, best_nl = 0;
-    float blo[2][3], bhi[2][3]; // boxes of the best split's sides
-    for (int a = 0; a < 3; ++a) {
-        // suffix boxes of the bins (area and count of "bins j+1 .."), then a prefix sweep
-        float ra[SAH_BINS];
-        int rn[SAH_BINS];
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        int cn = 0;
-        for (int j = SAH_BINS - 1; j >= 1; --j) {
-            const SahBin& b = nb[a * SAH_BINS + j];
-            if (b.count) {
-                for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], ord2f(b.lo[k])); hi[k] = fmaxf(hi[k], ord2f(b.hi[k])); }
-                cn += (int)b.count;
-            }
-            ra[j - 1] = cn ? sah_area(lo, hi) : 0.f;
-            rn[j - 1] = cn;
-        }
-        for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
-        cn = 0;
-        for (int j = 0; j < SAH_BINS - 1; ++j) {
-            const SahBin& b = nb[a * SAH_BINS + j];
-            if (b.count) {
-                for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], ord2f(b.lo[k])); hi[k] = fmaxf(hi[k], ord2f(b.hi[k])); }
-                cn += (int)b.count;
-            }
-            if (cn == 0 || rn[j] == 0) continue;
-            const float c = sah_area(lo, hi) * (float)cn + ra[j] * (float)rn[j];
-            if (c < best) { best = c; best_axis = a; best_bin = j; best_nl = cn; }
-        }
-    }
-    int nl;
-    float clo[2][3], chi[2][3]; // what the children's bins will span: the bounds of their leaves' centroids (SAH_CENTROID_BINS), else their boxes
-    if (best_axis < 0) { // every centroid in one bin on every axis: halve by position; the children's boxes are the node's (a superset: conservative)
-        nl = m / 2;
-        split[node] = -1 - nl;
-        for (int k = 0; k < 3; ++k) {
-            blo[0][k] = blo[1][k] = box[(size_t)node * 6 + k]; bhi[0][k] = bhi[1][k] = box[(size_t)node * 6 + 3 + k];
-            clo[0][k] = clo[1][k] = cbox[(size_t)node * 6 + k]; chi[0][k] = chi[1][k] = cbox[(size_t)node * 6 + 3 + k];
-        }
-    } else {
-        nl = best_nl;
-        split[node] = best_axis | (best_bin << 2);
-        for (int s = 0; s < 2; ++s) {
-            for (int k = 0; k < 3; ++k) { blo[s][k] = clo[s][k] = INFINITY; bhi[s][k] = chi[s][k] = -INFINITY; }
-            for (int j = s ? best_bin + 1 : 0; j <= (s ? SAH_BINS - 1 : best_bin); ++j) {
-                const SahBin& b = nb[best_axis * SAH_BINS + j];
-                if (!b.count) continue;
-                for (int k = 0; k < 3; ++k) {
-                    blo[s][k] = fminf(blo[s][k], ord2f(b.lo[k])); bhi[s][k] = fmaxf(bhi[s][k], ord2f(b.hi[k]));
-#if SAH_CENTROID_BINS
-                    clo[s][k] = fminf(clo[s][k], ord2f(b.clo[k])); chi[s][k] = fmaxf(chi[s][k], ord2f(b.chi[k]));
-#endif
-                }
-            }
-        }
-    }
-    for (int s = 0; s < 2; ++s) {
-        const int cf = s ? f + nl : f, cm = s ? m - nl : nl;
-        int child;
-        if (cm == 1) {
-            child = -2 - cf; // a single leaf: the scatter writes n - 1 + (the leaf that lands on position cf)
-        } else {
-            child = (int)atomicAdd(&ctl->next_id, 1u);
-            first[child] = cf;
-            cnt[child] = cm;
-            for (int k = 0; k < 3; ++k) { box[(size_t)child * 6 + k] = blo[s][k]; box[(size_t)child * 6 + 3 + k] = bhi[s][k]; }
-#if SAH_CENTROID_BINS
-            for (int k = 0; k < 3; ++k) { cbox[(size_t)child * 6 + k] = clo[s][k]; cbox[(size_t)child * 6 + 3 + k] = chi[s][k]; }
-#endif
-            if (cm > SAH_SMALL) {
-                const int sl = (int)atomicAdd(&ctl->nlarge_next, 1u);
-                slot_next[child] = sl;
-                active_next[sl] = child;
-                if (cm > SAH_BIG) atomicAdd(&ctl->nbig_next, 1u);
-            } else {
-                small_list[atomicAdd(&ctl->nsmall, 1u)] = child;
-            }
-        }
-        (s ? right : left)[node] = child;
-    }
-}
 __global__ void k_sah_flag(int n, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ node_of, const int* __restrict__ first, const int* __restrict__ split,
-                           const float* __restrict__ box, const float* __restrict__ cbox, uint32_t* __restrict__ flag) {
+                           const float* __restrict__ box, uint32_t* __restrict__ flag, SahCtl* __restrict__ ctl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
     uint32_t f = 0u;
     if (i < n) {
         const int node = node_of[i];
-        if (node >= 0) {
+        if (node >= 0 && SAH_OK(node < n - 1, 4, 0, ctl) && SAH_OK(prim[i] >= 0 && prim[i] < n, 4, 3, ctl)) {
             const int sp = split[node];
             if (sp < 0) {
                 f = (i - first[node]) < (-1 - sp) ? 1u : 0u;
             } else {
                 const int a = sp & 3;
                 const float* b = &box[(size_t)(nleaf_base + prim[i]) * 6];
-                const float* nb = &cbox[(size_t)node * 6];
+                const float* nb = &box[(size_t)node * 6];
                 f = sah_bin_of(0.5f * (b[a] + b[3 + a]), nb[a], nb[3 + a]) <= (sp >> 2) ? 1u : 0u;
             }
         }
     }
     flag[i] = f; // flag[n] = 0: the scan's last entry is the total
+#if PT_BVH_CHECK
+    if (g_sah_inject == 2 && i == n)
+        for (int k = 1; k <= 96; ++k) flag[n + k] = 0xdeadbeefu;
+#endif
 }
 __global__ void k_sah_scatter(int n, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ node_of, const int* __restrict__ first, const int* __restrict__ cnt_of,
                               const uint32_t* __restrict__ flag, const uint32_t* __restrict__ scan, int* __restrict__ left, int* __restrict__ right,
-                              int* __restrict__ prim_out, int* __restrict__ node_out) {
+                              int* __restrict__ prim_out, int* __restrict__ node_out, SahCtl* __restrict__ ctl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int node = node_of[i];
@@ -1532,14 +1586,18 @@ __global__ void k_sah_scatter(int n, int nleaf_base, const int* __restrict__ pri
         node_out[i] = -1;
         return;
     }
+    if (!SAH_OK(node < n - 1, 5, 0, ctl)) return;
+    if (!SAH_OK(first[node] >= 0 && cnt_of[node] > 0 && (long long)first[node] + cnt_of[node] <= n && i >= first[node] && i < first[node] + cnt_of[node], 5, 1, ctl)) return;
     const int f = first[node], m = cnt_of[node];
     const int nl = (int)(scan[f + m] - scan[f]);
     const int rl = (int)(scan[i] - scan[f]);
     const bool goes_left = flag[i] != 0u;
     const int pos = goes_left ? f + rl : f + nl + ((i - f) - rl);
     const int p = prim[i];
+    if (!SAH_OK(pos >= f && pos < f + m, 5, 2, ctl)) return; // the partition stays inside the node's own range
     prim_out[pos] = p;
     const int child = goes_left ? left[node] : right[node];
+    if (!SAH_OK(child <= -2 || (child >= 0 && child < n - 1), 5, 3, ctl)) return;
     if (child <= -2) { // the child is this single leaf
         (goes_left ? left : right)[node] = nleaf_base + p;
         node_out[pos] = -1;
@@ -1553,15 +1611,19 @@ __global__ void k_sah_small(const int* __restrict__ small_list, int nsmall, int 
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nsmall) return;
     const int root = small_list[t];
+    if (!SAH_OK(root >= 0 && root < nleaf_base, 6, 0, ctl)) return; // nleaf_base = n - 1
+    if (!SAH_OK(cnt[root] >= 2 && cnt[root] <= SAH_SMALL && first[root] >= 0 && first[root] + cnt[root] <= nleaf_base + 1, 6, 1, ctl)) return; // id[], lo[], hi[] hold SAH_SMALL leaves
     const int m0 = cnt[root], f0 = first[root];
     int id[SAH_SMALL];       // leaves of the subtree, reordered as the splits go
     float lo[SAH_SMALL][3], hi[SAH_SMALL][3];
     for (int k = 0; k < m0; ++k) {
         id[k] = prim[f0 + k];
+        if (!SAH_OK(id[k] >= 0 && id[k] <= nleaf_base, 6, 3, ctl)) return;
         const float* b = &box[(size_t)(nleaf_base + id[k]) * 6];
         for (int a = 0; a < 3; ++a) { lo[k][a] = b[a]; hi[k][a] = b[3 + a]; }
     }
     int next = m0 > 2 ? (int)atomicAdd(&ctl->next_id, (uint32_t)(m0 - 2)) : 0; // the subtree has m0 - 1 internal nodes, `root` is one of them
+    if (!SAH_OK(m0 <= 2 || next + (m0 - 2) <= nleaf_base, 6, 2, ctl)) return;
     int st_node[SAH_SMALL], st_f[SAH_SMALL], st_m[SAH_SMALL], sp = 0;
     st_node[0] = root; st_f[0] = 0; st_m[0] = m0; sp = 1;
     while (sp) {
@@ -1632,11 +1694,17 @@ static hipError_t build_sah(int n, int* left, int* right, float* box, int* cnt, 
     int *prim[2] = {nullptr, nullptr}, *node_of[2] = {nullptr, nullptr}, *first = nullptr, *split = nullptr, *slot[2] = {nullptr, nullptr}, *active[2] = {nullptr, nullptr}, *small_list = nullptr;
     uint32_t *flag = nullptr, *scan = nullptr;
     SahCtl* ctl = nullptr;
+    // Sizes, and the largest index each array is accessed with (what -DPT_BVH_CHECK=1 verifies on the device; profiles/r6_01_sah_fault.md):
+    //   prim, node_of: n, by leaf position < n | slot, first, split: n, by internal node id < n - 1 | active: n / (SAH_SMALL + 1) + 2, by the
+    //   level's large-node counter (large nodes are disjoint and hold more than SAH_SMALL leaves) | small_list: n / 2 + 2, by the small-subtree
+    //   counter (at least two leaves each) | flag, scan: n + 1, by position <= n | partial: 2 sets per window of SAH_WG positions |
+    //   bins: n / SAH_BIG + 2 sets, by the big-node counter (big nodes are disjoint and hold more than SAH_BIG leaves)
+    const size_t max_large = (size_t)n / (SAH_SMALL + 1) + 2, max_big = (size_t)n / SAH_BIG + 2;
     for (int k = 0; k < 2; ++k) {
         HIPCHK(mem.alloc(&prim[k], sizeof(int) * (size_t)n));
         HIPCHK(mem.alloc(&node_of[k], sizeof(int) * (size_t)n));
         HIPCHK(mem.alloc(&slot[k], sizeof(int) * (size_t)n));
-        HIPCHK(mem.alloc(&active[k], sizeof(int) * (size_t)(n / SAH_SMALL + 2)));
+        HIPCHK(mem.alloc(&active[k], sizeof(int) * max_large));
     }
     HIPCHK(mem.alloc(&first, sizeof(int) * (size_t)n));
     HIPCHK(mem.alloc(&split, sizeof(int) * (size_t)n));
@@ -1644,60 +1712,63 @@ static hipError_t build_sah(int n, int* left, int* right, float* box, int* cnt, 
     HIPCHK(mem.alloc(&flag, sizeof(uint32_t) * ((size_t)n + 1)));
     HIPCHK(mem.alloc(&scan, sizeof(uint32_t) * ((size_t)n + 1)));
     HIPCHK(mem.alloc(&ctl, sizeof(SahCtl)));
-    uint32_t* partial = nullptr; // per position window: the LDS bins of the window's first big node, and which node that was
+    uint32_t* partial = nullptr; // per position window: the merged LDS bins of the (at most two) big nodes the window meets, and which nodes those were
     int* partial_node = nullptr;
     const size_t nwin = ((size_t)n + SAH_WG - 1) / SAH_WG;
-    HIPCHK(mem.alloc(&partial, sizeof(uint32_t) * 2 * 3 * SAH_BINS * SAH_W * nwin));
+    HIPCHK(mem.alloc(&partial, sizeof(uint32_t) * 2 * SAH_NODE_WORDS * nwin));
     HIPCHK(mem.alloc(&partial_node, sizeof(int) * 2 * nwin));
-    // bins of the large nodes of one level: at most n / (SAH_SMALL + 1) of them
-    const size_t max_large = (size_t)n / (SAH_SMALL + 1) + 2;
-    SahBin* bins = nullptr;
-    HIPCHK(hipMalloc((void**)&bins, sizeof(SahBin) * 3 * SAH_BINS * max_large)); // (not from the arena: 1.3 KB per node)
-    struct BinsFree { SahBin* p; ~BinsFree() { hipFree(p); } } bins_free{bins};
+    uint32_t* bins = nullptr; // global bin sets of the big nodes of one level (1344 bytes each; every other node's bins never leave LDS)
+    HIPCHK(mem.alloc(&bins, sizeof(uint32_t) * SAH_NODE_WORDS * max_big));
     size_t tmp_bytes = 0;
     HIPCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, flag, scan, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
     void* tmp = nullptr;
     HIPCHK(mem.alloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+#if PT_BVH_CHECK
+    {
+        const char* ie = getenv("PT_BVH_INJECT");
+        const int inject = ie ? atoi(ie) : 0;
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sah_inject), &inject, sizeof(int)));
+    }
+#endif
     // root = internal node 0 over all leaves, its box = the scene's bounds
     const bool large_root = n > SAH_SMALL;
-    SahCtl h{1u, 0u, large_root ? 0u : 1u, 0u};
+    SahCtl h{1u, 0u, large_root ? 0u : 1u, 0u, 0u};
     HIPCHK(hipMemcpyAsync(ctl, &h, sizeof(h), hipMemcpyHostToDevice, stream));
     const int zero = 0;
     HIPCHK(hipMemcpyAsync(first, &zero, sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(cnt, &n, sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(box, bounds, sizeof(float) * 6, hipMemcpyHostToDevice, stream));
-    float* cbox = box; // what a node's bins span: its box, or (SAH_CENTROID_BINS) the bounds of its leaves' centroids — the root: the scene's bounds
-#if SAH_CENTROID_BINS
-    HIPCHK(mem.alloc(&cbox, sizeof(float) * 6 * (size_t)n));
-    HIPCHK(hipMemcpyAsync(cbox, bounds, sizeof(float) * 6, hipMemcpyHostToDevice, stream));
-#endif
-    HIPCHK(hipMemcpyAsync(slot[0], &zero, sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(slot[0], &zero, sizeof(int), hipMemcpyHostToDevice, stream)); // (the root's bin set, if it is big)
     HIPCHK(hipMemcpyAsync(large_root ? active[0] : small_list, &zero, sizeof(int), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_sah_init, dim3((n + B - 1) / B), dim3(B), 0, stream, n, prim[0], node_of[0], large_root ? 1 : 0);
     int cur = 0, nactive = large_root ? 1 : 0, nbig = n > SAH_BIG ? 1 : 0, levels = 0;
     while (nactive > 0) {
-        const uint32_t nwords = (uint32_t)((size_t)nactive * 3 * SAH_BINS * SAH_W);
-        hipLaunchKernelGGL(k_sah_clear_bins, dim3((nwords + B - 1) / B), dim3(B), 0, stream, bins, nwords);
         if (nbig > 0) {
-            hipLaunchKernelGGL(k_sah_bin, dim3((n + SAH_WG - 1) / SAH_WG), dim3(SAH_WG), 0, stream, n, nleaf_base, prim[cur], node_of[cur], cnt, box, cbox, partial, partial_node);
-            hipLaunchKernelGGL(k_sah_reduce, dim3(nactive, 32), dim3(256), 0, stream, active[cur], nactive, first, cnt, slot[cur], partial, partial_node, bins);
+            const uint32_t nwords = (uint32_t)((size_t)nbig * SAH_NODE_WORDS); // (nbig <= max_big, checked below before the next level is launched)
+            hipLaunchKernelGGL(k_sah_clear_bins, dim3((nwords + B - 1) / B), dim3(B), 0, stream, bins, nwords);
+            hipLaunchKernelGGL(k_sah_bin, dim3((n + SAH_WG - 1) / SAH_WG), dim3(SAH_WG), 0, stream, n, nleaf_base, prim[cur], node_of[cur], cnt, box, partial, partial_node, ctl);
+            hipLaunchKernelGGL(k_sah_reduce, dim3(nactive, 32), dim3(256), 0, stream, active[cur], nactive, n, first, cnt, slot[cur], partial, partial_node, bins, ctl);
         }
         {
             const int per_node = nactive <= 4096 ? 4 : 1;
-            hipLaunchKernelGGL(k_sah_bin_node, dim3(per_node == 4 ? nactive : (nactive + 3) / 4), dim3(256), 0, stream, active[cur], nactive, nleaf_base, prim[cur], first, cnt, slot[cur], box,
-                               cbox, bins, per_node);
+            hipLaunchKernelGGL(k_sah_node, dim3(per_node == 4 ? nactive : (nactive + 3) / 4), dim3(256), 0, stream, active[cur], nactive, n, nleaf_base, prim[cur], first, cnt, slot[cur], box,
+                               bins, left, right, split, slot[cur ^ 1], active[cur ^ 1], small_list, ctl, per_node);
         }
-        hipLaunchKernelGGL(k_sah_split, dim3((nactive + 63) / 64), dim3(64), 0, stream, active[cur], nactive, n, bins, slot[cur], first, cnt, box, left, right, split,
-                           slot[cur ^ 1], active[cur ^ 1], small_list, ctl, cbox);
-        hipLaunchKernelGGL(k_sah_flag, dim3((n + 1 + B - 1) / B), dim3(B), 0, stream, n, nleaf_base, prim[cur], node_of[cur], first, split, box, cbox, flag);
+        hipLaunchKernelGGL(k_sah_flag, dim3((n + 1 + B - 1) / B), dim3(B), 0, stream, n, nleaf_base, prim[cur], node_of[cur], first, split, box, flag, ctl);
         HIPCHK(rocprim::exclusive_scan(tmp, tmp_bytes, flag, scan, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
         hipLaunchKernelGGL(k_sah_scatter, dim3((n + B - 1) / B), dim3(B), 0, stream, n, nleaf_base, prim[cur], node_of[cur], first, cnt, flag, scan, left, right,
-                           prim[cur ^ 1], node_of[cur ^ 1]);
+                           prim[cur ^ 1], node_of[cur ^ 1], ctl);
         HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         nactive = (int)h.nlarge_next;
         nbig = (int)h.nbig_next;
-        if ((size_t)nactive > max_large || h.next_id > (uint32_t)(n - 1) || ++levels > 4096) return hipErrorUnknown;
+        // host-side bounds of what the next level indexes with these counters (the kernels that incremented them wrote at most that far:
+        // sah_make_children's capacity arguments; in ordinary builds this is where a broken invariant surfaces, before anything reads the lists)
+        if (h.fault) {
+            fprintf(stderr, "[pt_bvh] binned SAH: bounds check failed, fault bits 0x%x (kernel = bit / 4, index = bit %% 4; pt_bvh_build.hip SAH_OK)\n", h.fault);
+            return hipErrorUnknown;
+        }
+        if ((size_t)nactive > max_large || (size_t)nbig > max_big || (size_t)h.nsmall > (size_t)n / 2 + 2 || h.next_id > (uint32_t)(n - 1) || ++levels > 4096) return hipErrorUnknown;
         const uint32_t z = 0;
         HIPCHK(hipMemcpyAsync(&ctl->nlarge_next, &z, sizeof(z), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(&ctl->nbig_next, &z, sizeof(z), hipMemcpyHostToDevice, stream));
@@ -1707,6 +1778,10 @@ static hipError_t build_sah(int n, int* left, int* right, float* box, int* cnt, 
     HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipGetLastError());
+    if (h.fault) {
+        fprintf(stderr, "[pt_bvh] binned SAH: bounds check failed in the small-subtree kernel, fault bits 0x%x\n", h.fault);
+        return hipErrorUnknown;
+    }
     if (h.next_id != (uint32_t)(n - 1)) return hipErrorUnknown; // a binary tree over n leaves has n - 1 internal nodes
     if (getenv("PT_DEBUG_BVH")) fprintf(stderr, "[pt_bvh] binned SAH: %d levels of large nodes, %u small subtrees\n", levels, h.nsmall);
     *root_out = 0;
@@ -1934,10 +2009,11 @@ hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint3
                 pc.mark(kind == 1 ? "ploc hierarchy" : "sah hierarchy");
                 if (pe == hipSuccess) pe = build_bvh8(n, root, left, right, cnt, box, pad, tris, stream, &alt);
                 pc.mark(kind == 1 ? "wide tree 2" : "wide tree 3");
-                if (pe != hipSuccess) { // a challenger is optional: the standing tree stays
+                if (pe != hipSuccess) { // a challenger is optional: the standing tree stays — but never silently (the choice of tree then depended on free memory)
                     (void)hipGetLastError();
                     pt_bvh_free(&alt);
-                    if (getenv("PT_DEBUG_BVH")) fprintf(stderr, "[pt_bvh] the %s hierarchy failed (%s): skipped\n", names[kind], hipGetErrorString(pe));
+                    ++out->challengers_skipped;
+                    fprintf(stderr, "[pt_bvh] warning: the %s hierarchy could not be built (%s): the %s tree stays without a comparison\n", names[kind], hipGetErrorString(pe), names[out->builder]);
                     continue;
                 }
                 unsigned long long* counts = nullptr;
@@ -1973,6 +2049,15 @@ done:
     tfree(box);
     tfree(tris); // the Morton-ordered triangles only fed the wide tree's leaf arrays
     pc.mark("frees");
+    if (arena.guard) { // PT_BVH_GUARD=1: the bands behind the build's standing slices (the phases' own were checked when their marks were released)
+        HIPCHK(hipDeviceSynchronize());
+        arena.verify(0);
+        if (arena.guard_bad) {
+            fprintf(stderr, "[pt_bvh] %d arena guard band(s) overwritten: the build is refused\n", arena.guard_bad);
+            pt_bvh_free(out);
+            return hipErrorUnknown;
+        }
+    }
     return hipSuccess;
 }
 

@@ -59,6 +59,9 @@ k_path_loop(PathLoopArgs A) {
     PT_WLOG(const unsigned long long w_t0 = wall_clock64(); unsigned long long w_tpool = 0; unsigned long long w_trace = 0; unsigned long long w_shade = 0; uint32_t w_rounds = 0;)
     for (;;) {
         Trace8Args t = A.ta;
+#if PT_DEBUG_WAVELOG + 0 == 3
+        t.hist = A.ta.dbg ? A.ta.dbg + 53 : nullptr;
+#endif
         if (cur) { t.st.rayO = A.rayO1; t.st.rayD = A.rayD1; t.st.thr = A.thr1; t.st.hit = A.hit1; t.st.rf = A.rf1; t.queue.base = A.qbase1; }
         // ---- refill the window from the pool
         if (pool_open && n_cur < A.cap) {

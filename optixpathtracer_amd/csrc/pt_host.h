@@ -24,6 +24,7 @@ struct PtBvh {
     int levels8 = 0; // levels of the wide tree = upper bound of its traversal stack depth (one pushed group per level)
     Grid8 grid{}; // PT8_NODE64: what the one-line nodes' origins and steps are measured in (pt_bvh8.h)
     float calib_cost = 0.f; // node steps + 0.6 x triangle tests per calibration ray through the chosen tree (0: no calibration ran — small scenes, forced builder)
+    int challengers_skipped = 0; // candidate hierarchies that could not be built (out of memory, a failed check): the standing tree stayed uncompared
     int builder = 0; // hierarchy under the wide tree: 0 LBVH (Morton order, Karras 2012), 1 PLOC (Meister & Bittner 2018) — chosen by calibration rays unless PT_BVH_BUILDER=lbvh|ploc
 };
 

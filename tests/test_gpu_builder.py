@@ -205,3 +205,42 @@ def test_imported_hierarchy_is_validated(ptlib, monkeypatch, tmp_path):
         monkeypatch.setenv("PT_BVH_IMPORT", write(tree, "bad.tree"))
         with pytest.raises(RuntimeError):
             R.SampleRenderer(m)
+
+
+def _run_tool(args, env, timeout=600):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("PT_BVH_CLIMB", "PT_BVH_BUILDER", "PT_PLOC_TAIL", "PT_BVH_INJECT", "PT_BVH_GUARD", "PT_LIB"):
+        e.pop(k, None)
+    e.update(env)
+    return subprocess.run([sys.executable, os.path.join(root, "tools", "r6_bvh_check.py")] + args, capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def _chk_lib():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "optixpathtracer_amd", "variants", "libptamd_chk.so")
+    assert os.path.exists(lib), "variants/libptamd_chk.so is missing: __graft_entry__.build() (or tools/variants.sh chk \"-DPT_BVH_CHECK=1\") builds it"
+    return lib
+
+
+def test_bounds_checked_builder_on_every_shape(ptlib):
+    """the SAH kernels compiled with every data-derived index checked against its array (-DPT_BVH_CHECK=1) and the build
+    arena's slices separated by guard bands (PT_BVH_GUARD=1), on the shapes that stress the hierarchy (terrain, needle geometry, 6000
+    coincident triangles, 40 000 triangles on a line, the Cornell box): no check fires, no band is touched, every tree holds every primitive
+    once.  A process of its own: the library variant must not share a process with the product library."""
+    res = _run_tool(["build"], {"PT_LIB": _chk_lib(), "PT_BVH_GUARD": "1"})
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    assert res.stdout.count("ok ") == 10 and "ARENA GUARD" not in res.stderr and "bounds check failed" not in res.stderr, res.stdout + res.stderr[-2000:]
+
+
+@pytest.mark.parametrize("inject,what", [("1", "bounds check failed"), ("2", "ARENA GUARD")])
+def test_bounds_checks_and_guard_bands_fire(ptlib, inject, what):
+    """... and they do fire: with a leaf range pushed past its array (PT_BVH_INJECT=1) the next level's range check refuses the build; with 96
+    words written past the end of an arena slice (PT_BVH_INJECT=2) the guard band behind it is found overwritten — pt_create fails with an
+    error instead of a GPU memory access fault or a silently corrupted neighbour slice."""
+    res = _run_tool(["inject", "terrain70k"], {"PT_LIB": _chk_lib(), "PT_BVH_GUARD": "1", "PT_BVH_INJECT": inject})
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    assert "refused:" in res.stdout and what in res.stderr, res.stdout + res.stderr[-2000:]

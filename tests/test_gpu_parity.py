@@ -61,6 +61,24 @@ def small_probe():
     return scenes.sky_probe(256, 128).BuildCDF()
 
 
+# Both schedules of a synchronous frame meet the checker on the edge cases: "chain" = one launch per stage and bounce
+# (k_generate / k_trace8 / k_shade, PT_FUSED=0), "fused" = the bounce loop as one persistent kernel (k_path_loop, PT_FUSED=1: what a frame this
+# small takes by default).  The switch is read per context at pt_create.
+@pytest.fixture(params=["chain", "fused"])
+def sched(request, monkeypatch):
+    monkeypatch.setenv("PT_FUSED", "0" if request.param == "chain" else "1")
+    monkeypatch.setenv("PT_SCHED_TRIALS", "0")  # (the on-line choice between the two would otherwise pick per frame)
+    return request.param
+
+
+def _check_sched(g, sched):
+    st = g["stats"]
+    if sched == "fused":
+        assert st["fused_passes"] >= 1 and st["shade_launches"] == 0, st
+    else:
+        assert st["fused_passes"] == 0 and st["shade_launches"] >= 1, st
+
+
 # ---------------------------------------------------------------- function tables
 def test_division_sqrt_correctly_rounded(ptlib):
     """The numerics contract: device fp32 / and sqrt are IEEE correctly rounded (same bits as the host)."""
@@ -380,7 +398,7 @@ def test_trace_triangle_soup_adversarial(ptlib, orc_det, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["one_triangle", "three_triangles", "four_triangles", "five_triangles", "thousands_of_copies", "collinear_centroids", "flat_scene", "tiny_in_huge", "many_meshes"])
-def test_builder_degenerate_scenes(ptlib, orc_det, case, monkeypatch):
+def test_builder_degenerate_scenes(ptlib, orc_det, case, monkeypatch, small_probe):
     """Scenes that stress the on-GPU builder rather than the traversal: Morton codes that all tie, root boxes with zero extent
     on one or two axes (quantisation exponents), a single primitive, triangles far smaller than one 8-bit grid cell of the
     root box, and hundreds of one-triangle meshes (primitive ids across mesh boundaries)."""
@@ -434,6 +452,19 @@ def test_builder_degenerate_scenes(ptlib, orc_det, case, monkeypatch):
         assert_bits_equal(t, to, f"{case}: closest-hit t, {builder}")
         occ, _ = r.trace(rays, any_hit=True)
         assert np.array_equal(occ, occ_o)
+    # ... and a small frame of the same scene through BOTH schedules of a synchronous frame (launch chain, fused bounce loop) against the checker
+    monkeypatch.delenv("PT_BVH_BUILDER")
+    ctr = 0.5 * (tri.reshape(-1, 3).min(0) + tri.reshape(-1, 3).max(0))
+    ext = float(np.abs(tri.reshape(-1, 3) - ctr).max()) + 1.0
+    cam = dict(eye=tuple(float(x) for x in ctr + np.array([0.9, 0.7, 1.6], np.float32) * ext), lookat=tuple(float(x) for x in ctr), up=(0.0, 1.0, 0.0), fovY=50.0)
+    w, h = 40, 24
+    o = _oracle_render(orc_det, m, small_probe, cam, w, h, 2, use_bvh=False)
+    for fused in ("0", "1"):
+        monkeypatch.setenv("PT_FUSED", fused)
+        monkeypatch.setenv("PT_SCHED_TRIALS", "0")
+        g = _gpu_render(_renderer(m, small_probe, cam, w, h), 2)
+        _check_sched(g, "fused" if fused == "1" else "chain")
+        _compare(g, o)
 
 
 # ---------------------------------------------------------------- whole renders
@@ -597,13 +628,14 @@ def test_render_sample_chunking_invariant(ptlib, orc_det, small_probe):
         _compare(_gpu_render(r, 5), o)
 
 
-def test_render_terrain_all_material_branches(ptlib, orc_det):
+def test_render_terrain_all_material_branches(ptlib, orc_det, sched):
     """~70k-triangle voxel terrain, 8 material presets (transmission, subsurface, clearcoat, metal ...)."""
     m = scenes.voxel_terrain(n=96, target_tris=70000)
     probe = scenes.sky_probe(512, 256).BuildCDF()
     w, h = 160, 90
     r = _renderer(m, probe, scenes.TERRAIN_CAMERA, w, h)
     g = _gpu_render(r, 4)
+    _check_sched(g, sched)
     o = _oracle_render(orc_det, m, probe, scenes.TERRAIN_CAMERA, w, h, 4)
     _compare(g, o)
 
@@ -654,13 +686,14 @@ def test_render_shadow_catcher_pass_through_chains(ptlib, orc_det):
     _compare(g, o)
 
 
-def test_render_constant_probe_and_edge_sizes(ptlib, orc_det):
+def test_render_constant_probe_and_edge_sizes(ptlib, orc_det, sched):
     """Constant-white probe (loadColor, sv4 main.cpp:167-180); odd sizes that do not fill 8x8 blocks; 1x1."""
     m = scenes.cornell_box()
     probe = scenes.constant_probe().BuildCDF()
     for (w, h) in ((1, 1), (7, 5), (33, 17)):
         r = _renderer(m, probe, scenes.CORNELL_CAMERA, w, h)
         g = _gpu_render(r, 2)
+        _check_sched(g, sched)
         o = _oracle_render(orc_det, m, probe, scenes.CORNELL_CAMERA, w, h, 2)
         _compare(g, o)
 
@@ -1108,7 +1141,7 @@ def test_foveated_sv_sv2_initial_depth_and_aov_writes(ptlib, orc_det):
     assert (aov[0][..., :3] != 0).any()
 
 
-def test_textured_meshes(ptlib, orc_det):
+def test_textured_meshes(ptlib, orc_det, sched):
     """deviceProgram.cu:512-523 + createTextures (SimplePathtracer.cpp:603-654): albedo replaced by a wrap/bilinear
     tex2D of an RGBA8 texture at the barycentric texcoord; a mesh with a texture id but no texcoords keeps its colour."""
     import ctypes as C
@@ -1136,6 +1169,7 @@ def test_textured_meshes(ptlib, orc_det):
     cam = dict(eye=(3.0, 2.5, -4.5), lookat=(0.0, 0.6, 0.5), up=(0.0, 1.0, 0.0), fovY=45.0)
     rr = _renderer(m, probe, cam, w, h)
     gg = _gpu_render(rr, 3, subframes=2)
+    _check_sched(gg, sched)
     oo = _oracle_render(orc_det, m, probe, cam, w, h, 3, subframes=2, use_bvh=False)
     _compare(gg, oo)
     # the texture really shows up in the first-hit albedo buffer: many distinct albedos, not 3 material colours

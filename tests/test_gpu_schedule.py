@@ -491,3 +491,70 @@ def test_alternating_schedules_do_not_reallocate_the_path_state(ptlib, monkeypat
     assert ab[1] == ab[0] and ab[2] == ab[0], ab
     for k, (x, y) in enumerate(zip(fa, fb)):
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), k
+
+
+def _sched_ctx(monkeypatch, env, w=320, h=192, spp=2, world=1):
+    from optixpathtracer_amd import renderer as R
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = R.SampleRenderer(scenes.voxel_terrain(n=64, target_tris=30000))
+    for k in env:
+        monkeypatch.delenv(k)
+    r.setProbe(scenes.sky_probe(256, 128).BuildCDF())
+    if world > 1:
+        r.setPartition(0, world, 64, 16)
+    r.resize((w, h))
+    r.setCamera(R.make_camera(scenes.TERRAIN_CAMERA, w / h))
+    r.launchParams.samples_per_launch = spp
+    return r
+
+
+@pytest.mark.parametrize("initial,fake,want", [("fused", "1.0,2.0", 0), ("chain", "2.0,1.0", 1)])
+def test_online_schedule_choice_corrects_a_wrong_first_guess(ptlib, monkeypatch, initial, fake, want):
+    """the launch chain and the fused bounce loop are bit-identical, so the context times them against each other instead
+    of trusting thresholds.  The logic, with the measured times replaced by constants (PT_SCHED_FAKE: chain ms, fused ms) and the WRONG schedule
+    forced as the first guess (PT_SCHED_INITIAL): the frames alternate (guess first, one warm-up + three timed frames each), then every frame
+    takes the faster schedule; a change of the frame configuration (samples per launch) starts a new trial; the images never change."""
+    r = _sched_ctx(monkeypatch, {"PT_SCHED_TRIALS": "3", "PT_SCHED_INITIAL": initial, "PT_SCHED_FAKE": fake, "PT_SCHED_PROBE": "0"})
+    ref = _sched_ctx(monkeypatch, {"PT_SCHED_TRIALS": "0", "PT_FUSED": "0"})
+    first = 1 if initial == "fused" else 0
+    seq = []
+    for k in range(12):
+        for x in (r, ref):
+            x.launchParams.frame.subframe_index = k
+            x.render()
+        st = r.stats()
+        seq.append((st["schedule"] & 1, bool(st["schedule"] & 0x100), st["fused_passes"]))
+        assert np.array_equal(r.download(0).view(np.uint32), ref.download(0).view(np.uint32)), k
+    assert [s[0] for s in seq[:8]] == [first, 1 - first] * 4 and all(s[1] for s in seq[:8]), seq  # the trial: alternating, flagged
+    assert all(s[0] == want and not s[1] for s in seq[8:]), seq                                   # settled on the faster one
+    assert all(s[2] == s[0] for s in seq), seq                                                       # and the flag says what really ran
+    st = r.stats()
+    c, f = (float(x) for x in fake.split(","))
+    assert st["sched_chain_ms"] == c and st["sched_fused_ms"] == f
+    r.launchParams.samples_per_launch = 3  # another configuration: measured again
+    r.launchParams.frame.subframe_index = 12
+    r.render()
+    assert r.stats()["schedule"] & 0x100
+    r.close()
+    ref.close()
+
+
+def test_online_schedule_choice_measures_real_frames(ptlib, monkeypatch):
+    """The same with real device times on a 1/2 share of a small frame: after the trial the context reports both schedules' best frame
+    times, runs the one that measured faster, and looks at the loser again every PT_SCHED_PROBE frames without leaving its choice for noise."""
+    r = _sched_ctx(monkeypatch, {"PT_SCHED_TRIALS": "2", "PT_SCHED_PROBE": "4"}, w=640, h=360, spp=4, world=2)
+    flags = []
+    for k in range(6 + 12):
+        r.launchParams.frame.subframe_index = k
+        r.render()
+        flags.append(r.stats()["schedule"])
+    st = r.stats()
+    assert all(f & 0x100 for f in flags[:6]) and not flags[6] & 0x100, flags
+    assert st["sched_chain_ms"] > 0 and st["sched_fused_ms"] > 0
+    choice = 1 if st["sched_fused_ms"] < st["sched_chain_ms"] else 0
+    settled = [f & 1 for f in flags[6:] if not f & 0x100]
+    assert settled.count(choice) >= len(settled) // 2, (flags, st)  # (every fourth settled frame probes the other schedule; a probe that wins by
+    assert settled.count(1 - choice) >= 1, flags                    #  more than 5 % starts the trial over: sub-millisecond frames are noisy)
+    r.close()

@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3_terrain1M_1080p_4spp_d8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth", type=int, default=0, help="experiments only: override the workload's depth limit (the metric's is 8); the line then says so in config.max_depth")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-stream frames that give per-kernel (non-overlapped) durations")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --share-device rehearses the N>1 path on a 1-GPU box")
@@ -170,6 +171,8 @@ def main():
     from optixpathtracer_amd import scenes
 
     scene_name, cam_name, w, h, spp, depth = WORKLOADS[args.workload]
+    if args.depth > 0:
+        depth = args.depth
     if world > 1 and args.scaling == "weak":
         # per-GPU work fixed: the image grows to N x the pixels (same aspect, multiples of 8) and is tile-partitioned
         f = world ** 0.5

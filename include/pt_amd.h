@@ -166,6 +166,9 @@ typedef struct pt_stats {
                              * is still timing the two against each other for this frame configuration (pt_sched_* below) */
     double sched_chain_ms;  /* best device time of the configuration's trial frames as a launch chain / as one fused pass (0: not measured: */
     double sched_fused_ms;  /* the configuration is not eligible for both, or PT_SCHED_TRIALS=0) */
+    double create_ms;       /* host time of pt_create from the flattened scene to the finished context: uploads, the acceleration structure
+                             * (bvh_build_ms is the part between its first and last kernel), the probes that pick the streams — and, in the first
+                             * pt_create of a process, what loading the library's code objects costs beyond the time the scene upload hides */
 } pt_stats;
 
 /* SampleRenderer::SampleRenderer(const Model*) (SimplePathtracer.cpp:39-71): uploads the meshes

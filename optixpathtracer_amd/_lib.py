@@ -92,7 +92,7 @@ class Stats(C.Structure):
         ("bvh_nodes", C.c_uint32), ("bvh_bytes", C.c_uint64), ("bvh_build_ms", C.c_double), ("bvh_levels", C.c_uint32), ("shaded_hits", C.c_uint64),
         ("frames", C.c_uint64), ("total_radiance_rays", C.c_uint64), ("total_shadow_rays", C.c_uint64),
         ("bvh_builder", C.c_uint32), ("fused_passes", C.c_uint32), ("path_state_allocs", C.c_uint32),
-        ("bvh_challengers_skipped", C.c_uint32), ("schedule", C.c_uint32), ("sched_chain_ms", C.c_double), ("sched_fused_ms", C.c_double),
+        ("bvh_challengers_skipped", C.c_uint32), ("schedule", C.c_uint32), ("sched_chain_ms", C.c_double), ("sched_fused_ms", C.c_double), ("create_ms", C.c_double),
     ]
 
     def as_dict(self):

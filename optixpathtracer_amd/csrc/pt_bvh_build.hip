@@ -1213,8 +1213,8 @@ static hipError_t build_ploc(int n, int* left, int* right, float* box, int* cnt,
 //     (k_sah_node); a bigger one by position windows of SAH_WG leaves (k_sah_bin), merged per node (k_sah_reduce) into one of the few global
 //     bin sets there can be (at most n / SAH_BIG nodes are that big) which k_sah_node then loads.  The same wave then sweeps the
 //     3 x (SAH_BINS - 1) candidate planes — one lane per plane, from the bins in LDS — for the smallest A_L N_L + A_R N_R (no candidate with
-//     an empty side: the leaves are halved by position instead), and its first lane creates the two children with their exact boxes
-//     (unions of bins).  (Round 5 stored every node's bins to global memory — 1344 bytes per node, 150 MB for a million triangles — for a
+//     an empty side: the leaves are halved by position instead) and its first lane writes the decision and the sides' exact boxes (unions of
+//     bins), 56 bytes, from which one thread per node creates the children (k_sah_children).  (Round 5 stored every node's bins to global memory — 1344 bytes per node, 150 MB for a million triangles — for a
 //     kernel with one THREAD per node to sweep: 42 launches of 49 us, 2 of the hierarchy's 5.6 ms.)  The leaves are partitioned by one
 //     exclusive scan of the "goes left" flags and a scatter.  One 20-byte read-back per level tells the host how many large nodes are left.
 //   * A child with at most SAH_SMALL leaves is finished later by ONE thread: exact sweep SAH (every axis, every position of the sorted
@@ -1359,23 +1359,47 @@ __device__ __forceinline__ int sah_sweep_wave(const uint32_t* s_bins, int lane, 
     if (best_l == 0x7fffffff) return -1;
     return (best_l / (SAH_BINS - 1)) | ((best_l % (SAH_BINS - 1)) << 2);
 }
-// One thread: the two children of `node` (ids, ranges, exact boxes), who is large next, who gets a global bin set
-__device__ void sah_make_children(int node, int sp, int nl_best, const uint32_t* s_bins, int n, int* __restrict__ first, int* __restrict__ cnt, float* __restrict__ box,
-                                  int* __restrict__ left, int* __restrict__ right, int* __restrict__ split, int* __restrict__ slot_next, int* __restrict__ active_next,
-                                  int* __restrict__ small_list, SahCtl* __restrict__ ctl) {
+// What the sweep decided for a large node, written by the node's wave and read by k_sah_children (one THREAD per node): 56 bytes instead of the
+// 1344 bytes of bins round 5's split kernel read per thread.  The children are NOT created by the wave itself: handing out node ids and list
+// positions takes same-address atomics, the compiler folds those of a wave's lanes into one per wave, and one lane per wave doing them alone is
+// 64 times as many (measured: the hierarchy 5.6 -> 10.7 ms with 680 k lone atomics at 10.5 ns).
+struct SahDec {
+    int sp, nl;           // axis | bin << 2 and the leaves going left; sp < 0: halved by position
+    float blo[2][3], bhi[2][3]; // the sides' exact boxes (unions of bins)
+};
+__device__ __forceinline__ void sah_decide(int sp, int nl_best, const uint32_t* s_bins, SahDec* __restrict__ d) {
+    d->sp = sp;
+    d->nl = nl_best;
+    if (sp < 0) return; // (halved by position: the children take the node's box, k_sah_children reads it)
+    const uint32_t* ab = s_bins + (sp & 3) * SAH_BINS * SAH_W;
+    float lo[3], hi[3];
+    sah_union(ab, 0, sp >> 2, lo, hi);
+    for (int k = 0; k < 3; ++k) { d->blo[0][k] = lo[k]; d->bhi[0][k] = hi[k]; }
+    sah_union(ab, (sp >> 2) + 1, SAH_BINS - 1, lo, hi);
+    for (int k = 0; k < 3; ++k) { d->blo[1][k] = lo[k]; d->bhi[1][k] = hi[k]; }
+}
+// one thread per large node of this level: the two children (ids, ranges, exact boxes), who is large next, who gets a global bin set
+__global__ void k_sah_children(const int* __restrict__ active, int nactive, int n, const SahDec* __restrict__ dec, int* __restrict__ first, int* __restrict__ cnt,
+                               float* __restrict__ box, int* __restrict__ left, int* __restrict__ right, int* __restrict__ split, int* __restrict__ slot_next,
+                               int* __restrict__ active_next, int* __restrict__ small_list, SahCtl* __restrict__ ctl) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nactive) return;
+    const int node = active[t];
+    if (!SAH_OK(node >= 0 && node < n - 1, 3, 0, ctl)) return;
+    const SahDec d = dec[t];
     const int m = cnt[node], f = first[node];
+    if (!SAH_OK(f >= 0 && m > SAH_SMALL && (long long)f + m <= n && (d.sp < 0 || (d.nl > 0 && d.nl < m)), 3, 1, ctl)) return;
     int nl;
-    float blo[2][3], bhi[2][3]; // boxes of the split's sides
-    if (sp < 0) { // every centroid in one bin on every axis: halve by position; the children's boxes are the node's (a superset: conservative)
+    float blo[2][3], bhi[2][3];
+    if (d.sp < 0) { // every centroid in one bin on every axis: halve by position; the children's boxes are the node's (a superset: conservative)
         nl = m / 2;
         split[node] = -1 - nl;
         for (int k = 0; k < 3; ++k) { blo[0][k] = blo[1][k] = box[(size_t)node * 6 + k]; bhi[0][k] = bhi[1][k] = box[(size_t)node * 6 + 3 + k]; }
     } else {
-        nl = nl_best;
-        split[node] = sp;
-        const uint32_t* ab = s_bins + (sp & 3) * SAH_BINS * SAH_W;
-        sah_union(ab, 0, sp >> 2, blo[0], bhi[0]);
-        sah_union(ab, (sp >> 2) + 1, SAH_BINS - 1, blo[1], bhi[1]);
+        nl = d.nl;
+        split[node] = d.sp;
+        for (int s = 0; s < 2; ++s)
+            for (int k = 0; k < 3; ++k) { blo[s][k] = d.blo[s][k]; bhi[s][k] = d.bhi[s][k]; }
     }
     for (int s = 0; s < 2; ++s) {
         const int cf = s ? f + nl : f, cm = s ? m - nl : nl;
@@ -1412,11 +1436,11 @@ __device__ void sah_make_children(int node, int sp, int nl_best, const uint32_t*
 // One wave per large node of this level (per_node = 1: levels with many nodes) or the four waves of a workgroup (per_node = 4: levels with few
 // nodes: a lone wave looping over 8192 leaves is 128 dependent iterations, 0.3 ms): the node's bins in LDS that only these waves touch —
 // binned from its leaves, or, for a node of more than SAH_BIG leaves, loaded from the global set the window kernels filled — then the plane
-// sweep and the children, from LDS.  No global atomic on the bins and no bins in global memory for the 99.9 % of the nodes that are not big.
-__global__ void __launch_bounds__(256) k_sah_node(const int* __restrict__ active, int nactive, int n, int nleaf_base, const int* __restrict__ prim, int* __restrict__ first,
-                                                  int* __restrict__ cnt, const int* __restrict__ slot_of, float* __restrict__ box, const uint32_t* __restrict__ bins,
-                                                  int* __restrict__ left, int* __restrict__ right, int* __restrict__ split, int* __restrict__ slot_next,
-                                                  int* __restrict__ active_next, int* __restrict__ small_list, SahCtl* __restrict__ ctl, int per_node) {
+// sweep, from LDS, and the decision record for k_sah_children.  No global atomic on the bins and no bins in global memory for the 99.9 % of
+// the nodes that are not big.
+__global__ void __launch_bounds__(256) k_sah_node(const int* __restrict__ active, int nactive, int n, int nleaf_base, const int* __restrict__ prim, const int* __restrict__ first,
+                                                  const int* __restrict__ cnt, const int* __restrict__ slot_of, const float* __restrict__ box, const uint32_t* __restrict__ bins,
+                                                  SahDec* __restrict__ dec, SahCtl* __restrict__ ctl, int per_node) {
     __shared__ uint32_t s_all[4][SAH_NODE_WORDS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = per_node == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
@@ -1459,10 +1483,10 @@ __global__ void __launch_bounds__(256) k_sah_node(const int* __restrict__ active
         __syncthreads();
         if (wave != 0) return;
     }
-    if (node < 0) return;
+    if (t >= nactive) return;
     int nl = 0;
-    const int sp = sah_sweep_wave(s_bins, lane, &nl); // (per_node = 4: wave 0's set is s_all[0], the merged one)
-    if (lane == 0) sah_make_children(node, sp, nl, s_bins, n, first, cnt, box, left, right, split, slot_next, active_next, small_list, ctl);
+    const int sp = node < 0 ? -1 : sah_sweep_wave(s_bins, lane, &nl); // (per_node = 4: wave 0's set is s_all[0], the merged one; a dropped node: halved, and k_sah_children drops it too)
+    if (lane == 0) sah_decide(sp, nl, s_bins, &dec[t]);
 }
 // Big nodes (more than SAH_BIG leaves) by position windows of SAH_WG leaves.  A big node spans at least eight windows, so a window meets at most TWO of them
 // (one ending, one starting): each gets a set of bins per wave in LDS (grouped accumulation, sah_accumulate_wave), the sets are merged per window and
@@ -1719,6 +1743,8 @@ static hipError_t build_sah(int n, int* left, int* right, float* box, int* cnt, 
     HIPCHK(mem.alloc(&partial_node, sizeof(int) * 2 * nwin));
     uint32_t* bins = nullptr; // global bin sets of the big nodes of one level (1344 bytes each; every other node's bins never leave LDS)
     HIPCHK(mem.alloc(&bins, sizeof(uint32_t) * SAH_NODE_WORDS * max_big));
+    SahDec* dec = nullptr; // one decision per large node of the level, by its position in active[]
+    HIPCHK(mem.alloc(&dec, sizeof(SahDec) * max_large));
     size_t tmp_bytes = 0;
     HIPCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, flag, scan, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
     void* tmp = nullptr;
@@ -1752,7 +1778,9 @@ static hipError_t build_sah(int n, int* left, int* right, float* box, int* cnt, 
         {
             const int per_node = nactive <= 4096 ? 4 : 1;
             hipLaunchKernelGGL(k_sah_node, dim3(per_node == 4 ? nactive : (nactive + 3) / 4), dim3(256), 0, stream, active[cur], nactive, n, nleaf_base, prim[cur], first, cnt, slot[cur], box,
-                               bins, left, right, split, slot[cur ^ 1], active[cur ^ 1], small_list, ctl, per_node);
+                               bins, dec, ctl, per_node);
+            hipLaunchKernelGGL(k_sah_children, dim3((nactive + 63) / 64), dim3(64), 0, stream, active[cur], nactive, n, dec, first, cnt, box, left, right, split, slot[cur ^ 1], active[cur ^ 1],
+                               small_list, ctl);
         }
         hipLaunchKernelGGL(k_sah_flag, dim3((n + 1 + B - 1) / B), dim3(B), 0, stream, n, nleaf_base, prim[cur], node_of[cur], first, split, box, flag, ctl);
         HIPCHK(rocprim::exclusive_scan(tmp, tmp_bytes, flag, scan, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
@@ -1763,7 +1791,7 @@ static hipError_t build_sah(int n, int* left, int* right, float* box, int* cnt, 
         nactive = (int)h.nlarge_next;
         nbig = (int)h.nbig_next;
         // host-side bounds of what the next level indexes with these counters (the kernels that incremented them wrote at most that far:
-        // sah_make_children's capacity arguments; in ordinary builds this is where a broken invariant surfaces, before anything reads the lists)
+        // k_sah_children's capacity arguments; in ordinary builds this is where a broken invariant surfaces, before anything reads the lists)
         if (h.fault) {
             fprintf(stderr, "[pt_bvh] binned SAH: bounds check failed, fault bits 0x%x (kernel = bit / 4, index = bit %% 4; pt_bvh_build.hip SAH_OK)\n", h.fault);
             return hipErrorUnknown;
@@ -2059,6 +2087,15 @@ done:
         }
     }
     return hipSuccess;
+}
+
+// First use of this translation unit's device code in a process: the runtime loads the code object (the rocPRIM sort and scan templates make it
+// a few megabytes) when the first of its kernels is launched — 8 ms that used to sit in the first build's "bounds, morton, sort" phase.
+// pt_create launches this empty kernel from a helper thread while the scene is being uploaded (pt_api.hip create_from_flat).
+__global__ void k_warm_bvh() {}
+void pt_bvh_warm(hipStream_t stream) {
+    hipLaunchKernelGGL(k_warm_bvh, dim3(1), dim3(64), 0, stream);
+    (void)hipGetLastError();
 }
 
 void pt_bvh_free(PtBvh* b) {

@@ -31,3 +31,4 @@ struct PtBvh {
 // d_tri_mesh: mesh (= material record) of every triangle, stored with the leaf triangles (may be null: 0)
 hipError_t pt_bvh_build(const float* d_verts, const uint32_t* d_idx, const uint32_t* d_tri_mesh, uint32_t ntri, hipStream_t stream, PtBvh* out);
 void pt_bvh_free(PtBvh* b);
+void pt_bvh_warm(hipStream_t stream); // first use in a process: loads the code object of pt_bvh_build.hip (see there)

@@ -299,8 +299,19 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
         rand.seed2 = rf.y;
         int ps_row, ps_lo, ps_hi;
         float ps_r2;
+        // PT_ABL_*: traffic-attribution builds (round 6, profiles/r6_05_shade_traffic.md) — what k_shade's measured bytes are made of, by leaving one
+        // class of accesses out at a time; the images are wrong by construction, only the counters of the shade dispatches are read
+#ifdef PT_ABL_NO_PROBE
+        sample2d(rand, ps_r2, ps_r2); // (the two random numbers are still drawn: the paths stay the ones of the full build)
+        ps_row = ps_lo = ps_hi = 0;
+#else
         probe_search_begin(sp.probe, pm, rand, ps_row, ps_lo, ps_hi, ps_r2);
+#endif
+#ifdef PT_ABL_NO_TRINRM
+        const float4 tn = make_float4(0.f, 1.f, 0.f, 0.f);
+#else
         const float4 tn = sp.tri_nrm[leaf];
+#endif
         const int32_t mesh = __float_as_int(tn.w);
         // the SBT record's material (:481-484): when every hit of the wave is on the same mesh the record comes through the scalar cache (k_shade
         // is bound by the address rate of its vector loads: six fewer per hit, +1.5 %).  (An LDS copy of the table was measured: no difference.)
@@ -362,7 +373,11 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
             v3 wi, skyColor;
             float skyPdf;
             // (started at the reference's position: −0.3 % frame; the candidate lines' loads started early as well: 18 more live registers, spills, slower)
+#ifdef PT_ABL_NO_PROBE
+            wi = mk3(0.f, 1.f, 0.f); skyColor = mk3(1.f, 1.f, 1.f); skyPdf = 1.f + ps_r2;
+#else
             probe_search_end(sp.probe, pm, ps_row, ps_lo, ps_hi, ps_r2, wi, skyColor, skyPdf);
+#endif
             bool has_val = false;
             v3 val = mk3(0.f);
             {
@@ -447,9 +462,13 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
                         st.sD[bi] = make_float4(wi.x, wi.y, wi.z, 0.f);
                         st.pendB[bi] = pe;
                     } else {
+#ifndef PT_ABL_NO_SHADOW_ST
                         st_st<PT_NT_SHADE_ST>(&st.shO[sq], make_float4(P.x, P.y, P.z, 0.f));
                         st_st<PT_NT_SHADE_ST>(&st.shD[sq], make_float4(wi.x, wi.y, wi.z, 0.f));
                         st_st<PT_NT_SHADE_ST>(&st.shPend[sq], pe);
+#else
+                        if (sq == 0xffffffffu) st.shPend[0] = pe; // (keeps the values live)
+#endif
                     }
                 }
             }
@@ -470,7 +489,11 @@ PT_DEV void shade_path(const PathState& st, const ShadeParams& sp, const ProbeMa
         if (!CATCHER && depth >= sp.max_depth) push_next = false;
     }
     const uint32_t nq = queue_push<LOCAL>(push_next, p, sp.next_queue);
+#ifdef PT_ABL_NO_STATE_ST
+    if (push_next && nq == 0xffffffffu) { // (never true: keeps the values live without the stores)
+#else
     if (push_next) {
+#endif
         st_st<PT_NT_SHADE_ST>(&sp.oRayO[nq], make_float4(P_out.x, P_out.y, P_out.z, sp.tmin_radiance));
         st_st<PT_NT_SHADE_ST>(&sp.oRayD[nq], make_float4(dir_out.x, dir_out.y, dir_out.z, 1e16f));
         st_st<PT_NT_SHADE_ST>(&sp.oThr[nq], thr_out);

@@ -68,6 +68,7 @@ def small_probe():
 def sched(request, monkeypatch):
     monkeypatch.setenv("PT_FUSED", "0" if request.param == "chain" else "1")
     monkeypatch.setenv("PT_SCHED_TRIALS", "0")  # (the on-line choice between the two would otherwise pick per frame)
+    monkeypatch.setenv("PT_FUSED_MAX_COST", "1e9")  # (... and the first guess keeps scenes with expensive rays on the chain)
     return request.param
 
 
@@ -462,6 +463,7 @@ def test_builder_degenerate_scenes(ptlib, orc_det, case, monkeypatch, small_prob
     for fused in ("0", "1"):
         monkeypatch.setenv("PT_FUSED", fused)
         monkeypatch.setenv("PT_SCHED_TRIALS", "0")
+        monkeypatch.setenv("PT_FUSED_MAX_COST", "1e9")  # (5000 coincident triangles cost a calibration ray thousands of steps: the policy would keep the chain)
         g = _gpu_render(_renderer(m, small_probe, cam, w, h), 2)
         _check_sched(g, "fused" if fused == "1" else "chain")
         _compare(g, o)

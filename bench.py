@@ -250,6 +250,12 @@ def main():
     while not sv4 and opts["frames_in_flight"] < 2 and (r.stats()["schedule"] & 0x100) and warm < 64 * args.batch:
         render_frame(warm, args.batch)
         warm += args.batch
+    if dist is not None:  # every rank enters the timed loop at the same subframe index (a trial is 2 x (1 + PT_SCHED_TRIALS) frames on every rank, so this is a no-op unless a rank was disturbed)
+        wt = torch.tensor([warm], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+        while warm < int(wt.item()):
+            render_frame(warm, args.batch)
+            warm += args.batch
     barrier()
     keys = ("trace_ms", "shadow_ms", "shade_ms", "other_ms", "render_ms", "trace_launches", "shadow_launches", "shade_launches", "radiance_rays", "shadow_rays", "shaded_hits", "fused_passes")
     agg = dict.fromkeys(keys, 0.0)

@@ -156,7 +156,15 @@ typedef struct pt_stats {
                              * steps; PT_BVH_BUILDER=lbvh|ploc|sah forces one, PT_BVH_SAH=0 leaves the SAH candidate out.  Images do not
                              * depend on the choice (closest hit, lowest primitive on ties, hits confined to the triangle's padded box). */
     uint32_t fused_passes;  /* passes of the last render that ran as ONE persistent kernel (generate -> trace -> shade rounds per wave, no launch
-                             * chain: small synchronous frames, PT_FUSED; csrc/pt_fused.h); trace_launches counts each of them once */
+                             * chain: small synchronous frames, PT_FUSED; csrc/pt_fused.h); trace_launches counts each of them once.
+                             * WHICH frames: a synchronous pt_render / pt_render_batch of a scene without shadow-catcher materials, default
+                             * pt_options.streams and split_shadow, of at most PT_SCHED_MAX_PATHS (4.5 M) paths is rendered alternately as a
+                             * launch chain and as one fused pass over its first 2 x (1 + PT_SCHED_TRIALS) frames (both leave the same bits)
+                             * and then by whichever measured faster; `schedule`, `sched_chain_ms`, `sched_fused_ms` below report it.  The
+                             * first trial frame — and every frame when PT_SCHED_TRIALS=0 — follows the rule of round 5: fused when the frame
+                             * has at most PT_FUSED_MAX_PATHS (2.5 M) paths and the tree's calibration rays cost at most PT_FUSED_MAX_COST
+                             * (22) traversal steps; a tree that was never calibrated (PT_BVH_BUILDER forced, PT_BVH_IMPORT, a challenger that
+                             * could not be built) counts as expensive unless the scene has fewer than 4096 triangles. */
     uint32_t path_state_allocs; /* (re-)allocations of the per-path device state since pt_create.  The state only grows (sets, paths per set,
                              * pixels per set, each kept at the largest value any frame asked for), so alternating schedules — a fused-size
                              * synchronous frame, a foveated frame, frames in flight — re-allocates at most once per dimension. */

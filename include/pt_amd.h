@@ -171,7 +171,7 @@ typedef struct pt_stats {
     uint32_t bvh_challengers_skipped; /* candidate hierarchies pt_create could not build (out of device memory, a failed bounds check): the standing
                              * tree then stayed without a comparison — also reported on stderr; 0 in every healthy build */
     uint32_t schedule;      /* how the last synchronous pt_render ran: 0 launch chain, 1 fused bounce loop (k_path_loop); bit 8 set while the context
-                             * is still timing the two against each other for this frame configuration (pt_sched_* below) */
+                             * is still timing the two against each other for this frame configuration (sched_chain_ms / sched_fused_ms below; `fused_passes` above says which frames take part) */
     double sched_chain_ms;  /* best device time of the configuration's trial frames as a launch chain / as one fused pass (0: not measured: */
     double sched_fused_ms;  /* the configuration is not eligible for both, or PT_SCHED_TRIALS=0) */
     double create_ms;       /* host time of pt_create from the flattened scene to the finished context: uploads, the acceleration structure

@@ -417,7 +417,13 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     ctx->device = device;
     ctx->has_catcher = fs.has_catcher;
     if (const char* e = getenv("PT_TIMING")) ctx->env_timing = atoi(e) != 0;
-    auto bail = [&](int code) { g_create_error = ctx->err; pt_destroy(ctx); return code; };
+    std::thread warm_thread; // (first pt_create of a process: loads the library's code objects while the scene is uploaded, below)
+    auto bail = [&](int code) {
+        if (warm_thread.joinable()) warm_thread.join(); // it launches on the context's stream, which pt_destroy is about to destroy
+        g_create_error = ctx->err;
+        pt_destroy(ctx);
+        return code;
+    };
 #define CKC(call)                                                           \
     do {                                                                    \
         hipError_t e_ = (call);                                             \
@@ -440,7 +446,6 @@ static int create_from_flat(const FlatScene& fs, int device, pt_ctx** out_ctx) {
     // file) at their first kernel launch: about 8 + 2 ms that the first-build figure of round 5 (35 ms against 10 ms warm) contained.  A helper
     // thread launches an empty kernel of each now, while this thread uploads the scene (the copies below are synchronous and leave the CPU idle).
     static std::atomic<uint64_t> g_warmed{0}; // one bit per device
-    std::thread warm_thread;
     if (device < 64 && !((g_warmed.fetch_or(1ull << device) >> device) & 1ull))
         warm_thread = std::thread([device, stream = ctx->stream]() {
             if (hipSetDevice(device) != hipSuccess) return;

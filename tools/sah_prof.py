@@ -1,4 +1,5 @@
-"""two pt_create calls on the C3 terrain (the second build is the warm one) — what tools/r5_sah_prof.sh / r5_sah_exp.sh profile"""
+"""two pt_create calls on the C3 terrain (the second build is the warm one) — what tools/r5_sah_prof.sh, tools/r6_s1.sh and tools/r6_s2.sh profile
+(round 5 also ran it under an experiment script, r5_sah_exp.sh, that was never committed and is lost: profiles/r6_01_sah_fault.md)"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 from optixpathtracer_amd import renderer as R, scenes
